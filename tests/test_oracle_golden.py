@@ -1,0 +1,204 @@
+"""The oracle (CPU restatement) against the golden vectors captured from the
+reference's own functions (tools/capture_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from conftest import golden_sd, load_golden
+from oracle import stylegan2_ref as G
+from oracle import swav_ref as S
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_gv1_upfirdn2d():
+    d = load_golden("gv1_upfirdn2d")
+    k = T(d["kernel"])
+    close(G.fir_kernel(), d["kernel"])
+    close(G.upfirdn2d(T(d["x_mode1"]), k * 4, up=1, pad=(1, 1)), d["y_mode1"])
+    close(G.upfirdn2d(T(d["x_mode3"]), k * 4, up=2, pad=(2, 1)), d["y_mode3"])
+
+
+def test_gv2_modconv():
+    d = load_golden("gv2_modconv")
+    blur = G.fir_kernel() * 4
+    for tag, kw in (("plain", {}), ("up", dict(upsample=True, blur_kernel=blur)),
+                    ("rgb", dict(demodulate=False))):
+        y = G.modulated_conv(T(d[f"{tag}_x"]), T(d[f"{tag}_style"]), T(d[f"{tag}_weight"]),
+                             T(d[f"{tag}_mod_weight"]), T(d[f"{tag}_mod_bias"]), **kw)
+        close(y, d[f"{tag}_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_gv3_layers():
+    d = load_golden("gv3_layers")
+    for tag, up in (("plain", False), ("up", True)):
+        sd = {k[len(tag) + 4:]: T(v) for k, v in d.items() if k.startswith(f"{tag}_sd_")}
+        y = G.styled_conv(T(d[f"{tag}_x"]), T(d[f"{tag}_style"]), sd, "", T(d[f"{tag}_noise"]), up)
+        close(y, d[f"{tag}_y"], rtol=1e-4, atol=1e-5)
+    sd = {k[7:]: T(v) for k, v in d.items() if k.startswith("rgb_sd_")}
+    close(G.to_rgb(T(d["rgb_x"]), T(d["rgb_style"]), sd, "", T(d["rgb_skip"])), d["rgb_y_skip"],
+          rtol=1e-4, atol=1e-5)
+    close(G.to_rgb(T(d["rgb_x"]), T(d["rgb_style"]), sd, ""), d["rgb_y_noskip"], rtol=1e-4, atol=1e-5)
+    x = T(d["el_x"])
+    close(G.equal_linear(x, T(d["el_weight"]), T(d["el_bias"]), 0.01, True), d["el_y"])
+    close(G.equal_linear(x, T(d["el2_weight"]), T(d["el2_bias"])), d["el2_y"])
+    close(G.pixel_norm(x), d["pn_y"])
+
+
+def test_gv4_mini_generator():
+    d = load_golden("gv4_mini_generator")
+    sd = golden_sd(d)
+    w, ml = T(d["w"]), T(d["mean_latent"])
+    close(G.mapping(T(d["z"]), sd), d["w"], rtol=1e-5, atol=1e-6)
+    img, taps, lat = G.generator_forward(w, sd, 0.7, ml, input_is_latent=True)
+    close(lat, d["latent_trunc_once"])
+    close(img, d["img_once"], rtol=1e-4, atol=1e-5)
+    for i, t in enumerate(taps):
+        close(t, d[f"tap_once_{i}"], rtol=1e-4, atol=1e-5)
+    img2, taps2, _ = G.generator_forward(lat, sd, 0.7, ml, input_is_latent=True)
+    close(img2, d["img_twice"], rtol=1e-4, atol=1e-5)
+    for i, t in enumerate(taps2):
+        close(t, d[f"tap_twice_{i}"], rtol=1e-4, atol=1e-5)
+    imgz, tapsz, _ = G.generator_forward(T(d["z"]), sd, 1.0, None, input_is_latent=False)
+    close(imgz, d["img_z"], rtol=1e-4, atol=1e-5)
+    assert len(taps) == 7
+
+
+def test_gv5_pixel_features():
+    d = load_golden("gv5_pixel_features")
+    taps = [T(d[f"tap_{i}"]) for i in range(4)]
+    close(S.pixel_features(taps, int(d["hlen"])), d["stack"], 0, 0)
+    close(S.pixel_features(taps, 42), d["stack_full"], 0, 0)
+
+
+def test_gv6_codes():
+    d = load_golden("gv6_codes")
+    x = S.sample_pixels(T(d["hfeat"]), T(d["picks"]), int(d["patch_size"]))
+    close(S.codes(x, T(d["proj_weight"]), T(d["proto_weight"]), T(d["proto_bias"])), d["scores_train"])
+    preds, labels = None, None
+    xa = S.sample_pixels(T(d["hfeat"]), None, None)
+    preds = S.codes(xa, T(d["proj_weight"]), train=False).reshape(d["scores_pred"].shape)
+    close(preds, d["scores_pred"])
+    assert (preds.max(1)[1].numpy() == d["labels_pred"]).all()
+
+
+def test_gv7_sinkhorn():
+    d = load_golden("gv7_sinkhorn")
+    sc, img = T(d["scores"]), T(d["img"])
+    for tag, pdf in (("uniform_e05", "uniform"), ("image_e05", "image"),
+                     ("uniform_e005", "uniform"), ("image_e003", "image")):
+        s = sc * float(d[f"scale_{tag}"])
+        eps = float(d[f"eps_{tag}"])
+        q = S.sinkhorn_knopp(s, eps, int(d["niters"]), pdf, img)
+        close(q, d[f"q_{tag}"], rtol=1e-5, atol=1e-9)
+        # the fp64 run of the same algorithm is the same matrix on what the loss sees
+        qs = S.sinkhorn_knopp(s, eps, int(d["niters"]), pdf, img, fp64=True).numpy()
+        ref = d[f"q_{tag}"]
+        assert np.all(np.abs(qs - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    close(S.sinkhorn_knopp(T(d["scores_big"]), 0.01, 10), d["q_big_uniform_e01"], rtol=1e-5, atol=1e-9)
+    # the reference overflows (non-finite) on un-shifted fp32 exp; the fp64 run stays finite
+    assert not bool(d["overflow_all_finite"])
+    assert not torch.isfinite(S.sinkhorn_knopp(sc * float(d["overflow_scale"]), 0.005, 10)).all()
+    q_over = S.sinkhorn_knopp(sc * float(d["overflow_scale"]), 0.005, 10, fp64=True)
+    assert torch.isfinite(q_over).all()
+    close(q_over.sum(1), np.ones(sc.shape[0], np.float32), rtol=1e-5)
+
+
+def test_gv8_loss_and_grads():
+    d = load_golden("gv8_loss_grads")
+    pw = T(d["proj_weight"]).clone().requires_grad_(True)
+    cw = T(d["proto_weight"]).clone().requires_grad_(True)
+    cb = T(d["proto_bias"]).clone().requires_grad_(True)
+    n = d["scores_s"].shape[0]
+    ss = S.codes(S.sample_pixels(T(d["hs"]), T(d["picks"]), n), pw, cw, cb)
+    st = S.codes(S.sample_pixels(T(d["ht"]), T(d["picks"]), n), pw, cw, cb)
+    close(ss, d["scores_s"])
+    close(st, d["scores_t"])
+    with torch.no_grad():
+        qs = S.sinkhorn_knopp(ss, float(d["eps"]), 10)
+        qt = S.sinkhorn_knopp(st, float(d["eps"]), 10)
+    close(qs, d["q_s"], rtol=1e-5, atol=1e-9)
+    tt = float(d["temperature"])
+    loss = S.swapped_prediction_loss(ss / tt, st / tt, qs, qt)
+    close(loss, d["loss"], rtol=1e-6)
+    loss.backward()
+    close(pw.grad, d["g_proj"], rtol=1e-4, atol=1e-7)
+    close(cw.grad, d["g_proto_w"], rtol=1e-4, atol=1e-7)
+    close(cb.grad, d["g_proto_b"], rtol=1e-4, atol=1e-7)
+
+
+def test_gv9_view_and_rng_order():
+    d = load_golden("gv9_view_rng")
+    sd = golden_sd(d)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    ml = G.mean_latent(sd, 64, 16)
+    close(ml, d["mean_latent"], rtol=1e-5, atol=1e-6)
+    im = S.draw_image_reference_order(16, G.num_layers_of(sd), 3, 32 * 32, 0, transforms=False)
+    close(im.z, d["z"], 0, 0)
+    assert torch.equal(torch.randn(4), T(d["after"]))           # RNG state identical afterwards
+    w = G.mapping(im.z, sd)
+    close(w, d["w"], rtol=1e-5, atol=1e-6)
+    for v, tag in zip(im.views, "st"):
+        assert v.layer_no == int(d[f"layer_no_{tag}"])
+        stack, img = S.make_view(sd, w, ml, 0.7, v, hlen=56)
+        close(stack, d[f"stack_{tag}"], rtol=1e-4, atol=1e-5)
+        close(img, d[f"img_{tag}"], rtol=1e-4, atol=1e-5)
+
+
+def _gv10_run(d):
+    sd = golden_sd(d)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    return S.pretrain_reference_order(
+        sd, 16, num_latents_for_mean=64, psi=0.7, n_perturb_layers=3, num_test_samples=2,
+        num_epochs=3, num_patches=2, patch_size=300, hlen=56, nclasses=8, nprototypes=12,
+        temperature=0.1, eps=0.05, niters=10, lr=0.01, momentum=0.9, trust=0.01,
+        use_larc=False, transforms=False)
+
+
+def test_gv10_pretrain_trajectory():
+    d = load_golden("gv10_pretrain")
+    losses, params, _ = _gv10_run(d)
+    np.testing.assert_allclose(losses, d["losses"], rtol=1e-4)
+    close(params.proj_w, d["proj_weight"], rtol=1e-4, atol=1e-6)
+    close(params.proto_w, d["proto_weight"], rtol=1e-4, atol=1e-6)
+    close(params.proto_b, d["proto_bias"], rtol=1e-4, atol=1e-6)
+
+
+def test_gv11_predict():
+    d10, d = load_golden("gv10_pretrain"), load_golden("gv11_predict")
+    sd = golden_sd(d10)
+    preds, labels = S.predict_swav_codes(sd, T(d["w"]), T(d["mean_latent"]), 0.7,
+                                         T(d10["proj_weight"]), hlen=56)
+    close(preds, d["preds"], rtol=1e-4, atol=1e-5)
+    assert (labels.numpy() == d["labels"]).mean() > 0.999
+
+
+def test_rotflip_map_properties():
+    m0 = S.rotflip_index_map(0.0, False, 16, 16)
+    assert torch.equal(m0, torch.arange(256))
+    mf = S.rotflip_index_map(0.0, True, 8, 12).reshape(8, 12)
+    assert torch.equal(mf, torch.arange(96).reshape(8, 12).flip(1))
+    m = S.rotflip_index_map(7.5, False, 64, 64)
+    assert (m == -1).sum() > 0 and (m >= 0).float().mean() > 0.9
+    # centre pixel neighbourhood maps to itself for a small angle
+    c = 32 * 64 + 32
+    assert abs(int(m[c]) - c) <= 65
+
+
+def test_larc_restatement():
+    torch.manual_seed(0)
+    p, g = torch.randn(5, 7), torch.randn(5, 7)
+    p0 = p.clone()
+    bufs = S.larc_sgd_step([p], [g], [None], lr=0.01, momentum=0.9, trust=0.01)
+    scale = 0.01 * p0.norm() / (g.norm() + 1e-8)
+    close(p, (p0 - 0.01 * scale * g).numpy(), rtol=1e-6)
+    p1 = p.clone()
+    bufs2 = S.larc_sgd_step([p], [g], bufs, lr=0.01, momentum=0.9, trust=0.01)
+    scale2 = 0.01 * p1.norm() / (g.norm() + 1e-8)
+    close(bufs2[0], (0.9 * bufs[0] + scale2 * g).numpy(), rtol=1e-6)
