@@ -1,0 +1,94 @@
+"""ctypes binding of libganecdotes_hip.so (the C ABI declared in include/ganecdotes_hip.h).
+
+There is NO fallback: if the shared object is missing, or an entry point is, importing the
+product path fails loudly.  torch is imported first so that the HIP runtime already loaded by
+PyTorch-ROCm (SONAME libamdhip64.so.7) is the one the kernels run on.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libganecdotes_hip.so")
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/ganecdotes_hip.h
+SIGNATURES = {
+    "gx_version": (ctypes.c_char_p, []),
+    "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gx_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p,
+                          c_sz, c_p]),
+    "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
+    "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
+    "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
+    "gx_demod": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "gx_modconv_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
+    "gx_modconv_up_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gx_modconv_up_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p,
+                                c_p]),
+    "gx_torgb_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "gx_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "gx_rotflip_map": (c_i, [c_f, c_i, c_i, c_i, c_p, c_p]),
+    "gx_gather_taps": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "gx_row_sumsq": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p]),
+    "gx_norm_map": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "gx_row_l2_normalize": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p]),
+    "gx_l2_normalize_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_l, c_p]),
+    "gx_row_argmax": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p]),
+    "gx_colsum_workspace_bytes": (c_sz, [c_i]),
+    "gx_colsum": (c_i, [c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_workspace_bytes": (c_sz, [c_i]),
+    "gx_sinkhorn_u": (c_p, [c_p, c_i]),
+    "gx_sinkhorn_colmax": (c_i, [c_p, c_l, c_i, c_l, c_p, c_sz, c_p]),
+    "gx_sinkhorn_cmax_get": (c_i, [c_p, c_i, c_p, c_p]),
+    "gx_sinkhorn_cmax_set": (c_i, [c_p, c_i, c_p, c_p]),
+    "gx_sinkhorn_pass": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_update": (c_i, [c_p, c_p, c_i, c_i, c_p, c_f, c_p, c_p]),
+    "gx_sinkhorn": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_codes": (c_i, [c_p, c_l, c_i, c_l, c_f, c_p, c_p, c_l, c_p]),
+    "gx_hist_marginal": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
+    "gx_swapped_ce_workspace_bytes": (c_sz, []),
+    "gx_swapped_ce": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p,
+                            c_sz, c_p]),
+    "gx_sumsq_workspace_bytes": (c_sz, []),
+    "gx_sumsq": (c_i, [c_p, c_l, c_p, c_p, c_sz, c_p]),
+    "gx_larc_sgd": (c_i, [c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_i, c_i, c_p]),
+}
+
+ERRORS = {-1: "bad argument", -2: "misaligned pointer / leading dimension", -3: "workspace too small",
+          -4: "kernel launch failed (hipGetLastError)"}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and type every entry point.  Raises RuntimeError when the library or
+    a symbol is missing (build it with `python -m ganecdotes_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
+            "Build it with `python -m ganecdotes_amd.build` (needs hipcc).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libganecdotes_hip.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)} (code {rc})")

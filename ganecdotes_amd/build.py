@@ -1,0 +1,67 @@
+"""Build libganecdotes_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m ganecdotes_amd.build [--force]
+
+The shared object is written in-tree (ganecdotes_amd/libganecdotes_hip.so) so that it
+travels with the repository snapshot to the GPU box; it is git-ignored.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libganecdotes_hip.so")
+STAMP = LIB + ".srchash"
+SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: cannot build the gfx950 kernels")
+
+
+def _src_hash():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    want = _src_hash()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as f:
+            if f.read().strip() == want:
+                return LIB
+    hipcc = _hipcc()
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(bdir, s.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", CSRC, "-c",
+               os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(o)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(want)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

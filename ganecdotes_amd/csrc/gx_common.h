@@ -1,0 +1,64 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of ganecdotes_amd.
+// Wavefront = 64 lanes everywhere; no CUDA/warp-32 compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GX_OK 0
+#define GX_ERR_BAD_ARG (-1)       // null pointer / non-positive dimension / unsupported mode
+#define GX_ERR_ALIGN (-2)         // pointer or leading dimension not aligned as documented
+#define GX_ERR_WORKSPACE (-3)     // workspace too small
+#define GX_ERR_LAUNCH (-4)        // hipGetLastError() after launch
+
+#define GX_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        if (hipGetLastError() != hipSuccess) return GX_ERR_LAUNCH; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int gx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float gx_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gx_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reductions over a power-of-two team of consecutive lanes (team <= 64)
+__device__ __forceinline__ float gx_team_sum(float v, int team) {
+    for (int o = team >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gx_team_max(float v, int team) {
+    for (int o = team >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS.
+// Every thread gets the total.  Fixed summation order -> bitwise reproducible.
+__device__ __forceinline__ float gx_block_sum(float v, float* red) {
+    v = gx_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float gx_block_max(float v, float* red) {
+    v = gx_wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}

@@ -1,0 +1,417 @@
+// StyleGAN2 generator forward kernels for gfx950.
+//
+// Activations are NHWC ([b][y][x][c]): the implicit-GEMM A operand (pixel x (tap, cin)) is
+// then k-contiguous, and every hidden-feature tap is written once in exactly the layout the
+// SwAV gather wants (one contiguous C*4-byte row per pixel).
+//
+// Modulated conv (models/stylegan2/model.py:327-368) is re-associated so the weight is
+// shared by the whole batch:   out[b,co] = demod'[b,co] * sum_{tap,ci} (x[b,ci]*s[b,ci]) * W[co,ci,tap]
+// with demod'[b,co] = scale * rsqrt(scale^2 * sum_ci s[b,ci]^2 * Wsq[co,ci] + 1e-8), scale =
+// 1/sqrt(Cin k^2), Wsq = sum_taps W^2 (ToRGB: demod' = scale).  The contraction runs on the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) as an implicit GEMM, M = B*OH*OW, N = Cout,
+// K = ntaps*Cin; noise + bias + leaky-ReLU*sqrt2 (fused_bias_act_kernel.cu:18-85 semantics)
+// are the epilogue.  The stride-2 transposed conv of the upsampling layers is four such
+// GEMMs (one per output parity class, 4+2+2+1 taps) writing the (2H+1)^2 pre-blur image,
+// followed by one fused FIR-blur + demod + noise + bias + act pass (upfirdn2d mode 1,
+// upfirdn2d_kernel.cu:114-215 semantics).
+#include "gx_mfma.h"
+
+namespace gx {
+
+struct ConvArgs {
+    const float* in; int B, IH, IW, Cin;      // NHWC input
+    const float* wt;                           // [9 or 1][Cout][Cin]
+    const float* style;                        // [B][Cin] modulation or nullptr
+    int ntaps; int dy[9], dx[9], tw[9];        // input offsets and weight-tap index per tap
+    int OH, OW;                                // output sub-grid (M = B*OH*OW)
+    float* out; int outH, outW, Cout;          // NHWC output tensor
+    int ymul, yadd, xmul, xadd;                // out y = oy*ymul + yadd
+    const float* demod;                        // [B][Cout] or nullptr
+    const float* noise; long noise_bstride;    // [.][outH][outW] or nullptr
+    const float* noise_w;                      // device scalar
+    const float* bias;                         // [Cout] or nullptr
+    int act;                                   // 1: lrelu(0.2)*sqrt2
+    int vec_ok;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long Mtot = (long)g.B * g.OH * g.OW;
+    const bool vec = g.vec_ok != 0;
+
+    // the 4 pixel rows this thread stages
+    int rb[4], roy[4], rox[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = (long)m0 + (tid >> 3) + 32 * i;
+        if (m < Mtot) {
+            const int b = (int)(m / ((long)g.OH * g.OW));
+            const int rem = (int)(m - (long)b * g.OH * g.OW);
+            rb[i] = b; roy[i] = rem / g.OW; rox[i] = rem - roy[i] * g.OW;
+        } else { rb[i] = -1; roy[i] = 0; rox[i] = 0; }
+    }
+    const int kt_per_tap = (g.Cin + BK - 1) / BK;
+    const int nkt = g.ntaps * kt_per_tap;
+    const int kq = (tid & 7) * 4;
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    f32x4 ra[4], rw[4];
+
+    auto load_a = [&](int kt) {
+        const int tap = kt / kt_per_tap;
+        const int ci = (kt - tap * kt_per_tap) * BK + kq;
+        const int dy = g.dy[tap], dx = g.dx[tap];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = zero4();
+            const int iy = roy[i] + dy, ix = rox[i] + dx;
+            if (rb[i] >= 0 && ci < g.Cin && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                v = load4(g.in + (((long)rb[i] * g.IH + iy) * g.IW + ix) * g.Cin + ci, g.Cin - ci, vec);
+                if (g.style) {
+                    const f32x4 s = load4(g.style + (long)rb[i] * g.Cin + ci, g.Cin - ci, vec);
+                    v *= s;
+                }
+            }
+            ra[i] = v;
+        }
+    };
+    auto load_w = [&](int kt) {
+        const int tap = kt / kt_per_tap;
+        const int ci = (kt - tap * kt_per_tap) * BK + kq;
+        const float* base = g.wt + (long)g.tw[tap] * g.Cout * g.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = n0 + (tid >> 3) + 32 * i;
+            rw[i] = (co < g.Cout && ci < g.Cin) ? load4(base + (long)co * g.Cin + ci, g.Cin - ci, vec) : zero4();
+        }
+    };
+
+    load_a(0); load_w(0);
+    store_tile<true>(lds, ra, tid);
+    store_tile<true>(lds + TILE_FLOATS, rw, tid);
+    __syncthreads();
+    for (int t = 0; t < nkt; ++t) {
+        float* As = lds + (t & 1) * 2 * TILE_FLOATS;
+        float* Bs = As + TILE_FLOATS;
+        const bool more = (t + 1 < nkt);
+        if (more) { load_a(t + 1); load_w(t + 1); }
+        mfma_ktile<true, true>(As, Bs, acc, wr, wc, lane);
+        if (more) {
+            float* An = lds + ((t + 1) & 1) * 2 * TILE_FLOATS;
+            store_tile<true>(An, ra, tid);
+            store_tile<true>(An + TILE_FLOATS, rw, tid);
+        }
+        __syncthreads();
+    }
+
+    const float nw = (g.noise && g.noise_w) ? *g.noise_w : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = (long)m0 + acc_row(wr, mt, r, lane);
+            if (m >= Mtot) continue;
+            const int b = (int)(m / ((long)g.OH * g.OW));
+            const int rem = (int)(m - (long)b * g.OH * g.OW);
+            const int oy = rem / g.OW, ox = rem - oy * g.OW;
+            const int y = oy * g.ymul + g.yadd, x = ox * g.xmul + g.xadd;
+            const long pix = ((long)b * g.outH + y) * g.outW + x;
+            const float nz = g.noise ? nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = n0 + acc_col(wc, nt, lane);
+                if (co >= g.Cout) continue;
+                float v = acc[mt][nt][r];
+                if (g.demod) v *= g.demod[(long)b * g.Cout + co];
+                v += nz;
+                if (g.bias) v += g.bias[co];
+                if (g.act) v = lrelu_sqrt2(v);
+                g.out[pix * g.Cout + co] = v;
+            }
+        }
+}
+
+// demod'[b][co] = scale * rsqrt(scale^2 * sum_ci s[b][ci]^2 * wsq[co][ci] + 1e-8)   (one wave each)
+__global__ void demod_kernel(const float* __restrict__ s, const float* __restrict__ wsq, int B, int Cin, int Cout,
+                             float scale, float* __restrict__ demod) {
+    const long idx = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= (long)B * Cout) return;
+    const int b = (int)(idx / Cout), co = (int)(idx - (long)b * Cout), lane = threadIdx.x & 63;
+    float a = 0.f;
+    for (int ci = lane; ci < Cin; ci += 64) { const float sv = s[(long)b * Cin + ci]; a = fmaf(sv * sv, wsq[(long)co * Cin + ci], a); }
+    a = gx_wave_sum(a);
+    if (lane == 0) demod[idx] = scale * rsqrtf(scale * scale * a + 1e-8f);
+}
+
+// Blur of the (2H+1)^2 transposed-conv image with pad (1,1) + StyledConv epilogue:
+//   out[b,y,x,c] = act( demod[b,c] * sum_{fy,fx} kf[fy][fx] * T[b, y+fy-1, x+fx-1, c] + nw*noise + bias[c] )
+// kf is the FLIPPED 4x4 FIR (upfirdn2d correlates with the flipped kernel, model.py:88).
+__global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int TW, int C, const float* __restrict__ kf,
+                                const float* __restrict__ demod, const float* __restrict__ noise, long noise_bstride,
+                                const float* __restrict__ noise_w, const float* __restrict__ bias, int act,
+                                float* __restrict__ out, int OH, int OW) {
+    const int c4n = C >> 2;
+    const long total = (long)B * OH * OW * c4n;
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = kf[i];
+    const float nw = (noise && noise_w) ? *noise_w : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long pix = i / c4n;
+        const int x = (int)(pix % OW);
+        const int y = (int)((pix / OW) % OH);
+        const int b = (int)(pix / ((long)OW * OH));
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+            const int ty = y + fy - 1;
+            if (ty < 0 || ty >= TH) continue;
+#pragma unroll
+            for (int fx = 0; fx < 4; ++fx) {
+                const int tx = x + fx - 1;
+                if (tx < 0 || tx >= TW) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(T + (((long)b * TH + ty) * TW + tx) * C + c);
+                a += v * k[fy * 4 + fx];
+            }
+        }
+        const float nz = noise ? nw * noise[(long)b * noise_bstride + (long)y * OW + x] : 0.f;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = a[j];
+            if (demod) v *= demod[(long)b * C + c + j];
+            v += nz;
+            if (bias) v += bias[c + j];
+            o[j] = act ? lrelu_sqrt2(v) : v;
+        }
+        *reinterpret_cast<f32x4*>(out + pix * C + c) = o;
+    }
+}
+
+// ToRGB (model.py:445-454): 1x1 modulated conv without demod + bias + FIR-upsampled skip.
+//   img[b][c][y][x] = scale * sum_ci x[b,y,x,ci] s[b,ci] W[c][ci] + bias[c] + up2(prev)[b][c][y][x]
+// up2 = upfirdn2d(up=2, pad=(2,1)) with the flipped 4x4 FIR kf (already x4).  Image is planar
+// NCHW (3 channels).  One wave per pixel.
+__global__ void torgb_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ W,
+                             float scale, const float* __restrict__ bias, const float* __restrict__ prev,
+                             const float* __restrict__ kf, int B, int H, int Wd, int Cin, float* __restrict__ img) {
+    const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pix >= (long)B * H * Wd) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(pix / ((long)H * Wd));
+    const int rem = (int)(pix - (long)b * H * Wd);
+    const int y = rem / Wd, xx = rem - y * Wd;
+    const float* px = x + pix * Cin;
+    const float* ps = s + (long)b * Cin;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int ci = lane; ci < Cin; ci += 64) {
+        const float v = px[ci] * ps[ci];
+        a0 = fmaf(v, W[ci], a0); a1 = fmaf(v, W[Cin + ci], a1); a2 = fmaf(v, W[2 * Cin + ci], a2);
+    }
+    a0 = gx_wave_sum(a0); a1 = gx_wave_sum(a1); a2 = gx_wave_sum(a2);
+    if (lane < 3) {
+        float v = (lane == 0 ? a0 : (lane == 1 ? a1 : a2)) * scale + bias[lane];
+        if (prev) {
+            const int ph = H >> 1, pw = Wd >> 1;
+            const float* pp = prev + ((long)b * 3 + lane) * ph * pw;
+            float u = 0.f;
+#pragma unroll
+            for (int fy = 0; fy < 4; ++fy) {
+                const int zy = y + fy - 2;
+                if (zy < 0 || zy >= H || (zy & 1)) continue;
+#pragma unroll
+                for (int fx = 0; fx < 4; ++fx) {
+                    const int zx = xx + fx - 2;
+                    if (zx < 0 || zx >= Wd || (zx & 1)) continue;
+                    u = fmaf(kf[fy * 4 + fx], pp[(zy >> 1) * pw + (zx >> 1)], u);
+                }
+            }
+            v += u;
+        }
+        img[(((long)b * 3 + lane) * H + y) * Wd + xx] = v;
+    }
+}
+
+// PixelNorm (model.py:105-110): x * rsqrt(mean(x^2) + 1e-8), one wave per row.
+__global__ void pixel_norm_kernel(const float* __restrict__ x, long rows, int D, float* __restrict__ y) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = x[row * D + c]; s = fmaf(v, v, s); }
+    s = gx_wave_sum(s);
+    const float r = rsqrtf(s / (float)D + 1e-8f);
+    for (int c = lane; c < D; c += 64) y[row * D + c] = x[row * D + c] * r;
+}
+
+// y = act(x * alpha + bias[col] * bscale)   (EqualLinear epilogue, model.py:242-252)
+__global__ void bias_act_kernel(float* __restrict__ y, long rows, int N, float alpha, const float* __restrict__ bias,
+                                float bscale, int act) {
+    const long total = rows * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v = y[i] * alpha;
+        if (bias) v += bias[i % N] * bscale;
+        y[i] = act ? lrelu_sqrt2(v) : v;
+    }
+}
+
+// out = base + psi * (w - base), base broadcast over rows of length D  (truncation, model.py:594-602)
+__global__ void lerp_rows_kernel(const float* __restrict__ w, const float* __restrict__ base, long n, int D, float psi,
+                                 float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float m = base[i % D];
+        out[i] = m + psi * (w[i] - m);
+    }
+}
+
+// NCHW <-> NHWC (API boundary only: the reference hands taps around as NCHW)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, int HW, float* __restrict__ out) {
+    const long total = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long r = i / C; const int p = (int)(r % HW); const int b = (int)(r / HW);
+        out[i] = in[((long)b * C + c) * HW + p];
+    }
+}
+
+static int launch_conv(ConvArgs& g, hipStream_t stream) {
+    g.vec_ok = ((((uintptr_t)g.in | (uintptr_t)g.wt | (uintptr_t)g.style) & 15) == 0) && (g.Cin % 4 == 0);
+    const long M = (long)g.B * g.OH * g.OW;
+    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(g.Cout, BN);
+    hipLaunchKernelGGL(modconv_kernel, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // namespace gx
+
+using namespace gx;
+
+extern "C" {
+
+int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float scale, float* demod, void* stream) {
+    if (!s || !wsq || !demod || B <= 0 || Cin <= 0 || Cout <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(demod_kernel, dim3(gx_cdiv((long)B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, s, wsq, B,
+                       Cin, Cout, scale, demod);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// Plain 3x3 (pad 1) or 1x1 modulated conv with the StyledConv epilogue.
+//   x [B][H][W][Cin] NHWC; wt [k*k][Cout][Cin]; s [B][Cin]; demod [B][Cout] or null;
+//   noise [.][H][W] (batch stride noise_bstride, 0 = shared) or null; noise_w device scalar;
+//   bias [Cout] or null; act 1 = lrelu*sqrt2; out [B][H][W][Cout] NHWC.
+int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
+                   const float* demod, const float* noise, long noise_bstride, const float* noise_w,
+                   const float* bias, int act, float* out, void* stream) {
+    if (!x || !wt || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3))
+        return GX_ERR_BAD_ARG;
+    ConvArgs g{};
+    g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
+    g.ntaps = ksize * ksize;
+    for (int ky = 0; ky < ksize; ++ky)
+        for (int kx = 0; kx < ksize; ++kx) {
+            const int t = ky * ksize + kx;
+            g.dy[t] = ky - ksize / 2; g.dx[t] = kx - ksize / 2; g.tw[t] = t;
+        }
+    g.OH = H; g.OW = W; g.out = out; g.outH = H; g.outW = W; g.Cout = Cout;
+    g.ymul = 1; g.yadd = 0; g.xmul = 1; g.xadd = 0;
+    g.demod = demod; g.noise = noise; g.noise_bstride = noise_bstride; g.noise_w = noise_w; g.bias = bias; g.act = act;
+    return launch_conv(g, (hipStream_t)stream);
+}
+
+// Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur
+// pad (1,1) + demod + noise + bias + act -> out [B][2H][2W][Cout].
+//   T: caller-allocated scratch of B*(2H+1)*(2W+1)*Cout floats; kf: flipped 4x4 FIR (device, 16 floats)
+size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout) {
+    return (size_t)B * (2 * H + 1) * (2 * W + 1) * Cout * sizeof(float);
+}
+int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                      const float* demod, const float* kf, const float* noise, long noise_bstride,
+                      const float* noise_w, const float* bias, int act, float* T, float* out, void* stream) {
+    if (!x || !wt || !out || !T || !kf || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cout & 3))
+        return GX_ERR_BAD_ARG;
+    const int TH = 2 * H + 1, TW = 2 * W + 1;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvArgs g{};
+            g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
+            // T[u,v] = sum over (ky,kx) with u-ky, v-kx even: x[(u-ky)/2, (v-kx)/2] * W[.,.,ky,kx]
+            int n = 0;
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2) {
+                    g.dy[n] = -(ky >> 1); g.dx[n] = -(kx >> 1); g.tw[n] = ky * 3 + kx; ++n;
+                }
+            g.ntaps = n;
+            g.OH = py ? H : H + 1; g.OW = px ? W : W + 1;
+            g.out = T; g.outH = TH; g.outW = TW; g.Cout = Cout;
+            g.ymul = 2; g.yadd = py; g.xmul = 2; g.xadd = px;
+            g.demod = nullptr; g.noise = nullptr; g.noise_w = nullptr; g.bias = nullptr; g.act = 0;
+            const int rc = launch_conv(g, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    const long total = (long)B * 2 * H * 2 * W * (Cout >> 2);
+    long want = (total + 255) / 256;
+    const int nb = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, Cout, kf, demod,
+                       noise, noise_bstride, noise_w, bias, act, out, 2 * H, 2 * W);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, const float* s, float scale,
+                 const float* bias3, const float* prev_img, const float* kf, float* img, void* stream) {
+    if (!x || !w3 || !s || !bias3 || !img || B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return GX_ERR_BAD_ARG;
+    if (prev_img && (!kf || (H & 1) || (W & 1))) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(torgb_kernel, dim3(gx_cdiv((long)B * H * W, 4)), dim3(256), 0, (hipStream_t)stream, x, s, w3,
+                       scale, bias3, prev_img, kf, B, H, W, Cin, img);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream) {
+    if (!x || !y || rows <= 0 || D <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pixel_norm_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, D, y);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream) {
+    if (!y || rows <= 0 || N <= 0) return GX_ERR_BAD_ARG;
+    long want = (rows * N + 255) / 256;
+    const int nb = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, rows, N, alpha, bias, bscale, act);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream) {
+    if (!w || !base || !out || n <= 0 || D <= 0) return GX_ERR_BAD_ARG;
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(lerp_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, base, n, D, psi, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0 || HW <= 0) return GX_ERR_BAD_ARG;
+    long want = ((long)B * C * HW + 255) / 256;
+    const int nb = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, in, B, C, HW, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+const char* gx_version(void) { return "ganecdotes_amd-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// Dense fp32 MFMA GEMM for the SwAV contractions:
+//   C[m][n] = alpha * row_scale[m] * sum_k opA[m][k] * opB[k][n] + col_bias[n] + beta * C[m][n]
+// used as
+//   S3 projection      z      = X  Wp^T          (NT, K = C = 5376)
+//   S3 prototypes      scores = rnorm .* (z Wc^T) + b   (NT, K = D = 512; normalise fused as row scale)
+//   S6 dWc             = dS^T z_hat              (TN, long reduction over pixels -> split-K)
+//   S6 dz_hat          = dS Wc                   (NN)
+//   S6 dWp             = dz^T X                  (TN, split-K)
+// Reference op chain: hfc_with_swav/swav_clustering.py:171-175 and autograd of it (:459).
+#include "gx_mfma.h"
+
+namespace gx {
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    float alpha, beta;
+    const float* row_scale; const float* col_bias;
+    int k_per_split;      // multiple of BK
+    float* slab;          // split-K partials [splits][M][N] (raw sums) or nullptr
+    int vec_ok;
+    int tiles_m, tiles_n;
+};
+
+// TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
+    constexpr bool A_KC = !TA, B_KC = TB;
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A0 B0 A1 B1
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const bool vec = g.vec_ok != 0;
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    f32x4 ra[4], rb[4];
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, ra, tid, vec);
+        load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid, vec);
+        store_tile<A_KC>(lds, ra, tid);
+        store_tile<B_KC>(lds + TILE_FLOATS, rb, tid);
+    }
+    __syncthreads();
+    for (int t = 0; t < nkt; ++t) {
+        float* As = lds + (t & 1) * 2 * TILE_FLOATS;
+        float* Bs = As + TILE_FLOATS;
+        const bool more = (t + 1 < nkt);
+        if (more) {   // issue next tile's global loads before the MFMA phase (latency hides under it)
+            load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kend, ra, tid, vec);
+            load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, rb, tid, vec);
+        }
+        mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
+        if (more) {
+            float* An = lds + ((t + 1) & 1) * 2 * TILE_FLOATS;
+            store_tile<A_KC>(An, ra, tid);
+            store_tile<B_KC>(An + TILE_FLOATS, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
+    const long ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + acc_col(wc, nt, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + acc_row(wr, mt, r, lane);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mt][nt][r];
+                    if (!to_slab) {
+                        v *= g.alpha;
+                        if (g.row_scale) v *= g.row_scale[row];
+                        if (g.col_bias) v += g.col_bias[col];
+                        if (g.beta != 0.f) v += g.beta * out[(long)row * ldo + col];
+                    }
+                    out[(long)row * ldo + col] = v;
+                }
+            }
+        }
+}
+
+// Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
+__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int splits, float* __restrict__ C,
+                                          int M, int N, long ldc, float alpha, float beta,
+                                          const float* __restrict__ row_scale,
+                                          const float* __restrict__ col_bias) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(long)z * total + i];
+        const int row = (int)(i / N), col = (int)(i - (long)row * N);
+        float v = s * alpha;
+        if (row_scale) v *= row_scale[row];
+        if (col_bias) v += col_bias[col];
+        float* c = C + (long)row * ldc + col;
+        if (beta != 0.f) v += beta * *c;
+        *c = v;
+    }
+}
+
+static int launch_gemm(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
+                       long ldb, float* C, long ldc, float alpha, float beta, const float* row_scale,
+                       const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
+    g.vec_ok = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0);
+    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
+    const int ktiles = gx_cdiv(K, BK);
+    if (split_k < 1) split_k = 1;
+    if (split_k > ktiles) split_k = ktiles;
+    g.k_per_split = gx_cdiv(ktiles, split_k) * BK;
+    split_k = gx_cdiv(K, g.k_per_split);
+    g.slab = nullptr;
+    if (split_k > 1) {
+        if (!workspace || workspace_bytes < (size_t)split_k * M * N * sizeof(float)) return GX_ERR_WORKSPACE;
+        g.slab = workspace;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+    GX_CHECK_LAUNCH();
+    if (split_k > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g.slab, split_k, C, M,
+                           N, ldc, alpha, beta, row_scale, col_bias);
+        GX_CHECK_LAUNCH();
+    }
+    return GX_OK;
+}
+
+}  // namespace gx
+
+extern "C" {
+
+size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k) {
+    return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;
+}
+
+int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+    return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
+                           split_k, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,704 @@
+// HBM-bound kernels of the per-pixel SwAV path (SURVEY.md §8a rows S1, S1b, S1c, S2, S4, S5,
+// S6 (elementwise part), S7, S8, P1-argmax).  Layout: feature taps are NHWC ("pixel-major",
+// [b][y][x][c]) so that a sampled pixel is ONE contiguous C_l*4-byte read per tap; the sampled
+// panel X is (rows, hlen) row-major; scores are (rows, K) row-major.
+#include "gx_common.h"
+
+namespace gx {
+
+// ===================================================================== S1b: rotate+flip map
+// Source-pixel map of RandomRotation(nearest, centre, zero fill) followed by
+// RandomHorizontalFlip (call sites hfc_with_swav/swav_clustering.py:98-102, :358-359),
+// restated from torchvision's public tensor path: inverse affine for -angle about the image
+// centre on a pixel-centre grid, grid_sample(nearest, zeros, align_corners=False).
+__global__ void rotflip_map_kernel(int* __restrict__ map, int H, int W, float cs, float sn, int flip) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const int xr = flip ? (W - 1 - x) : x;              // flip is applied AFTER the rotation
+    const float bx = (float)xr - 0.5f * (float)W + 0.5f;
+    const float by = (float)y - 0.5f * (float)H + 0.5f;
+    // normalised grid coordinates, then grid_sample's un-normalisation
+    const float gxn = __fdiv_rn(__fadd_rn(__fmul_rn(bx, cs), __fmul_rn(by, sn)), 0.5f * (float)W);
+    const float gyn = __fdiv_rn(__fadd_rn(__fmul_rn(bx, -sn), __fmul_rn(by, cs)), 0.5f * (float)H);
+    const float ix = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(gxn, 1.f), (float)W), -1.f), 0.5f);
+    const float iy = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(gyn, 1.f), (float)H), -1.f), 0.5f);
+    const float rx = nearbyintf(ix), ry = nearbyintf(iy);
+    int src = -1;
+    if (rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1)) src = (int)ry * W + (int)rx;
+    map[p] = src;
+}
+
+// ===================================================================== S1 + S1b + S2: gather
+constexpr int MAX_TAPS = 16;
+struct TapList {
+    const float* ptr[MAX_TAPS];   // [B][res][res][C] NHWC
+    int C[MAX_TAPS];              // channels of the tap
+    int res[MAX_TAPS];            // spatial size (square)
+    int off[MAX_TAPS];            // channel offset in the concatenated descriptor
+    int n;
+};
+
+// X[row][:] = concat_l tap_l[b][(sy*res_l)/H][(sx*res_l)/W][:]  (first hlen channels), where
+// (sy,sx) = map_b[pick] (or the pick itself), zeros where the map says "filled".
+// Never materialises the (1, hlen, H, W) stack of swav_clustering.py:108-130 / :160-167.
+__global__ __launch_bounds__(256) void gather_taps_kernel(TapList taps, const int* __restrict__ picks,
+                                                          const int* __restrict__ maps, int rows_per_img,
+                                                          int H, int W, int hlen, float* __restrict__ X,
+                                                          long ldx, int total_rows) {
+    const int row = blockIdx.x;
+    if (row >= total_rows) return;
+    const int b = row / rows_per_img;
+    int pix = picks[row];
+    if (maps) pix = maps[(long)b * H * W + pix];
+    float* out = X + (long)row * ldx;
+    const bool vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+    const int sy = pix / W, sx = pix - sy * W;
+    for (int l = 0; l < taps.n; ++l) {
+        const int off = taps.off[l];
+        if (off >= hlen) break;
+        const int cl = min(taps.C[l], hlen - off);
+        const int r = taps.res[l];
+        const float* src = nullptr;
+        if (pix >= 0) {
+            const int ty = (sy * r) / H, tx = (sx * r) / W;
+            src = taps.ptr[l] + (((long)b * r + ty) * r + tx) * taps.C[l];
+        }
+        if (vec && (cl & 3) == 0 && (off & 3) == 0 && (taps.C[l] & 3) == 0) {
+            for (int c = threadIdx.x * 4; c < cl; c += blockDim.x * 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (src) v = *reinterpret_cast<const f32x4*>(src + c);
+                *reinterpret_cast<f32x4*>(out + off + c) = v;
+            }
+        } else {
+            for (int c = threadIdx.x; c < cl; c += blockDim.x) out[off + c] = src ? src[c] : 0.f;
+        }
+    }
+}
+
+// ===================================================================== row reductions
+// out[row] = sum_c x[row][c]^2 over the first `cused` of `ld` columns.  One wave per row.
+__global__ void row_sumsq_kernel(const float* __restrict__ x, long rows, int cused, long ld,
+                                 float* __restrict__ out) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + row * ld;
+    float s = 0.f;
+    for (int c = lane; c < cused; c += 64) { const float v = p[c]; s = fmaf(v, v, s); }
+    s = gx_wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// S1c: img[b][p] = sqrt(sum_l ss_l[b][src(p) -> tap pixel])  (torch.norm(stack, dim=1) after the
+// rotate/flip, swav_clustering.py:361-362), from per-tap native-resolution sums of squares.
+struct SsList { const float* ptr[MAX_TAPS]; int res[MAX_TAPS]; int n; };
+__global__ void norm_map_kernel(SsList ss, const int* __restrict__ maps, int B, int H, int W,
+                                float* __restrict__ img) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * H * W) return;
+    const int b = (int)(i / (H * W)), p = (int)(i - (long)b * H * W);
+    const int pix = maps ? maps[i] : p;
+    float s = 0.f;
+    if (pix >= 0) {
+        const int sy = pix / W, sx = pix - sy * W;
+        for (int l = 0; l < ss.n; ++l) {
+            const int r = ss.res[l];
+            s += ss.ptr[l][((long)b * r + (sy * r) / H) * r + (sx * r) / W];
+        }
+    }
+    img[i] = sqrtf(s);
+}
+
+// S3 normalise: z[row] <- z[row] / max(||z[row]||, 1e-12) in place; rnorm[row] = the factor.
+// (F.normalize(p=2, dim=1), swav_clustering.py:174).  One wave per row.
+__global__ void row_l2_normalize_kernel(float* __restrict__ z, long rows, int D, long ld,
+                                        float* __restrict__ rnorm) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = z + row * ld;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = p[c]; s = fmaf(v, v, s); }
+    s = gx_wave_sum(s);
+    const float rn = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < D; c += 64) p[c] *= rn;
+    if (rnorm && lane == 0) rnorm[row] = rn;
+}
+
+// S6 normalise-backward, in place on g (= d z_hat -> d z):
+//   dz = rnorm * (dzh - zh * <zh, dzh>)      (norm > 1e-12 branch of F.normalize)
+__global__ void l2_normalize_bwd_kernel(float* __restrict__ g, const float* __restrict__ zh,
+                                        const float* __restrict__ rnorm, long rows, int D, long ld) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* gp = g + row * ld;
+    const float* zp = zh + row * ld;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot = fmaf(gp[c], zp[c], dot);
+    dot = gx_wave_sum(dot);
+    const float rn = rnorm[row];
+    const bool clamped = rn >= 1e12f;       // ||z|| <= 1e-12: normalize divided by the constant eps
+    for (int c = lane; c < D; c += 64) gp[c] = clamped ? gp[c] * rn : rn * (gp[c] - zp[c] * dot);
+}
+
+// P1: labels[row] = argmax_c z[row][c] (first index on ties), swav_clustering.py:691.
+__global__ void row_argmax_kernel(const float* __restrict__ z, long rows, int D, long ld,
+                                  long long* __restrict__ labels) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = z + row * ld;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < D; c += 64) { const float v = p[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) labels[row] = bi;
+}
+
+// column sums over rows: part[block][k] = sum_{rows of block} x[row][k]; then reduce.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long rows, int K, long ld,
+                                      float* __restrict__ part) {
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += x[r * ld + k];
+        part[(long)blockIdx.x * K + k] = s;
+    }
+}
+// out[k] = alpha * sum_b part[b][k] + beta * out[k]
+__global__ void partial_reduce_kernel(const float* __restrict__ part, int nblk, int K, float alpha, float beta,
+                                      float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * K + k];
+    out[k] = alpha * s + (beta != 0.f ? beta * out[k] : 0.f);
+}
+
+// ===================================================================== S4: Sinkhorn-Knopp
+// Log-domain scaling-vector form of sinkhorn_knopp (swav_clustering.py:509-544).  With
+// E_kn = exp(S_nk/eps) the reference's iterate is Q = diag(a) E diag(b): each iteration sets
+// a_k = r_k / sum_n E_kn b_n (row normalisation) then b_n = c_n / sum_k a_k E_kn (column
+// normalisation), and the returned code is q[n][k] = a_k E_kn / sum_k' a_k' E_k'n — a softmax
+// over k of  w_nk = S_nk/eps + la_k  with la = log a (b and the initial 1/sum(Q) cancel).
+// We never form Q and carry la_k / lb_n = log b_n instead of a, b, so nothing overflows or
+// underflows where the reference's un-shifted fp32 exp() would:
+//   colmax : cmax_k = max_n S_nk                                  (la_k := -cmax_k/eps)
+//   first  : u_k = sum_n exp((S_nk - cmax_k)/eps)        [= row sums of Q0 up to exp(la)]
+//   sweep  : per sample n: lb_n = log c_n - logsumexp_k(w_nk);  u_k = sum_n exp(w_nk + lb_n)
+//   update : la_k += log r_k - log u_k      (after an all-reduce of u over ranks when sharded)
+// Every term of every sum is <= 1.  Each pass is one read of the score matrix; a row is
+// handled by a team of T lanes (T = 8..64), column sums go through LDS then fixed-order
+// per-block partials.
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__global__ void sk_colmax_kernel(const float* __restrict__ S, long rows, int K, long ld,
+                                 unsigned* __restrict__ cmax) {
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    if (r0 >= r1) return;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float v = -INFINITY;
+        for (long r = r0; r < r1; ++r) v = fmaxf(v, S[r * ld + k]);
+        atomicMax(&cmax[k], f2ord(v));
+    }
+}
+__global__ void sk_ord_decode_kernel(const unsigned* __restrict__ in, int K, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = ord2f(in[k]);
+}
+__global__ void sk_ord_encode_kernel(const float* __restrict__ in, int K, unsigned* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = f2ord(in[k]);
+}
+
+// One Sinkhorn pass (see above).  LDS: K floats of la (FIRST: -cmax/eps) + K floats of
+// block-local u accumulators.
+template <bool FIRST>
+__global__ void sk_pass_kernel(const float* __restrict__ S, long rows, int K, long ld, int team,
+                               float inv_eps, const unsigned* __restrict__ cmax,
+                               const float* __restrict__ la, const float* __restrict__ c, float c_uniform,
+                               float* __restrict__ lb_out, float* __restrict__ upart) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* uacc = sm;
+    float* las = sm + K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        uacc[k] = 0.f;
+        las[k] = FIRST ? -ord2f(cmax[k]) * inv_eps : la[k];
+    }
+    __syncthreads();
+    const int tpb = blockDim.x / team;
+    const int ti = threadIdx.x / team, tl = threadIdx.x % team;
+    const long nrow_iters = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    for (long it = 0; it < nrow_iters; ++it) {
+        const long row = (it * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows;
+        const float* p = S + (live ? row : 0) * ld;
+        float lb = 0.f;
+        if (!FIRST) {
+            float mx = -INFINITY;
+            if (live) for (int k = tl; k < K; k += team) mx = fmaxf(mx, fmaf(p[k], inv_eps, las[k]));
+            mx = gx_team_max(mx, team);
+            float sum = 0.f;
+            if (live) for (int k = tl; k < K; k += team) sum += expf(fmaf(p[k], inv_eps, las[k]) - mx);
+            sum = gx_team_sum(sum, team);
+            lb = live ? logf(c ? c[row] : c_uniform) - mx - logf(sum) : 0.f;
+            if (live && tl == 0 && lb_out) lb_out[row] = lb;
+        }
+        // column accumulation: lanes of different teams holding the same k are summed by
+        // shuffles (teams inside one wave) before one LDS atomic per (wave, k).
+        for (int k0 = 0; k0 < K; k0 += team) {
+            const int k = k0 + tl;
+            float e = 0.f;
+            if (live && k < K) e = expf(fmaf(p[k], inv_eps, las[k]) + lb);
+            for (int o = team; o < 64; o <<= 1) e += __shfl_xor(e, o, 64);
+            if ((threadIdx.x & 63) < team && k < K) atomicAdd(&uacc[k], e);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) upart[(long)blockIdx.x * K + k] = uacc[k];
+}
+
+// la_k = (first ? -cmax_k/eps : la_k) + log r_k - log u_k     (r uniform = 1/K when r == nullptr)
+__global__ void sk_update_la_kernel(const float* __restrict__ u, const float* __restrict__ r, int K, int first,
+                                    const unsigned* __restrict__ cmax, float inv_eps, float* __restrict__ la) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float base = first ? -ord2f(cmax[k]) * inv_eps : la[k];
+    la[k] = base + logf(r ? r[k] : 1.f / (float)K) - logf(u[k]);
+}
+
+// codes q[n][k] = softmax_k(S_nk/eps + la_k)   (the matrix sinkhorn_knopp returns)
+__global__ void sk_codes_kernel(const float* __restrict__ S, long rows, int K, long ld, int team,
+                                float inv_eps, const float* __restrict__ la, float* __restrict__ q, long ldq) {
+    const int tpb = blockDim.x / team;
+    const int ti = threadIdx.x / team, tl = threadIdx.x % team;
+    const long nrow_iters = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    for (long it = 0; it < nrow_iters; ++it) {
+        const long row = (it * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows;
+        const float* p = S + (live ? row : 0) * ld;
+        float mx = -INFINITY;
+        if (live) for (int k = tl; k < K; k += team) mx = fmaxf(mx, fmaf(p[k], inv_eps, la[k]));
+        mx = gx_team_max(mx, team);
+        float sum = 0.f;
+        if (live) for (int k = tl; k < K; k += team) sum += expf(fmaf(p[k], inv_eps, la[k]) - mx);
+        sum = gx_team_sum(sum, team);
+        if (live) for (int k = tl; k < K; k += team) q[row * ldq + k] = expf(fmaf(p[k], inv_eps, la[k]) - mx) / sum;
+    }
+}
+
+// ===================================================================== S5 + S6: swapped CE
+// Per row n (p = S/T, q = softmax_k(S/eps + la) from the Sinkhorn log-scaling vectors):
+//   loss_n = -1/2 [ sum_k q_s (p_t - lse_t) + sum_k q_t (p_s - lse_s) ]
+//   dS_t   = -gscale/(2T) (q_s - softmax(p_t) * sum_k q_s),  dS_s likewise with q_t
+// (calculate_swapped_prediction_loss, swav_clustering.py:547-570 with :408-409, and its
+// autograd).  gscale = 1/(N_total * num_patches [* num_images]); loss partial sums are per
+// block (fixed order) and are NOT yet scaled.
+__global__ void swapped_ce_kernel(const float* __restrict__ Ss, const float* __restrict__ St, long rows, int K,
+                                  long ld, int team, float inv_eps, float inv_T,
+                                  const float* __restrict__ las, const float* __restrict__ lat, float gscale,
+                                  float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
+                                  float* __restrict__ loss_part) {
+    const int tpb = blockDim.x / team;
+    const int ti = threadIdx.x / team, tl = threadIdx.x % team;
+    float lacc = 0.f;
+    const long nrow_iters = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    for (long it = 0; it < nrow_iters; ++it) {
+        const long row = (it * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows;
+        const float* ps = Ss + (live ? row : 0) * ld;
+        const float* pt = St + (live ? row : 0) * ld;
+        // row maxima of the Sinkhorn logits w = S/eps + la and of the scores themselves
+        float wms = -INFINITY, wmt = -INFINITY, m_s = -INFINITY, m_t = -INFINITY;
+        if (live) for (int k = tl; k < K; k += team) {
+            wms = fmaxf(wms, fmaf(ps[k], inv_eps, las[k])); wmt = fmaxf(wmt, fmaf(pt[k], inv_eps, lat[k]));
+            m_s = fmaxf(m_s, ps[k]); m_t = fmaxf(m_t, pt[k]);
+        }
+        wms = gx_team_max(wms, team); wmt = gx_team_max(wmt, team);
+        m_s = gx_team_max(m_s, team); m_t = gx_team_max(m_t, team);
+        float vs = 0.f, vt = 0.f, zs = 0.f, zt = 0.f;
+        if (live) for (int k = tl; k < K; k += team) {
+            vs += expf(fmaf(ps[k], inv_eps, las[k]) - wms);
+            vt += expf(fmaf(pt[k], inv_eps, lat[k]) - wmt);
+            zs += expf((ps[k] - m_s) * inv_T);
+            zt += expf((pt[k] - m_t) * inv_T);
+        }
+        vs = gx_team_sum(vs, team); vt = gx_team_sum(vt, team);
+        zs = gx_team_sum(zs, team); zt = gx_team_sum(zt, team);
+        const float lzs = logf(zs), lzt = logf(zt);
+        float qsum_s = 0.f, qsum_t = 0.f, l = 0.f;
+        if (live) for (int k = tl; k < K; k += team) {
+            const float qs = expf(fmaf(ps[k], inv_eps, las[k]) - wms) / vs;
+            const float qt = expf(fmaf(pt[k], inv_eps, lat[k]) - wmt) / vt;
+            qsum_s += qs; qsum_t += qt;
+            // log_softmax(p)[k] = (S_k - m)/T - log Z
+            l += qs * ((pt[k] - m_t) * inv_T - lzt) + qt * ((ps[k] - m_s) * inv_T - lzs);
+        }
+        qsum_s = gx_team_sum(qsum_s, team); qsum_t = gx_team_sum(qsum_t, team);
+        if (live && dSs) {
+            const float f = -0.5f * gscale * inv_T;
+            for (int k = tl; k < K; k += team) {
+                const float qs = expf(fmaf(ps[k], inv_eps, las[k]) - wms) / vs;
+                const float qt = expf(fmaf(pt[k], inv_eps, lat[k]) - wmt) / vt;
+                dSt[row * ldd + k] = f * (qs - expf((pt[k] - m_t) * inv_T) / zt * qsum_s);
+                dSs[row * ldd + k] = f * (qt - expf((ps[k] - m_s) * inv_T) / zs * qsum_t);
+            }
+        }
+        lacc += l;
+    }
+    __shared__ float red[16];
+    const float tot = gx_block_sum(lacc, red);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = -0.5f * tot;
+}
+
+// ===================================================================== S7 / S8
+// LARC(clip=False) around momentum SGD (swav_clustering.py:286-292; apex LARC.step restated):
+//   g' = g * trust*|p| / (|g| + 1e-8)  if |p| != 0 and |g| != 0 ;  buf = first ? g' : mom*buf + g'
+//   p -= lr * buf.       norms2 = {sum p^2, sum g^2} on the device (no host sync).
+__global__ void larc_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                long n, const float* __restrict__ norms2, float lr, float momentum,
+                                float trust, float eps, int first, int use_larc) {
+    float scale = 1.f;
+    if (use_larc) {
+        const float pn = sqrtf(norms2[0]), gn = sqrtf(norms2[1]);
+        if (pn != 0.f && gn != 0.f) scale = trust * pn / (gn + eps);
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * scale;
+        const float b = first ? gg : fmaf(momentum, buf[i], gg);
+        buf[i] = b;
+        p[i] = fmaf(-lr, b, p[i]);
+    }
+}
+
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i]; s = fmaf(v, v, s);
+    }
+    __shared__ float red[16];
+    s = gx_block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// ===================================================================== histc ('image' pdf)
+__global__ void minmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        lo = fminf(lo, x[i]); hi = fmaxf(hi, x[i]);
+    }
+    __shared__ float red[16];
+    hi = gx_block_max(hi, red);
+    lo = -gx_block_max(-lo, red);
+    if (threadIdx.x == 0) { atomicMax(&mm[1], f2ord(hi)); atomicMin(&mm[0], f2ord(lo)); }
+}
+// torch.histc(x, bins) with the data range: pos = int((x-lo)/(hi-lo)*bins), last bin closed.
+__global__ void histc_kernel(const float* __restrict__ x, long n, const unsigned* __restrict__ mm, int bins,
+                             float* __restrict__ hist) {
+    const float lo = ord2f(mm[0]), hi = ord2f(mm[1]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int pos = (hi > lo) ? (int)((x[i] - lo) / (hi - lo) * (float)bins) : 0;
+        pos = min(max(pos, 0), bins - 1);
+        atomicAdd(&hist[pos], 1.0f);
+    }
+}
+// h += 1e-9 ; h[0] = h[1] ; h /= sum(h)      (swav_clustering.py:524-530).  Single block.
+__global__ void hist_marginal_kernel(float* __restrict__ h, int bins) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) {
+        const float v = ((i == 0 && bins > 1) ? h[1] : h[i]) + 1e-9f;
+        s += v;
+    }
+    s = gx_block_sum(s, red);
+    const float h1 = (bins > 1 ? h[1] : h[0]) + 1e-9f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) {
+        const float v = (i == 0) ? h1 : h[i] + 1e-9f;
+        h[i] = v / s;
+    }
+}
+
+static inline int pick_team(int K) {
+    int t = 8;
+    while (t < 64 && t < K) t <<= 1;
+    return t;
+}
+
+}  // namespace gx
+
+using namespace gx;
+
+extern "C" {
+
+int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stream) {
+    if (!map || H <= 0 || W <= 0) return GX_ERR_BAD_ARG;
+    const double rot = -(double)angle_deg * 3.14159265358979323846 / 180.0;
+    const float cs = (float)cos(rot), sn = (float)sin(rot);
+    hipLaunchKernelGGL(rotflip_map_kernel, dim3(gx_cdiv((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       map, H, W, cs, sn, flip);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_gather_taps(int ntaps, const float* const* tap_ptrs, const int* tap_channels, const int* tap_res,
+                   int B, int H, int W, int hlen, const int* picks, int rows_per_img, const int* maps,
+                   float* X, long ldx, void* stream) {
+    if (ntaps <= 0 || ntaps > MAX_TAPS || !tap_ptrs || !tap_channels || !tap_res || !picks || !X || B <= 0 ||
+        rows_per_img <= 0 || hlen <= 0 || ldx < hlen)
+        return GX_ERR_BAD_ARG;
+    TapList t;
+    t.n = ntaps;
+    int off = 0;
+    for (int l = 0; l < ntaps; ++l) {
+        if (!tap_ptrs[l] || tap_channels[l] <= 0 || tap_res[l] <= 0) return GX_ERR_BAD_ARG;
+        t.ptr[l] = tap_ptrs[l]; t.C[l] = tap_channels[l]; t.res[l] = tap_res[l]; t.off[l] = off;
+        off += tap_channels[l];
+    }
+    if (off < hlen) return GX_ERR_BAD_ARG;
+    const int total = B * rows_per_img;
+    hipLaunchKernelGGL(gather_taps_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, t, picks, maps,
+                       rows_per_img, H, W, hlen, X, ldx, total);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_row_sumsq(const float* x, long rows, int cused, long ld, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || cused <= 0 || ld < cused) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, cused,
+                       ld, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_norm_map(int ntaps, const float* const* ss_ptrs, const int* tap_res, const int* maps, int B, int H, int W,
+                float* img, void* stream) {
+    if (ntaps <= 0 || ntaps > MAX_TAPS || !ss_ptrs || !tap_res || !img || B <= 0) return GX_ERR_BAD_ARG;
+    SsList s; s.n = ntaps;
+    for (int l = 0; l < ntaps; ++l) { s.ptr[l] = ss_ptrs[l]; s.res[l] = tap_res[l]; }
+    hipLaunchKernelGGL(norm_map_kernel, dim3(gx_cdiv((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, s,
+                       maps, B, H, W, img);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_row_l2_normalize(float* z, long rows, int D, long ld, float* rnorm, void* stream) {
+    if (!z || rows <= 0 || D <= 0 || ld < D) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(row_l2_normalize_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, z, rows,
+                       D, ld, rnorm);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_l2_normalize_bwd(float* g, const float* zhat, const float* rnorm, long rows, int D, long ld, void* stream) {
+    if (!g || !zhat || !rnorm || rows <= 0 || D <= 0 || ld < D) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, g, zhat,
+                       rnorm, rows, D, ld);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_row_argmax(const float* z, long rows, int D, long ld, long long* labels, void* stream) {
+    if (!z || !labels || rows <= 0 || D <= 0 || ld < D) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(row_argmax_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, z, rows, D, ld,
+                       labels);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// ---- column sums (db of the prototype bias): out = alpha*colsum(x) + beta*out ----
+#define GX_RED_BLOCKS 256
+size_t gx_colsum_workspace_bytes(int K) { return (size_t)GX_RED_BLOCKS * K * sizeof(float); }
+int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta, float* out, float* workspace,
+              size_t workspace_bytes, void* stream) {
+    if (!x || !out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_colsum_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    const int nb = (int)((rows < GX_RED_BLOCKS) ? rows : GX_RED_BLOCKS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, K, ld, workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nb,
+                       K, alpha, beta, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// ---- Sinkhorn ----------------------------------------------------------------------------
+#define GX_SK_BLOCKS 512
+// workspace layout (4-byte words): [0, K) cmax (ordered-uint), [K, 2K) u, [2K, 2K + BLOCKS*K) partials
+size_t gx_sinkhorn_workspace_bytes(int K) { return (size_t)(2 * (size_t)K + (size_t)GX_SK_BLOCKS * K) * sizeof(float); }
+float* gx_sinkhorn_u(float* workspace, int K) { return workspace + K; }
+
+static int sk_blocks(long rows, int team) {
+    const long tpb = 256 / team;
+    long nb = (rows + tpb - 1) / tpb;
+    return (int)(nb < GX_SK_BLOCKS ? nb : GX_SK_BLOCKS);
+}
+
+// cmax_k = max_n S_nk (kept in the workspace, ordered-uint encoded; reset here)
+int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (!S || !workspace || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
+    if (workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    if (hipMemsetAsync(workspace, 0, (size_t)K * 4, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
+    const int nb = (int)(rows < 256 ? rows : 256);
+    hipLaunchKernelGGL(sk_colmax_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, S, rows, K, ld,
+                       (unsigned*)workspace);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// Column-max exchange hooks for the sharded (multi-GPU) form: decode to / encode from floats.
+int gx_sinkhorn_cmax_get(const float* workspace, int K, float* out, void* stream) {
+    if (!workspace || !out || K <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_ord_decode_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)workspace, K, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_sinkhorn_cmax_set(float* workspace, int K, const float* in, void* stream) {
+    if (!workspace || !in || K <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_ord_encode_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, in, K,
+                       (unsigned*)workspace);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// One pass: first != 0 -> u_k = sum_n exp((S_nk - cmax_k)/eps); else the sweep with the log
+// scaling vector la (lb_out optional).  Result: local column sums u (K floats) at
+// gx_sinkhorn_u(workspace, K).
+int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,
+                     const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!S || rows <= 0 || K <= 0 || ld < K || eps <= 0.f || (!first && !la)) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    const int team = pick_team(K);
+    const int nb = sk_blocks(rows, team);
+    float* u = workspace + K;
+    float* part = u + K;
+    const size_t lds = (size_t)2 * K * sizeof(float);
+    if (lds > 160 * 1024) return GX_ERR_BAD_ARG;
+    if (first)
+        hipLaunchKernelGGL((sk_pass_kernel<true>), dim3(nb), dim3(256), lds, (hipStream_t)stream, S, rows, K, ld, team,
+                           1.f / eps, (const unsigned*)workspace, la, c, c_uniform, lb_out, part);
+    else
+        hipLaunchKernelGGL((sk_pass_kernel<false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, S, rows, K, ld,
+                           team, 1.f / eps, (const unsigned*)workspace, la, c, c_uniform, lb_out, part);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, part, nb, K,
+                       1.f, 0.f, u);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// la update from the (all-reduced) column sums u; `first` uses -cmax/eps from the workspace as base.
+int gx_sinkhorn_update(const float* u, const float* r, int K, int first, const float* workspace, float eps,
+                       float* la, void* stream) {
+    if (!u || !la || K <= 0 || (first && !workspace)) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_update_la_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, u, r, K, first,
+                       (const unsigned*)workspace, 1.f / eps, la);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// Whole single-device Sinkhorn: leaves the log scaling vector la[K].
+int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters, const float* r, const float* c,
+                float* la, float* workspace, size_t workspace_bytes, void* stream) {
+    if (niters < 1 || !la) return GX_ERR_BAD_ARG;
+    int rc = gx_sinkhorn_colmax(S, rows, K, ld, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    for (int it = 0; it < niters; ++it) {
+        rc = gx_sinkhorn_pass(S, rows, K, ld, eps, it == 0, la, c, 1.f / (float)rows, nullptr, workspace,
+                              workspace_bytes, stream);
+        if (rc) return rc;
+        rc = gx_sinkhorn_update(workspace + K, r, K, it == 0, workspace, eps, la, stream);
+        if (rc) return rc;
+    }
+    return GX_OK;
+}
+int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
+                      void* stream) {
+    if (!S || !la || !q || rows <= 0 || K <= 0 || ld < K || ldq < K || eps <= 0.f) return GX_ERR_BAD_ARG;
+    const int team = pick_team(K);
+    hipLaunchKernelGGL(sk_codes_kernel, dim3(sk_blocks(rows, team)), dim3(256), 0, (hipStream_t)stream, S, rows, K,
+                       ld, team, 1.f / eps, la, q, ldq);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// ---- swapped-prediction CE forward + d(scores) ---------------------------------------------
+// loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0]
+size_t gx_swapped_ce_workspace_bytes(void) { return (size_t)GX_SK_BLOCKS * sizeof(float); }
+int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
+                  const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
+                  float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
+                  void* stream) {
+    if (!Ss || !St || !la_s || !la_t || !loss_out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
+    if ((dSs == nullptr) != (dSt == nullptr) || (dSs && ldd < K)) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_swapped_ce_workspace_bytes()) return GX_ERR_WORKSPACE;
+    const int team = pick_team(K);
+    const int nb = sk_blocks(rows, team);
+    hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Ss, St, rows, K, ld, team,
+                       1.f / eps, 1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd, workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nb, 1, loss_scale,
+                       loss_beta, loss_out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------
+// norms2_out[0] = sum x^2 (deterministic two-stage)
+size_t gx_sumsq_workspace_bytes(void) { return (size_t)GX_RED_BLOCKS * sizeof(float); }
+int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || n <= 0) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sumsq_workspace_bytes()) return GX_ERR_WORKSPACE;
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < GX_RED_BLOCKS ? want : GX_RED_BLOCKS);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nb, 1, 1.f, 0.f, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_larc_sgd(float* p, const float* g, float* buf, long n, const float* norms2, float lr, float momentum,
+                float trust, int first_step, int use_larc, void* stream) {
+    if (!p || !g || !buf || n <= 0 || (use_larc && !norms2)) return GX_ERR_BAD_ARG;
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(larc_sgd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, norms2, lr,
+                       momentum, trust, 1e-8f, first_step, use_larc);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// ---- 'image' marginals: hist[bins] = normalised torch.histc(x, bins)+1e-9 with h[0]=h[1] ----
+// scratch: 2 uints (min,max ordered encodings)
+int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream) {
+    if (!x || !hist || !scratch || n <= 0 || bins <= 0) return GX_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0xFF, 4, s) != hipSuccess) return GX_ERR_LAUNCH;        // min <- +max
+    if (hipMemsetAsync(scratch + 1, 0, 4, s) != hipSuccess) return GX_ERR_LAUNCH;       // max <- lowest
+    if (hipMemsetAsync(hist, 0, (size_t)bins * 4, s) != hipSuccess) return GX_ERR_LAUNCH;
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, x, n, scratch);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(histc_kernel, dim3(nb), dim3(256), 0, s, x, n, scratch, bins, hist);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(hist_marginal_kernel, dim3(1), dim3(1024), 0, s, hist, bins);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // extern "C"

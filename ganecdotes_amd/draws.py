@@ -1,0 +1,53 @@
+"""Host-side randomness of one training image, drawn in the reference's order.
+
+"Same latent seeds" (BASELINE north star) only holds if the torch / numpy GLOBAL RNGs are
+consumed exactly as the reference consumes them.  Everything random
+in a step is drawn here, on the host, once — and then handed explicitly to the kernels, so
+the same draws can be replayed through the CPU oracle for parity tests.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class ViewDraws:
+    layer_no: int                      # perturbed StyleGAN block (latents 2l, 2l+1)
+    map_noise: torch.Tensor            # (2, S) z-noise pushed through the mapping MLP
+    angle: Optional[float] = None      # degrees, U(-10, 10); None = rotation/flip disabled
+    flip: bool = False
+
+
+@dataclass
+class ImageDraws:
+    z: torch.Tensor                                         # (1, S)
+    views: List[ViewDraws] = field(default_factory=list)    # [s, t]
+    picks: List[torch.Tensor] = field(default_factory=list)  # num_patches x randperm(H*W) (int64, CPU)
+
+
+def draw_image(style_dim, gen_num_layers, n_perturb_layers, hw, num_patches, transforms=True, degrees=10.0,
+               layer_no=None, discard_noise=True):
+    """One image's draws in reference order: z (swav_clustering.py:323); per view the
+    `gen_num_layers` noise maps of the discarded first generator call (models/stylegan2/
+    model.py:380 via swav_clustering.py:603-607; consumed and thrown away when
+    `discard_noise`), `np.random.choice` of the layer (:611), 2*n_perturb_layers mapping noises
+    (lib/oneshot/image_augmentor.py:47, only two are used); rotation angle then flip for s,
+    then for t (:358-359); one randperm per patch (:388)."""
+    z = torch.randn(1, style_dim)
+    views = []
+    for _ in range(2):
+        if discard_noise:
+            for i in range(gen_num_layers):
+                r = 2 ** ((i + 5) // 2)
+                torch.empty(1, 1, r, r).normal_()
+        lno = layer_no if layer_no is not None else int(np.random.choice(list(range(n_perturb_layers))))
+        maps = [torch.randn(1, style_dim) for _ in range(2 * n_perturb_layers)]
+        views.append(ViewDraws(lno, torch.cat([maps[2 * lno], maps[2 * lno + 1]], 0)))
+    if transforms:
+        for v in views:
+            v.angle = float(torch.empty(1).uniform_(-degrees, degrees).item())
+            v.flip = bool(torch.rand(1) < 0.5)
+    picks = [torch.randperm(hw) for _ in range(num_patches)]
+    return ImageDraws(z, views, picks)

@@ -1,0 +1,270 @@
+"""StyleGAN2 generator (feature source of the SwAV path) on hand-written gfx950 kernels.
+
+Same constructor, call signature, `style` / `mean_latent` helpers and state_dict keys as the
+reference's `Generator` (models/stylegan2/model.py:457-648), so rosinality `g_ema` checkpoints
+load unchanged (src/one_shot_pipeline.py:138-147).  Underneath, nothing is shared with it:
+activations are NHWC, the modulated convolutions run as batch-shared-weight implicit GEMMs on
+the fp32 MFMA with noise+bias+leaky-ReLU epilogues, and derived weights are cached once for
+the frozen network (see csrc/gx_conv.hip).  There is no CPU path: calling it on a non-HIP
+device raises RuntimeError.
+
+`forward` returns the 2*log2(size)-3 hidden-feature taps as tensors of logical shape
+(B, C, H, W) whose memory is NHWC (`tap.permute(0, 2, 3, 1)` is contiguous) — exactly what
+the gather kernel consumes.
+"""
+import math
+import random
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class _Bag(nn.Module):
+    """Parameter container (gives the reference's state_dict key structure)."""
+
+
+def _equal_linear_params(in_dim, out_dim, bias_init=0.0, lr_mul=1.0):
+    m = _Bag()
+    m.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+    m.bias = nn.Parameter(torch.full((out_dim,), float(bias_init)))
+    m.lr_mul = lr_mul
+    return m
+
+
+def _fir(taps):
+    k = torch.tensor(taps, dtype=torch.float32)
+    k = torch.outer(k, k)
+    return k / k.sum()
+
+
+def _styled_conv_params(cin, cout, ksize, style_dim, upsample, blur_kernel):
+    m = _Bag()
+    m.conv = _Bag()
+    m.conv.weight = nn.Parameter(torch.randn(1, cout, cin, ksize, ksize))
+    m.conv.modulation = _equal_linear_params(style_dim, cin, bias_init=1.0)
+    if upsample:
+        m.conv.blur = _Bag()
+        m.conv.blur.register_buffer("kernel", _fir(blur_kernel) * 4.0)
+    m.noise = _Bag()
+    m.noise.weight = nn.Parameter(torch.zeros(1))
+    m.activate = _Bag()
+    m.activate.bias = nn.Parameter(torch.zeros(cout))
+    m.upsample = upsample
+    return m
+
+
+def _to_rgb_params(cin, style_dim, upsample, blur_kernel):
+    m = _Bag()
+    if upsample:
+        m.upsample = _Bag()
+        m.upsample.register_buffer("kernel", _fir(blur_kernel) * 4.0)
+    m.conv = _Bag()
+    m.conv.weight = nn.Parameter(torch.randn(1, 3, cin, 1, 1))
+    m.conv.modulation = _equal_linear_params(style_dim, cin, bias_init=1.0)
+    m.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+    return m
+
+
+class MappingNetwork(nn.Module):
+    """`Generator.style`: PixelNorm + n_mlp EqualLinear(fused lrelu), lr_mul 0.01
+    (model.py:473-482).  Children are named "1".."n_mlp" like the reference Sequential."""
+
+    def __init__(self, style_dim, n_mlp, lr_mlp):
+        super().__init__()
+        self.n_mlp = n_mlp
+        self.lr_mlp = lr_mlp
+        for i in range(n_mlp):
+            self.add_module(str(i + 1), _equal_linear_params(style_dim, style_dim, lr_mul=lr_mlp))
+
+    def forward(self, z):
+        if not z.is_cuda:
+            raise RuntimeError("ganecdotes_amd.Generator runs on HIP devices only (no CPU fallback)")
+        shape = z.shape
+        h = ops.pixel_norm(z.reshape(-1, shape[-1]).contiguous().float())
+        for i in range(self.n_mlp):
+            lin = getattr(self, str(i + 1))
+            w = lin.weight.detach()
+            y = ops.gemm(h, w, False, True)
+            h = ops.bias_act_(y, alpha=(1.0 / math.sqrt(w.shape[1])) * self.lr_mlp, bias=lin.bias.detach(),
+                              bscale=self.lr_mlp, act=True)
+        return h.reshape(shape)
+
+
+class Generator(nn.Module):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01,
+                 channels=None):
+        super().__init__()
+        self.size = size
+        self.style_dim = style_dim
+        self.style = MappingNetwork(style_dim, n_mlp, lr_mlp)
+        self.channels = channels or {
+            4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+            256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        ch = self.channels
+        self.input = _Bag()
+        self.input.input = nn.Parameter(torch.randn(1, ch[4], 4, 4))
+        self.conv1 = _styled_conv_params(ch[4], ch[4], 3, style_dim, False, blur_kernel)
+        self.to_rgb1 = _to_rgb_params(ch[4], style_dim, False, blur_kernel)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = _Bag()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", torch.randn(1, 1, 2 ** res, 2 ** res))
+        cin = ch[4]
+        for i in range(3, self.log_size + 1):
+            cout = ch[2 ** i]
+            self.convs.append(_styled_conv_params(cin, cout, 3, style_dim, True, blur_kernel))
+            self.convs.append(_styled_conv_params(cout, cout, 3, style_dim, False, blur_kernel))
+            self.to_rgbs.append(_to_rgb_params(cout, style_dim, True, blur_kernel))
+            cin = cout
+        self.n_latent = self.log_size * 2 - 2
+        self._derived = None
+        self.want_image = True          # ToRGB branch can be skipped by feature-only callers
+
+    # ------------------------------------------------------------------ derived (frozen) weights
+    def _invalidate(self):
+        self._derived = None
+
+    def load_state_dict(self, *a, **k):
+        self._invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def _prepare(self):
+        """Weight re-layouts for the kernels, computed once (the generator is frozen on this
+        path): conv weights tap-major [k*k][Cout][Cin], sum-of-squares for demodulation,
+        flipped FIR kernels, the NHWC constant input."""
+        if self._derived is not None:
+            return self._derived
+        d = {}
+
+        def conv(m, key):
+            w = m.conv.weight.detach()[0]                                  # (Cout, Cin, k, k)
+            cout, cin, k, _ = w.shape
+            d[key + ".wt"] = w.permute(2, 3, 0, 1).reshape(k * k, cout, cin).contiguous()
+            d[key + ".wsq"] = w.pow(2).sum(dim=(2, 3)).contiguous()
+            d[key + ".scale"] = 1.0 / math.sqrt(cin * k * k)
+            if hasattr(m.conv, "blur"):
+                d[key + ".kf"] = torch.flip(m.conv.blur.kernel.detach(), [0, 1]).contiguous()
+
+        def rgb(m, key):
+            w = m.conv.weight.detach()[0, :, :, 0, 0]
+            d[key + ".w3"] = w.contiguous()
+            d[key + ".scale"] = 1.0 / math.sqrt(w.shape[1])
+            d[key + ".bias"] = m.bias.detach().reshape(3).contiguous()
+            if hasattr(m, "upsample"):
+                d[key + ".kf"] = torch.flip(m.upsample.kernel.detach(), [0, 1]).contiguous()
+
+        conv(self.conv1, "conv1")
+        rgb(self.to_rgb1, "to_rgb1")
+        for i, m in enumerate(self.convs):
+            conv(m, f"convs.{i}")
+        for i, m in enumerate(self.to_rgbs):
+            rgb(m, f"to_rgbs.{i}")
+        d["const"] = self.input.input.detach().permute(0, 2, 3, 1).contiguous()     # (1,4,4,C)
+        self._derived = d
+        return d
+
+    # ------------------------------------------------------------------ helpers of the reference API
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):
+        """mean of style(z) over n_latent draws (model.py:554-560)."""
+        z = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        w = self.style(z)
+        out = torch.empty(self.style_dim, dtype=torch.float32, device=w.device)
+        ops.colsum(w, out, alpha=1.0 / n_latent)
+        return out.reshape(1, self.style_dim)
+
+    def get_latent(self, z):
+        return self.style(z)
+
+    # ------------------------------------------------------------------ layers
+    def _affine(self, m, lat):
+        w = m.conv.modulation.weight.detach()
+        return ops.gemm(lat, w, False, True, alpha=1.0 / math.sqrt(w.shape[1]),
+                        col_bias=m.conv.modulation.bias.detach())
+
+    def _styled(self, m, key, x, lat, noise, d):
+        s = self._affine(m, lat)
+        dm = ops.demod(s, d[key + ".wsq"], d[key + ".scale"])
+        nw = m.noise.weight.detach()
+        b = m.activate.bias.detach()
+        if m.upsample:
+            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True)
+        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True)
+
+    def _rgb(self, m, key, x, lat, skip, d):
+        s = self._affine(m, lat)
+        return ops.torgb(x, d[key + ".w3"], s, d[key + ".scale"], d[key + ".bias"], skip, d.get(key + ".kf"))
+
+    def synthesis(self, latent, noise):
+        """latent (B, n_latent, S) -> (image (B,3,size,size) or None, [NHWC taps])."""
+        d = self._prepare()
+        bsz = latent.shape[0]
+        lat = [latent[:, i].contiguous() for i in range(self.n_latent)]
+
+        def nz(i, res):
+            if noise[i] is None:
+                return torch.randn(bsz, 1, res, res, device=latent.device)
+            return noise[i].contiguous()
+
+        x = d["const"].expand(bsz, -1, -1, -1).contiguous()
+        x = self._styled(self.conv1, "conv1", x, lat[0], nz(0, 4), d)
+        taps = [x]
+        skip = self._rgb(self.to_rgb1, "to_rgb1", x, lat[1], None, d) if self.want_image else None
+        i = 1
+        for blk in range(len(self.to_rgbs)):
+            res = 2 ** (blk + 3)
+            x = self._styled(self.convs[2 * blk], f"convs.{2 * blk}", x, lat[i], nz(2 * blk + 1, res), d)
+            taps.append(x)
+            x = self._styled(self.convs[2 * blk + 1], f"convs.{2 * blk + 1}", x, lat[i + 1], nz(2 * blk + 2, res), d)
+            taps.append(x)
+            if self.want_image:
+                skip = self._rgb(self.to_rgbs[blk], f"to_rgbs.{blk}", x, lat[i + 2], skip, d)
+            i += 2
+        return skip, taps
+
+    # ------------------------------------------------------------------ reference call signature
+    @torch.no_grad()
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True):
+        if not self.input.input.is_cuda:
+            raise RuntimeError("ganecdotes_amd.Generator runs on HIP devices only (no CPU fallback)")
+        styles = [s.float() for s in styles]
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]        # 3-D styles are mapped layer-wise too
+        if noise is None:
+            if randomize_noise:
+                noise = [None] * self.num_layers
+            else:
+                noise = [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+        if truncation < 1:
+            base = truncation_latent.reshape(-1).contiguous().float()
+            styles = [ops.lerp_rows(s.contiguous(), base, float(truncation)) for s in styles]
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            latent = styles[0] if styles[0].ndim == 3 else styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        image, taps = self.synthesis(latent.contiguous(), noise)
+        if return_latents:
+            return image, latent
+        return image, [t.permute(0, 3, 1, 2) for t in taps]

@@ -1,0 +1,368 @@
+"""Thin torch-tensor front end of the C ABI (include/ganecdotes_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+computation below is a hand-written gfx950 kernel reached through ctypes.  No function in
+this module has a CPU or eager-PyTorch fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_WS = {}
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("ganecdotes_amd ops need HIP (cuda) tensors: no CPU fallback exists")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("expected a contiguous tensor")
+
+
+def workspace(tag, nbytes, device):
+    """Grow-only scratch arena per (tag, device); all users are ordered on the current stream."""
+    key = (tag, str(device))
+    n = max(1, (int(nbytes) + 3) // 4)
+    t = _WS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(int(n * 1.25) + 64, dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+# ------------------------------------------------------------------------------------- GEMM
+def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
+         split_k=1):
+    """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
+    op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K)."""
+    _chk(a, b, out, row_scale, col_bias)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    if k != kb:
+        raise RuntimeError(f"gemm: inner dimensions differ ({k} vs {kb})")
+    if out is None:
+        if beta != 0.0:
+            raise RuntimeError("gemm: beta != 0 needs `out`")
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (m, n):
+        raise RuntimeError("gemm: bad `out` shape")
+    L = lib()
+    ws, wsb = None, 0
+    if split_k > 1:
+        wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
+        ws = workspace("gemm", wsb, a.device)
+    _lib.check(L.gx_gemm_f32(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(out),
+                             out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws), wsb,
+                             _stream()), "gx_gemm_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------- generator pieces
+def pixel_norm(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    _lib.check(lib().gx_pixel_norm(_p(x), x.shape[0], x.shape[1], _p(y), _stream()), "gx_pixel_norm")
+    return y
+
+
+def bias_act_(y, alpha=1.0, bias=None, bscale=1.0, act=True):
+    _chk(y, bias)
+    _lib.check(lib().gx_bias_act(_p(y), y.shape[0], y.shape[1], alpha, _p(bias), bscale, int(act), _stream()),
+               "gx_bias_act")
+    return y
+
+
+def lerp_rows(w, base, psi):
+    """base + psi * (w - base); base (1, D) or (D,) broadcast over the rows of w (..., D)."""
+    _chk(w, base)
+    out = torch.empty_like(w)
+    _lib.check(lib().gx_lerp_rows(_p(w), _p(base), w.numel(), w.shape[-1], psi, _p(out), _stream()), "gx_lerp_rows")
+    return out
+
+
+def demod(s, wsq, scale):
+    _chk(s, wsq)
+    b, cin = s.shape
+    cout = wsq.shape[0]
+    d = torch.empty(b, cout, dtype=torch.float32, device=s.device)
+    _lib.check(lib().gx_demod(_p(s), _p(wsq), b, cin, cout, scale, _p(d), _stream()), "gx_demod")
+    return d
+
+
+def _noise_args(noise, b, h, w):
+    if noise is None:
+        return None, 0
+    _chk(noise)
+    if noise.numel() == h * w:
+        return noise, 0
+    if noise.numel() == b * h * w:
+        return noise, h * w
+    raise RuntimeError("noise must be (1,1,H,W) or (B,1,H,W)")
+
+
+def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True):
+    """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin)."""
+    _chk(x, wt, s, dmod, noise_w, bias)
+    b, h, w, cin = x.shape
+    cout = wt.shape[1]
+    nz, nbs = _noise_args(noise, b, h, w)
+    out = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
+    _lib.check(lib().gx_modconv_fwd(_p(x), b, h, w, cin, _p(wt), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
+                                    _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_modconv_fwd")
+    return out
+
+
+def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True):
+    """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC."""
+    _chk(x, wt, s, dmod, kf, noise_w, bias)
+    b, h, w, cin = x.shape
+    cout = wt.shape[1]
+    nz, nbs = _noise_args(noise, b, 2 * h, 2 * w)
+    L = lib()
+    scratch = workspace("upconv", L.gx_modconv_up_scratch_bytes(b, h, w, cout), x.device)
+    out = torch.empty(b, 2 * h, 2 * w, cout, dtype=torch.float32, device=x.device)
+    _lib.check(L.gx_modconv_up_fwd(_p(x), b, h, w, cin, _p(wt), cout, _p(s), _p(dmod), _p(kf), _p(nz), nbs,
+                                   _p(noise_w), _p(bias), int(act), _p(scratch), _p(out), _stream()),
+               "gx_modconv_up_fwd")
+    return out
+
+
+def torgb(x, w3, s, scale, bias3, prev_img, kf):
+    """x (B,H,W,Cin) NHWC -> image (B,3,H,W) planar."""
+    _chk(x, w3, s, bias3, prev_img, kf)
+    b, h, w, cin = x.shape
+    img = torch.empty(b, 3, h, w, dtype=torch.float32, device=x.device)
+    _lib.check(lib().gx_torgb_fwd(_p(x), b, h, w, cin, _p(w3), _p(s), scale, _p(bias3), _p(prev_img), _p(kf),
+                                  _p(img), _stream()), "gx_torgb_fwd")
+    return img
+
+
+def nchw_to_nhwc(x):
+    _chk(x)
+    b, c, h, w = x.shape
+    out = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
+    _lib.check(lib().gx_nchw_to_nhwc(_p(x), b, c, h * w, _p(out), _stream()), "gx_nchw_to_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------- gather
+def rotflip_map(angle_deg, flip, h, w, device, out=None):
+    if out is None:
+        out = torch.empty(h * w, dtype=torch.int32, device=device)
+    _lib.check(lib().gx_rotflip_map(float(angle_deg), int(bool(flip)), h, w, _p(out), _stream()), "gx_rotflip_map")
+    return out
+
+
+class TapSet:
+    """Host-side descriptor of the NHWC taps of a batch of views: device pointers + shapes,
+    marshalled once per view batch for gx_gather_taps / gx_norm_map."""
+
+    def __init__(self, taps):
+        for t in taps:
+            _chk(t)
+            if t.dim() != 4 or t.shape[1] != t.shape[2]:
+                raise RuntimeError("taps must be (B, r, r, C) NHWC")
+        self.taps = taps
+        n = len(taps)
+        self.n = n
+        self.B = taps[0].shape[0]
+        self.ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in taps])
+        self.chans = (ctypes.c_int * n)(*[t.shape[3] for t in taps])
+        self.res = (ctypes.c_int * n)(*[t.shape[1] for t in taps])
+        self.total_c = sum(t.shape[3] for t in taps)
+        self.size = max(t.shape[1] for t in taps)
+
+
+def gather_taps(tapset, picks, hlen, maps=None, out=None):
+    """picks (B, N) int32 pixel indices; maps (B, H*W) int32 or None -> X (B*N, hlen)."""
+    b, n = picks.shape
+    if b != tapset.B or picks.dtype != torch.int32 or not picks.is_cuda or not picks.is_contiguous():
+        raise RuntimeError("picks must be a contiguous (B, N) int32 HIP tensor")
+    if maps is not None and (maps.dtype != torch.int32 or not maps.is_contiguous()):
+        raise RuntimeError("maps must be contiguous int32")
+    hw = tapset.size
+    if out is None:
+        out = torch.empty(b * n, hlen, dtype=torch.float32, device=picks.device)
+    _lib.check(lib().gx_gather_taps(tapset.n, tapset.ptrs, tapset.chans, tapset.res, b, hw, hw, hlen, _p(picks), n,
+                                    _p(maps), _p(out), out.stride(0), _stream()), "gx_gather_taps")
+    return out
+
+
+def row_sumsq(x2d, cused=None):
+    _chk(x2d)
+    rows, ld = x2d.shape
+    out = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _lib.check(lib().gx_row_sumsq(_p(x2d), rows, cused or ld, ld, _p(out), _stream()), "gx_row_sumsq")
+    return out
+
+
+def norm_map(tapset, hlen, maps=None):
+    """(B, H, W) per-pixel L2 norm of the (rotated/flipped) first-hlen-channel stack."""
+    ss, off = [], 0
+    for t in tapset.taps:
+        c = t.shape[3]
+        if off >= hlen:
+            break
+        ss.append(row_sumsq(t.reshape(-1, c), min(c, hlen - off)))
+        off += c
+    n = len(ss)
+    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in ss])
+    res = (ctypes.c_int * n)(*[t.shape[1] for t in tapset.taps[:n]])
+    hw = tapset.size
+    img = torch.empty(tapset.B, hw, hw, dtype=torch.float32, device=ss[0].device)
+    _lib.check(lib().gx_norm_map(n, ptrs, res, _p(maps), tapset.B, hw, hw, _p(img), _stream()), "gx_norm_map")
+    return img
+
+
+# ------------------------------------------------------------------------------------- row helpers
+def row_l2_normalize_(z, want_rnorm=True):
+    _chk(z)
+    rn = torch.empty(z.shape[0], dtype=torch.float32, device=z.device) if want_rnorm else None
+    _lib.check(lib().gx_row_l2_normalize(_p(z), z.shape[0], z.shape[1], z.stride(0), _p(rn), _stream()),
+               "gx_row_l2_normalize")
+    return rn
+
+
+def l2_normalize_bwd_(g, zhat, rnorm):
+    _chk(g, zhat, rnorm)
+    _lib.check(lib().gx_l2_normalize_bwd(_p(g), _p(zhat), _p(rnorm), g.shape[0], g.shape[1], g.stride(0), _stream()),
+               "gx_l2_normalize_bwd")
+    return g
+
+
+def row_argmax(z):
+    _chk(z)
+    out = torch.empty(z.shape[0], dtype=torch.int64, device=z.device)
+    _lib.check(lib().gx_row_argmax(_p(z), z.shape[0], z.shape[1], z.stride(0), _p(out), _stream()), "gx_row_argmax")
+    return out
+
+
+def colsum(x, out, alpha=1.0, beta=0.0):
+    _chk(x, out)
+    L = lib()
+    k = x.shape[1]
+    wsb = L.gx_colsum_workspace_bytes(k)
+    ws = workspace("colsum", wsb, x.device)
+    _lib.check(L.gx_colsum(_p(x), x.shape[0], k, x.stride(0), alpha, beta, _p(out), _p(ws), wsb, _stream()),
+               "gx_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------- Sinkhorn
+class Sinkhorn:
+    """Log-domain scaling-vector Sinkhorn-Knopp state for one score matrix (rows, K).
+
+    After run(): `la` (K,) with codes q = softmax_k(S/eps + la).  Single device: `run()`.
+    Sharded: pass `reduce(tensor, op)` that all-reduces in place over the ranks ('max' for the K
+    column maxima, 'sum' for the K column sums) and c_uniform = 1/rows_global."""
+
+    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="sk"):
+        _chk(scores, r, c)
+        self.S = scores
+        self.rows, self.K = scores.shape
+        self.eps, self.niters = float(eps), int(niters)
+        self.r, self.c = r, c
+        self.c_uniform = 1.0 / self.rows if c_uniform is None else float(c_uniform)
+        L = lib()
+        self.wsb = L.gx_sinkhorn_workspace_bytes(self.K)
+        self.ws = workspace(tag, self.wsb, scores.device)
+        self.la = torch.empty(self.K, dtype=torch.float32, device=scores.device)
+
+    def run(self, reduce=None):
+        L, S, K = lib(), self.S, self.K
+        if reduce is None and self.c_uniform == 1.0 / self.rows:
+            _lib.check(L.gx_sinkhorn(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r), _p(self.c),
+                                     _p(self.la), _p(self.ws), self.wsb, _stream()), "gx_sinkhorn")
+            return self
+        _lib.check(L.gx_sinkhorn_colmax(_p(S), self.rows, K, S.stride(0), _p(self.ws), self.wsb, _stream()),
+                   "gx_sinkhorn_colmax")
+        if reduce is not None:
+            cm = torch.empty(K, dtype=torch.float32, device=S.device)
+            _lib.check(L.gx_sinkhorn_cmax_get(_p(self.ws), K, _p(cm), _stream()), "gx_sinkhorn_cmax_get")
+            reduce(cm, "max")
+            _lib.check(L.gx_sinkhorn_cmax_set(_p(self.ws), K, _p(cm), _stream()), "gx_sinkhorn_cmax_set")
+        u = self.ws[K:2 * K]
+        for it in range(self.niters):
+            _lib.check(L.gx_sinkhorn_pass(_p(S), self.rows, K, S.stride(0), self.eps, int(it == 0), _p(self.la),
+                                          _p(self.c), self.c_uniform, None, _p(self.ws), self.wsb, _stream()),
+                       "gx_sinkhorn_pass")
+            if reduce is not None:
+                reduce(u, "sum")
+            _lib.check(L.gx_sinkhorn_update(_p(u), _p(self.r), K, int(it == 0), _p(self.ws), self.eps, _p(self.la),
+                                            _stream()), "gx_sinkhorn_update")
+        return self
+
+    def codes(self):
+        q = torch.empty(self.rows, self.K, dtype=torch.float32, device=self.S.device)
+        _lib.check(lib().gx_sinkhorn_codes(_p(self.S), self.rows, self.K, self.S.stride(0), self.eps, _p(self.la),
+                                           _p(q), q.stride(0), _stream()), "gx_sinkhorn_codes")
+        return q
+
+
+def hist_marginal(x, bins):
+    _chk(x)
+    hist = torch.empty(bins, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(2, dtype=torch.int32, device=x.device)
+    _lib.check(lib().gx_hist_marginal(_p(x), x.numel(), bins, _p(hist), _p(scratch), _stream()), "gx_hist_marginal")
+    return hist
+
+
+def swapped_ce(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s=None, d_t=None):
+    """Fused Sinkhorn-codes + swapped-prediction CE forward (+ d scores).  sk_* are run()
+    Sinkhorn states of the two views; loss_out is a 1-element HIP tensor (accumulated)."""
+    S, T = sk_s.S, sk_t.S
+    _chk(loss_out, d_s, d_t)
+    L = lib()
+    wsb = L.gx_swapped_ce_workspace_bytes()
+    ws = workspace("ce", wsb, S.device)
+    _lib.check(L.gx_swapped_ce(_p(S), _p(T), sk_s.rows, sk_s.K, S.stride(0), sk_s.eps, temperature, _p(sk_s.la),
+                               _p(sk_t.la), grad_scale, _p(d_s), _p(d_t),
+                               (d_s.stride(0) if d_s is not None else 0), loss_scale, loss_beta, _p(loss_out), _p(ws),
+                               wsb, _stream()), "gx_swapped_ce")
+    return loss_out
+
+
+# ------------------------------------------------------------------------------------- optimizer
+def sumsq(x, out):
+    """out[0] = sum(x^2) (deterministic)."""
+    _chk(x, out)
+    L = lib()
+    wsb = L.gx_sumsq_workspace_bytes()
+    ws = workspace("sumsq", wsb, x.device)
+    _lib.check(L.gx_sumsq(_p(x), x.numel(), _p(out), _p(ws), wsb, _stream()), "gx_sumsq")
+    return out
+
+
+def larc_sgd_(p, g, buf, lr, momentum, trust, first_step, use_larc=True):
+    _chk(p, g, buf)
+    norms = None
+    if use_larc:
+        norms = torch.empty(2, dtype=torch.float32, device=p.device)
+        sumsq(p, norms[0:1])
+        sumsq(g, norms[1:2])
+    _lib.check(lib().gx_larc_sgd(_p(p), _p(g), _p(buf), p.numel(), _p(norms), lr, momentum, trust, int(first_step),
+                                 int(use_larc), _stream()), "gx_larc_sgd")
+    return p
+
+
+def sqrt_fan(cin, k):
+    return 1.0 / math.sqrt(cin * k * k)

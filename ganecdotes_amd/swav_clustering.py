@@ -1,0 +1,363 @@
+"""Per-pixel SwAV clustering on MI355X — the `preprocessor` plugin of `--method=hfc_with_swav`.
+
+Mirrors the reference class `SwAVClustering` (hfc_with_swav/swav_clustering.py:28-693): same
+constructor keywords, `preprocess` / `pretrain` / `predict_swav_codes`, the `projection` /
+`prototype` torch modules and the `projection.pt` / `prototypes.pt` files.  The arithmetic is
+not the reference's op chain but hand-written gfx950 kernels reached through the C ABI
+(`ganecdotes_amd.ops`):
+
+  views      : batched NHWC generator forward (the reference's discarded first forward is
+               replaced by the 3-line latent computation it was run for)
+  S1/S1b/S2  : one gather kernel (taps -> sampled panel X), never the 1.3 GiB stack
+  S3         : fp32-MFMA GEMMs, L2-normalise in place
+  S4         : log-domain scaling-vector Sinkhorn (12 passes over the scores, Q never formed)
+  S5/S6      : fused codes + swapped-CE + d(scores); MFMA GEMMs for dWc, dz, dWp (split-K)
+  S7/S8      : row normalise, LARC-SGD
+
+Extensions over the reference (opt-in `swav_args` keys, defaults = reference behaviour):
+  batch_size      images per optimizer step on this rank (reference: 1)
+  sinkhorn_scope  'image' (per-image Sinkhorn, == reference steps with gradient averaging) or
+                  'global' (Sinkhorn over all pixels of the global batch, SURVEY.md par. 8e)
+  use_larc, transforms   switches used by parity tests
+Multi-GPU: pass `dist_group` (torch.distributed, backend nccl = RCCL); images shard over
+ranks, the Sinkhorn column sums / maxima and the parameter gradients are all-reduced.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .draws import ImageDraws, draw_image
+
+
+class _NullLogger:
+    def info(self, *_):
+        pass
+
+
+class SwAVClustering(object):
+
+    def __init__(self, model, model_config, perturb_args, swav_args, sinkhorn_args, logger=None, train=True,
+                 out_dir=None, device='cuda', tb=None, layer_hf_dim=None, dist_group=None):
+        self.model = model
+        self.model_config = model_config
+        self.perturb_args = perturb_args
+        self.swav_args = swav_args
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("SwAVClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
+        ops.lib()                                   # fail loudly if the HIP extension is missing
+        self.writer = tb
+        self.nclasses = swav_args['nclasses']
+        self.nprototypes = swav_args['nprototypes']
+        self.niters = sinkhorn_args['niters']
+        self.eps = sinkhorn_args['eps']
+        self.sinkhorn_args = sinkhorn_args.copy()
+        self.logger = logger or _NullLogger()
+        self.train = train
+        self.out_dir = out_dir
+        self.dist_group = dist_group
+        self.world = 1
+        self.rank = 0
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(dist_group)
+            self.rank = dist.get_rank(dist_group)
+        if out_dir is not None:
+            self.swav_dir = os.path.join(out_dir, 'swav')
+            os.makedirs(self.swav_dir, exist_ok=True)
+            self.prototype_file = os.path.join(out_dir, 'prototypes.pt')
+            self.projection_file = os.path.join(out_dir, 'projection.pt')
+        else:
+            self.prototype_file = self.projection_file = None
+        self.projection = None
+        self.prototype = None
+        if not self.train and self.projection_file is not None:
+            if os.path.exists(self.projection_file):
+                self.projection = torch.load(self.projection_file, weights_only=False).to(self.device)
+                self.prototype = torch.load(self.prototype_file, weights_only=False).to(self.device)
+            else:
+                self.logger.info("Prototype File not found - pretraining ...")
+        with torch.no_grad():
+            self.mean_latent = self.model.mean_latent(self.model_config.num_latents_for_mean)
+            self.truncation = self.model_config.truncation
+        self.layer_hf_dim = layer_hf_dim
+        self._bufs = None
+        self._step_no = 0
+
+    # ------------------------------------------------------------------------------------- modules
+    def build_heads(self):
+        """projection + prototype layers as torch modules (swav_clustering.py:244-271) — the
+        objects that are pickled to projection.pt / prototypes.pt."""
+        hlen = self.swav_args['hlen']
+        if self.swav_args['projn_nw'] != 'linear':
+            raise NotImplementedError("only projn_nw='linear' (every shipped config) has a HIP path")
+        self.projection = nn.Sequential(nn.Linear(hlen, self.nclasses, bias=False)).to(self.device)
+        self.prototype = nn.Linear(self.nclasses, self.nprototypes).to(self.device)
+        for p in list(self.projection.parameters()) + list(self.prototype.parameters()):
+            p.requires_grad_(False)
+        self._bufs = None
+        self._step_no = 0
+
+    def _params(self):
+        return [self.projection[0].weight.data, self.prototype.weight.data, self.prototype.bias.data]
+
+    # ------------------------------------------------------------------------------------- reference API
+    def preprocess(self, input_latent):
+        if self.train or self.projection_file is None or not os.path.exists(self.projection_file):
+            self.pretrain(input_latent)
+
+    def create_pixel_feature_vectors(self, features, pred=False):
+        """API-compatibility shim of swav_clustering.py:108-130: returns the materialised
+        (B, hlen, H, W) stack through the gather kernel with the identity pick list."""
+        taps = [f.permute(0, 2, 3, 1).contiguous() for f in features]
+        ts = ops.TapSet(taps)
+        hw = ts.size * ts.size
+        picks = torch.arange(hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
+        x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
+        return x.reshape(ts.B, ts.size, ts.size, -1).permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------------------------- views
+    def _view_latents(self, w, vds):
+        """Latents of the feature-producing forward for a batch of images and ONE view each
+        (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents."""
+        n_latent = self.model.n_latent
+        psi = self.truncation
+        lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(psi))
+        lat = lat.unsqueeze(1).repeat(1, n_latent, 1)
+        noise = torch.cat([vd.map_noise for vd in vds], 0).to(self.device)          # (2B, S)
+        nw = self.model.style(noise).reshape(len(vds), 2, -1)
+        for b, vd in enumerate(vds):
+            sig = float(self.perturb_args['perturb_std'][vd.layer_no])
+            for j in range(2):
+                n = 2 * vd.layer_no + j
+                lat[b, n] = (1.0 - sig) * lat[b, n] + sig * nw[b, j]
+        return lat
+
+    def make_views(self, images):
+        """Both views of a batch of ImageDraws -> per view (TapSet, maps or None, image)."""
+        z = torch.cat([im.z for im in images], 0).to(self.device)
+        w = self.model.style(z)
+        out = []
+        for v in range(2):
+            vds = [im.views[v] for im in images]
+            lat = self._view_latents(w, vds)
+            img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
+                                    input_is_latent=True, randomize_noise=False)
+            ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
+            maps = None
+            if any(vd.angle is not None for vd in vds):
+                hw = ts.size
+                maps = torch.empty(len(vds), hw * hw, dtype=torch.int32, device=self.device)
+                for b, vd in enumerate(vds):
+                    ops.rotflip_map(vd.angle or 0.0, vd.flip, hw, hw, self.device, out=maps[b])
+            out.append((ts, maps, img))
+        return out
+
+    def create_hidden_features_from_perturbed_vectors(self, layer_no=None, input_latent=None,
+                                                      input_is_latent=True):
+        """Reference-shaped single-view helper (swav_clustering.py:574-656): returns
+        (stack (1,hlen,H,W), image, layer_no).  Draws from the global RNGs like the reference."""
+        sd = self.model.style_dim
+        if input_latent is None:
+            input_latent = torch.randn(1, sd).to(self.device)
+            input_is_latent = False
+        w = input_latent if input_is_latent else self.model.style(input_latent)
+        im = draw_image(sd, self.model.num_layers, self.perturb_args['n_layers'], 1, 0, transforms=False,
+                        layer_no=layer_no)
+        vd = im.views[0]
+        lat = self._view_latents(w.reshape(1, sd), [vd])
+        img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
+                                input_is_latent=True, randomize_noise=False)
+        return self.create_pixel_feature_vectors(feats), img, vd.layer_no
+
+    # ------------------------------------------------------------------------------------- collectives
+    def _reduce(self, t, op):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.dist_group)
+
+    # ------------------------------------------------------------------------------------- one step
+    def _marginals(self, img, k, nrows):
+        """'image' source pdf (swav_clustering.py:523-532): r from a K-bin, c from an nrows-bin
+        histogram of the whole norm map."""
+        if self.world > 1:
+            raise NotImplementedError("source_pdf='image' is single-rank in this round")
+        return ops.hist_marginal(img, k), ops.hist_marginal(img, nrows)
+
+    def _split_k(self, m, n, k):
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        want = max(1, 1024 // tiles)
+        return int(max(1, min(want, k // 256)))
+
+    def train_step(self, images, return_aux=False):
+        """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
+        as a 1-element HIP tensor (global mean; no host sync)."""
+        sa = self.swav_args
+        P, N, hlen = sa['num_patches'], sa['patch_size'], sa['hlen']
+        T = sa['temperature']
+        scope = sa.get('sinkhorn_scope', 'image')
+        use_larc = sa.get('use_larc', True)
+        B = len(images)
+        Bg = B * self.world
+        Wp, Wc, bc = self._params()
+        D, K = Wp.shape[0], Wc.shape[0]
+        dev = self.device
+
+        # S7: prototype rows to unit norm (bias untouched)
+        ops.row_l2_normalize_(Wc, want_rnorm=False)
+
+        views = self.make_views(images)
+        hw = views[0][0].size
+        if N is None or N >= hw * hw:
+            N = hw * hw
+        imgs = None
+        if self.sinkhorn_args['source_pdf'] == 'image':
+            imgs = [ops.norm_map(ts, hlen, maps) for ts, maps, _ in views]
+
+        if self._bufs is None:
+            self._bufs = [torch.zeros_like(p) for p in (Wp, Wc, bc)]
+            self._grads = [torch.empty_like(p) for p in (Wp, Wc, bc)]
+        gWp, gWc, gb = self._grads
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        rows = B * N
+        gscale = 1.0 / (N * P * Bg)
+        first_acc = True
+        aux = {}
+        for pno in range(P):
+            picks = torch.stack([im.picks[pno][:N] for im in images]).to(torch.int32).to(dev)
+            X, Zh, Rn, Sc = [], [], [], []
+            for ts, maps, _ in views:
+                x = ops.gather_taps(ts, picks, hlen, maps)                     # (B*N, hlen)
+                z = ops.gemm(x, Wp, False, True)                               # (B*N, D)
+                rn = ops.row_l2_normalize_(z)                                  # z -> z_hat
+                sc = ops.gemm(z, Wc, False, True, col_bias=bc)                 # (B*N, K)
+                X.append(x); Zh.append(z); Rn.append(rn); Sc.append(sc)
+            dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
+            if scope == 'global':
+                groups = [(0, rows)]
+            else:
+                groups = [(b * N, (b + 1) * N) for b in range(B)]
+            for (r0, r1) in groups:
+                sk = []
+                for v in range(2):
+                    r = c = None
+                    if imgs is not None:
+                        img = imgs[v] if scope == 'global' else imgs[v][r0 // N:r0 // N + 1]
+                        r, c = self._marginals(img.contiguous(), K, r1 - r0)
+                    nglob = (r1 - r0) * (self.world if scope == 'global' else 1)
+                    s = ops.Sinkhorn(Sc[v][r0:r1], self.eps, self.niters, r=r, c=c, c_uniform=1.0 / nglob,
+                                     tag=f"sk{v}")
+                    s.run(self._reduce if (scope == 'global' and self.world > 1) else None)
+                    sk.append(s)
+                ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
+                if return_aux and pno == 0 and r0 == 0:
+                    aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
+                               q_s=sk[0].codes(), q_t=sk[1].codes())
+            # S6: backward GEMMs (gradients accumulate over views and patches)
+            for v in range(2):
+                beta = 0.0 if first_acc else 1.0
+                ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
+                ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
+                dz = ops.gemm(dS[v], Wc, False, False)                         # (B*N, D)
+                ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
+                ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
+                first_acc = False
+            del X, Zh, Rn, Sc, dS
+        if self.world > 1:
+            import torch.distributed as dist
+            flat = torch.cat([g.reshape(-1) for g in self._grads] + [loss])
+            dist.all_reduce(flat, group=self.dist_group)
+            o = 0
+            for g in self._grads:
+                g.copy_(flat[o:o + g.numel()].reshape(g.shape)); o += g.numel()
+            loss.copy_(flat[o:o + 1])
+        # S8: LARC + momentum SGD
+        lr = sa['train_args']['lr']
+        mom = sa['train_args'].get('momentum', 0.0)
+        if sa.get('use_scheduler', False) and getattr(self, '_lr_schedule', None) is not None:
+            lr = float(self._lr_schedule[min(self._step_no, len(self._lr_schedule) - 1)])
+        for p, g, buf in zip((Wp, Wc, bc), self._grads, self._bufs):
+            ops.larc_sgd_(p, g, buf, lr, mom, sa['trust_coeff'], first_step=(self._step_no == 0), use_larc=use_larc)
+        self._step_no += 1
+        return (loss, aux) if return_aux else loss
+
+    # ------------------------------------------------------------------------------------- training loop
+    def _schedule(self):
+        sa = self.swav_args
+        ns = sa['num_samples']
+        warm = np.linspace(sa['start_warmup'], sa['base_lr'], ns * sa['warmup_epochs'])
+        it = np.arange(ns * (sa['num_epochs'] - sa['warmup_epochs']))
+        cos = np.array([sa['final_lr'] + 0.5 * (sa['base_lr'] - sa['final_lr']) *
+                        (1 + math.cos(math.pi * t / (sa['num_epochs'] - sa['warmup_epochs']))) for t in it])
+        return np.concatenate((warm, cos))
+
+    def draw_batch(self, batch):
+        sa = self.swav_args
+        hw = self.model.size * self.model.size
+        return [draw_image(self.model.style_dim, self.model.num_layers, self.perturb_args['n_layers'], hw,
+                           sa['num_patches'], transforms=sa.get('transforms', True),
+                           layer_no=self.perturb_args['layer_no']) for _ in range(batch)]
+
+    def pretrain(self, input_latent, num_test_samples=5):
+        """Self-supervised pretraining loop (swav_clustering.py:205-505): num_epochs x num_samples
+        optimizer steps, each over `batch_size` freshly drawn latents; logs ` E:<e> | Loss | T`
+        and saves prototypes.pt / projection.pt."""
+        sa = self.swav_args
+        sd = self.model.style_dim
+        # reference RNG order at entry: test latents + their randomized-noise forwards (:224-237)
+        for _ in range(num_test_samples):
+            torch.randn(1, sd)
+        for _ in range(num_test_samples):
+            for i in range(self.model.num_layers):
+                r = 2 ** ((i + 5) // 2)
+                torch.empty(1, 1, r, r).normal_()
+        self.build_heads()
+        self.logger.info("Projection Network:")
+        self.logger.info(self.projection.__str__())
+        self.logger.info("Prototype Matrix:")
+        self.logger.info(self.prototype.__str__())
+        self.logger.info("SwAV Parameters:")
+        for k, v in sa.items():
+            self.logger.info(f"{k}: {v}")
+        self.logger.info("Sinkhorn-Knopp Algo. Parameters:")
+        for k, v in self.sinkhorn_args.items():
+            self.logger.info(f"{k}: {v}")
+        self._lr_schedule = self._schedule()
+        batch = sa.get('batch_size', 1)
+        t0 = time.time()
+        self.loss_history = []
+        for e in range(sa['num_epochs']):
+            for _ in range(sa['num_samples']):
+                loss = self.train_step(self.draw_batch(batch))
+                self.loss_history.append(loss)
+                if self.writer is not None:
+                    self.writer.add_scalar('swav/loss', loss.item(), e)
+            if e % sa['epoch_print_freq'] == 0:
+                self.logger.info(f" E:{e}\t|\tLoss: {loss.item():.03f} \t|\tT: {time.time() - t0:.03f}")
+        self.logger.info("Finished pretraining - Saving projection file")
+        if self.prototype_file is not None and self.rank == 0:
+            torch.save(self.prototype, self.prototype_file)
+            torch.save(self.projection, self.projection_file)
+
+    # ------------------------------------------------------------------------------------- inference
+    def predict_swav_codes(self, input_latent, input_is_latent=True):
+        """(swav_clustering.py:659-693) generator with fixed noise and ONE truncation ->
+        projection of every pixel -> (out_preds (b,D,h,w) fp32, out_labels (b,h,w) int64 =
+        argmax over the D projection channels).  Like the reference, the latent is always
+        treated as a W latent."""
+        lat = input_latent.to(self.device).float()
+        img, feats = self.model([lat], truncation=self.model_config.truncation,
+                                truncation_latent=self.mean_latent, input_is_latent=True, randomize_noise=False)
+        ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
+        hw = ts.size
+        picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
+        x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
+        wp = self.projection[0].weight.data
+        z = ops.gemm(x, wp, False, True)                                       # (b*h*w, D) == NHWC
+        labels = ops.row_argmax(z).reshape(ts.B, hw, hw)
+        preds = z.reshape(ts.B, hw, hw, wp.shape[0]).permute(0, 3, 1, 2)
+        return preds, labels

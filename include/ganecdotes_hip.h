@@ -1,0 +1,147 @@
+/* ganecdotes_hip.h — C ABI of libganecdotes_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the per-pixel SwAV clustering hot path of avm-debatr/ganecdotes
+ * (`--method=hfc_with_swav`).  The reference's existing native boundary is two JIT-built
+ * pybind11 torch extensions — `upfirdn2d(Tensor input, Tensor kernel, int up_x, up_y, down_x,
+ * down_y, pad_x0, pad_x1, pad_y0, pad_y1)` (lib/gan/optim/upfirdn2d.cpp:18-39) and
+ * `fused_bias_act(Tensor input, Tensor bias, Tensor refer, int act, int grad, float alpha,
+ * float scale)` (lib/gan/optim/fused_bias_act.cpp:18-36) — plus chains of torch ops in
+ * hfc_with_swav/swav_clustering.py and models/stylegan2/model.py.  This header replaces both
+ * with plain-pointer entry points; INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all functions):
+ *   - every pointer is a DEVICE pointer (HIP, one process per GPU) unless said otherwise;
+ *     the CALLER allocates every output and workspace (the reference's callee-allocates
+ *     convention, upfirdn2d_kernel.cu:252-253, is dropped so nothing allocates in the hot loop);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - return 0 (GX_OK) or a negative GX_ERR_* code; the Python wrapper raises RuntimeError,
+ *     mirroring TORCH_CHECK -> RuntimeError of the reference boundary (upfirdn2d.cpp:9-15);
+ *   - thread-safe for distinct streams; no global state;
+ *   - feature maps are NHWC ([b][y][x][c]) fp32; matrices row-major fp32; indices int32.
+ */
+#ifndef GANECDOTES_HIP_H
+#define GANECDOTES_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GX_OK 0
+#define GX_ERR_BAD_ARG (-1)
+#define GX_ERR_ALIGN (-2)
+#define GX_ERR_WORKSPACE (-3)
+#define GX_ERR_LAUNCH (-4)
+
+const char* gx_version(void);
+
+/* ---- dense fp32-MFMA GEMM -------------------------------------------------------------------
+ * C = alpha * row_scale[m] * opA opB + col_bias[n] + beta * C.   transA=0: A is [M][K] (lda),
+ * 1: [K][M].  transB=0: B is [K][N] (ldb), 1: [N][K].  split_k>1 needs a workspace of
+ * gx_gemm_f32_workspace_bytes() and sums the K-slices in a fixed order.
+ * Replaces: F.linear / autograd matmuls of swav_clustering.py:171-175, :459. */
+size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k);
+int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                int split_k, float* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
+ * gx_pixel_norm      PixelNorm                                   model.py:105-110
+ * gx_bias_act        EqualLinear epilogue / fused_leaky_relu     model.py:32-43, :242-252;
+ *                    fused_bias_act_kernel.cu:18-85 (act=lrelu 0.2, scale sqrt2, grad=0)
+ * gx_lerp_rows       truncation  m + psi (w - m)                 model.py:594-602
+ * gx_demod           demodulation factors                        model.py:333-335
+ * gx_modconv_fwd     ModulatedConv2d (k=3 pad 1, or k=1) + NoiseInjection + FusedLeakyReLU
+ *                                                                model.py:362-366, :377-382, :426-432
+ * gx_modconv_up_fwd  upsample variant: conv_transpose2d stride 2 + Blur(pad (1,1))
+ *                                                                model.py:341-352, :166-182;
+ *                    upfirdn2d_kernel.cu:114-215 mode 1 (up1 down1 4x4)
+ * gx_torgb_fwd       ToRGB incl. Upsample of the skip            model.py:445-454, :124-142;
+ *                    upfirdn2d_kernel.cu mode 3 (up2 down1 4x4, pad (2,1))
+ * gx_nchw_to_nhwc    layout change at the API boundary */
+int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream);
+int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream);
+int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream);
+int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float scale, float* demod, void* stream);
+int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
+                   const float* demod, const float* noise, long noise_bstride, const float* noise_w,
+                   const float* bias, int act, float* out, void* stream);
+size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout);
+int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                      const float* demod, const float* kf, const float* noise, long noise_bstride,
+                      const float* noise_w, const float* bias, int act, float* T, float* out, void* stream);
+int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, const float* s, float scale,
+                 const float* bias3, const float* prev_img, const float* kf, float* img, void* stream);
+int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* stream);
+
+/* ---- multi-scale upsample + concat + rotate/flip + pixel sampling ---------------------------
+ * gx_rotflip_map   source-pixel map of RandomRotation(10)+RandomHorizontalFlip
+ *                                                  swav_clustering.py:98-102, :358-359 (torchvision, restated)
+ * gx_gather_taps   X[row] = first hlen channels of concat_l nearest-upsampled tap_l at the
+ *                  sampled (and rotated/flipped) pixel; row = b*rows_per_img + i, pixel =
+ *                  picks[row], optional maps[b][H*W] (-1 = zero fill)
+ *                                                  swav_clustering.py:108-130, :160-167
+ * gx_row_sumsq / gx_norm_map   per-pixel L2 norm map of the stack   swav_clustering.py:361-362 */
+int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stream);
+int gx_gather_taps(int ntaps, const float* const* tap_ptrs /*host array of device ptrs*/, const int* tap_channels /*host*/,
+                   const int* tap_res /*host*/, int B, int H, int W, int hlen, const int* picks, int rows_per_img,
+                   const int* maps, float* X, long ldx, void* stream);
+int gx_row_sumsq(const float* x, long rows, int cused, long ld, float* out, void* stream);
+int gx_norm_map(int ntaps, const float* const* ss_ptrs /*host array*/, const int* tap_res /*host*/, const int* maps,
+                int B, int H, int W, float* img, void* stream);
+
+/* ---- projection / prototype helpers ---------------------------------------------------------
+ * gx_row_l2_normalize   F.normalize(p=2, dim=1) in place, rnorm out     swav_clustering.py:174
+ * gx_l2_normalize_bwd   its backward (autograd of :174)                  swav_clustering.py:459
+ * gx_row_argmax         out_preds.max(1)[1]                              swav_clustering.py:691
+ * gx_colsum             out = alpha*colsum(x) + beta*out (prototype-bias gradient) */
+int gx_row_l2_normalize(float* z, long rows, int D, long ld, float* rnorm, void* stream);
+int gx_l2_normalize_bwd(float* g, const float* zhat, const float* rnorm, long rows, int D, long ld, void* stream);
+int gx_row_argmax(const float* z, long rows, int D, long ld, long long* labels, void* stream);
+size_t gx_colsum_workspace_bytes(int K);
+int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta, float* out, float* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ---- Sinkhorn-Knopp (log-domain scaling-vector form)   swav_clustering.py:509-544 ------------
+ * The returned code is q[n][k] = softmax_k(S_nk/eps + la_k); gx_sinkhorn() leaves la[K]
+ * (la = log of the reference's accumulated row scaling).  Codes via gx_sinkhorn_codes or fused
+ * into gx_swapped_ce.  Sharded over ranks (SURVEY.md par. 8e): colmax -> all_reduce(MAX) of the
+ * K column maxima (cmax_get / cmax_set) -> {pass -> all_reduce(SUM) of gx_sinkhorn_u(ws,K)[K]
+ * -> update} x niters, `first` = 1 on the first iteration.  r (K) / c (rows) are the 'image'
+ * marginals (NULL = uniform 1/K, c_uniform = 1/rows_global). */
+size_t gx_sinkhorn_workspace_bytes(int K);
+float* gx_sinkhorn_u(float* workspace, int K);
+int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspace, size_t workspace_bytes,
+                       void* stream);
+int gx_sinkhorn_cmax_get(const float* workspace, int K, float* out, void* stream);
+int gx_sinkhorn_cmax_set(float* workspace, int K, const float* in, void* stream);
+int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,
+                     const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                     void* stream);
+int gx_sinkhorn_update(const float* u, const float* r, int K, int first, const float* workspace, float eps,
+                       float* la, void* stream);
+int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters, const float* r, const float* c,
+                float* la, float* workspace, size_t workspace_bytes, void* stream);
+int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
+                      void* stream);
+int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);
+
+/* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
+ * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).
+ * loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0];
+ * dS_t = -grad_scale/(2T) (q_s - softmax(S_t/T) sum_k q_s), dS_s likewise (NULL,NULL = forward only). */
+size_t gx_swapped_ce_workspace_bytes(void);
+int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
+                  const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
+                  float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* ---- optimizer: apex LARC(clip=False) around SGD(momentum)   swav_clustering.py:286-292 ------ */
+size_t gx_sumsq_workspace_bytes(void);
+int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t workspace_bytes, void* stream);
+int gx_larc_sgd(float* p, const float* g, float* buf, long n, const float* norms2 /*{sum p^2, sum g^2}*/, float lr,
+                float momentum, float trust, int first_step, int use_larc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

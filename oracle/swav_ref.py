@@ -169,6 +169,7 @@ class ViewDraws:
     map_noise: torch.Tensor          # (2, S): z-noise fed to the mapping MLP for latents 2l, 2l+1
     angle: Optional[float] = None    # degrees; None = rotation/flip disabled
     flip: bool = False
+    index_map: Optional[torch.Tensor] = None   # explicit source map (overrides angle/flip) for parity tests
 
 
 @dataclass
@@ -226,7 +227,9 @@ def make_view(sd, w, mean_latent, psi, vd: ViewDraws, hlen, perturb_std=1.0):
     img, taps, _ = G.generator_forward(new, sd, truncation=psi, truncation_latent=mean_latent,
                                        input_is_latent=True)
     stack = pixel_features(taps, hlen)
-    if vd.angle is not None:
+    if vd.index_map is not None:
+        stack = apply_index_map(stack, vd.index_map)
+    elif vd.angle is not None:
         stack = apply_index_map(stack, rotflip_index_map(vd.angle, vd.flip, stack.shape[2],
                                                          stack.shape[3]))
     return stack, img

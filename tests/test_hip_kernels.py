@@ -1,0 +1,381 @@
+"""Parity of each HIP kernel (through the C ABI) against the oracle / golden vectors.
+Runs on a real MI355X only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ganecdotes_amd import ops as O
+    O.lib()
+    return O
+
+
+def dev(x):
+    if isinstance(x, np.ndarray):
+        x = T(x)
+    return x.cuda().contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (200, 72, 100), (1, 512, 512), (333, 129, 37), (64, 8, 516)])
+def test_gemm_layouts(ops, ta, tb, m, n, k):
+    torch.manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(k, m) if ta else torch.randn(m, k)
+    b = torch.randn(n, k) if tb else torch.randn(k, n)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    out = ops.gemm(dev(a), dev(b), ta, tb)
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_gemm_asymmetric_identity(ops):
+    # A = I with an ASYMMETRIC B catches a transposed C write
+    n = 160
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) * 1e-3
+    out = ops.gemm(dev(torch.eye(n)), dev(b), False, False)
+    assert torch.equal(out.cpu(), b)
+    out = ops.gemm(dev(torch.eye(n)), dev(b), False, True)
+    assert torch.equal(out.cpu(), b.t().contiguous())
+
+
+def test_gemm_epilogue_and_splitk(ops):
+    torch.manual_seed(3)
+    m, n, k = 300, 200, 5000
+    a, b = torch.randn(k, m), torch.randn(k, n)
+    rs, cb, c0 = torch.rand(m) + 0.5, torch.randn(n), torch.randn(m, n)
+    ref = 0.7 * rs[:, None].double() * (a.t().double() @ b.double()) + cb.double() + 0.3 * c0.double()
+    for sk in (1, 4, 7):
+        out = dev(c0.clone())
+        ops.gemm(dev(a), dev(b), True, False, out=out, alpha=0.7, beta=0.3, row_scale=dev(rs), col_bias=dev(cb),
+                 split_k=sk)
+        assert rel_err(out, ref) < 3e-6
+    # matches the k-ordered fp32 chain closely enough to be compared with a torch fp32 matmul
+    ref32 = (a.t() @ b)
+    out = ops.gemm(dev(a), dev(b), True, False, split_k=1)
+    assert rel_err(out, ref32) < 1e-5
+
+
+def test_gemm_big_ffhq_shape(ops):
+    # ffhq projection shape at reduced rows: (N, 5376) x (512, 5376)^T
+    torch.manual_seed(5)
+    x = torch.randn(1000, 5376)
+    w = torch.randn(512, 5376) / 73.0
+    out = ops.gemm(dev(x), dev(w), False, True)
+    assert rel_err(out, x.double() @ w.double().t()) < 3e-6
+
+
+# ------------------------------------------------------------------------------------- Sinkhorn
+def _sk_cases():
+    d = load_golden("gv7_sinkhorn")
+    return d
+
+
+@pytest.mark.parametrize("tag", ["uniform_e05", "uniform_e005"])
+def test_sinkhorn_golden_uniform(ops, tag):
+    d = _sk_cases()
+    s = T(d["scores"]) * float(d[f"scale_{tag}"])
+    sk = ops.Sinkhorn(dev(s), float(d[f"eps_{tag}"]), int(d["niters"])).run()
+    q = sk.codes().cpu().numpy()
+    ref = d[f"q_{tag}"]
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    np.testing.assert_allclose(q.sum(1), 1.0, rtol=1e-5)
+
+
+def test_sinkhorn_golden_big_and_overflow(ops):
+    from oracle import swav_ref as S
+    d = _sk_cases()
+    sk = ops.Sinkhorn(dev(d["scores_big"]), 0.01, 10).run()
+    q = sk.codes().cpu().numpy()
+    ref = d["q_big_uniform_e01"]
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    # where the reference's fp32 exp() overflows, the fp64 run of the same algorithm is the checker
+    s = T(d["scores"]) * float(d["overflow_scale"])
+    ref = S.sinkhorn_knopp(s, 0.005, 10, fp64=True).numpy()
+    q = ops.Sinkhorn(dev(s), 0.005, 10).run().codes().cpu().numpy()
+    assert np.isfinite(q).all()
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+
+
+@pytest.mark.parametrize("tag", ["image_e05", "image_e003"])
+def test_sinkhorn_image_pdf(ops, tag):
+    from oracle import swav_ref as S
+    d = _sk_cases()
+    s = T(d["scores"]) * float(d[f"scale_{tag}"])
+    img = T(d["img"])
+    n, k = s.shape
+    r = ops.hist_marginal(dev(img), k)
+    c = ops.hist_marginal(dev(img), n)
+    rk, cb = S.image_marginals(img, k, n)
+    np.testing.assert_allclose(r.cpu().numpy(), rk.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(c.cpu().numpy(), cb.numpy(), rtol=1e-5, atol=1e-9)
+    q = ops.Sinkhorn(dev(s), float(d[f"eps_{tag}"]), 10, r=r, c=c).run().codes().cpu().numpy()
+    ref = d[f"q_{tag}"]
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+
+
+@pytest.mark.parametrize("n,k,eps", [(2000, 8, 0.005), (777, 16, 0.003), (500, 1000, 0.01), (64, 5000, 0.005)])
+def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
+    from oracle import swav_ref as S
+    torch.manual_seed(n + k)
+    z = torch.nn.functional.normalize(torch.randn(n, 32), dim=1)
+    w = torch.nn.functional.normalize(torch.randn(k, 32), dim=1)
+    s = 0.4 * z @ w.t()
+    ref = S.sinkhorn_knopp(s, eps, 10, fp64=True).numpy()
+    q = ops.Sinkhorn(dev(s), eps, 10).run().codes().cpu().numpy()
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    # argmax agreement wherever the reference's top-2 gap is not a numerical tie
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    decided = (top2[:, 1] - top2[:, 0]) > 1e-2 * top2[:, 1]
+    assert (q.argmax(1) == ref.argmax(1))[decided].all()
+
+
+def test_sinkhorn_sharded_equals_single(ops):
+    """W-rank result == 1-rank result on the concatenated pixels (ranks faked)."""
+    torch.manual_seed(11)
+    n, k, eps = 1200, 24, 0.01
+    s = dev(0.3 * torch.randn(n, k))
+    single = ops.Sinkhorn(s, eps, 10).run()
+    shards = [s[i * 300:(i + 1) * 300].contiguous() for i in range(4)]
+    states = [ops.Sinkhorn(x, eps, 10, c_uniform=1.0 / n, tag=f"sk{i}") for i, x in enumerate(shards)]
+    # emulate the collectives: run the rank loops in lock-step through the reduce hook
+    import threading
+    nr = len(states)
+    barrier = threading.Barrier(nr)
+    slots = [None] * nr
+
+    def make_reduce(rank):
+        def reduce(t, op):
+            torch.cuda.synchronize()
+            slots[rank] = t.clone()
+            barrier.wait()
+            st = torch.stack(slots)
+            red = st.max(0)[0] if op == "max" else st.sum(0)
+            barrier.wait()
+            t.copy_(red)
+        return reduce
+
+    ths = [threading.Thread(target=lambda i=i: states[i].run(make_reduce(i))) for i in range(nr)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    q = torch.cat([x.codes() for x in states]).cpu().numpy()
+    ref = single.codes().cpu().numpy()
+    assert np.all(np.abs(q - ref) <= 1e-4 * ref.max(axis=1, keepdims=True))
+
+
+# ------------------------------------------------------------------------------------- CE + grads
+def test_swapped_ce_golden_gv8(ops):
+    d = load_golden("gv8_loss_grads")
+    ss, st = dev(d["scores_s"]), dev(d["scores_t"])
+    n, k = ss.shape
+    eps, tt = float(d["eps"]), float(d["temperature"])
+    sk_s = ops.Sinkhorn(ss, eps, 10).run()
+    sk_t = ops.Sinkhorn(st, eps, 10, tag="sk2").run()
+    loss = torch.zeros(1, device="cuda")
+    ds, dt = torch.empty_like(ss), torch.empty_like(st)
+    ops.swapped_ce(sk_s, sk_t, tt, 1.0 / n, loss, 1.0 / n, 0.0, ds, dt)
+    np.testing.assert_allclose(loss.item(), float(d["loss"]), rtol=1e-4)
+    # d(scores) against autograd of the oracle loss with the GOLDEN codes
+    from oracle import swav_ref as S
+    s1 = T(d["scores_s"]).clone().requires_grad_(True)
+    t1 = T(d["scores_t"]).clone().requires_grad_(True)
+    S.swapped_prediction_loss(s1 / tt, t1 / tt, T(d["q_s"]), T(d["q_t"])).backward()
+    assert rel_err(ds, s1.grad) < 1e-3
+    assert rel_err(dt, t1.grad) < 1e-3
+
+
+@pytest.mark.parametrize("n,k", [(1000, 8), (300, 700)])
+def test_swapped_ce_vs_oracle(ops, n, k):
+    from oracle import swav_ref as S
+    torch.manual_seed(n)
+    s = 0.3 * torch.randn(n, k)
+    t = s + 0.1 * torch.randn(n, k)
+    eps, tt = 0.01, 0.05
+    qs = S.sinkhorn_knopp(s, eps, 10, fp64=True)
+    qt = S.sinkhorn_knopp(t, eps, 10, fp64=True)
+    s1, t1 = s.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    ref = S.swapped_prediction_loss(s1 / tt, t1 / tt, qs, qt)
+    ref.backward()
+    sk_s = ops.Sinkhorn(dev(s), eps, 10).run()
+    sk_t = ops.Sinkhorn(dev(t), eps, 10, tag="sk2").run()
+    loss = torch.zeros(1, device="cuda")
+    ds, dt = torch.empty(n, k, device="cuda"), torch.empty(n, k, device="cuda")
+    ops.swapped_ce(sk_s, sk_t, tt, 1.0 / n, loss, 1.0 / n, 0.0, ds, dt)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-3)
+    assert rel_err(ds, s1.grad) < 1e-3 and rel_err(dt, t1.grad) < 1e-3
+
+
+# ------------------------------------------------------------------------------------- gather
+def test_gather_golden_gv5(ops):
+    d = load_golden("gv5_pixel_features")
+    taps = [T(d[f"tap_{i}"]) for i in range(4)]
+    ts = ops.TapSet([dev(t.permute(0, 2, 3, 1)) for t in taps])
+    hw = 16 * 16
+    picks = torch.randperm(hw, dtype=torch.int32).reshape(1, hw).cuda()
+    for hlen, key in ((37, "stack"), (42, "stack_full")):
+        x = ops.gather_taps(ts, picks, hlen).cpu()
+        ref = T(d[key]).reshape(hlen, hw).t()[picks.cpu().long().reshape(-1)]
+        assert torch.equal(x, ref)
+
+
+def test_gather_rotflip_batch(ops):
+    from oracle import swav_ref as S
+    torch.manual_seed(9)
+    b, hw = 3, 32
+    taps = [torch.randn(b, 8, 4, 4), torch.randn(b, 12, 16, 16), torch.randn(b, 4, 32, 32)]
+    ts = ops.TapSet([dev(t.permute(0, 2, 3, 1)) for t in taps])
+    angles, flips = [7.3, -4.1, 0.0], [True, False, True]
+    maps = torch.stack([ops.rotflip_map(a, f, hw, hw, "cuda") for a, f in zip(angles, flips)])
+    picks = torch.stack([torch.randperm(hw * hw)[:200] for _ in range(b)]).int().cuda()
+    x = ops.gather_taps(ts, picks, 24, maps).cpu().reshape(b, 200, 24)
+    img = ops.norm_map(ts, 24, maps).cpu()
+    for i in range(b):
+        omap = S.rotflip_index_map(angles[i], flips[i], hw, hw)
+        agree = (omap == maps[i].cpu().long()).float().mean()
+        assert agree > 0.999                                  # nearest-rounding ties only
+        stack = S.pixel_features([t[i:i + 1] for t in taps], 24)
+        stack = S.apply_index_map(stack, maps[i].cpu().long())   # same map -> exact gather parity
+        ref = S.sample_pixels(stack, picks[i].cpu().long(), 200)
+        assert torch.equal(x[i], ref)
+        np.testing.assert_allclose(img[i].numpy(), S.norm_map(stack)[0].numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- rows / optimizer
+def test_row_ops(ops):
+    torch.manual_seed(2)
+    z = torch.randn(1001, 512)
+    zd = dev(z.clone())
+    rn = ops.row_l2_normalize_(zd)
+    ref = torch.nn.functional.normalize(z, dim=1)
+    assert rel_err(zd, ref) < 1e-6
+    np.testing.assert_allclose(rn.cpu().numpy(), (1 / z.norm(dim=1)).numpy(), rtol=1e-5)
+    # backward of normalize
+    z1 = z.clone().requires_grad_(True)
+    g = torch.randn(1001, 512)
+    torch.nn.functional.normalize(z1, dim=1).backward(g)
+    gd = dev(g.clone())
+    ops.l2_normalize_bwd_(gd, zd, rn)
+    assert rel_err(gd, z1.grad) < 1e-5
+    assert torch.equal(ops.row_argmax(dev(z)).cpu(), z.max(1)[1])
+    out = torch.zeros(512, device="cuda")
+    ops.colsum(dev(z), out)
+    assert rel_err(out, z.double().sum(0)) < 1e-5
+
+
+def test_larc_sgd(ops):
+    from oracle import swav_ref as S
+    torch.manual_seed(4)
+    p, g = torch.randn(512, 777), torch.randn(512, 777) * 1e-3
+    pd, gd, bd = dev(p.clone()), dev(g), torch.zeros(512, 777, device="cuda")
+    bufs = [None]
+    for step in range(3):
+        bufs = S.larc_sgd_step([p], [g], bufs, lr=0.01, momentum=0.9, trust=0.01)
+        ops.larc_sgd_(pd, gd, bd, 0.01, 0.9, 0.01, first_step=(step == 0))
+        assert rel_err(pd, p) < 1e-6 and rel_err(bd, bufs[0]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------- generator layers
+def _prep_conv(weight):
+    """(1,Cout,Cin,k,k) -> wt (k*k,Cout,Cin), wsq (Cout,Cin)"""
+    w = weight[0]
+    cout, cin, k, _ = w.shape
+    return w.permute(2, 3, 0, 1).reshape(k * k, cout, cin).contiguous(), w.pow(2).sum(dim=(2, 3)).contiguous()
+
+
+def _style(ops, style, mod_w, mod_b):
+    s = ops.gemm(dev(style), dev(mod_w), False, True, alpha=1.0 / math.sqrt(mod_w.shape[1]), col_bias=dev(mod_b))
+    return s
+
+
+def test_modconv_golden_gv2(ops):
+    d = load_golden("gv2_modconv")
+    kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
+    for tag in ("plain", "up", "rgb"):
+        w = T(d[f"{tag}_weight"])
+        wt, wsq = _prep_conv(w)
+        cin, k = w.shape[2], w.shape[3]
+        scale = 1.0 / math.sqrt(cin * k * k)
+        s = _style(ops, T(d[f"{tag}_style"]), T(d[f"{tag}_mod_weight"]), T(d[f"{tag}_mod_bias"]))
+        x = dev(T(d[f"{tag}_x"]).permute(0, 2, 3, 1))
+        ref = T(d[f"{tag}_y"])
+        if tag == "plain":
+            y = ops.modconv(x, dev(wt), 3, s, ops.demod(s, dev(wsq), scale), None, None, None, act=False)
+        elif tag == "up":
+            y = ops.modconv_up(x, dev(wt), s, ops.demod(s, dev(wsq), scale), kf, None, None, None, act=False)
+        else:
+            y = ops.modconv(x, dev(wt), 1, s, None, None, None, None, act=False) * scale
+        assert rel_err(y.permute(0, 3, 1, 2), ref) < 5e-6, tag
+
+
+def test_styled_conv_and_torgb_golden_gv3(ops):
+    d = load_golden("gv3_layers")
+    kf = dev(torch.flip(T(d["up_sd_conv.blur.kernel"]), [0, 1]))
+    for tag in ("plain", "up"):
+        sd = {k[len(tag) + 4:]: T(v) for k, v in d.items() if k.startswith(f"{tag}_sd_")}
+        wt, wsq = _prep_conv(sd["conv.weight"])
+        cin = sd["conv.weight"].shape[2]
+        scale = 1.0 / math.sqrt(cin * 9)
+        s = _style(ops, T(d[f"{tag}_style"]), sd["conv.modulation.weight"], sd["conv.modulation.bias"])
+        dm = ops.demod(s, dev(wsq), scale)
+        x = dev(T(d[f"{tag}_x"]).permute(0, 2, 3, 1))
+        args = (dev(T(d[f"{tag}_noise"])), dev(sd["noise.weight"]), dev(sd["activate.bias"]))
+        y = ops.modconv(x, dev(wt), 3, s, dm, *args) if tag == "plain" else ops.modconv_up(x, dev(wt), s, dm, kf, *args)
+        assert rel_err(y.permute(0, 3, 1, 2), T(d[f"{tag}_y"])) < 5e-6, tag
+    sd = {k[7:]: T(v) for k, v in d.items() if k.startswith("rgb_sd_")}
+    w3 = sd["conv.weight"][0, :, :, 0, 0].contiguous()
+    s = _style(ops, T(d["rgb_style"]), sd["conv.modulation.weight"], sd["conv.modulation.bias"])
+    x = dev(T(d["rgb_x"]).permute(0, 2, 3, 1))
+    kfu = dev(torch.flip(sd["upsample.kernel"], [0, 1]))
+    b3 = dev(sd["bias"].reshape(3))
+    scale = 1.0 / math.sqrt(w3.shape[1])
+    y = ops.torgb(x, dev(w3), s, scale, b3, dev(T(d["rgb_skip"])), kfu)
+    assert rel_err(y, T(d["rgb_y_skip"])) < 5e-6
+    y = ops.torgb(x, dev(w3), s, scale, b3, None, None)
+    assert rel_err(y, T(d["rgb_y_noskip"])) < 5e-6
+
+
+def test_mapping_pieces_golden_gv3(ops):
+    d = load_golden("gv3_layers")
+    x = T(d["el_x"])
+    assert rel_err(ops.pixel_norm(dev(x)), T(d["pn_y"])) < 1e-6
+    y = ops.gemm(dev(x), dev(d["el_weight"]), False, True)
+    ops.bias_act_(y, alpha=0.01 / math.sqrt(16), bias=dev(d["el_bias"]), bscale=0.01, act=True)
+    assert rel_err(y, T(d["el_y"])) < 1e-5
+
+
+def test_modconv_ffhq_shapes(ops):
+    """A real-width layer (512->512 @ 16x16, batch 2) against the oracle."""
+    from oracle import stylegan2_ref as G
+    torch.manual_seed(21)
+    b, cin, cout, h = 2, 512, 512, 16
+    w = torch.randn(1, cout, cin, 3, 3)
+    mod_w, mod_b = torch.randn(cin, 512), torch.ones(cin)
+    x, style = torch.randn(b, cin, h, h), torch.randn(b, 512)
+    blur = G.fir_kernel() * 4
+    wt, wsq = _prep_conv(w)
+    scale = 1.0 / math.sqrt(cin * 9)
+    s = _style(ops, style, mod_w, mod_b)
+    dm = ops.demod(s, dev(wsq), scale)
+    xd = dev(x.permute(0, 2, 3, 1))
+    y = ops.modconv(xd, dev(wt), 3, s, dm, None, None, None, act=False)
+    ref = G.modulated_conv(x, style, w, mod_w, mod_b)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
+    y = ops.modconv_up(xd, dev(wt), s, dm, dev(torch.flip(blur, [0, 1])), None, None, None, act=False)
+    ref = G.modulated_conv(x, style, w, mod_w, mod_b, upsample=True, blur_kernel=blur)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
