@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pretrain images/sec of the per-pixel SwAV path (ffhq-256, hfc_with_swav).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one optimizer step of the hot path over one batch of synthetic latents on every
+rank: draws -> 2 views (generator taps) -> 5 patches x {gather, projection, prototypes,
+Sinkhorn, swapped CE, backward} -> LARC-SGD.  Workload = BASELINE.json configs[1]
+(ffhq-256 hfc_with_swav, 8 prototypes, batch 16 per GPU); random-init generator weights
+under seed 42 and random latents (no checkpoints exist offline).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, dense v_mfma_f32_32x32x2_f32
+PEAK_HBM = 8.0e12
+
+
+class ModelCfg:
+    num_latents_for_mean = 4096
+    truncation = 0.7
+    latent_dim = 512
+
+
+def workload(batch, nproto, size=256, patch=20000, scope="global"):
+    layer_hf_dim = [512, 1024, 1024, 1024, 1024, 512, 256] if size == 256 else None
+    hlen = 5376
+    return dict(
+        perturb_args=dict(truncation=0.7, n_layers=6, n_samples=1, layer_no=None, perturb_std=[1.0] * 6),
+        swav_args=dict(num_epochs=1, num_samples=1, num_patches=5, sampling_method="random", patch_size=patch,
+                       hf_interp="nearest", warmup_epochs=1, start_warmup=0.01, use_scheduler=False, base_lr=0.01,
+                       final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9),
+                       projn_nw="linear", temperature=0.01, nprototypes=nproto, nclasses=512, hlen=hlen,
+                       add_local_loss=False, plot_test_images=False, epoch_print_freq=5, max_masks=4,
+                       batch_size=batch, sinkhorn_scope=scope),
+        sinkhorn_args=dict(source_pdf="uniform", niters=10, eps=0.005),
+        layer_hf_dim=layer_hf_dim)
+
+
+def build_generator(size, device):
+    from ganecdotes_amd.generator import Generator
+    torch.manual_seed(42)
+    g = Generator(size, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)        # init is 0 => the noise path would be untested (SURVEY par. 8d)
+    return g.eval().to(device)
+
+
+def cpu_baseline(nproto, threads):
+    """The oracle (CPU restatement of the reference op sequence) timed on the host cores on a
+    bounded sample of the same workload: both views of ONE image at full size + ONE of the 5
+    patches forward/backward; images/s = 1 / (t_views + 5 * t_patch)."""
+    from oracle import stylegan2_ref as G
+    from oracle import swav_ref as S
+    from ganecdotes_amd.generator import Generator
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    g = Generator(256, 512, 8)
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    for k in sd:
+        if k.endswith("noise.weight"):
+            sd[k].fill_(0.1)
+    del g
+    with torch.no_grad():
+        ml = G.mean_latent(sd, 256, 512)
+    proj_w, _ = S.init_linear_like_torch(512, 5376, False)
+    proto_w, proto_b = S.init_linear_like_torch(nproto, 512, True)
+    im = S.draw_image_reference_order(512, 13, 6, 256 * 256, 1, transforms=True)
+    t0 = time.time()
+    with torch.no_grad():
+        w = G.mapping(im.z, sd)
+        stacks = [S.make_view(sd, w, ml, 0.7, vd, 5376)[0] for vd in im.views]
+        _ = [S.norm_map(s) for s in stacks]
+    t_views = time.time() - t0
+    t0 = time.time()
+    leaves = [proj_w.requires_grad_(True), proto_w.requires_grad_(True), proto_b.requires_grad_(True)]
+    sc = [S.codes(S.sample_pixels(s, im.picks[0], 20000), *leaves) for s in stacks]
+    with torch.no_grad():
+        q = [S.sinkhorn_knopp(s, 0.005, 10) for s in sc]
+    loss = S.swapped_prediction_loss(sc[0] / 0.01, sc[1] / 0.01, q[0], q[1])
+    loss.backward()
+    t_patch = time.time() - t0
+    return dict(value=1.0 / (t_views + 5.0 * t_patch), unit="images/s", cores=threads, kind="port",
+                sample=f"1 image: 2 views at 256x256 ({t_views:.1f} s) + 1 of 5 patches fwd+bwd at N=20000 "
+                       f"({t_patch:.1f} s), extrapolated to 5 patches; oracle (torch CPU fp32, "
+                       f"{threads} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--prototypes", type=int, default=8)
+    ap.add_argument("--scope", default="global", choices=["global", "image"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    g = build_generator(256, dev)
+    wl = workload(args.batch, args.prototypes, scope=args.scope)
+    sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
+    torch.manual_seed(42 + rank)
+    np.random.seed(42 + rank)
+    sw.build_heads()
+    if world > 1:   # replicated heads: rank 0's init everywhere
+        import torch.distributed as dist
+        for p in sw._params():
+            dist.broadcast(p, 0)
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sw.train_step(sw.draw_batch(args.batch))
+    sw.kernel_events = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = sw.train_step(sw.draw_batch(args.batch))
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    images = args.steps * args.batch * world
+
+    # dominant kernel: the projection GEMM z = X Wp^T (fp32 MFMA), timed with HIP events on the
+    # launch stream inside the timed region
+    ev = sw.kernel_events.get("proj_fwd", [])
+    roof = None
+    if ev:
+        ms = [a.elapsed_time(b) for a, b in ev]
+        rows = args.batch * 20000
+        flops = 2.0 * rows * 5376 * 512
+        ach = flops / (np.mean(ms) * 1e-3)
+        roof = dict(bound="mfma", achieved=ach / 1e12, peak=PEAK_F32_MFMA / 1e12, unit="TFLOP/s",
+                    frac=ach / PEAK_F32_MFMA, traffic=None, kernel="gemm_f32_kernel<NT> (projection fwd)",
+                    launches=len(ms), avg_ms=float(np.mean(ms)),
+                    others={k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in
+                            sw.kernel_events.items() if k != "proj_fwd"})
+    out = {
+        "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
+                               f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
+                               f"T=0.01, sinkhorn_scope={args.scope}",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": float(loss.item())},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.prototypes, max(1, min(os.cpu_count() or 1, 16)))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,7 @@ Extensions over the reference (opt-in `swav_args` keys, defaults = reference beh
 Multi-GPU: pass `dist_group` (torch.distributed, backend nccl = RCCL); images shard over
 ranks, the Sinkhorn column sums / maxima and the parameter gradients are all-reduced.
 """
+import contextlib
 import math
 import os
 import time
@@ -88,6 +89,19 @@ class SwAVClustering(object):
         self.layer_hf_dim = layer_hf_dim
         self._bufs = None
         self._step_no = 0
+        self.kernel_events = None       # bench.py: {tag: [(start, end) HIP events]} when a dict
+
+    @contextlib.contextmanager
+    def _timed(self, tag):
+        """HIP-event bracket on the launch stream (only when bench.py asks for it)."""
+        if self.kernel_events is None:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.kernel_events.setdefault(tag, []).append((a, b))
 
     # ------------------------------------------------------------------------------------- modules
     def build_heads(self):
@@ -210,7 +224,8 @@ class SwAVClustering(object):
         # S7: prototype rows to unit norm (bias untouched)
         ops.row_l2_normalize_(Wc, want_rnorm=False)
 
-        views = self.make_views(images)
+        with self._timed("views"):
+            views = self.make_views(images)
         hw = views[0][0].size
         if N is None or N >= hw * hw:
             N = hw * hw
@@ -231,8 +246,10 @@ class SwAVClustering(object):
             picks = torch.stack([im.picks[pno][:N] for im in images]).to(torch.int32).to(dev)
             X, Zh, Rn, Sc = [], [], [], []
             for ts, maps, _ in views:
-                x = ops.gather_taps(ts, picks, hlen, maps)                     # (B*N, hlen)
-                z = ops.gemm(x, Wp, False, True)                               # (B*N, D)
+                with self._timed("gather"):
+                    x = ops.gather_taps(ts, picks, hlen, maps)                 # (B*N, hlen)
+                with self._timed("proj_fwd"):
+                    z = ops.gemm(x, Wp, False, True)                           # (B*N, D)
                 rn = ops.row_l2_normalize_(z)                                  # z -> z_hat
                 sc = ops.gemm(z, Wc, False, True, col_bias=bc)                 # (B*N, K)
                 X.append(x); Zh.append(z); Rn.append(rn); Sc.append(sc)
@@ -264,7 +281,8 @@ class SwAVClustering(object):
                 ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
                 dz = ops.gemm(dS[v], Wc, False, False)                         # (B*N, D)
                 ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
-                ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
+                with self._timed("proj_dW"):
+                    ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
                 first_acc = False
             del X, Zh, Rn, Sc, dS
         if self.world > 1:
