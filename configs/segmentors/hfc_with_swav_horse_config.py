@@ -1,0 +1,5 @@
+"""Segmentor / preprocessor config (plugin surface; values follow the reference's
+configs/segmentors/hfc_with_swav_horse_config.py)."""
+from ganecdotes_amd.config_defaults import BAGGAN_256_HF_DIM, swav_segmentor
+
+globals().update(swav_segmentor(5000, 0.003, 'XXS', num_epochs=50))

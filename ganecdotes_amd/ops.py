@@ -293,23 +293,35 @@ class Sinkhorn:
             _lib.check(L.gx_sinkhorn(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r), _p(self.c),
                                      _p(self.la), _p(self.ws), self.wsb, _stream()), "gx_sinkhorn")
             return self
-        _lib.check(L.gx_sinkhorn_colmax(_p(S), self.rows, K, S.stride(0), _p(self.ws), self.wsb, _stream()),
+        from .sharded import run_sinkhorn
+        return run_sinkhorn(self, self.niters, reduce)
+
+    # --- kernel object interface of sharded.run_sinkhorn ---
+    def colmax(self):
+        S = self.S
+        _lib.check(lib().gx_sinkhorn_colmax(_p(S), self.rows, self.K, S.stride(0), _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_colmax")
-        if reduce is not None:
-            cm = torch.empty(K, dtype=torch.float32, device=S.device)
-            _lib.check(L.gx_sinkhorn_cmax_get(_p(self.ws), K, _p(cm), _stream()), "gx_sinkhorn_cmax_get")
-            reduce(cm, "max")
-            _lib.check(L.gx_sinkhorn_cmax_set(_p(self.ws), K, _p(cm), _stream()), "gx_sinkhorn_cmax_set")
-        u = self.ws[K:2 * K]
-        for it in range(self.niters):
-            _lib.check(L.gx_sinkhorn_pass(_p(S), self.rows, K, S.stride(0), self.eps, int(it == 0), _p(self.la),
+
+    def cmax_get(self):
+        cm = torch.empty(self.K, dtype=torch.float32, device=self.S.device)
+        _lib.check(lib().gx_sinkhorn_cmax_get(_p(self.ws), self.K, _p(cm), _stream()), "gx_sinkhorn_cmax_get")
+        return cm
+
+    def cmax_set(self, cm):
+        _lib.check(lib().gx_sinkhorn_cmax_set(_p(self.ws), self.K, _p(cm), _stream()), "gx_sinkhorn_cmax_set")
+
+    def sweep(self, first):
+        S = self.S
+        _lib.check(lib().gx_sinkhorn_pass(_p(S), self.rows, self.K, S.stride(0), self.eps, int(first), _p(self.la),
                                           _p(self.c), self.c_uniform, None, _p(self.ws), self.wsb, _stream()),
-                       "gx_sinkhorn_pass")
-            if reduce is not None:
-                reduce(u, "sum")
-            _lib.check(L.gx_sinkhorn_update(_p(u), _p(self.r), K, int(it == 0), _p(self.ws), self.eps, _p(self.la),
-                                            _stream()), "gx_sinkhorn_update")
-        return self
+                   "gx_sinkhorn_pass")
+
+    def colsums(self):
+        return self.ws[self.K:2 * self.K]
+
+    def update(self, first):
+        _lib.check(lib().gx_sinkhorn_update(_p(self.colsums()), _p(self.r), self.K, int(first), _p(self.ws), self.eps,
+                                            _p(self.la), _stream()), "gx_sinkhorn_update")
 
     def codes(self):
         q = torch.empty(self.rows, self.K, dtype=torch.float32, device=self.S.device)

@@ -1,0 +1,60 @@
+"""Multi-GPU protocol of the hot path (SURVEY.md par. 8e): one process per GPU, images sharded
+over ranks, prototypes / projection replicated.
+
+Backend-agnostic host logic: the collectives and their order live here; the per-rank compute
+is supplied by a kernel object (HIP: `ops.Sinkhorn`; the gloo CPU tests plug in a torch
+stand-in), so the N>1 control flow is exercised by world_size-2 tests without a GPU.
+
+Exchange steps (everything else is rank-local):
+  Sinkhorn, per call :  all_reduce(MAX) of the K column maxima, then per iteration one
+                        all_reduce(SUM) of the K column sums (20 KB at K=5000; latency-bound)
+  optimizer step     :  one all_reduce(SUM) of the flattened {dWp, dWc, db, loss}
+"""
+import torch
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for `rank`; sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def make_reduce(group):
+    """reduce(tensor, 'max'|'sum') -> in-place all-reduce over `group` (RCCL on GPUs, gloo in tests)."""
+    import torch.distributed as dist
+
+    def reduce(t, op):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=group)
+    return reduce
+
+
+def run_sinkhorn(k, niters, reduce=None):
+    """Drive one log-domain Sinkhorn over a row-sharded score matrix.
+
+    `k` provides: colmax() ; cmax_get() -> tensor(K) ; cmax_set(tensor) ; sweep(first: bool) ;
+    colsums() -> tensor(K) view that update() reads ; update(first: bool).
+    With reduce=None it is the single-rank algorithm (no exchange)."""
+    k.colmax()
+    if reduce is not None:
+        cm = k.cmax_get()
+        reduce(cm, "max")
+        k.cmax_set(cm)
+    for it in range(niters):
+        k.sweep(it == 0)
+        if reduce is not None:
+            reduce(k.colsums(), "sum")
+        k.update(it == 0)
+    return k
+
+
+def allreduce_flat(tensors, group):
+    """Sum-all-reduce a list of tensors as ONE message (gradients + loss: 21 MB at K=5000)."""
+    import torch.distributed as dist
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, group=group)
+    o = 0
+    for t in tensors:
+        t.copy_(flat[o:o + t.numel()].reshape(t.shape))
+        o += t.numel()
+    return tensors

@@ -31,7 +31,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, sharded
 from .draws import ImageDraws, draw_image
 
 
@@ -191,8 +191,9 @@ class SwAVClustering(object):
 
     # ------------------------------------------------------------------------------------- collectives
     def _reduce(self, t, op):
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.dist_group)
+        if getattr(self, "_reduce_fn", None) is None:
+            self._reduce_fn = sharded.make_reduce(self.dist_group)
+        self._reduce_fn(t, op)
 
     # ------------------------------------------------------------------------------------- one step
     def _marginals(self, img, k, nrows):
@@ -286,13 +287,7 @@ class SwAVClustering(object):
                 first_acc = False
             del X, Zh, Rn, Sc, dS
         if self.world > 1:
-            import torch.distributed as dist
-            flat = torch.cat([g.reshape(-1) for g in self._grads] + [loss])
-            dist.all_reduce(flat, group=self.dist_group)
-            o = 0
-            for g in self._grads:
-                g.copy_(flat[o:o + g.numel()].reshape(g.shape)); o += g.numel()
-            loss.copy_(flat[o:o + 1])
+            sharded.allreduce_flat(list(self._grads) + [loss], self.dist_group)
         # S8: LARC + momentum SGD
         lr = sa['train_args']['lr']
         mom = sa['train_args'].get('momentum', 0.0)

@@ -1,0 +1,109 @@
+"""N>1 control flow on CPU: world_size-2 gloo processes drive the product's sharding protocol
+(ganecdotes_amd/sharded.py) with a torch stand-in for the per-rank HIP kernels; the result must
+equal the 1-rank oracle on the concatenated pixels (SURVEY.md par. 8e)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ganecdotes_amd import sharded
+
+
+class TorchSinkhornKernels:
+    """CPU stand-in with the interface sharded.run_sinkhorn expects (same maths as
+    csrc/gx_swav.hip: colmax / first pass / sweep / update in the log domain)."""
+
+    def __init__(self, scores, eps, n_global):
+        self.S, self.eps, self.K = scores, eps, scores.shape[1]
+        self.cmax = None
+        self.la = torch.zeros(self.K)
+        self.u = torch.zeros(self.K)
+        self.logc = float(np.log(1.0 / n_global))
+
+    def colmax(self):
+        self.cmax = self.S.max(0)[0]
+
+    def cmax_get(self):
+        return self.cmax.clone()
+
+    def cmax_set(self, cm):
+        self.cmax = cm
+
+    def sweep(self, first):
+        if first:
+            self.u.copy_(torch.exp((self.S - self.cmax) / self.eps).sum(0))
+        else:
+            w = self.S / self.eps + self.la
+            lb = self.logc - torch.logsumexp(w, dim=1, keepdim=True)
+            self.u.copy_(torch.exp(w + lb).sum(0))
+
+    def colsums(self):
+        return self.u
+
+    def update(self, first):
+        base = -self.cmax / self.eps if first else self.la
+        self.la = base + float(np.log(1.0 / self.K)) - torch.log(self.u)
+
+    def codes(self):
+        return torch.softmax(self.S / self.eps + self.la, dim=1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scores, eps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharded.shard_range(scores.shape[0], rank, world)
+    k = TorchSinkhornKernels(scores[lo:hi].clone(), eps, scores.shape[0])
+    sharded.run_sinkhorn(k, 10, sharded.make_reduce(dist.group.WORLD))
+    q = k.codes()
+    # gradient message: every rank contributes rank+1 -> sum = 3 everywhere
+    g = [torch.full((3, 4), float(rank + 1)), torch.full((5,), float(rank + 1)), torch.tensor([float(rank + 1)])]
+    sharded.allreduce_flat(g, dist.group.WORLD)
+    assert all(bool((t == 3.0).all()) for t in g)
+    out[rank] = (lo, hi, q.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 16, 33):
+        for w in (1, 2, 3, 8):
+            spans = [sharded.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_sinkhorn_two_ranks_equals_oracle_on_concatenation():
+    from oracle import swav_ref as S
+    torch.manual_seed(5)
+    n, k, eps = 301, 24, 0.02
+    scores = 0.3 * torch.randn(n, k)
+    ref = S.sinkhorn_knopp(scores, eps, 10, fp64=True).numpy()
+    # single-rank run of the same protocol
+    k1 = TorchSinkhornKernels(scores.clone(), eps, n)
+    sharded.run_sinkhorn(k1, 10, None)
+    q1 = k1.codes().numpy()
+    assert np.all(np.abs(q1 - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, scores, eps, out), nprocs=2, join=True)
+    q = np.zeros_like(ref)
+    for r in range(2):
+        lo, hi, qr = out[r]
+        q[lo:hi] = qr
+    assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+    np.testing.assert_allclose(q, q1, rtol=2e-4, atol=1e-7)

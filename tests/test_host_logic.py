@@ -64,3 +64,66 @@ def test_product_path_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_registry_and_config_surface():
+    """configs/mapper.py keys and the attribute names of the config modules = plugin surface
+    (reference: configs/mapper.py:9-67, hfc_with_swav_ffhq_config.py:1-78, ffhq_256.py:3-35)."""
+    from configs import mapper
+    from lib.util.util import load_config
+    for key in ('hfc_with_swav', 'hfc_with_swav_ffhq', 'hfc_with_swav_cat', 'hfc_with_swav_car',
+                'hfc_with_swav_horse', 'hfc_with_swav_pidray', 'hfc_with_simclr'):
+        cfg = load_config(mapper.segmentors[key], 'seg_config')
+        for attr in ('hfc_prep_args', 'seg_args', 'train_hfc', 'n_layers', 'n_hfc_layers', 'layer_hf_dim', 'hlen',
+                     'nclasses'):
+            assert hasattr(cfg, attr), (key, attr)
+        assert set(cfg.hfc_prep_args) >= {'perturb_args', 'train', 'layer_hf_dim'}
+    expect = {'hfc_with_swav_ffhq': (5000, 0.005, 'uniform', 'XXS', 5376), 'hfc_with_swav_cat': (5000, 0.003, 'image', 'XS', 5376),
+              'hfc_with_swav_car': (4000, 0.01, 'uniform', 'XS', 5376), 'hfc_with_swav_horse': (5000, 0.003, 'uniform', 'XXS', 5376),
+              'hfc_with_swav_pidray': (4000, 0.005, 'uniform', 'XXS', 2528), 'hfc_with_swav': (8000, 0.005, 'uniform', 'XXS', 5376)}
+    for key, (k, eps, pdf, size, hlen) in expect.items():
+        cfg = load_config(mapper.segmentors[key], 'seg_config')
+        sa, sk = cfg.hfc_prep_args['swav_args'], cfg.hfc_prep_args['sinkhorn_args']
+        assert (sa['nprototypes'], sk['eps'], sk['source_pdf'], cfg.seg_args['size'], sa['hlen']) == (k, eps, pdf, size, hlen)
+        assert sa['patch_size'] == 20000 and sa['num_patches'] == 5 and sk['niters'] == 10 and sa['temperature'] == 0.01
+        assert set(sa) >= {'num_epochs', 'num_samples', 'sampling_method', 'hf_interp', 'warmup_epochs', 'start_warmup',
+                           'use_scheduler', 'base_lr', 'final_lr', 'trust_coeff', 'train_args', 'projn_nw',
+                           'nclasses', 'add_local_loss', 'plot_test_images', 'epoch_print_freq', 'max_masks'}
+    for key in ('ffhq-256', 'cat-256', 'car-512', 'horse-256', 'afhq-256', 'pidray-256'):
+        m = load_config(mapper.models[key], 'model_config')
+        for attr in ('num_latents_for_mean', 'truncation', 'image_size', 'latent_dim', 'gen_args', 'is_baggan',
+                     'sample_latents', 'sample_labels', 'one_shot_ind', 'classes'):
+            assert hasattr(m, attr), (key, attr)
+    assert set(mapper.losses) == {'bce', 'softmax', 'sigmoid', 'tanh', 'logloss', 'cross_entropy'}
+    assert set(mapper.lr_scheduler) == {'step', 'plateau', 'cosine'} and 'supervised' in mapper.trainer
+
+
+def test_cli_method_remap():
+    import pretrain, evaluate
+    assert pretrain.remap('hfc_with_swav', 'ffhq-256') == 'hfc_with_swav_ffhq'
+    assert pretrain.remap('hfc_with_swav', 'cat-256') == 'hfc_with_swav_cat'
+    assert pretrain.remap('hfc_with_swav', 'car-512') == 'hfc_with_swav_car'
+    assert pretrain.remap('hfc_with_swav', 'horse-256') == 'hfc_with_swav_horse'
+    assert pretrain.remap('hfc_with_swav', 'pidray-hammer-256') == 'hfc_with_swav_pidray'
+    assert pretrain.remap('hfc_with_swav', 'afhq-256') == 'hfc_with_swav'
+    assert evaluate.remap('hfc_with_simclr', 'ffhq-256') == 'hfc_with_simclr'
+
+
+def test_plugin_exports_and_generator_state_dict_keys():
+    import hfc_with_swav.base as base
+    from models.stylegan2.model import Generator
+    assert base.preprocessor.__name__ == 'SwAVClustering' and base.segmentor.__name__ == 'OneShotSegmentor'
+    for m in ('preprocess', 'pretrain', 'predict_swav_codes'):
+        assert callable(getattr(base.preprocessor, m))
+    g = Generator(256, 512, 8)
+    keys = set(g.state_dict())
+    assert len(keys) == 135          # SURVEY par. 8b: 135 entries at 256^2
+    for k in ('style.1.weight', 'style.8.bias', 'input.input', 'conv1.conv.weight', 'conv1.conv.modulation.weight',
+              'conv1.noise.weight', 'conv1.activate.bias', 'to_rgb1.bias', 'convs.0.conv.blur.kernel',
+              'convs.11.activate.bias', 'to_rgbs.5.upsample.kernel', 'noises.noise_12'):
+        assert k in keys, k
+    assert g.state_dict()['conv1.conv.weight'].shape == (1, 512, 512, 3, 3)
+    assert g.state_dict()['input.input'].shape == (1, 512, 4, 4)
+    seg = base.segmentor(512, 8, 'XXS')
+    assert [type(l).__name__ for l in seg.layers] == ['Conv2d']
+    assert len(base.segmentor(512, 8, 'XS').layers) == 5
