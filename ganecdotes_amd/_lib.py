@@ -24,6 +24,11 @@ SIGNATURES = {
     "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "gx_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p,
                           c_sz, c_p]),
+    "gx_gemm_f32_cat": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p]),
+    "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "gx_sumpool2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "gx_gather_rows_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "gx_normalize_bwd_scatter": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),

@@ -21,6 +21,9 @@ struct GemmArgs {
     float* slab;          // split-K partials [splits][M][N] (raw sums) or nullptr
     int vec_ok;
     int tiles_m, tiles_n;
+    // optional second A source, concatenated along K after the first K1 columns (A = [A | A2]);
+    // K1 is a multiple of BK (K1 == K when unused).  Non-transposed A only.
+    const float* A2; long lda2; int K1;
 };
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
@@ -41,9 +44,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     zero_acc(acc);
     f32x4 ra[4], rb[4];
 
+    auto load_a = [&](int k0) {
+        if (TA || k0 < g.K1) load_tile<A_KC>(g.A, g.lda, m0, g.M, k0, TA ? kend : min(kend, g.K1), ra, tid, vec);
+        else load_tile<A_KC>(g.A2, g.lda2, m0, g.M, k0 - g.K1, kend - g.K1, ra, tid, vec);
+    };
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (nkt > 0) {
-        load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, ra, tid, vec);
+        load_a(kbeg);
         load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid, vec);
         store_tile<A_KC>(lds, ra, tid);
         store_tile<B_KC>(lds + TILE_FLOATS, rb, tid);
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         float* Bs = As + TILE_FLOATS;
         const bool more = (t + 1 < nkt);
         if (more) {   // issue next tile's global loads before the MFMA phase (latency hides under it)
-            load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kend, ra, tid, vec);
+            load_a(kbeg + (t + 1) * BK);
             load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, rb, tid, vec);
         }
         mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
@@ -113,12 +120,15 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int sp
 static int launch_gemm(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
                        long ldb, float* C, long ldc, float alpha, float beta, const float* row_scale,
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
+    g.A2 = A2; g.lda2 = lda2; g.K1 = (A2 ? K1 : K);
+    if (A2 && (transA || K1 <= 0 || K1 >= K || (K1 % BK) != 0 || lda2 <= 0)) return GX_ERR_BAD_ARG;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
-    g.vec_ok = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0);
+    g.vec_ok = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
+               (lda2 % 4 == 0);
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -160,6 +170,17 @@ int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lon
                 int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
                            split_k, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// C = alpha * [A1 | A2] opB + ... : A1 is [M][K1], A2 is [M][K2]; K1 must be a multiple of 32.
+// (two same-resolution feature taps contracted against adjacent column blocks of the
+// projection weight in one launch)
+int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                    const float* B, long ldb, float* C, long ldc, float alpha, float beta, const float* col_bias,
+                    void* stream) {
+    if (!A2 || K2 <= 0) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(0, transB, M, N, K1 + K2, A1, lda1, B, ldb, C, ldc, alpha, beta, nullptr, col_bias, 1,
+                           nullptr, 0, (hipStream_t)stream, A2, lda2, K1);
 }
 
 }  // extern "C"

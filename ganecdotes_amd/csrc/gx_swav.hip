@@ -702,3 +702,138 @@ int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* sc
 }
 
 }  // extern "C"
+
+// ============================================================================================
+// Pyramid projection (factorised S1+S2+S3): the projection commutes with the
+// nearest-neighbour upsampling, so each tap is projected ONCE at its native resolution,
+//   P_j = sum_{taps l at resolution r_j} tap_l Wp[:, cols_l]^T        (fp32-MFMA GEMMs)
+//   Z_j = P_j + up2(Z_{j-1})                                          (gx_upsample2_add)
+// and the projected descriptor of a sampled pixel is ONE row of the full-resolution table Z_J.
+// Backward is the adjoint: scatter-add d z rows into G_J, G_{j-1} = sumpool2(G_j), then
+// dWp[:, cols_l] += G_j^T tap_l.
+namespace gx {
+
+// fine[b][y][x][:] += coarse[b][y/2][x/2][:]     fine is (2rc x 2rc), float4 over D
+__global__ void upsample2_add_kernel(const float* __restrict__ coarse, float* __restrict__ fine, int B, int rc,
+                                     int D) {
+    const int d4n = D >> 2, rf = 2 * rc;
+    const long total = (long)B * rf * rf * d4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % d4n) * 4;
+        const long pix = i / d4n;
+        const int x = (int)(pix % rf), y = (int)((pix / rf) % rf), b = (int)(pix / ((long)rf * rf));
+        const f32x4 c = *reinterpret_cast<const f32x4*>(coarse + (((long)b * rc + (y >> 1)) * rc + (x >> 1)) * D + d);
+        f32x4* f = reinterpret_cast<f32x4*>(fine + pix * D + d);
+        *f = *f + c;
+    }
+}
+
+// coarse[b][y][x][:] = sum of the 2x2 block of fine (fixed order)
+__global__ void sumpool2_kernel(const float* __restrict__ fine, float* __restrict__ coarse, int B, int rc, int D) {
+    const int d4n = D >> 2, rf = 2 * rc;
+    const long total = (long)B * rc * rc * d4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % d4n) * 4;
+        const long pix = i / d4n;
+        const int x = (int)(pix % rc), y = (int)((pix / rc) % rc), b = (int)(pix / ((long)rc * rc));
+        const float* f = fine + (((long)b * rf + 2 * y) * rf + 2 * x) * D + d;
+        const f32x4 s = (*reinterpret_cast<const f32x4*>(f) + *reinterpret_cast<const f32x4*>(f + D)) +
+                        (*reinterpret_cast<const f32x4*>(f + (long)rf * D) +
+                         *reinterpret_cast<const f32x4*>(f + (long)rf * D + D));
+        *reinterpret_cast<f32x4*>(coarse + pix * D + d) = s;
+    }
+}
+
+// zhat[row] = normalize(Z[b][src(pick[row])]) (zero row where the rotation zero-filled), rnorm[row].
+// One wave per row.
+__global__ void gather_rows_normalize_kernel(const float* __restrict__ Z, int HW, int D, const int* __restrict__ picks,
+                                             const int* __restrict__ maps, int rows_per_img, long rows,
+                                             float* __restrict__ zhat, float* __restrict__ rnorm) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(row / rows_per_img);
+    int pix = picks[row];
+    if (maps) pix = maps[(long)b * HW + pix];
+    float* out = zhat + row * D;
+    if (pix < 0) {
+        for (int c = lane; c < D; c += 64) out[c] = 0.f;
+        if (lane == 0) rnorm[row] = 1e12f;
+        return;
+    }
+    const float* src = Z + ((long)b * HW + pix) * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = src[c]; s = fmaf(v, v, s); }
+    s = gx_wave_sum(s);
+    const float rn = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < D; c += 64) out[c] = src[c] * rn;
+    if (lane == 0) rnorm[row] = rn;
+}
+
+// G[b][src(pick[row])][:] += rnorm * (dzh - zh <zh, dzh>)   (normalise-backward fused with the
+// adjoint of the row gather; float atomics, 256 contiguous bytes per wave-instruction)
+__global__ void normalize_bwd_scatter_kernel(const float* __restrict__ dzh, const float* __restrict__ zh,
+                                             const float* __restrict__ rnorm, int HW, int D,
+                                             const int* __restrict__ picks, const int* __restrict__ maps,
+                                             int rows_per_img, long rows, float* __restrict__ G) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(row / rows_per_img);
+    int pix = picks[row];
+    if (maps) pix = maps[(long)b * HW + pix];
+    if (pix < 0) return;                       // zero-filled pixel: X row is 0, no gradient reaches Wp
+    const float* gp = dzh + row * D;
+    const float* zp = zh + row * D;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot = fmaf(gp[c], zp[c], dot);
+    dot = gx_wave_sum(dot);
+    const float rn = rnorm[row];
+    const bool clamped = rn >= 1e12f;
+    float* dst = G + ((long)b * HW + pix) * D;
+    for (int c = lane; c < D; c += 64) atomicAdd(dst + c, clamped ? gp[c] * rn : rn * (gp[c] - zp[c] * dot));
+}
+
+}  // namespace gx
+
+extern "C" {
+
+int gx_upsample2_add(const float* coarse, float* fine, int B, int rc, int D, void* stream) {
+    if (!coarse || !fine || B <= 0 || rc <= 0 || D <= 0 || (D & 3)) return GX_ERR_BAD_ARG;
+    const long total = (long)B * 4 * rc * rc * (D >> 2);
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(gx::upsample2_add_kernel, dim3((int)(want < 16384 ? want : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, coarse, fine, B, rc, D);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_sumpool2(const float* fine, float* coarse, int B, int rc, int D, void* stream) {
+    if (!coarse || !fine || B <= 0 || rc <= 0 || D <= 0 || (D & 3)) return GX_ERR_BAD_ARG;
+    const long total = (long)B * rc * rc * (D >> 2);
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(gx::sumpool2_kernel, dim3((int)(want < 16384 ? want : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, fine, coarse, B, rc, D);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
+                             float* zhat, float* rnorm, void* stream) {
+    if (!Z || !picks || !zhat || !rnorm || B <= 0 || HW <= 0 || D <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
+    const long rows = (long)B * rows_per_img;
+    hipLaunchKernelGGL(gx::gather_rows_normalize_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, Z,
+                       HW, D, picks, maps, rows_per_img, rows, zhat, rnorm);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float* rnorm, int B, int HW, int D,
+                             const int* picks, int rows_per_img, const int* maps, float* G, void* stream) {
+    if (!dzhat || !zhat || !rnorm || !picks || !G || B <= 0 || HW <= 0 || D <= 0 || rows_per_img <= 0)
+        return GX_ERR_BAD_ARG;
+    const long rows = (long)B * rows_per_img;
+    hipLaunchKernelGGL(gx::normalize_bwd_scatter_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       dzhat, zhat, rnorm, HW, D, picks, maps, rows_per_img, rows, G);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // extern "C"

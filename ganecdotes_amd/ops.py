@@ -50,11 +50,22 @@ def workspace(tag, nbytes, device):
 
 
 # ------------------------------------------------------------------------------------- GEMM
+def _chk2d(*ts):
+    """2-D fp32 HIP tensors with unit inner stride (row-strided views such as W[:, a:b] are fine)."""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError("expected a 2-D float32 HIP tensor with unit inner stride")
+
+
 def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
          split_k=1):
     """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
-    op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K)."""
-    _chk(a, b, out, row_scale, col_bias)
+    op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K).
+    a, b, out may be row-strided views (leading dimension = stride(0))."""
+    _chk2d(a, b, out)
+    _chk(row_scale, col_bias)
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     if k != kb:
@@ -74,6 +85,59 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
                              out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws), wsb,
                              _stream()), "gx_gemm_f32")
     return out
+
+
+def gemm_cat(a1, a2, b, out, trans_b=True, alpha=1.0, beta=0.0):
+    """out = alpha * [a1 | a2] @ op(b) + beta*out; a1 (M,K1), a2 (M,K2), K1 % 32 == 0."""
+    _chk2d(a1, a2, b, out)
+    m, k1 = a1.shape
+    k2 = a2.shape[1]
+    n = b.shape[0] if trans_b else b.shape[1]
+    if a2.shape[0] != m or tuple(out.shape) != (m, n) or (b.shape[1] if trans_b else b.shape[0]) != k1 + k2:
+        raise RuntimeError("gemm_cat: shape mismatch")
+    _lib.check(lib().gx_gemm_f32_cat(int(trans_b), m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), a2.stride(0), _p(b),
+                                     b.stride(0), _p(out), out.stride(0), alpha, beta, None, _stream()),
+               "gx_gemm_f32_cat")
+    return out
+
+
+# ------------------------------------------------------------------------------------- pyramid projection
+def upsample2_add_(coarse, fine):
+    """fine (B, 2r, 2r, D) += nearest-upsampled coarse (B, r, r, D)."""
+    _chk(coarse, fine)
+    b, r, _, d = coarse.shape
+    _lib.check(lib().gx_upsample2_add(_p(coarse), _p(fine), b, r, d, _stream()), "gx_upsample2_add")
+    return fine
+
+
+def sumpool2(fine):
+    """(B, 2r, 2r, D) -> (B, r, r, D) sums of 2x2 blocks (adjoint of upsample2_add_)."""
+    _chk(fine)
+    b, rf, _, d = fine.shape
+    out = torch.empty(b, rf // 2, rf // 2, d, dtype=torch.float32, device=fine.device)
+    _lib.check(lib().gx_sumpool2(_p(fine), _p(out), b, rf // 2, d, _stream()), "gx_sumpool2")
+    return out
+
+
+def gather_rows_normalize(z, picks, maps=None):
+    """z (B, H, W, D) table; picks (B, N) int32 -> zhat (B*N, D) L2-normalised rows, rnorm (B*N)."""
+    _chk(z)
+    b, h, w, d = z.shape
+    n = picks.shape[1]
+    zhat = torch.empty(b * n, d, dtype=torch.float32, device=z.device)
+    rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
+    _lib.check(lib().gx_gather_rows_normalize(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(zhat), _p(rn), _stream()),
+               "gx_gather_rows_normalize")
+    return zhat, rn
+
+
+def normalize_bwd_scatter_(dzhat, zhat, rnorm, picks, maps, g):
+    """g (B, H, W, D) += scatter of normalize-backward(dzhat) rows (float atomics)."""
+    _chk(dzhat, zhat, rnorm, g)
+    b, h, w, d = g.shape
+    _lib.check(lib().gx_normalize_bwd_scatter(_p(dzhat), _p(zhat), _p(rnorm), b, h * w, d, _p(picks), picks.shape[1],
+                                              _p(maps), _p(g), _stream()), "gx_normalize_bwd_scatter")
+    return g
 
 
 # ------------------------------------------------------------------------------------- generator pieces

@@ -15,6 +15,9 @@ not the reference's op chain but hand-written gfx950 kernels reached through the
   S7/S8      : row normalise, LARC-SGD
 
 Extensions over the reference (opt-in `swav_args` keys, defaults = reference behaviour):
+  projection_mode 'pyramid' (default: project every tap once at native resolution, see
+                  pyramid.py) or 'panel' (gather the sampled descriptors and run the reference's
+                  N x 5376 GEMM per view-patch)
   batch_size      images per optimizer step on this rank (reference: 1)
   sinkhorn_scope  'image' (per-image Sinkhorn, == reference steps with gradient averaging) or
                   'global' (Sinkhorn over all pixels of the global batch, SURVEY.md par. 8e)
@@ -33,6 +36,7 @@ from torch import nn
 
 from . import ops, sharded
 from .draws import ImageDraws, draw_image
+from .pyramid import Pyramid
 
 
 class _NullLogger:
@@ -243,17 +247,28 @@ class SwAVClustering(object):
         gscale = 1.0 / (N * P * Bg)
         first_acc = True
         aux = {}
+        mode = sa.get('projection_mode', 'pyramid')
+        if mode == 'pyramid':
+            with self._timed("pyramid_fwd"):
+                pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
+                Zt = [p.project(Wp) for p in pyr]                              # (B, H, W, D) per view
+            Gt = [torch.zeros_like(z) for z in Zt]
         for pno in range(P):
             picks = torch.stack([im.picks[pno][:N] for im in images]).to(torch.int32).to(dev)
             X, Zh, Rn, Sc = [], [], [], []
-            for ts, maps, _ in views:
-                with self._timed("gather"):
-                    x = ops.gather_taps(ts, picks, hlen, maps)                 # (B*N, hlen)
-                with self._timed("proj_fwd"):
-                    z = ops.gemm(x, Wp, False, True)                           # (B*N, D)
-                rn = ops.row_l2_normalize_(z)                                  # z -> z_hat
+            for v, (ts, maps, _) in enumerate(views):
+                if mode == 'pyramid':
+                    with self._timed("gather_rows"):
+                        z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
+                else:
+                    with self._timed("gather"):
+                        x = ops.gather_taps(ts, picks, hlen, maps)             # (B*N, hlen)
+                    with self._timed("proj_fwd"):
+                        z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
+                    rn = ops.row_l2_normalize_(z)                              # z -> z_hat
+                    X.append(x)
                 sc = ops.gemm(z, Wc, False, True, col_bias=bc)                 # (B*N, K)
-                X.append(x); Zh.append(z); Rn.append(rn); Sc.append(sc)
+                Zh.append(z); Rn.append(rn); Sc.append(sc)
             dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
             if scope == 'global':
                 groups = [(0, rows)]
@@ -275,17 +290,26 @@ class SwAVClustering(object):
                 if return_aux and pno == 0 and r0 == 0:
                     aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
                                q_s=sk[0].codes(), q_t=sk[1].codes())
-            # S6: backward GEMMs (gradients accumulate over views and patches)
+            # S6: backward (gradients accumulate over views and patches)
             for v in range(2):
                 beta = 0.0 if first_acc else 1.0
                 ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                 ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
-                dz = ops.gemm(dS[v], Wc, False, False)                         # (B*N, D)
-                ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
-                with self._timed("proj_dW"):
-                    ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
+                dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)
+                if mode == 'pyramid':
+                    with self._timed("scatter_rows"):
+                        ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])
+                else:
+                    ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
+                    with self._timed("proj_dW"):
+                        ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
                 first_acc = False
             del X, Zh, Rn, Sc, dS
+        if mode == 'pyramid':
+            with self._timed("pyramid_bwd"):
+                for v in range(2):
+                    pyr[v].backward(Gt[v], gWp, accumulate=(v > 0))
+            del Zt, Gt
         if self.world > 1:
             sharded.allreduce_flat(list(self._grads) + [loss], self.dist_group)
         # S8: LARC + momentum SGD
@@ -367,10 +391,13 @@ class SwAVClustering(object):
                                 truncation_latent=self.mean_latent, input_is_latent=True, randomize_noise=False)
         ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
         hw = ts.size
-        picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
-        x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
         wp = self.projection[0].weight.data
-        z = ops.gemm(x, wp, False, True)                                       # (b*h*w, D) == NHWC
+        if self.swav_args.get('projection_mode', 'pyramid') == 'pyramid':
+            z = Pyramid(ts, self.swav_args['hlen']).project(wp).reshape(ts.B * hw * hw, -1)
+        else:
+            picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
+            x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
+            z = ops.gemm(x, wp, False, True)                                   # (b*h*w, D) == NHWC
         labels = ops.row_argmax(z).reshape(ts.B, hw, hw)
         preds = z.reshape(ts.B, hw, hw, wp.shape[0]).permute(0, 3, 1, 2)
         return preds, labels

@@ -44,6 +44,12 @@ int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lon
                 float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                 int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
+/* C = alpha * [A1 | A2] opB + col_bias + beta*C with A1 [M][K1] and A2 [M][K2] side by side along K
+ * (K1 % 32 == 0): two same-resolution taps against adjacent column blocks of the projection. */
+int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                    const float* B, long ldb, float* C, long ldc, float alpha, float beta, const float* col_bias,
+                    void* stream);
+
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110
  * gx_bias_act        EqualLinear epilogue / fused_leaky_relu     model.py:32-43, :242-252;
@@ -88,6 +94,20 @@ int gx_gather_taps(int ntaps, const float* const* tap_ptrs /*host array of devic
 int gx_row_sumsq(const float* x, long rows, int cused, long ld, float* out, void* stream);
 int gx_norm_map(int ntaps, const float* const* ss_ptrs /*host array*/, const int* tap_res /*host*/, const int* maps,
                 int B, int H, int W, float* img, void* stream);
+
+/* ---- pyramid projection: S1+S2+S3 factorised through the nearest-upsampling ---------
+ * The projection (swav_clustering.py:171) commutes with F.interpolate(nearest) (:123): project each
+ * tap at native resolution, gx_upsample2_add the levels into one full-resolution table Z
+ * ([B][H*W][D]); a sampled pixel's projected descriptor is one row of Z:
+ *   gx_gather_rows_normalize  zhat[row] = normalize(Z[b][map_b[picks[row]]]) (0 where filled), rnorm
+ *   gx_normalize_bwd_scatter  G[b][map_b[picks[row]]] += normalize-backward(dzhat[row])   (atomics)
+ *   gx_sumpool2               adjoint of gx_upsample2_add (G_{j-1} = 2x2 sums of G_j) */
+int gx_upsample2_add(const float* coarse, float* fine, int B, int rc, int D, void* stream);
+int gx_sumpool2(const float* fine, float* coarse, int B, int rc, int D, void* stream);
+int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
+                             float* zhat, float* rnorm, void* stream);
+int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float* rnorm, int B, int HW, int D,
+                             const int* picks, int rows_per_img, const int* maps, float* G, void* stream);
 
 /* ---- projection / prototype helpers ---------------------------------------------------------
  * gx_row_l2_normalize   F.normalize(p=2, dim=1) in place, rnorm out     swav_clustering.py:174

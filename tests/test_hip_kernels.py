@@ -256,6 +256,60 @@ def test_gather_rotflip_batch(ops):
         np.testing.assert_allclose(img[i].numpy(), S.norm_map(stack)[0].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_gemm_cat_and_strided_views(ops):
+    torch.manual_seed(8)
+    m, k1, k2, n = 300, 64, 40, 72
+    a1, a2 = torch.randn(m, k1), torch.randn(m, k2 + 8)
+    w = torch.randn(n, 500)
+    out = torch.empty(m, n, device="cuda")
+    wd = dev(w)
+    ops.gemm_cat(dev(a1), dev(a2)[:, :k2], wd[:, 100:100 + k1 + k2], out)
+    ref = torch.cat([a1, a2[:, :k2]], 1).double() @ w[:, 100:100 + k1 + k2].double().t()
+    assert rel_err(out, ref) < 3e-6
+    # TN with a column-sliced output (gradient block of the projection weight)
+    g, t = torch.randn(700, 48), torch.randn(700, 96)
+    gw = torch.zeros(48, 500, device="cuda")
+    ops.gemm(dev(g), dev(t)[:, :80], True, False, out=gw[:, 200:280], split_k=3)
+    assert rel_err(gw[:, 200:280], g.double().t() @ t[:, :80].double()) < 3e-6
+    assert float(gw[:, :200].abs().max()) == 0 and float(gw[:, 280:].abs().max()) == 0
+
+
+def test_pyramid_pieces(ops):
+    torch.manual_seed(12)
+    b, r, d = 2, 8, 24
+    coarse, fine = torch.randn(b, r, r, d), torch.randn(b, 2 * r, 2 * r, d)
+    fd = dev(fine.clone())
+    ops.upsample2_add_(dev(coarse), fd)
+    up = coarse.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert torch.equal(fd.cpu(), fine + up)
+    pooled = ops.sumpool2(dev(fine)).cpu()
+    ref = fine.reshape(b, r, 2, r, 2, d).sum(dim=(2, 4))
+    assert rel_err(pooled, ref) < 1e-6
+    # adjointness <up(c), f> == <c, pool(f)>
+    assert abs(float((up * fine).sum()) - float((coarse * ref).sum())) < 1e-3
+    # gather + normalise and its scatter adjoint
+    hw = 2 * r
+    z = dev(fine)
+    picks = torch.stack([torch.randperm(hw * hw)[:100] for _ in range(b)]).int().cuda()
+    maps = torch.stack([ops.rotflip_map(9.0, True, hw, hw, "cuda"), ops.rotflip_map(-3.0, False, hw, hw, "cuda")])
+    zh, rn = ops.gather_rows_normalize(z, picks, maps)
+    src = torch.gather(maps.cpu().long(), 1, picks.cpu().long())                    # (b, 100)
+    flat = fine.reshape(b, hw * hw, d)
+    rows = torch.stack([flat[i][src[i].clamp(min=0)] * (src[i] >= 0).float()[:, None] for i in range(b)])
+    ref = torch.nn.functional.normalize(rows.reshape(-1, d), dim=1)
+    assert rel_err(zh, ref) < 1e-6
+    gin = torch.randn(b * 100, d)
+    x1 = rows.reshape(-1, d).clone().requires_grad_(True)
+    torch.nn.functional.normalize(x1, dim=1).backward(gin)
+    gfull = torch.zeros(b, hw, hw, d, device="cuda")
+    ops.normalize_bwd_scatter_(dev(gin), zh, rn, picks, maps, gfull)
+    want = torch.zeros(b, hw * hw, d)
+    for i in range(b):
+        ok = src[i] >= 0
+        want[i].index_add_(0, src[i][ok], x1.grad.reshape(b, 100, d)[i][ok])
+    assert rel_err(gfull.reshape(b, hw * hw, d), want) < 1e-5
+
+
 # ------------------------------------------------------------------------------------- rows / optimizer
 def test_row_ops(ops):
     torch.manual_seed(2)

@@ -160,15 +160,17 @@ def test_pretrain_trajectory_golden_gv10_and_predict_gv11(gpu, tmp_path):
 
 
 # ------------------------------------------------------------------------------------- one step vs oracle
+@pytest.mark.parametrize("mode", ["pyramid", "panel"])
 @pytest.mark.parametrize("scope,batch,pdf", [("image", 1, "uniform"), ("image", 2, "uniform"),
                                              ("global", 3, "uniform"), ("image", 1, "image")])
-def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf):
+def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
     from oracle import swav_ref as S
     from ganecdotes_amd.draws import draw_image
     d = load_golden("gv10_pretrain")
     sd = golden_sd(d)
     g = mini_gen(sd, gpu)
-    sw = make_swav(g, gpu, tmp_path, sinkhorn_scope=scope, batch_size=batch, sinkhorn_args=dict(source_pdf=pdf))
+    sw = make_swav(g, gpu, tmp_path, sinkhorn_scope=scope, batch_size=batch, projection_mode=mode,
+                   sinkhorn_args=dict(source_pdf=pdf))
     torch.manual_seed(123)
     np.random.seed(123)
     ml = S.G.mean_latent(sd, 64, 16)
@@ -194,6 +196,44 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf):
             assert rel(got, want) < 2e-3
         for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
             assert rel(got, want) < 1e-4
+
+
+def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path):
+    """Full-width 64x64 generator (512-channel taps, hlen cutting the last tap): the pyramid
+    projection and the reference-shaped panel GEMM give the same loss / gradients / predictions."""
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.generator import Generator
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.manual_seed(3)
+    np.random.seed(3)
+    g = Generator(64, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)
+    g = g.eval().to(gpu)
+
+    class C:
+        num_latents_for_mean, truncation, latent_dim = 128, 0.7, 512
+    hlen = 512 * 8 + 300                                   # cuts inside the last 64x64 tap
+    out = {}
+    imgs = [draw_image(512, 9, 4, 64 * 64, 2) for _ in range(2)]
+    wlat = g.style(torch.randn(1, 512, device="cuda"))
+    for mode in ("panel", "pyramid"):
+        a = toy_args(projection_mode=mode, hlen=hlen, nclasses=64, nprototypes=40, patch_size=1500,
+                     sinkhorn_scope="global", temperature=0.1)
+        a["perturb_args"] = dict(truncation=0.7, n_layers=4, n_samples=1, layer_no=None, perturb_std=[1.0] * 4)
+        a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.05)
+        sw = SwAVClustering(model=g, model_config=C, out_dir=None, device="cuda", **a)
+        torch.manual_seed(11)
+        sw.build_heads()
+        loss = sw.train_step(imgs)
+        preds, labels = sw.predict_swav_codes(wlat)
+        out[mode] = (loss.item(), [x.clone() for x in sw._grads], preds.clone(), labels.clone())
+    np.testing.assert_allclose(out["pyramid"][0], out["panel"][0], rtol=1e-4)
+    for a, b in zip(out["pyramid"][1], out["panel"][1]):
+        assert rel(a, b) < 1e-3
+    assert rel(out["pyramid"][2], out["panel"][2]) < 1e-4
+    assert (out["pyramid"][3] == out["panel"][3]).float().mean() > 0.999
 
 
 def test_no_cpu_fallback(tmp_path):
