@@ -139,13 +139,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import queue
+    import threading
+
+    def feed(n):
+        """Background producer: host draws (reference RNG order) + pinned upload of batch i+1
+        overlap the kernels of batch i.  Started INSIDE the timed region for the timed steps."""
+        q = queue.Queue(maxsize=2)
+
+        def run():
+            for _ in range(n):
+                q.put(sw.prepare_batch(sw.draw_batch(args.batch)))
+        threading.Thread(target=run, daemon=True).start()
+        return q
+
+    q = feed(args.warmup)
     for _ in range(args.warmup):
-        sw.train_step(sw.draw_batch(args.batch))
+        sw.train_step(q.get())
     sw.kernel_events = {}
     sync()
     t0 = time.perf_counter()
+    q = feed(args.steps)
     for _ in range(args.steps):
-        loss = sw.train_step(sw.draw_batch(args.batch))
+        loss = sw.train_step(q.get())
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -158,6 +174,11 @@ def main():
     # dominant kernel: the projection GEMM z = X Wp^T (fp32 MFMA), timed with HIP events on the
     # launch stream inside the timed region
     ev = sw.kernel_events.get("proj_fwd", [])
+    if os.environ.get("GX_BENCH_EVENTS"):
+        for k, v in sw.kernel_events.items():
+            ms = [a.elapsed_time(b) for a, b in v]
+            print(f"# {k:14s} n={len(ms):4d} avg={np.mean(ms):9.3f} ms total/step={np.sum(ms) / args.steps:9.2f} ms",
+                  file=sys.stderr)
     roof = None
     if ev:
         ms = [a.elapsed_time(b) for a, b in ev]

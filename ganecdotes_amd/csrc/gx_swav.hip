@@ -171,14 +171,29 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, long rows, in
         part[(long)blockIdx.x * K + k] = s;
     }
 }
-// out[k] = alpha * sum_b part[b][k] + beta * out[k]
+// out[k] = alpha * sum_b part[b][k] + beta * out[k].  Block = kx columns x (256/kx) partial
+// groups: coalesced across k, fixed-order tree over the groups (bitwise reproducible).
 __global__ void partial_reduce_kernel(const float* __restrict__ part, int nblk, int K, float alpha, float beta,
-                                      float* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+                                      float* __restrict__ out, int kx) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x % kx, ty = threadIdx.x / kx, ny = blockDim.x / kx;
+    const int k = blockIdx.x * kx + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * K + k];
-    out[k] = alpha * s + (beta != 0.f ? beta * out[k] : 0.f);
+    if (k < K) for (int b = ty; b < nblk; b += ny) s += part[(long)b * K + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = ny >> 1; h > 0; h >>= 1) {
+        if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * kx];
+        __syncthreads();
+    }
+    if (ty == 0 && k < K) out[k] = alpha * red[tx] + (beta != 0.f ? beta * out[k] : 0.f);
+}
+static inline void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out,
+                                         hipStream_t stream) {
+    int kx = 1;
+    while (kx < 64 && kx < K) kx <<= 1;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx), dim3(256), 0, stream, part, nblk, K, alpha,
+                       beta, out, kx);
 }
 
 // ===================================================================== S4: Sinkhorn-Knopp
@@ -530,8 +545,7 @@ int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta
     const int nb = (int)((rows < GX_RED_BLOCKS) ? rows : GX_RED_BLOCKS);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, K, ld, workspace);
     GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nb,
-                       K, alpha, beta, out);
+    launch_partial_reduce(workspace, nb, K, alpha, beta, out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -597,8 +611,7 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
         hipLaunchKernelGGL((sk_pass_kernel<false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, S, rows, K, ld,
                            team, 1.f / eps, (const unsigned*)workspace, la, c, c_uniform, lb_out, part);
     GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, part, nb, K,
-                       1.f, 0.f, u);
+    launch_partial_reduce(part, nb, K, 1.f, 0.f, u, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -651,8 +664,7 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
     hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Ss, St, rows, K, ld, team,
                        1.f / eps, 1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd, workspace);
     GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nb, 1, loss_scale,
-                       loss_beta, loss_out);
+    launch_partial_reduce(workspace, nb, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -667,7 +679,7 @@ int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t worksp
     const int nb = (int)(want < GX_RED_BLOCKS ? want : GX_RED_BLOCKS);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, workspace);
     GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nb, 1, 1.f, 0.f, out);
+    launch_partial_reduce(workspace, nb, 1, 1.f, 0.f, out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

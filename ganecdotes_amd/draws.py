@@ -28,23 +28,30 @@ class ImageDraws:
 
 
 def draw_image(style_dim, gen_num_layers, n_perturb_layers, hw, num_patches, transforms=True, degrees=10.0,
-               layer_no=None, discard_noise=True):
-    """One image's draws in reference order: z (swav_clustering.py:323); per view the
-    `gen_num_layers` noise maps of the discarded first generator call (models/stylegan2/
-    model.py:380 via swav_clustering.py:603-607; consumed and thrown away when
-    `discard_noise`), `np.random.choice` of the layer (:611), 2*n_perturb_layers mapping noises
-    (lib/oneshot/image_augmentor.py:47, only two are used); rotation angle then flip for s,
-    then for t (:358-359); one randperm per patch (:388)."""
+               layer_no=None, cpu_reference_rng=False):
+    """One image's draws in reference order: z (swav_clustering.py:323); per view
+    `np.random.choice` of the layer (:611) and the mapping noises of the two perturbed latents
+    (lib/oneshot/image_augmentor.py:47); rotation angle then flip for s, then for t (:358-359);
+    one randperm per patch (:388).
+
+    On a GPU the reference draws the per-layer noise maps of its discarded first generator call
+    (models/stylegan2/model.py:380) and all 2*n_perturb_layers mapping noises from the DEVICE
+    generator, so they never touch the host RNG stream.  `cpu_reference_rng=True` reproduces the
+    host stream of a CPU run of the reference instead (noise maps drawn and thrown away, all
+    2*n_perturb_layers mapping noises drawn): that is what the golden fixtures were captured with."""
     z = torch.randn(1, style_dim)
     views = []
     for _ in range(2):
-        if discard_noise:
+        if cpu_reference_rng:
             for i in range(gen_num_layers):
                 r = 2 ** ((i + 5) // 2)
                 torch.empty(1, 1, r, r).normal_()
         lno = layer_no if layer_no is not None else int(np.random.choice(list(range(n_perturb_layers))))
-        maps = [torch.randn(1, style_dim) for _ in range(2 * n_perturb_layers)]
-        views.append(ViewDraws(lno, torch.cat([maps[2 * lno], maps[2 * lno + 1]], 0)))
+        if cpu_reference_rng:
+            maps = [torch.randn(1, style_dim) for _ in range(2 * n_perturb_layers)]
+            views.append(ViewDraws(lno, torch.cat([maps[2 * lno], maps[2 * lno + 1]], 0)))
+        else:
+            views.append(ViewDraws(lno, torch.randn(2, style_dim)))
     if transforms:
         for v in views:
             v.angle = float(torch.empty(1).uniform_(-degrees, degrees).item())

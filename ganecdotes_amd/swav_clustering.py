@@ -21,7 +21,8 @@ Extensions over the reference (opt-in `swav_args` keys, defaults = reference beh
   batch_size      images per optimizer step on this rank (reference: 1)
   sinkhorn_scope  'image' (per-image Sinkhorn, == reference steps with gradient averaging) or
                   'global' (Sinkhorn over all pixels of the global batch, SURVEY.md par. 8e)
-  use_larc, transforms   switches used by parity tests
+  use_larc, transforms, cpu_reference_rng   switches used by parity tests (the last one makes
+                  the host RNG stream that of a CPU run of the reference, see draws.py)
 Multi-GPU: pass `dist_group` (torch.distributed, backend nccl = RCCL); images shard over
 ranks, the Sinkhorn column sums / maxima and the parameter gradients are all-reduced.
 """
@@ -37,6 +38,12 @@ from torch import nn
 from . import ops, sharded
 from .draws import ImageDraws, draw_image
 from .pyramid import Pyramid
+
+
+class PreparedBatch:
+    """Device-side form of a batch of ImageDraws: staged through pinned host memory and copied
+    on a side stream, so drawing / uploading step i+1 overlaps the kernels of step i."""
+    __slots__ = ("n", "z", "map_noise", "mix", "xforms", "picks", "ready", "_keep")
 
 
 class _NullLogger:
@@ -140,39 +147,99 @@ class SwAVClustering(object):
         return x.reshape(ts.B, ts.size, ts.size, -1).permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------------------------- views
-    def _view_latents(self, w, vds):
+    def prepare_batch(self, images):
+        """Pack a list of ImageDraws into two pinned staging buffers (floats, int32 picks) and
+        upload them with non-blocking copies on a side stream."""
+        if isinstance(images, PreparedBatch):
+            return images
+        sa = self.swav_args
+        B, S, nl = len(images), self.model.style_dim, self.model.n_latent
+        hw = self.model.size * self.model.size
+        N = sa['patch_size']
+        N = hw if (N is None or N >= hw) else N
+        P = len(images[0].picks)
+        nf = B * S + 2 * (2 * B * S) + 2 * (B * nl * 2)
+        if not hasattr(self, "_staging"):
+            self._staging, self._stage_i, self._copy_stream = {}, 0, torch.cuda.Stream(device=self.device)
+        key = (nf, P * B * N)
+        ring = self._staging.setdefault(key, [])
+        if len(ring) < 3:
+            ring.append([torch.empty(nf, dtype=torch.float32).pin_memory(),
+                         torch.empty(max(1, P * B * N), dtype=torch.int32).pin_memory(), None])
+            slot = ring[-1]
+        else:
+            slot = ring[self._stage_i % 3]
+            self._stage_i += 1
+            if slot[2] is not None:
+                slot[2].synchronize()              # its previous upload has been consumed
+        hf, hi, _ = slot
+        o = 0
+        hf[o:o + B * S].view(B, S).copy_(torch.cat([im.z for im in images], 0)); o += B * S
+        for v in range(2):
+            hf[o:o + 2 * B * S].view(2 * B, S).copy_(torch.cat([im.views[v].map_noise for im in images], 0))
+            o += 2 * B * S
+        for v in range(2):
+            mix = hf[o:o + B * nl * 2].view(B, nl, 2)
+            mix.zero_()
+            for b, im in enumerate(images):
+                vd = im.views[v]
+                sig = float(self.perturb_args['perturb_std'][vd.layer_no])
+                mix[b, 2 * vd.layer_no, 0] = sig
+                mix[b, 2 * vd.layer_no + 1, 1] = sig
+            o += B * nl * 2
+        if P:
+            hi.view(P, B, N).copy_(torch.stack([torch.stack([im.picks[p][:N] for im in images]) for p in range(P)]))
+        pb = PreparedBatch()
+        pb.n = B
+        with torch.cuda.stream(self._copy_stream):
+            df = hf.to(self.device, non_blocking=True)
+            di = hi.to(self.device, non_blocking=True)
+            pb.ready = torch.cuda.Event()
+            pb.ready.record()
+        slot[2] = pb.ready
+        o = 0
+        pb.z = df[o:o + B * S].view(B, S); o += B * S
+        pb.map_noise = []
+        for v in range(2):
+            pb.map_noise.append(df[o:o + 2 * B * S].view(2 * B, S)); o += 2 * B * S
+        pb.mix = []
+        for v in range(2):
+            pb.mix.append(df[o:o + B * nl * 2].view(B, nl, 2)); o += B * nl * 2
+        pb.picks = di[:P * B * N].view(P, B, N) if P else None
+        pb.xforms = [[(im.views[v].angle, im.views[v].flip) for im in images] for v in range(2)]
+        pb._keep = (df, di)
+        return pb
+
+    def _view_latents(self, w, map_noise, mix):
         """Latents of the feature-producing forward for a batch of images and ONE view each
-        (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents."""
+        (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents;
+        map_noise (2B,S); mix (B, n_latent, 2) = sigma at the two perturbed latents:
+        lat[b, 2l+j] = (1-sigma) lat + sigma style(noise_j)."""
         n_latent = self.model.n_latent
-        psi = self.truncation
-        lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(psi))
+        lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation))
         lat = lat.unsqueeze(1).repeat(1, n_latent, 1)
-        noise = torch.cat([vd.map_noise for vd in vds], 0).to(self.device)          # (2B, S)
-        nw = self.model.style(noise).reshape(len(vds), 2, -1)
-        for b, vd in enumerate(vds):
-            sig = float(self.perturb_args['perturb_std'][vd.layer_no])
-            for j in range(2):
-                n = 2 * vd.layer_no + j
-                lat[b, n] = (1.0 - sig) * lat[b, n] + sig * nw[b, j]
-        return lat
+        nw = self.model.style(map_noise).reshape(w.shape[0], 2, -1)
+        keep = 1.0 - mix.sum(dim=2, keepdim=True)
+        return lat * keep + torch.einsum('blj,bjs->bls', mix, nw)
 
     def make_views(self, images):
-        """Both views of a batch of ImageDraws -> per view (TapSet, maps or None, image)."""
-        z = torch.cat([im.z for im in images], 0).to(self.device)
-        w = self.model.style(z)
+        """Both views of a batch (list of ImageDraws or PreparedBatch) ->
+        per view (TapSet, maps or None, image)."""
+        pb = self.prepare_batch(images)
+        torch.cuda.current_stream().wait_event(pb.ready)
+        w = self.model.style(pb.z)
         out = []
         for v in range(2):
-            vds = [im.views[v] for im in images]
-            lat = self._view_latents(w, vds)
+            lat = self._view_latents(w, pb.map_noise[v], pb.mix[v])
             img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
                                     input_is_latent=True, randomize_noise=False)
             ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
             maps = None
-            if any(vd.angle is not None for vd in vds):
+            if any(a is not None for a, _ in pb.xforms[v]):
                 hw = ts.size
-                maps = torch.empty(len(vds), hw * hw, dtype=torch.int32, device=self.device)
-                for b, vd in enumerate(vds):
-                    ops.rotflip_map(vd.angle or 0.0, vd.flip, hw, hw, self.device, out=maps[b])
+                maps = torch.empty(pb.n, hw * hw, dtype=torch.int32, device=self.device)
+                for b, (a, f) in enumerate(pb.xforms[v]):
+                    ops.rotflip_map(a or 0.0, f, hw, hw, self.device, out=maps[b])
             out.append((ts, maps, img))
         return out
 
@@ -188,7 +255,10 @@ class SwAVClustering(object):
         im = draw_image(sd, self.model.num_layers, self.perturb_args['n_layers'], 1, 0, transforms=False,
                         layer_no=layer_no)
         vd = im.views[0]
-        lat = self._view_latents(w.reshape(1, sd), [vd])
+        mix = torch.zeros(1, self.model.n_latent, 2)
+        sig = float(self.perturb_args['perturb_std'][vd.layer_no])
+        mix[0, 2 * vd.layer_no, 0] = mix[0, 2 * vd.layer_no + 1, 1] = sig
+        lat = self._view_latents(w.reshape(1, sd), vd.map_noise.to(self.device), mix.to(self.device))
         img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
                                 input_is_latent=True, randomize_noise=False)
         return self.create_pixel_feature_vectors(feats), img, vd.layer_no
@@ -220,7 +290,8 @@ class SwAVClustering(object):
         T = sa['temperature']
         scope = sa.get('sinkhorn_scope', 'image')
         use_larc = sa.get('use_larc', True)
-        B = len(images)
+        pb = self.prepare_batch(images)
+        B = pb.n
         Bg = B * self.world
         Wp, Wc, bc = self._params()
         D, K = Wp.shape[0], Wc.shape[0]
@@ -230,7 +301,7 @@ class SwAVClustering(object):
         ops.row_l2_normalize_(Wc, want_rnorm=False)
 
         with self._timed("views"):
-            views = self.make_views(images)
+            views = self.make_views(pb)
         hw = views[0][0].size
         if N is None or N >= hw * hw:
             N = hw * hw
@@ -254,7 +325,7 @@ class SwAVClustering(object):
                 Zt = [p.project(Wp) for p in pyr]                              # (B, H, W, D) per view
             Gt = [torch.zeros_like(z) for z in Zt]
         for pno in range(P):
-            picks = torch.stack([im.picks[pno][:N] for im in images]).to(torch.int32).to(dev)
+            picks = pb.picks[pno]
             X, Zh, Rn, Sc = [], [], [], []
             for v, (ts, maps, _) in enumerate(views):
                 if mode == 'pyramid':
@@ -337,7 +408,8 @@ class SwAVClustering(object):
         hw = self.model.size * self.model.size
         return [draw_image(self.model.style_dim, self.model.num_layers, self.perturb_args['n_layers'], hw,
                            sa['num_patches'], transforms=sa.get('transforms', True),
-                           layer_no=self.perturb_args['layer_no']) for _ in range(batch)]
+                           layer_no=self.perturb_args['layer_no'],
+                           cpu_reference_rng=sa.get('cpu_reference_rng', False)) for _ in range(batch)]
 
     def pretrain(self, input_latent, num_test_samples=5):
         """Self-supervised pretraining loop (swav_clustering.py:205-505): num_epochs x num_samples

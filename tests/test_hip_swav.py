@@ -134,7 +134,7 @@ def test_views_golden_gv9(gpu, tmp_path):
 def test_pretrain_trajectory_golden_gv10_and_predict_gv11(gpu, tmp_path):
     d = load_golden("gv10_pretrain")
     g = mini_gen(golden_sd(d), gpu)
-    sw = make_swav(g, gpu, tmp_path, use_larc=False, transforms=False)
+    sw = make_swav(g, gpu, tmp_path, use_larc=False, transforms=False, cpu_reference_rng=True)
     torch.manual_seed(42)
     np.random.seed(42)
     z = torch.randn(64, 16)                              # the reference constructor's mean_latent draw
@@ -179,7 +179,7 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
     params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
     bufs = [None] * 3
     for step in range(2):
-        images = [draw_image(16, 7, 3, 32 * 32, 2, transforms=True, discard_noise=False) for _ in range(batch)]
+        images = [draw_image(16, 7, 3, 32 * 32, 2, transforms=True) for _ in range(batch)]
         # the device rotate/flip map and the oracle's may differ on nearest-rounding ties only;
         # parity of everything downstream is checked on identical draws
         loss = sw.train_step(images)
@@ -218,12 +218,14 @@ def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path):
     out = {}
     imgs = [draw_image(512, 9, 4, 64 * 64, 2) for _ in range(2)]
     wlat = g.style(torch.randn(1, 512, device="cuda"))
+    ml = g.mean_latent(128)
     for mode in ("panel", "pyramid"):
         a = toy_args(projection_mode=mode, hlen=hlen, nclasses=64, nprototypes=40, patch_size=1500,
                      sinkhorn_scope="global", temperature=0.1)
         a["perturb_args"] = dict(truncation=0.7, n_layers=4, n_samples=1, layer_no=None, perturb_std=[1.0] * 4)
         a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.05)
         sw = SwAVClustering(model=g, model_config=C, out_dir=None, device="cuda", **a)
+        sw.mean_latent = ml
         torch.manual_seed(11)
         sw.build_heads()
         loss = sw.train_step(imgs)
