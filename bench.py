@@ -41,7 +41,7 @@ def workload(batch, nproto, size=256, patch=20000, scope="global"):
                        final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9),
                        projn_nw="linear", temperature=0.01, nprototypes=nproto, nclasses=512, hlen=hlen,
                        add_local_loss=False, plot_test_images=False, epoch_print_freq=5, max_masks=4,
-                       batch_size=batch, sinkhorn_scope=scope),
+                       batch_size=batch, sinkhorn_scope=scope, pick_source="device"),
         sinkhorn_args=dict(source_pdf="uniform", niters=10, eps=0.005),
         layer_hf_dim=layer_hf_dim)
 
@@ -112,6 +112,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))   # the box's CPU share
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
@@ -196,7 +197,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
-                               f"T=0.01, sinkhorn_scope={args.scope}",
+                               f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = first N of a random permutation drawn on "
+                               f"the device generator",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": float(loss.item())},
         "roofline": roof,

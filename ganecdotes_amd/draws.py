@@ -56,5 +56,5 @@ def draw_image(style_dim, gen_num_layers, n_perturb_layers, hw, num_patches, tra
         for v in views:
             v.angle = float(torch.empty(1).uniform_(-degrees, degrees).item())
             v.flip = bool(torch.rand(1) < 0.5)
-    picks = [torch.randperm(hw) for _ in range(num_patches)]
+    picks = [torch.randperm(hw) for _ in range(num_patches)] if num_patches > 0 else []
     return ImageDraws(z, views, picks)

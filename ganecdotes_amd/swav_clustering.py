@@ -21,6 +21,8 @@ Extensions over the reference (opt-in `swav_args` keys, defaults = reference beh
   batch_size      images per optimizer step on this rank (reference: 1)
   sinkhorn_scope  'image' (per-image Sinkhorn, == reference steps with gradient averaging) or
                   'global' (Sinkhorn over all pixels of the global batch, SURVEY.md par. 8e)
+  pick_source     'host' (torch.randperm on the host generator, the reference's stream) or
+                  'device' (same distribution, drawn on the device generator: no host work)
   use_larc, transforms, cpu_reference_rng   switches used by parity tests (the last one makes
                   the host RNG stream that of a CPU run of the reference, see draws.py)
 Multi-GPU: pass `dist_group` (torch.distributed, backend nccl = RCCL); images shard over
@@ -158,6 +160,7 @@ class SwAVClustering(object):
         N = sa['patch_size']
         N = hw if (N is None or N >= hw) else N
         P = len(images[0].picks)
+        dev_picks = (P == 0 and sa.get('pick_source', 'host') == 'device')
         nf = B * S + 2 * (2 * B * S) + 2 * (B * nl * 2)
         if not hasattr(self, "_staging"):
             self._staging, self._stage_i, self._copy_stream = {}, 0, torch.cuda.Stream(device=self.device)
@@ -206,6 +209,15 @@ class SwAVClustering(object):
         for v in range(2):
             pb.mix.append(df[o:o + B * nl * 2].view(B, nl, 2)); o += B * nl * 2
         pb.picks = di[:P * B * N].view(P, B, N) if P else None
+        if dev_picks:
+            # picks = first N of a uniform random permutation of the H*W pixels, per image and
+            # patch, drawn on the device generator (one batched argsort of uniform keys)
+            with torch.cuda.stream(self._copy_stream):
+                keys = torch.rand(sa['num_patches'] * B, hw, device=self.device)
+                pb.picks = keys.argsort(dim=1)[:, :N].to(torch.int32).reshape(sa['num_patches'], B, N).contiguous()
+                pb.ready = torch.cuda.Event()
+                pb.ready.record()
+            slot[2] = pb.ready
         pb.xforms = [[(im.views[v].angle, im.views[v].flip) for im in images] for v in range(2)]
         pb._keep = (df, di)
         return pb
@@ -406,8 +418,9 @@ class SwAVClustering(object):
     def draw_batch(self, batch):
         sa = self.swav_args
         hw = self.model.size * self.model.size
+        npick = 0 if sa.get('pick_source', 'host') == 'device' else sa['num_patches']
         return [draw_image(self.model.style_dim, self.model.num_layers, self.perturb_args['n_layers'], hw,
-                           sa['num_patches'], transforms=sa.get('transforms', True),
+                           npick, transforms=sa.get('transforms', True),
                            layer_no=self.perturb_args['layer_no'],
                            cpu_reference_rng=sa.get('cpu_reference_rng', False)) for _ in range(batch)]
 
