@@ -33,10 +33,13 @@ struct ConvArgs {
     int act;                                   // 1: lrelu(0.2)*sqrt2
     int vec_ok;
     int tiles_m, tiles_n;
+    unsigned in_bytes, wt_bytes, style_bytes;  // extents for the buffer descriptors (VEC path)
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
 
+// VEC: in / wt / style 16-B aligned and Cin % 4 == 0 (every real layer); otherwise the scalar path.
+template <bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
@@ -45,18 +48,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const long Mtot = (long)g.B * g.OH * g.OW;
-    const bool vec = g.vec_ok != 0;
 
-    // the 4 pixel rows this thread stages
-    int rb[4], roy[4], rox[4];
+    // per-thread constants of the 4 pixel rows it stages: input offset of the (un-shifted)
+    // pixel, style row offset, and one validity bit per tap (zero padding / row >= M)
+    long pix_off[4];
+    int soff[4];
+    unsigned tapmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long m = (long)m0 + (tid >> 3) + 32 * i;
+        pix_off[i] = 0; soff[i] = 0; tapmask[i] = 0;
         if (m < Mtot) {
             const int b = (int)(m / ((long)g.OH * g.OW));
             const int rem = (int)(m - (long)b * g.OH * g.OW);
-            rb[i] = b; roy[i] = rem / g.OW; rox[i] = rem - roy[i] * g.OW;
-        } else { rb[i] = -1; roy[i] = 0; rox[i] = 0; }
+            const int oy = rem / g.OW, ox = rem - oy * g.OW;
+            pix_off[i] = (((long)b * g.IH + oy) * g.IW + ox) * g.Cin;
+            soff[i] = b * g.Cin;
+            for (int t = 0; t < g.ntaps; ++t) {
+                const int iy = oy + g.dy[t], ix = ox + g.dx[t];
+                if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) tapmask[i] |= 1u << t;
+            }
+        }
     }
     const int kt_per_tap = (g.Cin + BK - 1) / BK;
     const int nkt = g.ntaps * kt_per_tap;
@@ -65,20 +77,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     f32x16 acc[2][2];
     zero_acc(acc);
     f32x4 ra[4], rw[4];
+    // VEC: whole-tensor buffer descriptors (host guarantees < 4 GB); an invalid lane's offset
+    // is pushed out of range and the hardware returns zeros — no branches around the loads.
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(g.in, VEC ? g.in_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(g.style ? g.style : g.in, (VEC && g.style) ? g.style_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
 
     auto load_a = [&](int kt) {
         const int tap = kt / kt_per_tap;
         const int ci = (kt - tap * kt_per_tap) * BK + kq;
-        const int dy = g.dy[tap], dx = g.dx[tap];
+        const long toff = ((long)g.dy[tap] * g.IW + g.dx[tap]) * g.Cin + ci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 v = zero4();
-            const int iy = roy[i] + dy, ix = rox[i] + dx;
-            if (rb[i] >= 0 && ci < g.Cin && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
-                v = load4(g.in + (((long)rb[i] * g.IH + iy) * g.IW + ix) * g.Cin + ci, g.Cin - ci, vec);
-                if (g.style) {
-                    const f32x4 s = load4(g.style + (long)rb[i] * g.Cin + ci, g.Cin - ci, vec);
-                    v *= s;
+            const bool ok = ((tapmask[i] >> tap) & 1u) && ci < g.Cin;
+            f32x4 v;
+            if (VEC) {
+                const unsigned om = oob_mask(ok);
+                v = buf_load4(rs_in, (unsigned)((pix_off[i] + toff) * 4) | om);
+                if (g.style) v *= buf_load4(rs_st, (unsigned)((soff[i] + ci) * 4) | om);
+            } else {
+                v = zero4();
+                if (ok) {
+                    v = load4(g.in + pix_off[i] + toff, g.Cin - ci, false);
+                    if (g.style) v *= load4(g.style + soff[i] + ci, g.Cin - ci, false);
                 }
             }
             ra[i] = v;
@@ -91,7 +112,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = n0 + (tid >> 3) + 32 * i;
-            rw[i] = (co < g.Cout && ci < g.Cin) ? load4(base + (long)co * g.Cin + ci, g.Cin - ci, vec) : zero4();
+            const bool ok = co < g.Cout && ci < g.Cin;
+            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)((((long)g.tw[tap] * g.Cout + co) * g.Cin + ci) * 4) |
+                                                  oob_mask(ok));
+            else rw[i] = ok ? load4(base + (long)co * g.Cin + ci, g.Cin - ci, false) : zero4();
         }
     };
 
@@ -284,10 +308,18 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, 
 }
 
 static int launch_conv(ConvArgs& g, hipStream_t stream) {
-    g.vec_ok = ((((uintptr_t)g.in | (uintptr_t)g.wt | (uintptr_t)g.style) & 15) == 0) && (g.Cin % 4 == 0);
+    int wtaps = 1;
+    for (int t = 0; t < g.ntaps; ++t) wtaps = g.tw[t] + 1 > wtaps ? g.tw[t] + 1 : wtaps;
+    const size_t inb = (size_t)g.B * g.IH * g.IW * g.Cin * 4, wtb = (size_t)wtaps * g.Cout * g.Cin * 4;
+    g.vec_ok = ((((uintptr_t)g.in | (uintptr_t)g.wt | (uintptr_t)g.style) & 15) == 0) && (g.Cin % 4 == 0) &&
+               inb < 0xFFFFFFF0ull && wtb < 0xFFFFFFF0ull;
+    g.in_bytes = (unsigned)inb;
+    g.wt_bytes = (unsigned)wtb;
+    g.style_bytes = (unsigned)((size_t)g.B * g.Cin * 4);
     const long M = (long)g.B * g.OH * g.OW;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(g.Cout, BN);
-    hipLaunchKernelGGL(modconv_kernel, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
+    if (g.vec_ok) hipLaunchKernelGGL(modconv_kernel<true>, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL(modconv_kernel<false>, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -27,7 +27,8 @@ struct GemmArgs {
 };
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
-template <bool TA, bool TB>
+// VEC: every operand is 16-B aligned with ld % 4 == 0 and (MC operands) M/N % 4 == 0, K % 4 == 0.
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr bool A_KC = !TA, B_KC = TB;
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A0 B0 A1 B1
@@ -38,20 +39,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
-    const bool vec = g.vec_ok != 0;
 
     f32x16 acc[2][2];
     zero_acc(acc);
     f32x4 ra[4], rb[4];
 
-    auto load_a = [&](int k0) {
-        if (TA || k0 < g.K1) load_tile<A_KC>(g.A, g.lda, m0, g.M, k0, TA ? kend : min(kend, g.K1), ra, tid, vec);
-        else load_tile<A_KC>(g.A2, g.lda2, m0, g.M, k0 - g.K1, kend - g.K1, ra, tid, vec);
+    auto load_a = [&](int k0) {       // scalar (wave-uniform) selects only: no divergent control flow
+        const bool second = !TA && k0 >= g.K1;
+        load_tile<A_KC, VEC>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M, second ? k0 - g.K1 : k0,
+                             second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, tid);
     };
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (nkt > 0) {
         load_a(kbeg);
-        load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid, vec);
+        load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
         store_tile<A_KC>(lds, ra, tid);
         store_tile<B_KC>(lds + TILE_FLOATS, rb, tid);
     }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         const bool more = (t + 1 < nkt);
         if (more) {   // issue next tile's global loads before the MFMA phase (latency hides under it)
             load_a(kbeg + (t + 1) * BK);
-            load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, rb, tid, vec);
+            load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, rb, tid);
         }
         mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
         if (more) {
@@ -128,7 +129,8 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.vec_ok = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
-               (lda2 % 4 == 0);
+               (lda2 % 4 == 0) && lda < (1 << 22) && ldb < (1 << 22) && lda2 < (1 << 22) && (K % 4 == 0) && (g.K1 % 4 == 0) && (!transA || M % 4 == 0) &&
+               (transB || N % 4 == 0);
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -141,10 +143,16 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         g.slab = workspace;
     }
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
-    if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+#define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
+    do {                                                                                                       \
+        if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g);      \
+        else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, g);              \
+    } while (0)
+    if (!transA && transB) GX_LAUNCH_GEMM(false, true);
+    else if (!transA && !transB) GX_LAUNCH_GEMM(false, false);
+    else if (transA && !transB) GX_LAUNCH_GEMM(true, false);
+    else GX_LAUNCH_GEMM(true, true);
+#undef GX_LAUNCH_GEMM
     GX_CHECK_LAUNCH();
     if (split_k > 1) {
         const long total = (long)M * N;

@@ -38,24 +38,73 @@ __device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec_ok) 
     return v;
 }
 
+// ---- buffer (SRD) loads: hardware range check instead of branches ------------------------------
+// A 128 x 32 operand tile is addressed through a buffer descriptor whose base is the tile's first
+// element and whose extent ends at the tile's last valid element, so rows past the matrix edge
+// read as zero with no branch and no select; the (thread-constant) column validity is folded
+// into the offset.  All descriptor inputs are wave-uniform (kernel arguments, blockIdx, loop
+// counters), so hipcc keeps them in SGPRs (no waterfall loops).
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+// 0 for a valid lane, 0xFFFFFFF0 (OR-ed into the byte offset -> out of range -> zeros) otherwise.
+// The empty asm keeps the value opaque so hipcc cannot turn the select into divergent branches
+// around the loads (it does otherwise, serialising them behind s_waitcnt vmcnt(0)).
+__device__ __forceinline__ unsigned oob_mask(bool ok) {
+    unsigned m = ok ? 0u : 0xFFFFFFF0u;
+    asm volatile("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)nbytes, 0x00020000);
+}
+
 // Global -> registers for one 128 x 32 operand tile (4 float4 per thread).
 //  KC: element (row, k) at P[row*ld + k];  MC: element (row, k) at P[k*ld + row].
-template <bool KC>
+//  VEC (fast path): 16-B aligned base, ld % 4 == 0, K % 4 == 0 (and rows % 4 == 0 for MC), ld < 2^22.
+template <bool KC, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int row0, int nrows,
-                                          int k0, int kend, f32x4 (&v)[4], int tid, bool vec_ok) {
+                                          int k0, int kend, f32x4 (&v)[4], int tid) {
+    if (VEC) {
+        const unsigned uld = (unsigned)ld;
+        if (KC) {
+            const int nv = min(128, nrows - row0), kv = min(BK, kend - k0);
+            const unsigned nbytes = (nv > 0 && kv > 0) ? ((unsigned)(nv - 1) * uld + (unsigned)kv) * 4u : 0u;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(P + (long)row0 * ld + k0, nbytes);
+            const unsigned kk = (tid & 7) * 4;
+            const unsigned km = oob_mask((int)kk < kv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned r = (tid >> 3) + 32 * i;
+                v[i] = buf_load4(rs, ((r * uld + kk) * 4u) | km);
+            }
+        } else {
+            const int kv = min(BK, kend - k0), mv = min(128, nrows - row0);
+            const unsigned nbytes = (kv > 0 && mv > 0) ? ((unsigned)(kv - 1) * uld + (unsigned)mv) * 4u : 0u;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(P + (long)k0 * ld + row0, nbytes);
+            const unsigned mm = (tid & 31) * 4;
+            const unsigned km = oob_mask((int)mm < mv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned kr = (tid >> 5) + 8 * i;
+                v[i] = buf_load4(rs, ((kr * uld + mm) * 4u) | km);
+            }
+        }
+        return;
+    }
     if (KC) {
         const int k = k0 + (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + (tid >> 3) + 32 * i;
-            v[i] = (row < nrows && k < kend) ? load4(P + (long)row * ld + k, kend - k, vec_ok) : zero4();
+            v[i] = (row < nrows && k < kend) ? load4(P + (long)row * ld + k, kend - k, false) : zero4();
         }
     } else {
         const int m = row0 + (tid & 31) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int kr = k0 + (tid >> 5) + 8 * i;
-            v[i] = (kr < kend && m < nrows) ? load4(P + (long)kr * ld + m, nrows - m, vec_ok) : zero4();
+            v[i] = (kr < kend && m < nrows) ? load4(P + (long)kr * ld + m, nrows - m, false) : zero4();
         }
     }
 }
