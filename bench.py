@@ -157,7 +157,8 @@ def main():
     q = feed(args.warmup)
     for _ in range(args.warmup):
         sw.train_step(q.get())
-    sw.kernel_events = {}
+    from ganecdotes_amd import ops
+    ops.PROFILE = {}
     sync()
     t0 = time.perf_counter()
     q = feed(args.steps)
@@ -172,25 +173,36 @@ def main():
     dt = float(t.item())
     images = args.steps * args.batch * world
 
-    # dominant kernel: the projection GEMM z = X Wp^T (fp32 MFMA), timed with HIP events on the
-    # launch stream inside the timed region
-    ev = sw.kernel_events.get("proj_fwd", [])
+    # roofline of the dominant kernel, measured live with HIP events on the launch stream over
+    # the timed region (ops.record brackets every launch of the MFMA kernels with its
+    # algorithmic FLOPs: SURVEY par. 8d figures x the units the launch processes)
+    prof, ops.PROFILE = ops.PROFILE, None
+    stats = {}
+    for tag, evs in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b, *_ in evs)
+        stats[tag] = dict(ms_per_step=ms / args.steps, launches_per_step=sum(e[4] for e in evs) / args.steps,
+                          flops_per_step=sum(e[2] for e in evs) / args.steps,
+                          bytes_per_step=sum(e[3] for e in evs) / args.steps)
     if os.environ.get("GX_BENCH_EVENTS"):
-        for k, v in sw.kernel_events.items():
-            ms = [a.elapsed_time(b) for a, b in v]
-            print(f"# {k:14s} n={len(ms):4d} avg={np.mean(ms):9.3f} ms total/step={np.sum(ms) / args.steps:9.2f} ms",
-                  file=sys.stderr)
+        for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            print(f"# {k:24s} {v['ms_per_step']:9.2f} ms/step  {v['launches_per_step']:7.1f} launches  "
+                  f"{v['flops_per_step'] / max(v['ms_per_step'], 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
     roof = None
-    if ev:
-        ms = [a.elapsed_time(b) for a, b in ev]
-        rows = args.batch * 20000
-        flops = 2.0 * rows * 5376 * 512
-        ach = flops / (np.mean(ms) * 1e-3)
+    kern = {k: v for k, v in stats.items() if not k.startswith("phase:") and v["flops_per_step"] > 0}
+    if kern:
+        name = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        v = kern[name]
+        ach = v["flops_per_step"] / (v["ms_per_step"] * 1e-3)
+        what = {"modconv_kernel": "gx::modconv_kernel<true> (3x3 modulated conv, implicit GEMM on fp32 MFMA; "
+                                  "algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
+                "gemm_f32_kernel": "gx::gemm_f32_kernel (pyramid projection / prototype / gradient GEMMs on fp32 "
+                                   "MFMA; algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
         roof = dict(bound="mfma", achieved=ach / 1e12, peak=PEAK_F32_MFMA / 1e12, unit="TFLOP/s",
-                    frac=ach / PEAK_F32_MFMA, traffic=None, kernel="gemm_f32_kernel<NT> (projection fwd)",
-                    launches=len(ms), avg_ms=float(np.mean(ms)),
-                    others={k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in
-                            sw.kernel_events.items() if k != "proj_fwd"})
+                    frac=ach / PEAK_F32_MFMA, traffic=None, kernel=what,
+                    launches_per_step=v["launches_per_step"],
+                    avg_launch_ms=v["ms_per_step"] / v["launches_per_step"],
+                    gflop_per_launch=v["flops_per_step"] / v["launches_per_step"] / 1e9,
+                    ms_per_step_by_kernel={k: round(x["ms_per_step"], 3) for k, x in stats.items()})
     out = {
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,

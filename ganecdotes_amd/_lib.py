@@ -33,10 +33,14 @@ SIGNATURES = {
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
     "gx_demod": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
-    "gx_modconv_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
+    "gx_modconv_slab_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gx_modconv_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_sz,
+                             c_p]),
     "gx_modconv_up_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gx_modconv_up_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p,
-                                c_p]),
+                                c_p, c_sz, c_p]),
+    "gx_modconv_up_convt": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_blur_act_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
     "gx_torgb_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "gx_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_rotflip_map": (c_i, [c_f, c_i, c_i, c_i, c_p, c_p]),

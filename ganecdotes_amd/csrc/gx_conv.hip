@@ -18,22 +18,28 @@
 
 namespace gx {
 
+struct ConvSub {                               // one implicit-GEMM sub-problem of a launch
+    int ntaps; int dy[9], dx[9], tw[9];        // input offsets and weight-tap index per tap
+    int OH, OW;                                // output sub-grid (M = B*OH*OW)
+    int yadd, xadd;                            // out y = oy*ymul + yadd
+    int tile_base, tiles_m;                    // logical tile ids [tile_base, tile_base + tiles_m*tiles_n)
+};
 struct ConvArgs {
     const float* in; int B, IH, IW, Cin;      // NHWC input
     const float* wt;                           // [9 or 1][Cout][Cin]
     const float* style;                        // [B][Cin] modulation or nullptr
-    int ntaps; int dy[9], dx[9], tw[9];        // input offsets and weight-tap index per tap
-    int OH, OW;                                // output sub-grid (M = B*OH*OW)
+    int nsub; ConvSub sub[4];                  // 1 (plain conv) or 4 (parity classes of the stride-2 transposed conv)
     float* out; int outH, outW, Cout;          // NHWC output tensor
-    int ymul, yadd, xmul, xadd;                // out y = oy*ymul + yadd
+    int ymul, xmul;
     const float* demod;                        // [B][Cout] or nullptr
     const float* noise; long noise_bstride;    // [.][outH][outW] or nullptr
     const float* noise_w;                      // device scalar
     const float* bias;                         // [Cout] or nullptr
     int act;                                   // 1: lrelu(0.2)*sqrt2
     int vec_ok;
-    int tiles_m, tiles_n;
+    int tiles_n, ntile;
     unsigned in_bytes, wt_bytes, style_bytes;  // extents for the buffer descriptors (VEC path)
+    int splits; float* slab;                   // split-K over k-tiles: raw partial sums [split][B*outH*outW*Cout]
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
@@ -43,11 +49,18 @@ template <bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, ntile);
-    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    // sub-problem from the block id range; XCD-aware remap INSIDE the sub-problem so that every
+    // XCD gets an equal share of each class (classes differ 4x in work per tile)
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.nsub && (int)blockIdx.x >= g.sub[i].tile_base) si = i;
+    const ConvSub& sb = g.sub[si];
+    const int local = xcd_remap(blockIdx.x - sb.tile_base, sb.tiles_m * g.tiles_n);
+    const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const long Mtot = (long)g.B * g.OH * g.OW;
+    const int OH = sb.OH, OW = sb.OW, ntaps = sb.ntaps;
+    const long Mtot = (long)g.B * OH * OW;
 
     // per-thread constants of the 4 pixel rows it stages: input offset of the (un-shifted)
     // pixel, style row offset, and one validity bit per tap (zero padding / row >= M)
@@ -59,19 +72,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
         const long m = (long)m0 + (tid >> 3) + 32 * i;
         pix_off[i] = 0; soff[i] = 0; tapmask[i] = 0;
         if (m < Mtot) {
-            const int b = (int)(m / ((long)g.OH * g.OW));
-            const int rem = (int)(m - (long)b * g.OH * g.OW);
-            const int oy = rem / g.OW, ox = rem - oy * g.OW;
+            const int b = (int)(m / ((long)OH * OW));
+            const int rem = (int)(m - (long)b * OH * OW);
+            const int oy = rem / OW, ox = rem - oy * OW;
             pix_off[i] = (((long)b * g.IH + oy) * g.IW + ox) * g.Cin;
             soff[i] = b * g.Cin;
-            for (int t = 0; t < g.ntaps; ++t) {
-                const int iy = oy + g.dy[t], ix = ox + g.dx[t];
+            for (int t = 0; t < ntaps; ++t) {
+                const int iy = oy + sb.dy[t], ix = ox + sb.dx[t];
                 if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) tapmask[i] |= 1u << t;
             }
         }
     }
     const int kt_per_tap = (g.Cin + BK - 1) / BK;
-    const int nkt = g.ntaps * kt_per_tap;
+    const int nkt_all = ntaps * kt_per_tap;
+    const int kps = (nkt_all + g.splits - 1) / g.splits;        // k-tiles per split
+    const int kt0 = blockIdx.y * kps;
+    const int nkt = max(0, min(nkt_all, kt0 + kps) - kt0);
     const int kq = (tid & 7) * 4;
 
     f32x16 acc[2][2];
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     auto load_a = [&](int kt) {
         const int tap = kt / kt_per_tap;
         const int ci = (kt - tap * kt_per_tap) * BK + kq;
-        const long toff = ((long)g.dy[tap] * g.IW + g.dx[tap]) * g.Cin + ci;
+        const long toff = ((long)sb.dy[tap] * g.IW + sb.dx[tap]) * g.Cin + ci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = ((tapmask[i] >> tap) & 1u) && ci < g.Cin;
@@ -108,26 +124,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     auto load_w = [&](int kt) {
         const int tap = kt / kt_per_tap;
         const int ci = (kt - tap * kt_per_tap) * BK + kq;
-        const float* base = g.wt + (long)g.tw[tap] * g.Cout * g.Cin;
+        const long wbase = (long)sb.tw[tap] * g.Cout;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = n0 + (tid >> 3) + 32 * i;
             const bool ok = co < g.Cout && ci < g.Cin;
-            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)((((long)g.tw[tap] * g.Cout + co) * g.Cin + ci) * 4) |
-                                                  oob_mask(ok));
-            else rw[i] = ok ? load4(base + (long)co * g.Cin + ci, g.Cin - ci, false) : zero4();
+            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)(((wbase + co) * g.Cin + ci) * 4) | oob_mask(ok));
+            else rw[i] = ok ? load4(g.wt + (wbase + co) * g.Cin + ci, g.Cin - ci, false) : zero4();
         }
     };
 
-    load_a(0); load_w(0);
-    store_tile<true>(lds, ra, tid);
-    store_tile<true>(lds + TILE_FLOATS, rw, tid);
+    if (nkt > 0) {
+        load_a(kt0); load_w(kt0);
+        store_tile<true>(lds, ra, tid);
+        store_tile<true>(lds + TILE_FLOATS, rw, tid);
+    }
     __syncthreads();
     for (int t = 0; t < nkt; ++t) {
         float* As = lds + (t & 1) * 2 * TILE_FLOATS;
         float* Bs = As + TILE_FLOATS;
         const bool more = (t + 1 < nkt);
-        if (more) { load_a(t + 1); load_w(t + 1); }
+        if (more) { load_a(kt0 + t + 1); load_w(kt0 + t + 1); }
         mfma_ktile<true, true>(As, Bs, acc, wr, wc, lane);
         if (more) {
             float* An = lds + ((t + 1) & 1) * 2 * TILE_FLOATS;
@@ -137,31 +154,56 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
         __syncthreads();
     }
 
-    const float nw = (g.noise && g.noise_w) ? *g.noise_w : 0.f;
+    const bool to_slab = g.slab != nullptr;
+    float* outp = to_slab ? g.slab + (long)blockIdx.y * g.B * g.outH * g.outW * g.Cout : g.out;
+    const float nw = (!to_slab && g.noise && g.noise_w) ? *g.noise_w : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long m = (long)m0 + acc_row(wr, mt, r, lane);
             if (m >= Mtot) continue;
-            const int b = (int)(m / ((long)g.OH * g.OW));
-            const int rem = (int)(m - (long)b * g.OH * g.OW);
-            const int oy = rem / g.OW, ox = rem - oy * g.OW;
-            const int y = oy * g.ymul + g.yadd, x = ox * g.xmul + g.xadd;
+            const int b = (int)(m / ((long)OH * OW));
+            const int rem = (int)(m - (long)b * OH * OW);
+            const int oy = rem / OW, ox = rem - oy * OW;
+            const int y = oy * g.ymul + sb.yadd, x = ox * g.xmul + sb.xadd;
             const long pix = ((long)b * g.outH + y) * g.outW + x;
-            const float nz = g.noise ? nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x] : 0.f;
+            const float nz = (!to_slab && g.noise) ? nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int co = n0 + acc_col(wc, nt, lane);
                 if (co >= g.Cout) continue;
                 float v = acc[mt][nt][r];
-                if (g.demod) v *= g.demod[(long)b * g.Cout + co];
-                v += nz;
-                if (g.bias) v += g.bias[co];
-                if (g.act) v = lrelu_sqrt2(v);
-                g.out[pix * g.Cout + co] = v;
+                if (!to_slab) {
+                    if (g.demod) v *= g.demod[(long)b * g.Cout + co];
+                    v += nz;
+                    if (g.bias) v += g.bias[co];
+                    if (g.act) v = lrelu_sqrt2(v);
+                }
+                outp[pix * g.Cout + co] = v;
             }
         }
+}
+
+// Split-K tail: out = epilogue(sum_s slab[s]) over the whole NHWC output (fixed order).
+__global__ void conv_splitk_epilogue_kernel(const float* __restrict__ slab, int splits, long total, int B, int outH,
+                                            int outW, int Cout, const float* __restrict__ demod,
+                                            const float* __restrict__ noise, long noise_bstride,
+                                            const float* __restrict__ noise_w, const float* __restrict__ bias, int act,
+                                            float* __restrict__ out) {
+    const float nw = (noise && noise_w) ? *noise_w : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += slab[(long)z * total + i];
+        const int co = (int)(i % Cout);
+        const long pix = i / Cout;
+        const int b = (int)(pix / ((long)outH * outW));
+        const long yx = pix - (long)b * outH * outW;
+        if (demod) v *= demod[(long)b * Cout + co];
+        if (noise) v += nw * noise[(long)b * noise_bstride + yx];
+        if (bias) v += bias[co];
+        out[i] = act ? lrelu_sqrt2(v) : v;
+    }
 }
 
 // demod'[b][co] = scale * rsqrt(scale^2 * sum_ci s[b][ci]^2 * wsq[co][ci] + 1e-8)   (one wave each)
@@ -179,75 +221,118 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
 // Blur of the (2H+1)^2 transposed-conv image with pad (1,1) + StyledConv epilogue:
 //   out[b,y,x,c] = act( demod[b,c] * sum_{fy,fx} kf[fy][fx] * T[b, y+fy-1, x+fx-1, c] + nw*noise + bias[c] )
 // kf is the FLIPPED 4x4 FIR (upfirdn2d correlates with the flipped kernel, model.py:88).
+// A thread owns a (x, 4-channel) column strip of BLUR_ROWS output rows and slides down it: each
+// input row is loaded once (4 float4) and scattered into the 4 outputs in flight, instead of 16
+// loads per output.  Accumulator slots are compile-time ((j - fy) & 3) so they stay in registers.
+constexpr int BLUR_ROWS = 16;
 __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int TW, int C, const float* __restrict__ kf,
                                 const float* __restrict__ demod, const float* __restrict__ noise, long noise_bstride,
                                 const float* __restrict__ noise_w, const float* __restrict__ bias, int act,
                                 float* __restrict__ out, int OH, int OW) {
     const int c4n = C >> 2;
-    const long total = (long)B * OH * OW * c4n;
+    const int nseg = (OH + BLUR_ROWS - 1) / BLUR_ROWS;
+    const long total = (long)B * nseg * OW * c4n;
     float k[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) k[i] = kf[i];
     const float nw = (noise && noise_w) ? *noise_w : 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
-        const long pix = i / c4n;
-        const int x = (int)(pix % OW);
-        const int y = (int)((pix / OW) % OH);
-        const int b = (int)(pix / ((long)OW * OH));
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        long rest = i / c4n;
+        const int x = (int)(rest % OW); rest /= OW;
+        const int seg = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int y0 = seg * BLUR_ROWS;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f};
+        if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
+        if (demod) dm4 = *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
+        f32x4 acc[4];
 #pragma unroll
-        for (int fy = 0; fy < 4; ++fy) {
-            const int ty = y + fy - 1;
-            if (ty < 0 || ty >= TH) continue;
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Tb = T + (long)b * TH * TW * C + c;
+#pragma unroll 1
+        for (int g4 = 0; g4 < BLUR_ROWS / 4 + 1; ++g4) {
 #pragma unroll
-            for (int fx = 0; fx < 4; ++fx) {
-                const int tx = x + fx - 1;
-                if (tx < 0 || tx >= TW) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(T + (((long)b * TH + ty) * TW + tx) * C + c);
-                a += v * k[fy * 4 + fx];
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g4 + j;                 // input row y0 - 1 + r
+                if (r > BLUR_ROWS + 2) break;
+                const int ty = y0 - 1 + r;
+                f32x4 v[4];
+#pragma unroll
+                for (int fx = 0; fx < 4; ++fx) {
+                    const int tx = x + fx - 1;
+                    v[fx] = (ty >= 0 && ty < TH && tx >= 0 && tx < TW)
+                                ? *reinterpret_cast<const f32x4*>(Tb + ((long)ty * TW + tx) * C)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int fy = 0; fy < 4; ++fy) {          // contributes to output rel row o = r - fy
+                    const f32x4 h = v[0] * k[fy * 4 + 0] + v[1] * k[fy * 4 + 1] + v[2] * k[fy * 4 + 2] +
+                                    v[3] * k[fy * 4 + 3];
+                    acc[(j - fy) & 3] += h;
+                }
+                const int o = r - 3;                      // this output row is now complete
+                const int y = y0 + o;
+                if (o >= 0 && o < BLUR_ROWS && y < OH) {
+                    const f32x4 a = acc[(j + 1) & 3];
+                    const float nz = noise ? nw * noise[(long)b * noise_bstride + (long)y * OW + x] : 0.f;
+                    f32x4 ov;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = a[q] * dm4[q] + nz + bias4[q];
+                        ov[q] = act ? lrelu_sqrt2(t) : t;
+                    }
+                    *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;
+                }
+                acc[(j + 1) & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const float nz = noise ? nw * noise[(long)b * noise_bstride + (long)y * OW + x] : 0.f;
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = a[j];
-            if (demod) v *= demod[(long)b * C + c + j];
-            v += nz;
-            if (bias) v += bias[c + j];
-            o[j] = act ? lrelu_sqrt2(v) : v;
-        }
-        *reinterpret_cast<f32x4*>(out + pix * C + c) = o;
     }
 }
 
 // ToRGB (model.py:445-454): 1x1 modulated conv without demod + bias + FIR-upsampled skip.
 //   img[b][c][y][x] = scale * sum_ci x[b,y,x,ci] s[b,ci] W[c][ci] + bias[c] + up2(prev)[b][c][y][x]
 // up2 = upfirdn2d(up=2, pad=(2,1)) with the flipped 4x4 FIR kf (already x4).  Image is planar
-// NCHW (3 channels).  One wave per pixel.
+// NCHW (3 channels).  A team of `lp` lanes (lp = min(64, Cin/4), power of two) owns a pixel and
+// reads its Cin floats as float4: one fully coalesced pass over the tap.
 __global__ void torgb_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ W,
                              float scale, const float* __restrict__ bias, const float* __restrict__ prev,
-                             const float* __restrict__ kf, int B, int H, int Wd, int Cin, float* __restrict__ img) {
-    const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pix >= (long)B * H * Wd) return;
-    const int lane = threadIdx.x & 63;
-    const int b = (int)(pix / ((long)H * Wd));
-    const int rem = (int)(pix - (long)b * H * Wd);
-    const int y = rem / Wd, xx = rem - y * Wd;
-    const float* px = x + pix * Cin;
-    const float* ps = s + (long)b * Cin;
+                             const float* __restrict__ kf, int B, int H, int Wd, int Cin, int lp,
+                             float* __restrict__ img) {
+    const int ppw = 64 / lp;                                       // pixels per wave
+    const int lane = threadIdx.x & 63, tl = lane % lp;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long pix = wave * ppw + lane / lp;
+    const bool live = pix < (long)B * H * Wd;
+    const int b = live ? (int)(pix / ((long)H * Wd)) : 0;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int ci = lane; ci < Cin; ci += 64) {
-        const float v = px[ci] * ps[ci];
-        a0 = fmaf(v, W[ci], a0); a1 = fmaf(v, W[Cin + ci], a1); a2 = fmaf(v, W[2 * Cin + ci], a2);
+    if (live) {
+        const float* px = x + pix * Cin;
+        const float* ps = s + (long)b * Cin;
+        if ((Cin & 3) == 0) {
+            for (int ci = tl * 4; ci < Cin; ci += lp * 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(px + ci) * *reinterpret_cast<const f32x4*>(ps + ci);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + ci);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(W + Cin + ci);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(W + 2 * Cin + ci);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a0 = fmaf(v[q], w0[q], a0); a1 = fmaf(v[q], w1[q], a1); a2 = fmaf(v[q], w2[q], a2); }
+            }
+        } else {
+            for (int ci = tl; ci < Cin; ci += lp) {
+                const float v = px[ci] * ps[ci];
+                a0 = fmaf(v, W[ci], a0); a1 = fmaf(v, W[Cin + ci], a1); a2 = fmaf(v, W[2 * Cin + ci], a2);
+            }
+        }
     }
-    a0 = gx_wave_sum(a0); a1 = gx_wave_sum(a1); a2 = gx_wave_sum(a2);
-    if (lane < 3) {
-        float v = (lane == 0 ? a0 : (lane == 1 ? a1 : a2)) * scale + bias[lane];
+    a0 = gx_team_sum(a0, lp); a1 = gx_team_sum(a1, lp); a2 = gx_team_sum(a2, lp);
+    if (live && tl < 3) {
+        const int rem = (int)(pix - (long)b * H * Wd);
+        const int y = rem / Wd, xx = rem - y * Wd;
+        float v = (tl == 0 ? a0 : (tl == 1 ? a1 : a2)) * scale + bias[tl];
         if (prev) {
             const int ph = H >> 1, pw = Wd >> 1;
-            const float* pp = prev + ((long)b * 3 + lane) * ph * pw;
+            const float* pp = prev + ((long)b * 3 + tl) * ph * pw;
             float u = 0.f;
 #pragma unroll
             for (int fy = 0; fy < 4; ++fy) {
@@ -262,7 +347,7 @@ __global__ void torgb_kernel(const float* __restrict__ x, const float* __restric
             }
             v += u;
         }
-        img[(((long)b * 3 + lane) * H + y) * Wd + xx] = v;
+        img[(((long)b * 3 + tl) * H + y) * Wd + xx] = v;
     }
 }
 
@@ -307,20 +392,57 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, 
     }
 }
 
-static int launch_conv(ConvArgs& g, hipStream_t stream) {
+// Small layers (fewer tiles than CUs) are split over their k-tiles so that the chip is filled.
+size_t conv_slab_bytes(int B, int outH, int outW, int Cout, int splits) {
+    return splits > 1 ? (size_t)splits * B * outH * outW * Cout * sizeof(float) : 0;
+}
+static int conv_pick_splits(long max_m, int Cout, int nsub_tiles_total, int min_ktiles) {
+    (void)max_m; (void)Cout;
+    if (nsub_tiles_total >= 256) return 1;
+    int s = (512 + nsub_tiles_total - 1) / nsub_tiles_total;
+    if (s > min_ktiles) s = min_ktiles;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t stream) {
     int wtaps = 1;
-    for (int t = 0; t < g.ntaps; ++t) wtaps = g.tw[t] + 1 > wtaps ? g.tw[t] + 1 : wtaps;
+    for (int i = 0; i < g.nsub; ++i)
+        for (int t = 0; t < g.sub[i].ntaps; ++t) wtaps = g.sub[i].tw[t] + 1 > wtaps ? g.sub[i].tw[t] + 1 : wtaps;
     const size_t inb = (size_t)g.B * g.IH * g.IW * g.Cin * 4, wtb = (size_t)wtaps * g.Cout * g.Cin * 4;
     g.vec_ok = ((((uintptr_t)g.in | (uintptr_t)g.wt | (uintptr_t)g.style) & 15) == 0) && (g.Cin % 4 == 0) &&
                inb < 0xFFFFFFF0ull && wtb < 0xFFFFFFF0ull;
     g.in_bytes = (unsigned)inb;
     g.wt_bytes = (unsigned)wtb;
     g.style_bytes = (unsigned)((size_t)g.B * g.Cin * 4);
-    const long M = (long)g.B * g.OH * g.OW;
-    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(g.Cout, BN);
-    if (g.vec_ok) hipLaunchKernelGGL(modconv_kernel<true>, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
-    else hipLaunchKernelGGL(modconv_kernel<false>, dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), 0, stream, g);
+    g.tiles_n = gx_cdiv(g.Cout, BN);
+    int base = 0, min_kt = 1 << 30;
+    for (int i = 0; i < g.nsub; ++i) {
+        g.sub[i].tile_base = base;
+        g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, BM);
+        base += g.sub[i].tiles_m * g.tiles_n;
+        const int kt = g.sub[i].ntaps * gx_cdiv(g.Cin, BK);
+        min_kt = kt < min_kt ? kt : min_kt;
+    }
+    g.ntile = base;
+    g.splits = conv_pick_splits(0, g.Cout, base, min_kt);
+    g.slab = nullptr;
+    if (g.splits > 1) {
+        if (!slab || slab_bytes < conv_slab_bytes(g.B, g.outH, g.outW, g.Cout, g.splits)) g.splits = 1;   // no scratch: unsplit
+        else g.slab = slab;
+    }
+    dim3 grid(g.ntile, g.splits);
+    if (g.vec_ok) hipLaunchKernelGGL(modconv_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL(modconv_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
     GX_CHECK_LAUNCH();
+    if (g.splits > 1) {
+        const long total = (long)g.B * g.outH * g.outW * g.Cout;
+        long want = (total + 255) / 256;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
+                           g.slab, g.splits, total, g.B, g.outH, g.outW, g.Cout, g.demod, g.noise, g.noise_bstride,
+                           g.noise_w, g.bias, g.act, g.out);
+        GX_CHECK_LAUNCH();
+    }
     return GX_OK;
 }
 
@@ -342,23 +464,30 @@ int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float s
 //   x [B][H][W][Cin] NHWC; wt [k*k][Cout][Cin]; s [B][Cin]; demod [B][Cout] or null;
 //   noise [.][H][W] (batch stride noise_bstride, 0 = shared) or null; noise_w device scalar;
 //   bias [Cout] or null; act 1 = lrelu*sqrt2; out [B][H][W][Cout] NHWC.
+// Split-K scratch for the small (low-resolution) layers: pass at least this many bytes as `slab`
+// (0 bytes / NULL is allowed: the layer then runs unsplit).
+size_t gx_modconv_slab_bytes(int B, int outH, int outW, int Cout) { return conv_slab_bytes(B, outH, outW, Cout, 16); }
+
 int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
                    const float* demod, const float* noise, long noise_bstride, const float* noise_w,
-                   const float* bias, int act, float* out, void* stream) {
+                   const float* bias, int act, float* out, float* slab, size_t slab_bytes, void* stream) {
     if (!x || !wt || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3))
         return GX_ERR_BAD_ARG;
     ConvArgs g{};
     g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
-    g.ntaps = ksize * ksize;
+    g.nsub = 1;
+    ConvSub& sb = g.sub[0];
+    sb.ntaps = ksize * ksize;
     for (int ky = 0; ky < ksize; ++ky)
         for (int kx = 0; kx < ksize; ++kx) {
             const int t = ky * ksize + kx;
-            g.dy[t] = ky - ksize / 2; g.dx[t] = kx - ksize / 2; g.tw[t] = t;
+            sb.dy[t] = ky - ksize / 2; sb.dx[t] = kx - ksize / 2; sb.tw[t] = t;
         }
-    g.OH = H; g.OW = W; g.out = out; g.outH = H; g.outW = W; g.Cout = Cout;
-    g.ymul = 1; g.yadd = 0; g.xmul = 1; g.xadd = 0;
+    sb.OH = H; sb.OW = W; sb.yadd = 0; sb.xadd = 0;
+    g.out = out; g.outH = H; g.outW = W; g.Cout = Cout;
+    g.ymul = 1; g.xmul = 1;
     g.demod = demod; g.noise = noise; g.noise_bstride = noise_bstride; g.noise_w = noise_w; g.bias = bias; g.act = act;
-    return launch_conv(g, (hipStream_t)stream);
+    return launch_conv(g, slab, slab_bytes, (hipStream_t)stream);
 }
 
 // Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur
@@ -367,45 +496,69 @@ int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt
 size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout) {
     return (size_t)B * (2 * H + 1) * (2 * W + 1) * Cout * sizeof(float);
 }
-int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
-                      const float* demod, const float* kf, const float* noise, long noise_bstride,
-                      const float* noise_w, const float* bias, int act, float* T, float* out, void* stream) {
-    if (!x || !wt || !out || !T || !kf || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cout & 3))
-        return GX_ERR_BAD_ARG;
-    const int TH = 2 * H + 1, TW = 2 * W + 1;
+// Stage 2 of an upsampling StyledConv: blur (pad (1,1)) of the (TH x TW) transposed-conv image +
+// demod + noise + bias + act -> out [B][TH-1][TW-1][C]   (upfirdn2d mode 1 + fused_bias_act).
+int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
+                    const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
+                    float* out, void* stream) {
+    if (!T || !kf || !out || B <= 0 || TH < 2 || TW < 2 || C <= 0 || (C & 3)) return GX_ERR_BAD_ARG;
+    const int OH = TH - 1, OW = TW - 1;
+    const long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
+    long want = (total + 255) / 256;
+    const int nb = (int)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod,
+                       noise, noise_bstride, noise_w, bias, act, out, OH, OW);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// Stage 1: conv_transpose2d(stride 2, pad 0) of the modulated input as four implicit GEMMs (one
+// per output parity class) -> T [B][2H+1][2W+1][Cout] (raw sums, no demod).
+int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                        float* T, float* slab, size_t slab_bytes, void* stream) {
+    if (!x || !wt || !T || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return GX_ERR_BAD_ARG;
+    ConvArgs g{};
+    g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
+    g.nsub = 4;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            ConvArgs g{};
-            g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
+            ConvSub& sb = g.sub[py * 2 + px];
             // T[u,v] = sum over (ky,kx) with u-ky, v-kx even: x[(u-ky)/2, (v-kx)/2] * W[.,.,ky,kx]
             int n = 0;
             for (int ky = py; ky < 3; ky += 2)
                 for (int kx = px; kx < 3; kx += 2) {
-                    g.dy[n] = -(ky >> 1); g.dx[n] = -(kx >> 1); g.tw[n] = ky * 3 + kx; ++n;
+                    sb.dy[n] = -(ky >> 1); sb.dx[n] = -(kx >> 1); sb.tw[n] = ky * 3 + kx; ++n;
                 }
-            g.ntaps = n;
-            g.OH = py ? H : H + 1; g.OW = px ? W : W + 1;
-            g.out = T; g.outH = TH; g.outW = TW; g.Cout = Cout;
-            g.ymul = 2; g.yadd = py; g.xmul = 2; g.xadd = px;
-            g.demod = nullptr; g.noise = nullptr; g.noise_w = nullptr; g.bias = nullptr; g.act = 0;
-            const int rc = launch_conv(g, (hipStream_t)stream);
-            if (rc) return rc;
+            sb.ntaps = n;
+            sb.OH = py ? H : H + 1; sb.OW = px ? W : W + 1;
+            sb.yadd = py; sb.xadd = px;
         }
-    const long total = (long)B * 2 * H * 2 * W * (Cout >> 2);
-    long want = (total + 255) / 256;
-    const int nb = (int)(want < 8192 ? want : 8192);
-    hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, Cout, kf, demod,
-                       noise, noise_bstride, noise_w, bias, act, out, 2 * H, 2 * W);
-    GX_CHECK_LAUNCH();
-    return GX_OK;
+    g.out = T; g.outH = 2 * H + 1; g.outW = 2 * W + 1; g.Cout = Cout;
+    g.ymul = 2; g.xmul = 2;
+    g.demod = nullptr; g.noise = nullptr; g.noise_w = nullptr; g.bias = nullptr; g.act = 0;
+    return launch_conv(g, slab, slab_bytes, (hipStream_t)stream);
+}
+
+int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                      const float* demod, const float* kf, const float* noise, long noise_bstride,
+                      const float* noise_w, const float* bias, int act, float* T, float* out, float* slab,
+                      size_t slab_bytes, void* stream) {
+    if (!out || !kf || (Cout & 3)) return GX_ERR_BAD_ARG;
+    const int rc = gx_modconv_up_convt(x, B, H, W, Cin, wt, Cout, s, T, slab, slab_bytes, stream);
+    if (rc) return rc;
+    return gx_blur_act_fwd(T, B, 2 * H + 1, 2 * W + 1, Cout, kf, demod, noise, noise_bstride, noise_w, bias, act, out,
+                           stream);
 }
 
 int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, const float* s, float scale,
                  const float* bias3, const float* prev_img, const float* kf, float* img, void* stream) {
     if (!x || !w3 || !s || !bias3 || !img || B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return GX_ERR_BAD_ARG;
     if (prev_img && (!kf || (H & 1) || (W & 1))) return GX_ERR_BAD_ARG;
-    hipLaunchKernelGGL(torgb_kernel, dim3(gx_cdiv((long)B * H * W, 4)), dim3(256), 0, (hipStream_t)stream, x, s, w3,
-                       scale, bias3, prev_img, kf, B, H, W, Cin, img);
+    int lp = 4;                                   // lanes per pixel: >= 4 (three output lanes), <= 64
+    while (lp < 64 && lp * 4 < Cin) lp <<= 1;
+    const long waves = ((long)B * H * W + (64 / lp) - 1) / (64 / lp);
+    hipLaunchKernelGGL(torgb_kernel, dim3(gx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, s, w3, scale,
+                       bias3, prev_img, kf, B, H, W, Cin, lp, img);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -12,6 +12,28 @@ import torch
 from . import _lib
 
 _WS = {}
+PROFILE = None      # bench.py sets this to a dict: {tag: [(start_event, end_event, flops, bytes)]}
+
+
+class record:
+    """HIP-event bracket on the launch stream around one kernel (or a run of launches of the same
+    kernel), with the algorithmic FLOPs / bytes it performs.  Inactive unless ops.PROFILE is a dict."""
+
+    def __init__(self, tag, flops=0.0, nbytes=0.0, launches=1):
+        self.tag, self.flops, self.nbytes, self.launches = tag, flops, nbytes, launches
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.b.record()
+            PROFILE.setdefault(self.tag, []).append((self.a, self.b, self.flops, self.nbytes, self.launches))
+        return False
 
 
 def lib():
@@ -81,9 +103,10 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
     if split_k > 1:
         wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
         ws = workspace("gemm", wsb, a.device)
-    _lib.check(L.gx_gemm_f32(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(out),
-                             out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws), wsb,
-                             _stream()), "gx_gemm_f32")
+    with record("gemm_f32_kernel", 2.0 * m * n * k):
+        _lib.check(L.gx_gemm_f32(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
+                                 _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
+                                 wsb, _stream()), "gx_gemm_f32")
     return out
 
 
@@ -95,9 +118,10 @@ def gemm_cat(a1, a2, b, out, trans_b=True, alpha=1.0, beta=0.0):
     n = b.shape[0] if trans_b else b.shape[1]
     if a2.shape[0] != m or tuple(out.shape) != (m, n) or (b.shape[1] if trans_b else b.shape[0]) != k1 + k2:
         raise RuntimeError("gemm_cat: shape mismatch")
-    _lib.check(lib().gx_gemm_f32_cat(int(trans_b), m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), a2.stride(0), _p(b),
-                                     b.stride(0), _p(out), out.stride(0), alpha, beta, None, _stream()),
-               "gx_gemm_f32_cat")
+    with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
+        _lib.check(lib().gx_gemm_f32_cat(int(trans_b), m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), a2.stride(0),
+                                         _p(b), b.stride(0), _p(out), out.stride(0), alpha, beta, None, _stream()),
+                   "gx_gemm_f32_cat")
     return out
 
 
@@ -183,6 +207,14 @@ def _noise_args(noise, b, h, w):
     raise RuntimeError("noise must be (1,1,H,W) or (B,1,H,W)")
 
 
+def _conv_slab(L, b, oh, ow, cout, device):
+    """split-K scratch, only for layers too small to fill the chip (< 256 output tiles)"""
+    if ((b * oh * ow + 127) // 128) * ((cout + 127) // 128) >= 256:
+        return None, 0
+    nbytes = L.gx_modconv_slab_bytes(b, oh, ow, cout)
+    return workspace("convslab", nbytes, device), nbytes
+
+
 def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True):
     """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin)."""
     _chk(x, wt, s, dmod, noise_w, bias)
@@ -190,8 +222,12 @@ def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True):
     cout = wt.shape[1]
     nz, nbs = _noise_args(noise, b, h, w)
     out = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
-    _lib.check(lib().gx_modconv_fwd(_p(x), b, h, w, cin, _p(wt), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
-                                    _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_modconv_fwd")
+    L = lib()
+    slab, sbytes = _conv_slab(L, b, h, w, cout, x.device)
+    with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
+        _lib.check(L.gx_modconv_fwd(_p(x), b, h, w, cin, _p(wt), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
+                                    _p(noise_w), _p(bias), int(act), _p(out), _p(slab), sbytes, _stream()),
+                   "gx_modconv_fwd")
     return out
 
 
@@ -204,9 +240,14 @@ def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True):
     L = lib()
     scratch = workspace("upconv", L.gx_modconv_up_scratch_bytes(b, h, w, cout), x.device)
     out = torch.empty(b, 2 * h, 2 * w, cout, dtype=torch.float32, device=x.device)
-    _lib.check(L.gx_modconv_up_fwd(_p(x), b, h, w, cin, _p(wt), cout, _p(s), _p(dmod), _p(kf), _p(nz), nbs,
-                                   _p(noise_w), _p(bias), int(act), _p(scratch), _p(out), _stream()),
-               "gx_modconv_up_fwd")
+    slab, sbytes = _conv_slab(L, b, 2 * h + 1, 2 * w + 1, cout, x.device)
+    with record("modconv_kernel", 2.0 * b * h * w * cin * cout * 9):
+        _lib.check(L.gx_modconv_up_convt(_p(x), b, h, w, cin, _p(wt), cout, _p(s), _p(scratch), _p(slab), sbytes,
+                                         _stream()), "gx_modconv_up_convt")
+    tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
+    with record("blur_act_kernel", 0.0, tbytes):
+        _lib.check(L.gx_blur_act_fwd(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,
+                                     _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_blur_act_fwd")
     return out
 
 

@@ -102,19 +102,10 @@ class SwAVClustering(object):
         self.layer_hf_dim = layer_hf_dim
         self._bufs = None
         self._step_no = 0
-        self.kernel_events = None       # bench.py: {tag: [(start, end) HIP events]} when a dict
 
-    @contextlib.contextmanager
-    def _timed(self, tag):
-        """HIP-event bracket on the launch stream (only when bench.py asks for it)."""
-        if self.kernel_events is None:
-            yield
-            return
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        yield
-        b.record()
-        self.kernel_events.setdefault(tag, []).append((a, b))
+    def _timed(self, tag, flops=0.0, nbytes=0.0):
+        """HIP-event bracket of a phase of the step (active only when ops.PROFILE is a dict)."""
+        return ops.record("phase:" + tag, flops, nbytes)
 
     # ------------------------------------------------------------------------------------- modules
     def build_heads(self):

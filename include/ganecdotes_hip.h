@@ -68,13 +68,20 @@ int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream);
 int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream);
 int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream);
 int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float scale, float* demod, void* stream);
+size_t gx_modconv_slab_bytes(int B, int outH, int outW, int Cout);   /* optional split-K scratch (small layers) */
 int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
                    const float* demod, const float* noise, long noise_bstride, const float* noise_w,
-                   const float* bias, int act, float* out, void* stream);
+                   const float* bias, int act, float* out, float* slab, size_t slab_bytes, void* stream);
 size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout);
 int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
                       const float* demod, const float* kf, const float* noise, long noise_bstride,
-                      const float* noise_w, const float* bias, int act, float* T, float* out, void* stream);
+                      const float* noise_w, const float* bias, int act, float* T, float* out, float* slab,
+                      size_t slab_bytes, void* stream);
+int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                        float* T, float* slab, size_t slab_bytes, void* stream);   /* stage 1: transposed conv -> T */
+int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
+                    const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
+                    float* out, void* stream);                         /* stage 2: blur + epilogue */
 int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, const float* s, float scale,
                  const float* bias3, const float* prev_img, const float* kf, float* img, void* stream);
 int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* stream);
