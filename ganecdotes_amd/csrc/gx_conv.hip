@@ -100,8 +100,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
 
     auto load_a = [&](int kt) {
-        const int tap = kt / kt_per_tap;
-        const int ci = (kt - tap * kt_per_tap) * BK + kq;
+        // k order: channel chunk outer, tap inner — the 9 shifted reads of one 32-channel slab
+        // of the input rows are consecutive, so they hit L1/L2 instead of streaming 9x from HBM
+        const int cc = kt / ntaps, tap = kt - cc * ntaps;
+        const int ci = cc * BK + kq;
         const long toff = ((long)sb.dy[tap] * g.IW + sb.dx[tap]) * g.Cin + ci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
         }
     };
     auto load_w = [&](int kt) {
-        const int tap = kt / kt_per_tap;
-        const int ci = (kt - tap * kt_per_tap) * BK + kq;
+        const int cc = kt / ntaps, tap = kt - cc * ntaps;
+        const int ci = cc * BK + kq;
         const long wbase = (long)sb.tw[tap] * g.Cout;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
