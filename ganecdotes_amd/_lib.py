@@ -29,6 +29,10 @@ SIGNATURES = {
     "gx_sumpool2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "gx_gather_rows_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_normalize_bwd_scatter": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "gx_proto_small_workspace_bytes": (c_sz, [c_i, c_i]),
+    "gx_proto_fwd_small": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "gx_proto_bwd_small": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,
+                                 c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
@@ -60,6 +64,7 @@ SIGNATURES = {
     "gx_sinkhorn_pass": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_update": (c_i, [c_p, c_p, c_i, c_i, c_p, c_f, c_p, c_p]),
     "gx_sinkhorn": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_small": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_codes": (c_i, [c_p, c_l, c_i, c_l, c_f, c_p, c_p, c_l, c_p]),
     "gx_hist_marginal": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
     "gx_swapped_ce_workspace_bytes": (c_sz, []),

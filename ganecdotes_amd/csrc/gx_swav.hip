@@ -849,3 +849,381 @@ int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float*
 }
 
 }  // extern "C"
+
+// ============================================================================================
+// Single-rank Sinkhorn for few prototypes (K <= 64): one launch per iteration.  The la update
+// that follows pass i-1 (fixed-order reduction of its per-block column sums) is folded into the
+// prologue of pass i, so an iteration is ONE kernel instead of {pass, reduce, update}; the column
+// maxima use a team-per-row kernel.  (The sharded form keeps the 3-kernel sequence because the
+// column sums must be all-reduced between passes.)
+namespace gx {
+
+__global__ void sk_colmax_small_kernel(const float* __restrict__ S, long rows, int K, long ld, int team,
+                                       unsigned* __restrict__ cmax) {
+    __shared__ unsigned smax[64];
+    if (threadIdx.x < 64) smax[threadIdx.x] = 0u;
+    __syncthreads();
+    const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
+    float v = -INFINITY;
+    if (tl < K)
+        for (long row = (long)blockIdx.x * tpb + ti; row < rows; row += (long)gridDim.x * tpb)
+            v = fmaxf(v, S[row * ld + tl]);
+    if (tl < K) atomicMax(&smax[tl], f2ord(v));
+    __syncthreads();
+    if (threadIdx.x < K) atomicMax(&cmax[threadIdx.x], smax[threadIdx.x]);
+}
+
+// la_cur[k] = base[k] + log r_k - log(sum_b upart_prev[b][k]);  base = first_update ? -cmax/eps : la_prev.
+// Result left in LDS las[0..K) for every thread (and written to la_out by the caller if wanted).
+__device__ __forceinline__ void sk_fold_update(const float* __restrict__ upart_prev, int nblk_prev, int K, int kx,
+                                               const float* __restrict__ la_prev, const unsigned* __restrict__ cmax,
+                                               bool first_update, float inv_eps, const float* __restrict__ r,
+                                               float* las, float* red) {
+    const int tx = threadIdx.x % kx, ty = threadIdx.x / kx, ny = blockDim.x / kx;
+    float s = 0.f;
+    if (tx < K) for (int b = ty; b < nblk_prev; b += ny) s += upart_prev[(long)b * K + tx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = ny >> 1; h > 0; h >>= 1) {
+        if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * kx];
+        __syncthreads();
+    }
+    if (ty == 0 && tx < K) {
+        const float base = first_update ? -ord2f(cmax[tx]) * inv_eps : la_prev[tx];
+        las[tx] = base + logf(r ? r[tx] : 1.f / (float)K) - logf(red[tx]);
+    }
+    __syncthreads();
+}
+
+// it == 0: u_k = sum_n exp((S_nk - cmax_k)/eps).  it >= 1: fold the update of pass it-1, then sweep.
+__global__ void sk_pass_small_kernel(const float* __restrict__ S, long rows, int K, long ld, int team, int kx,
+                                     float inv_eps, int it, const unsigned* __restrict__ cmax,
+                                     const float* __restrict__ r, const float* __restrict__ c, float c_uniform,
+                                     const float* __restrict__ upart_prev, int nblk_prev,
+                                     const float* __restrict__ la_prev, float* __restrict__ la_cur,
+                                     float* __restrict__ upart) {
+    __shared__ float las[64], uacc[64], red[256];
+    if (threadIdx.x < 64) uacc[threadIdx.x] = 0.f;
+    if (it == 0) {
+        if (threadIdx.x < K) las[threadIdx.x] = -ord2f(cmax[threadIdx.x]) * inv_eps;
+        __syncthreads();
+    } else {
+        sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < K && la_cur) la_cur[threadIdx.x] = las[threadIdx.x];
+    const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
+    const long nrow_iters = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    float ul = 0.f;                                           // this lane's column (k = tl) partial: K <= team
+    for (long itr = 0; itr < nrow_iters; ++itr) {
+        const long row = (itr * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows && tl < K;
+        const float w = live ? fmaf(S[row * ld + tl], inv_eps, las[tl]) : -INFINITY;
+        float lb = 0.f;
+        if (it > 0) {
+            const float mx = gx_team_max(w, team);
+            const float sum = gx_team_sum(live ? expf(w - mx) : 0.f, team);
+            lb = logf(c ? c[row < rows ? row : 0] : c_uniform) - mx - logf(sum);
+        }
+        if (live) ul += expf(w + lb);
+    }
+    for (int o = team; o < 64; o <<= 1) ul += __shfl_xor(ul, o, 64);
+    if ((threadIdx.x & 63) < team && tl < K) atomicAdd(&uacc[tl], ul);
+    __syncthreads();
+    if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
+}
+
+__global__ void sk_finish_small_kernel(const float* __restrict__ upart_prev, int nblk_prev, int K, int kx,
+                                       const float* __restrict__ la_prev, const unsigned* __restrict__ cmax,
+                                       int first_update, float inv_eps, const float* __restrict__ r,
+                                       float* __restrict__ la_out) {
+    __shared__ float las[64], red[256];
+    sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, first_update != 0, inv_eps, r, las, red);
+    if (threadIdx.x < K) la_out[threadIdx.x] = las[threadIdx.x];
+}
+
+}  // namespace gx
+
+extern "C" {
+// Single-rank Sinkhorn for K <= 64 (same result as gx_sinkhorn; niters + 2 launches).
+// Workspace: gx_sinkhorn_workspace_bytes(K).
+int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
+                      const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S || !la || rows <= 0 || K <= 0 || K > 64 || ld < K || eps <= 0.f || niters < 1) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int team = gx::pick_team(K);
+    int nb = sk_blocks(rows, team);
+    if (nb > 250) nb = 250;                                     // two partial buffers must fit the workspace
+    int kx = 1;
+    while (kx < 64 && kx < K) kx <<= 1;
+    unsigned* cmax = (unsigned*)workspace;                      // [K]
+    float* labuf = workspace + K;                               // [2][K]  (the "u" slot is not used here)
+    float* part = workspace + 3 * (size_t)K;                    // [2][nb][K]  (fits: 2K + BLOCKS*K >= 3K + 2*nb*K? checked below)
+    if ((size_t)3 * K + (size_t)2 * nb * K > (size_t)2 * K + (size_t)GX_SK_BLOCKS * K) {
+        return GX_ERR_WORKSPACE;
+    }
+    if (hipMemsetAsync(cmax, 0, (size_t)K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
+    hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb), dim3(256), 0, st, S, rows, K, ld, team, cmax);
+    GX_CHECK_LAUNCH();
+    const float c_uniform = 1.f / (float)rows;
+    for (int it = 0; it < niters; ++it) {
+        float* up_prev = part + (size_t)((it + 1) & 1) * nb * K;
+        float* up_cur = part + (size_t)(it & 1) * nb * K;
+        hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb), dim3(256), 0, st, S, rows, K, ld, team, kx, 1.f / eps, it,
+                           cmax, r, c, c_uniform, up_prev, nb, labuf + (size_t)((it + 1) & 1) * K,
+                           labuf + (size_t)(it & 1) * K, up_cur);
+        GX_CHECK_LAUNCH();
+    }
+    const int last = niters - 1;
+    hipLaunchKernelGGL(gx::sk_finish_small_kernel, dim3(1), dim3(256), 0, st, part + (size_t)(last & 1) * nb * K, nb, K,
+                       kx, labuf + (size_t)(last & 1) * K, cmax, niters == 1 ? 1 : 0, 1.f / eps, r, la);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+}  // extern "C"
+
+// ============================================================================================
+// Small-prototype fast path (K <= 16, e.g. BASELINE configs with 8 / 16 prototypes): with so few
+// prototypes the prototype layer is HBM-bound row work, not a GEMM.  Two fused kernels replace
+// {row gather, normalise, scores GEMM} and {dz GEMM, dWc GEMM, db column sums, normalise-backward,
+// scatter}: each reads its rows exactly once; prototype rows live in LDS; row sums use wavefront
+// shuffles (a halving butterfly reduces the K partial dot products with K-1 + log2(64/K) shuffles).
+namespace gx {
+
+constexpr int PS_MAXV = 4;     // float4 per lane: D <= 1024
+
+// Reduce v[0..KP) across the 64 lanes; afterwards every lane holds the total of ONE index,
+// k = ps_lane_k<KP>(lane).
+template <int KP>
+__device__ __forceinline__ float ps_reduce(float (&v)[KP], int lane) {
+    int o = 32;
+#pragma unroll
+    for (int half = KP / 2; half >= 1; half >>= 1) {
+        const bool hi = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float keep = hi ? v[half + i] : v[i];
+            const float send = hi ? v[i] : v[half + i];
+            v[i] = keep + __shfl_xor(send, o, 64);
+        }
+        o >>= 1;
+    }
+    float r = v[0];
+    for (; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+    return r;
+}
+template <int KP>
+__device__ __forceinline__ int ps_lane_k(int lane) {
+    int k = 0, o = 32;
+#pragma unroll
+    for (int half = KP / 2; half >= 1; half >>= 1) { if (lane & o) k += half; o >>= 1; }
+    return k;
+}
+template <int KP>
+__device__ __forceinline__ bool ps_lane_owner(int lane) { return (lane & ((64 / KP) - 1)) == 0; }
+
+// zhat[row] = normalize(Z[b][src(pick)]) ; rnorm ; scores[row][k] = <zhat, Wc[k]> + bias[k]
+template <int KP>
+__global__ __launch_bounds__(256) void proto_fwd_small_kernel(const float* __restrict__ Z, int HW, int D,
+                                                              const int* __restrict__ picks,
+                                                              const int* __restrict__ maps, int rows_per_img,
+                                                              long rows, const float* __restrict__ Wc,
+                                                              const float* __restrict__ bias, int K,
+                                                              float* __restrict__ zhat, float* __restrict__ rnorm,
+                                                              float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] (rows >= K are zero)
+    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nv = D >> 8;                      // float4 per lane (D % 256 == 0)
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    const int myk = ps_lane_k<KP>(lane);
+    const bool owner = ps_lane_owner<KP>(lane) && myk < K;
+    const float myb = (owner && bias) ? bias[myk] : 0.f;
+    for (long row = wave0; row < rows; row += nwave) {
+        const int b = (int)(row / rows_per_img);
+        int pix = picks[row];
+        if (maps) pix = maps[(long)b * HW + pix];
+        f32x4 z[PS_MAXV];
+        float ss = 0.f;
+        if (pix >= 0) {
+            const float* src = Z + ((long)b * HW + pix) * D;
+#pragma unroll
+            for (int i = 0; i < PS_MAXV; ++i)
+                if (i < nv) {
+                    z[i] = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+                    ss += z[i][0] * z[i][0] + z[i][1] * z[i][1] + z[i][2] * z[i][2] + z[i][3] * z[i][3];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PS_MAXV; ++i) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ss = gx_wave_sum(ss);
+        const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        float p[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) p[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PS_MAXV; ++i)
+            if (i < nv) {
+                z[i] *= rn;
+                *reinterpret_cast<f32x4*>(zhat + row * D + (i * 64 + lane) * 4) = z[i];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
+                    p[k] += z[i][0] * w[0] + z[i][1] * w[1] + z[i][2] * w[2] + z[i][3] * w[3];
+                }
+            }
+        const float sc = ps_reduce<KP>(p, lane);
+        if (owner) scores[row * K + myk] = sc + myb;
+        if (lane == 0) rnorm[row] = rn;
+    }
+}
+
+// Per row: dzh = dS[row] Wc ; dz = normalize-backward(dzh) scattered (atomics) into G ;
+// block partials of gWc[k][:] += dS[row][k] zhat[row] and gb[k] += dS[row][k].
+template <int KP>
+__global__ __launch_bounds__(256) void proto_bwd_small_kernel(const float* __restrict__ dS, const float* __restrict__ zhat,
+                                                              const float* __restrict__ rnorm, int HW, int D,
+                                                              const int* __restrict__ picks,
+                                                              const int* __restrict__ maps, int rows_per_img,
+                                                              long rows, const float* __restrict__ Wc, int K,
+                                                              float* __restrict__ G, float* __restrict__ part_w,
+                                                              float* __restrict__ part_b) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] prototypes, then reused
+    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    __syncthreads();
+    // lane l owns columns c = j*64 + l (j < D/64 <= 8): every wave-instruction of the atomic
+    // scatter then covers 256 CONTIGUOUS bytes (the full-rate shape of global float atomics)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nj = D >> 6;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wid;
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    float gw[KP][8];                                                      // D <= 512 on this path
+    float gbk[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        gbk[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gw[k][j] = 0.f;
+    }
+    for (long row = wave0; row < rows; row += nwave) {
+        const int b = (int)(row / rows_per_img);
+        int pix = picks[row];
+        if (maps) pix = maps[(long)b * HW + pix];
+        float ds[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) ds[k] = k < K ? dS[row * K + k] : 0.f;
+        const float rn = rnorm[row];
+        float z[8], dzh[8];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nj) {
+                const int c = j * 64 + lane;
+                z[j] = zhat[row * D + c];
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    a = fmaf(wsm[k * D + c], ds[k], a);
+                    gw[k][j] = fmaf(z[j], ds[k], gw[k][j]);
+                }
+                dzh[j] = a;
+                dot = fmaf(a, z[j], dot);
+            }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) gbk[k] += ds[k];
+        dot = gx_wave_sum(dot);
+        if (pix >= 0) {                                                   // zero-filled pixel: no gradient to Wp
+            const bool clamped = rn >= 1e12f;
+            float* dst = G + ((long)b * HW + pix) * D;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) atomicAdd(dst + j * 64 + lane, clamped ? dzh[j] * rn : rn * (dzh[j] - z[j] * dot));
+        }
+    }
+    // block partial: sum the 4 waves through LDS (fixed order), one [K][D] slab + K bias sums per block
+    __syncthreads();                                                       // prototypes no longer needed
+    float* red = wsm;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {          // fully unrolled: gw[k] must stay a register (no dynamic index)
+        if (k < K) {                        // K is block-uniform, so the barriers below are uniform too
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) red[wid * D + j * 64 + lane] = gw[k][j];
+            __syncthreads();
+            for (int c = threadIdx.x; c < D; c += blockDim.x)
+                part_w[((long)blockIdx.x * K + k) * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
+            __syncthreads();
+        }
+    }
+    // bias partial: every lane of a wave holds the same gbk
+    if (lane == 0)
+        for (int k = 0; k < K; ++k) red[wid * KP + k] = gbk[k];
+    __syncthreads();
+    if (threadIdx.x < K)
+        part_b[(long)blockIdx.x * K + threadIdx.x] = (red[threadIdx.x] + red[KP + threadIdx.x]) +
+                                                     (red[2 * KP + threadIdx.x] + red[3 * KP + threadIdx.x]);
+}
+
+}  // namespace gx
+
+extern "C" {
+
+#define GX_PS_BLOCKS 1024
+// workspace for gx_proto_bwd_small: block partials of gWc and gb
+size_t gx_proto_small_workspace_bytes(int K, int D) { return (size_t)GX_PS_BLOCKS * ((size_t)K * D + K) * sizeof(float); }
+
+// Fused forward for K <= 16 prototypes: zhat (rows, D), rnorm (rows), scores (rows, K).
+// Needs D % 256 == 0, D <= 1024.
+int gx_proto_fwd_small(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
+                       const float* Wc, const float* bias, int K, float* zhat, float* rnorm, float* scores,
+                       void* stream) {
+    if (!Z || !picks || !Wc || !zhat || !rnorm || !scores || B <= 0 || HW <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
+    if (K < 1 || K > 16 || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
+    const long rows = (long)B * rows_per_img;
+    long nb = (rows + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    const int kp = K <= 8 ? 8 : 16;
+    const size_t lds = (size_t)kp * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::proto_fwd_small_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z, HW, D,
+                           picks, maps, rows_per_img, rows, Wc, bias, K, zhat, rnorm, scores);
+    else
+        hipLaunchKernelGGL((gx::proto_fwd_small_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z, HW,
+                           D, picks, maps, rows_per_img, rows, Wc, bias, K, zhat, rnorm, scores);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// Fused backward for K <= 16: G += scatter(normalize-bwd(dS Wc)); gWc = beta*gWc + dS^T zhat;
+// gb = beta*gb + colsum(dS).  Needs D % 256 == 0, D <= 512.
+int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, int B, int HW, int D, const int* picks,
+                       int rows_per_img, const int* maps, const float* Wc, int K, float* G, float* gWc, float* gb,
+                       float beta, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dS || !zhat || !rnorm || !picks || !Wc || !G || !gWc || !gb || B <= 0 || HW <= 0 || rows_per_img <= 0)
+        return GX_ERR_BAD_ARG;
+    if (K < 1 || K > 16 || (D & 255) || D > 512) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_proto_small_workspace_bytes(K, D)) return GX_ERR_WORKSPACE;
+    const long rows = (long)B * rows_per_img;
+    long nb = (rows + 3) / 4;
+    if (nb > GX_PS_BLOCKS) nb = GX_PS_BLOCKS;
+    float* part_w = workspace;
+    float* part_b = workspace + (size_t)GX_PS_BLOCKS * K * D;
+    const int kp = K <= 8 ? 8 : 16;
+    size_t lds = (size_t)kp * D * sizeof(float);
+    if (lds < (size_t)4 * D * sizeof(float)) lds = (size_t)4 * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::proto_bwd_small_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, dS, zhat,
+                           rnorm, HW, D, picks, maps, rows_per_img, rows, Wc, K, G, part_w, part_b);
+    else
+        hipLaunchKernelGGL((gx::proto_bwd_small_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, dS,
+                           zhat, rnorm, HW, D, picks, maps, rows_per_img, rows, Wc, K, G, part_w, part_b);
+    GX_CHECK_LAUNCH();
+    gx::launch_partial_reduce(part_w, (int)nb, K * D, 1.f, beta, gWc, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    gx::launch_partial_reduce(part_b, (int)nb, K, 1.f, beta, gb, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // extern "C"

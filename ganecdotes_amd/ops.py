@@ -164,6 +164,36 @@ def normalize_bwd_scatter_(dzhat, zhat, rnorm, picks, maps, g):
     return g
 
 
+def proto_small_ok(k, d):
+    return k <= 16 and d % 256 == 0 and d <= 512
+
+
+def proto_fwd_small(z, picks, maps, wc, bias):
+    """Fused row gather + normalise + scores for K <= 16 prototypes."""
+    _chk(z, wc, bias)
+    b, h, w, d = z.shape
+    n, k = picks.shape[1], wc.shape[0]
+    zhat = torch.empty(b * n, d, dtype=torch.float32, device=z.device)
+    rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
+    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device)
+    _lib.check(lib().gx_proto_fwd_small(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(wc), _p(bias), k, _p(zhat),
+                                        _p(rn), _p(sc), _stream()), "gx_proto_fwd_small")
+    return zhat, rn, sc
+
+
+def proto_bwd_small_(ds, zhat, rnorm, picks, maps, wc, g, gwc, gb, beta):
+    """Fused dz GEMM + dWc GEMM + db + normalise-backward + scatter for K <= 16 prototypes."""
+    _chk(ds, zhat, rnorm, wc, g, gwc, gb)
+    b, h, w, d = g.shape
+    k = wc.shape[0]
+    L = lib()
+    wsb = L.gx_proto_small_workspace_bytes(k, d)
+    ws = workspace("protosmall", wsb, g.device)
+    _lib.check(L.gx_proto_bwd_small(_p(ds), _p(zhat), _p(rnorm), b, h * w, d, _p(picks), picks.shape[1], _p(maps),
+                                    _p(wc), k, _p(g), _p(gwc), _p(gb), beta, _p(ws), wsb, _stream()),
+               "gx_proto_bwd_small")
+
+
 # ------------------------------------------------------------------------------------- generator pieces
 def pixel_norm(x):
     _chk(x)
@@ -395,6 +425,11 @@ class Sinkhorn:
     def run(self, reduce=None):
         L, S, K = lib(), self.S, self.K
         if reduce is None and self.c_uniform == 1.0 / self.rows:
+            if K <= 64 and self.rows >= 4096:
+                _lib.check(L.gx_sinkhorn_small(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r),
+                                               _p(self.c), _p(self.la), _p(self.ws), self.wsb, _stream()),
+                           "gx_sinkhorn_small")
+                return self
             _lib.check(L.gx_sinkhorn(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r), _p(self.c),
                                      _p(self.la), _p(self.ws), self.wsb, _stream()), "gx_sinkhorn")
             return self

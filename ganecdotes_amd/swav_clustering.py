@@ -322,6 +322,7 @@ class SwAVClustering(object):
         first_acc = True
         aux = {}
         mode = sa.get('projection_mode', 'pyramid')
+        small = sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D)
         if mode == 'pyramid':
             with self._timed("pyramid_fwd"):
                 pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
@@ -331,6 +332,11 @@ class SwAVClustering(object):
             picks = pb.picks[pno]
             X, Zh, Rn, Sc = [], [], [], []
             for v, (ts, maps, _) in enumerate(views):
+                if mode == 'pyramid' and small:
+                    with self._timed("proto_fwd_small"):
+                        z, rn, sc = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc)
+                    Zh.append(z); Rn.append(rn); Sc.append(sc)
+                    continue
                 if mode == 'pyramid':
                     with self._timed("gather_rows"):
                         z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
@@ -367,6 +373,11 @@ class SwAVClustering(object):
             # S6: backward (gradients accumulate over views and patches)
             for v in range(2):
                 beta = 0.0 if first_acc else 1.0
+                if mode == 'pyramid' and small:
+                    with self._timed("proto_bwd_small"):
+                        ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
+                    first_acc = False
+                    continue
                 ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                 ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
                 dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)

@@ -116,6 +116,18 @@ int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* pi
 int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float* rnorm, int B, int HW, int D,
                              const int* picks, int rows_per_img, const int* maps, float* G, void* stream);
 
+/* ---- small-prototype fast path (K <= 16): the prototype layer as fused HBM-bound row kernels ----
+ * gx_proto_fwd_small  = gx_gather_rows_normalize + scores = zhat Wc^T + b   (swav_clustering.py:171-175)
+ * gx_proto_bwd_small  = dz_hat = dS Wc, gWc (+)= dS^T zhat, gb (+)= colsum(dS), normalise-backward,
+ *                       scatter into G                                      (autograd of :171-175) */
+size_t gx_proto_small_workspace_bytes(int K, int D);
+int gx_proto_fwd_small(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
+                       const float* Wc, const float* bias, int K, float* zhat, float* rnorm, float* scores,
+                       void* stream);
+int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, int B, int HW, int D, const int* picks,
+                       int rows_per_img, const int* maps, const float* Wc, int K, float* G, float* gWc, float* gb,
+                       float beta, float* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- projection / prototype helpers ---------------------------------------------------------
  * gx_row_l2_normalize   F.normalize(p=2, dim=1) in place, rnorm out     swav_clustering.py:174
  * gx_l2_normalize_bwd   its backward (autograd of :174)                  swav_clustering.py:459
@@ -148,6 +160,9 @@ int gx_sinkhorn_update(const float* u, const float* r, int K, int first, const f
                        float* la, void* stream);
 int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters, const float* r, const float* c,
                 float* la, float* workspace, size_t workspace_bytes, void* stream);
+int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
+                      const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream);
+                      /* same result for K <= 64 on one rank: one launch per iteration */
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);

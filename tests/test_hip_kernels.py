@@ -146,6 +146,31 @@ def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
     assert (q.argmax(1) == ref.argmax(1))[decided].all()
 
 
+@pytest.mark.parametrize("n,k,eps,pdf", [(5000, 8, 0.005, "uniform"), (9000, 40, 0.01, "uniform"),
+                                         (4100, 16, 0.003, "image"), (320000, 8, 0.005, "uniform")])
+def test_sinkhorn_small_fused_path(ops, n, k, eps, pdf):
+    """rows >= 4096 and K <= 64 take gx_sinkhorn_small (one launch per iteration): same codes as
+    the generic 3-kernel sequence and as the oracle"""
+    from oracle import swav_ref as S
+    torch.manual_seed(n + k)
+    s = 0.3 * torch.nn.functional.normalize(torch.randn(n, 16), dim=1) @ \
+        torch.nn.functional.normalize(torch.randn(k, 16), dim=1).t()
+    sd = dev(s)
+    r = c = None
+    img = torch.rand(1, 64, 64) * 2 + 0.1
+    if pdf == "image":
+        r, c = ops.hist_marginal(dev(img), k), ops.hist_marginal(dev(img), n)
+    q = ops.Sinkhorn(sd, eps, 10, r=r, c=c).run().codes().cpu().numpy()
+    generic = ops.Sinkhorn(sd, eps, 10, r=r, c=c, tag="skg")
+    from ganecdotes_amd.sharded import run_sinkhorn
+    run_sinkhorn(generic, 10, None)
+    qg = generic.codes().cpu().numpy()
+    np.testing.assert_allclose(q, qg, rtol=2e-4, atol=1e-7)
+    if n <= 10000:
+        ref = S.sinkhorn_knopp(s, eps, 10, pdf, img, fp64=True).numpy()
+        assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
+
+
 def test_sinkhorn_sharded_equals_single(ops):
     """W-rank result == 1-rank result on the concatenated pixels (ranks faked)."""
     torch.manual_seed(11)
@@ -308,6 +333,36 @@ def test_pyramid_pieces(ops):
         ok = src[i] >= 0
         want[i].index_add_(0, src[i][ok], x1.grad.reshape(b, 100, d)[i][ok])
     assert rel_err(gfull.reshape(b, hw * hw, d), want) < 1e-5
+
+
+@pytest.mark.parametrize("d,k", [(256, 8), (512, 12), (512, 16), (256, 3)])
+def test_small_prototype_fused_kernels(ops, d, k):
+    """fused K<=16 kernels == the unfused gather/normalise/GEMM/colsum/scatter chain"""
+    torch.manual_seed(d + k)
+    b, hw, n = 2, 16, 150
+    z = dev(torch.randn(b, hw, hw, d))
+    wc = dev(torch.nn.functional.normalize(torch.randn(k, d), dim=1))
+    bias = dev(0.01 * torch.randn(k))
+    picks = torch.stack([torch.randperm(hw * hw)[:n] for _ in range(b)]).int().cuda()
+    maps = torch.stack([ops.rotflip_map(8.0, False, hw, hw, "cuda"), ops.rotflip_map(-5.0, True, hw, hw, "cuda")])
+    assert ops.proto_small_ok(k, d)
+    zh, rn, sc = ops.proto_fwd_small(z, picks, maps, wc, bias)
+    zh0, rn0 = ops.gather_rows_normalize(z, picks, maps)
+    sc0 = ops.gemm(zh0, wc, False, True, col_bias=bias)
+    assert rel_err(zh, zh0) < 1e-6 and rel_err(rn, rn0) < 1e-6
+    assert rel_err(sc, sc0) < 2e-6
+    ds = dev(1e-3 * torch.randn(b * n, k))
+    g1 = torch.zeros(b, hw, hw, d, device="cuda")
+    gw1, gb1 = torch.full((k, d), 0.5, device="cuda"), torch.full((k,), 0.25, device="cuda")
+    ops.proto_bwd_small_(ds, zh, rn, picks, maps, wc, g1, gw1, gb1, 1.0)
+    g0 = torch.zeros(b, hw, hw, d, device="cuda")
+    gw0, gb0 = torch.full((k, d), 0.5, device="cuda"), torch.full((k,), 0.25, device="cuda")
+    ops.gemm(ds, zh0, True, False, out=gw0, beta=1.0, split_k=1)
+    ops.colsum(ds, gb0, alpha=1.0, beta=1.0)
+    dz = ops.gemm(ds, wc, False, False)
+    ops.normalize_bwd_scatter_(dz, zh0, rn0, picks, maps, g0)
+    assert rel_err(gw1, gw0) < 1e-5 and rel_err(gb1, gb0) < 1e-5
+    assert rel_err(g1, g0) < 1e-5
 
 
 # ------------------------------------------------------------------------------------- rows / optimizer
