@@ -48,7 +48,7 @@ def build(force=False, verbose=True):
     os.makedirs(bdir, exist_ok=True)
     for s in SOURCES:
         o = os.path.join(bdir, s.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", CSRC, "-c",
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", *os.environ.get("GX_EXTRA_FLAGS", "").split(), "-I", CSRC, "-c",
                os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

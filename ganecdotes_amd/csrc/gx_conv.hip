@@ -44,6 +44,87 @@ struct ConvArgs {
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
 
+// Main loop of one output tile for a sub-problem with NT taps (compile-time: the tap loop is
+// unrolled, so per-tap offsets live in SGPRs and nothing is fetched from the argument block inside
+// the loop).  k order = channel chunk (32 ch) outer, tap inner: the NT shifted reads of one
+// 32-channel slab of the input rows are consecutive (L1/L2 hits), and the modulation vector of
+// the chunk is loaded once per chunk, not per tap.
+template <bool VEC, int NT>
+__device__ __forceinline__ void conv_mainloop(const ConvArgs& g, const ConvSub& sb, float* lds, f32x16 (&acc)[2][2],
+                                              const long (&pix_off)[4], const int (&soff)[4],
+                                              const unsigned (&tapmask)[4], int n0, int cc0, int ncc, int tid, int wr,
+                                              int wc, int lane) {
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(g.in, VEC ? g.in_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(g.style ? g.style : g.in, (VEC && g.style) ? g.style_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
+    const int kq = (tid & 7) * 4;
+    long toff[NT], wb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        toff[t] = ((long)sb.dy[t] * g.IW + sb.dx[t]) * g.Cin;
+        wb[t] = (long)sb.tw[t] * g.Cout * g.Cin;
+    }
+    unsigned rowok[4];                                            // weight rows (co) this thread stages
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowok[i] = (n0 + (tid >> 3) + 32 * i) < g.Cout;
+    f32x4 ra[4], rw[4], st[4];
+
+    auto load_style = [&](int cc) {                               // once per channel chunk
+        const int ci = cc * BK + kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!g.style) { st[i] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
+            if (VEC) st[i] = buf_load4(rs_st, (unsigned)((soff[i] + ci) * 4) | oob_mask(ci < g.Cin));
+            else st[i] = ci < g.Cin ? load4(g.style + soff[i] + ci, g.Cin - ci, false) : zero4();
+        }
+    };
+    auto load_ab = [&](int cc, int tap, long to, long wbt) {      // tap / to / wbt are compile-time-indexed
+        const int ci = cc * BK + kq;
+        const bool cok = ci < g.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+            if (VEC) ra[i] = buf_load4(rs_in, (unsigned)((pix_off[i] + to + ci) * 4) | oob_mask(ok));
+            else ra[i] = ok ? load4(g.in + pix_off[i] + to + ci, g.Cin - ci, false) : zero4();
+            const long wo = wbt + (long)(n0 + (tid >> 3) + 32 * i) * g.Cin + ci;
+            const bool wok = rowok[i] && cok;
+            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)(wo * 4) | oob_mask(wok));
+            else rw[i] = wok ? load4(g.wt + wo, g.Cin - ci, false) : zero4();
+        }
+    };
+    auto stage = [&](float* dst) {                                // modulate, then registers -> LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] *= st[i];
+        store_tile<true>(dst, ra, tid);
+        store_tile<true>(dst + TILE_FLOATS, rw, tid);
+    };
+
+    if (ncc > 0) {
+        load_style(cc0);
+        load_ab(cc0, 0, toff[0], wb[0]);
+        stage(lds);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int cc = cc0; cc < cc0 + ncc; ++cc) {
+        const bool last_cc = (cc + 1 == cc0 + ncc);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            float* As = lds + buf * 2 * TILE_FLOATS;
+            const bool wrap = (tap + 1 == NT);
+            const bool more = !(wrap && last_cc);
+            if (more) load_ab(wrap ? cc + 1 : cc, wrap ? 0 : tap + 1, toff[wrap ? 0 : tap + 1], wb[wrap ? 0 : tap + 1]);
+            mfma_ktile<true, true>(As, As + TILE_FLOATS, acc, wr, wc, lane);
+            if (more) {
+                if (wrap) load_style(cc + 1);                     // next chunk's modulation (used by stage below)
+                stage(lds + (buf ^ 1) * 2 * TILE_FLOATS);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+}
+
 // VEC: in / wt / style 16-B aligned and Cin % 4 == 0 (every real layer); otherwise the scalar path.
 template <bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
@@ -60,7 +141,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int OH = sb.OH, OW = sb.OW, ntaps = sb.ntaps;
-    const long Mtot = (long)g.B * OH * OW;
+    const unsigned ohw = (unsigned)OH * (unsigned)OW;
+    const unsigned Mtot = (unsigned)g.B * ohw;                    // host guarantees < 2^31
 
     // per-thread constants of the 4 pixel rows it stages: input offset of the (un-shifted)
     // pixel, style row offset, and one validity bit per tap (zero padding / row >= M)
@@ -69,122 +151,83 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     unsigned tapmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long m = (long)m0 + (tid >> 3) + 32 * i;
+        const unsigned m = (unsigned)m0 + (tid >> 3) + 32 * i;
         pix_off[i] = 0; soff[i] = 0; tapmask[i] = 0;
         if (m < Mtot) {
-            const int b = (int)(m / ((long)OH * OW));
-            const int rem = (int)(m - (long)b * OH * OW);
-            const int oy = rem / OW, ox = rem - oy * OW;
+            const unsigned b = m / ohw, rem = m - b * ohw;
+            const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
             pix_off[i] = (((long)b * g.IH + oy) * g.IW + ox) * g.Cin;
-            soff[i] = b * g.Cin;
+            soff[i] = (int)b * g.Cin;
             for (int t = 0; t < ntaps; ++t) {
                 const int iy = oy + sb.dy[t], ix = ox + sb.dx[t];
                 if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) tapmask[i] |= 1u << t;
             }
         }
     }
-    const int kt_per_tap = (g.Cin + BK - 1) / BK;
-    const int nkt_all = ntaps * kt_per_tap;
-    const int kps = (nkt_all + g.splits - 1) / g.splits;        // k-tiles per split
-    const int kt0 = blockIdx.y * kps;
-    const int nkt = max(0, min(nkt_all, kt0 + kps) - kt0);
-    const int kq = (tid & 7) * 4;
+    // split-K over channel chunks
+    const int ncc_all = (g.Cin + BK - 1) / BK;
+    const int cps = (ncc_all + g.splits - 1) / g.splits;
+    const int cc0 = blockIdx.y * cps;
+    const int ncc = max(0, min(ncc_all, cc0 + cps) - cc0);
 
     f32x16 acc[2][2];
     zero_acc(acc);
-    f32x4 ra[4], rw[4];
-    // VEC: whole-tensor buffer descriptors (host guarantees < 4 GB); an invalid lane's offset
-    // is pushed out of range and the hardware returns zeros — no branches around the loads.
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(g.in, VEC ? g.in_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(g.style ? g.style : g.in, (VEC && g.style) ? g.style_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
-
-    auto load_a = [&](int kt) {
-        // k order: channel chunk outer, tap inner — the 9 shifted reads of one 32-channel slab
-        // of the input rows are consecutive, so they hit L1/L2 instead of streaming 9x from HBM
-        const int cc = kt / ntaps, tap = kt - cc * ntaps;
-        const int ci = cc * BK + kq;
-        const long toff = ((long)sb.dy[tap] * g.IW + sb.dx[tap]) * g.Cin + ci;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = ((tapmask[i] >> tap) & 1u) && ci < g.Cin;
-            f32x4 v;
-            if (VEC) {
-                const unsigned om = oob_mask(ok);
-                v = buf_load4(rs_in, (unsigned)((pix_off[i] + toff) * 4) | om);
-                if (g.style) v *= buf_load4(rs_st, (unsigned)((soff[i] + ci) * 4) | om);
-            } else {
-                v = zero4();
-                if (ok) {
-                    v = load4(g.in + pix_off[i] + toff, g.Cin - ci, false);
-                    if (g.style) v *= load4(g.style + soff[i] + ci, g.Cin - ci, false);
-                }
-            }
-            ra[i] = v;
-        }
-    };
-    auto load_w = [&](int kt) {
-        const int cc = kt / ntaps, tap = kt - cc * ntaps;
-        const int ci = cc * BK + kq;
-        const long wbase = (long)sb.tw[tap] * g.Cout;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = n0 + (tid >> 3) + 32 * i;
-            const bool ok = co < g.Cout && ci < g.Cin;
-            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)(((wbase + co) * g.Cin + ci) * 4) | oob_mask(ok));
-            else rw[i] = ok ? load4(g.wt + (wbase + co) * g.Cin + ci, g.Cin - ci, false) : zero4();
-        }
-    };
-
-    if (nkt > 0) {
-        load_a(kt0); load_w(kt0);
-        store_tile<true>(lds, ra, tid);
-        store_tile<true>(lds + TILE_FLOATS, rw, tid);
-    }
-    __syncthreads();
-    for (int t = 0; t < nkt; ++t) {
-        float* As = lds + (t & 1) * 2 * TILE_FLOATS;
-        float* Bs = As + TILE_FLOATS;
-        const bool more = (t + 1 < nkt);
-        if (more) { load_a(kt0 + t + 1); load_w(kt0 + t + 1); }
-        mfma_ktile<true, true>(As, Bs, acc, wr, wc, lane);
-        if (more) {
-            float* An = lds + ((t + 1) & 1) * 2 * TILE_FLOATS;
-            store_tile<true>(An, ra, tid);
-            store_tile<true>(An + TILE_FLOATS, rw, tid);
-        }
-        __syncthreads();
+    switch (ntaps) {
+        case 9: conv_mainloop<VEC, 9>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
+        case 4: conv_mainloop<VEC, 4>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
+        case 2: conv_mainloop<VEC, 2>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
+        default: conv_mainloop<VEC, 1>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
     }
 
+    // ---- epilogue.  A lane's 16 rows of an MFMA tile are m = base + (r&3) + 8*(r>>2): decode the
+    // base once, then walk the rows with carries instead of 64 integer divisions per lane.
     const bool to_slab = g.slab != nullptr;
     float* outp = to_slab ? g.slab + (long)blockIdx.y * g.B * g.outH * g.outW * g.Cout : g.out;
     const float nw = (!to_slab && g.noise && g.noise_w) ? *g.noise_w : 0.f;
+    int co[2]; bool cok[2]; float bias_c[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < 2; ++nt) {
+        co[nt] = n0 + acc_col(wc, nt, lane);
+        cok[nt] = co[nt] < g.Cout;
+        bias_c[nt] = (!to_slab && g.bias && cok[nt]) ? g.bias[co[nt]] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const unsigned mbase = (unsigned)m0 + acc_row(wr, mt, 0, lane);
+        unsigned b = mbase / ohw, rem = mbase - b * ohw;
+        int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+        int prev = 0, bcur = -1;
+        float dm[2] = {1.f, 1.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = (long)m0 + acc_row(wr, mt, r, lane);
-            if (m >= Mtot) continue;
-            const int b = (int)(m / ((long)OH * OW));
-            const int rem = (int)(m - (long)b * OH * OW);
-            const int oy = rem / OW, ox = rem - oy * OW;
+            const int delta = (r & 3) + 8 * (r >> 2);
+            ox += delta - prev; prev = delta;
+            while (ox >= OW) { ox -= OW; ++oy; }
+            while (oy >= OH) { oy -= OH; ++b; }
+            if (mbase + delta >= Mtot) continue;
             const int y = oy * g.ymul + sb.yadd, x = ox * g.xmul + sb.xadd;
             const long pix = ((long)b * g.outH + y) * g.outW + x;
-            const float nz = (!to_slab && g.noise) ? nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x] : 0.f;
+            float nz = 0.f;
+            if (!to_slab) {
+                if (g.noise) nz = nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x];
+                if (g.demod && (int)b != bcur) {
+                    bcur = (int)b;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) dm[nt] = cok[nt] ? g.demod[(long)b * g.Cout + co[nt]] : 1.f;
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int co = n0 + acc_col(wc, nt, lane);
-                if (co >= g.Cout) continue;
+                if (!cok[nt]) continue;
                 float v = acc[mt][nt][r];
                 if (!to_slab) {
-                    if (g.demod) v *= g.demod[(long)b * g.Cout + co];
-                    v += nz;
-                    if (g.bias) v += g.bias[co];
+                    v = fmaf(v, dm[nt], nz + bias_c[nt]);
                     if (g.act) v = lrelu_sqrt2(v);
                 }
-                outp[pix * g.Cout + co] = v;
+                outp[pix * g.Cout + co[nt]] = v;
             }
         }
+    }
 }
 
 // Split-K tail: out = epilogue(sum_s slab[s]) over the whole NHWC output (fixed order).
@@ -423,8 +466,9 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         g.sub[i].tile_base = base;
         g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, BM);
         base += g.sub[i].tiles_m * g.tiles_n;
-        const int kt = g.sub[i].ntaps * gx_cdiv(g.Cin, BK);
+        const int kt = gx_cdiv(g.Cin, BK);                     // split-K granularity = channel chunks
         min_kt = kt < min_kt ? kt : min_kt;
+        if ((long)g.B * g.sub[i].OH * g.sub[i].OW >= (1L << 31)) return GX_ERR_BAD_ARG;
     }
     g.ntile = base;
     g.splits = conv_pick_splits(0, g.Cout, base, min_kt);
