@@ -33,6 +33,10 @@ SIGNATURES = {
     "gx_proto_fwd_small": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_bwd_small": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,
                                  c_p]),
+    "gx_lowrank_stride": (c_i, []),
+    "gx_proto_fwd_lowrank": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "gx_proto_bwd_lowrank": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz, c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),

@@ -1227,3 +1227,236 @@ int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, i
 }
 
 }  // extern "C"
+
+// ============================================================================================
+// Low-rank prototype backward (K <= 15).  With few prototypes the gradient that reaches a
+// projected pixel is confined to span{Wc_1..Wc_K, Z[q]}:
+//     dz(row) = rn * (dS Wc - zhat <zhat, dS Wc>) = sum_k (rn dS_k) Wc_k - (rn^2 dot) Z[q],
+//     dot = <zhat, dS Wc> = sum_k dS_k (score_k - b_k)          (zhat = rn Z[q], q = src(pick))
+// so a row contributes K+1 COEFFICIENTS to its pixel instead of a D-vector: the per-patch
+// scatter shrinks from D*4 = 2 KB of float atomics per row to (K+1)*4 B, and zhat is never
+// written.  Once per view (after all patches) one dense pass rebuilds
+//     G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]        and        gWc += C[:, :K]^T Z
+// (gWc[k] = sum_rows dS_k zhat = sum_q C[q][k] Z[q] with the same coefficients).
+namespace gx {
+
+constexpr int LR_STRIDE = 16;          // coefficient slots per pixel: K <= 15 prototype slots + 1
+
+// scores[row][k] = rn * <Z[q], Wc_k> + b_k ; rnorm[row] = rn.  One wave per row.
+template <int KP>
+__global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __restrict__ Z, int HW, int D,
+                                                                const int* __restrict__ picks,
+                                                                const int* __restrict__ maps, int rows_per_img,
+                                                                long rows, const float* __restrict__ Wc,
+                                                                const float* __restrict__ bias, int K,
+                                                                float* __restrict__ rnorm, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] (rows >= K are zero)
+    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nv = D >> 8;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    const int myk = ps_lane_k<KP>(lane);
+    const bool owner = ps_lane_owner<KP>(lane) && myk < K;
+    const float myb = (owner && bias) ? bias[myk] : 0.f;
+    for (long row = wave0; row < rows; row += nwave) {
+        const int b = (int)(row / rows_per_img);
+        int pix = picks[row];
+        if (maps) pix = maps[(long)b * HW + pix];
+        float p[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) p[k] = 0.f;
+        float ss = 0.f;
+        if (pix >= 0) {
+            const float* src = Z + ((long)b * HW + pix) * D;
+#pragma unroll
+            for (int i = 0; i < PS_MAXV; ++i)
+                if (i < nv) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+                    ss += z[0] * z[0] + z[1] * z[1] + z[2] * z[2] + z[3] * z[3];
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
+                        p[k] += z[0] * w[0] + z[1] * w[1] + z[2] * w[2] + z[3] * w[3];
+                    }
+                }
+        }
+        ss = gx_wave_sum(ss);
+        const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        const float sc = ps_reduce<KP>(p, lane);
+        if (owner) scores[row * K + myk] = fmaf(sc, rn, myb);
+        if (lane == 0) rnorm[row] = rn;
+    }
+}
+
+// One THREAD per row: coefficient scatter + per-block partial of gb.
+__global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const float* __restrict__ scores,
+                                         const float* __restrict__ rnorm, const float* __restrict__ bias, int HW, int K,
+                                         const int* __restrict__ picks, const int* __restrict__ maps, int rows_per_img,
+                                         long rows, float* __restrict__ C, float* __restrict__ part_b) {
+    __shared__ float sb[LR_STRIDE];
+    if (threadIdx.x < LR_STRIDE) sb[threadIdx.x] = 0.f;
+    __syncthreads();
+    float gb[LR_STRIDE - 1];
+#pragma unroll
+    for (int k = 0; k < LR_STRIDE - 1; ++k) gb[k] = 0.f;
+    for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(row / rows_per_img);
+        int pix = picks[row];
+        if (maps) pix = maps[(long)b * HW + pix];
+        const float rn = rnorm[row];
+        float dot = 0.f;
+        float* dst = C + ((long)b * HW + (pix >= 0 ? pix : 0)) * LR_STRIDE;
+#pragma unroll
+        for (int k = 0; k < LR_STRIDE - 1; ++k)
+            if (k < K) {
+                const float d = dS[row * K + k];
+                gb[k] += d;
+                dot = fmaf(d, scores[row * K + k] - (bias ? bias[k] : 0.f), dot);
+                if (pix >= 0) atomicAdd(dst + k, rn * d);
+            }
+        if (pix >= 0) atomicAdd(dst + K, -rn * rn * dot);
+    }
+#pragma unroll
+    for (int k = 0; k < LR_STRIDE - 1; ++k)
+        if (k < K) {
+            const float s = gx_wave_sum(gb[k]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&sb[k], s);
+        }
+    __syncthreads();
+    if (threadIdx.x < K) part_b[(long)blockIdx.x * K + threadIdx.x] = sb[threadIdx.x];
+}
+
+// Dense finish, one wave per pixel: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of
+// gWc[k] += C[q][k] Z[q].  Lane l owns columns j*64 + l.
+template <int KP>
+__global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* __restrict__ C, const float* __restrict__ Z,
+                                                                   long npix, int D, const float* __restrict__ Wc, int K,
+                                                                   float* __restrict__ G, float* __restrict__ part_w) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D]
+    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nj = D >> 6;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wid;
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    float gw[KP][8];
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gw[k][j] = 0.f;
+    for (long q = wave0; q < npix; q += nwave) {
+        float c[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) c[k] = k < K ? C[q * LR_STRIDE + k] : 0.f;
+        const float cz = C[q * LR_STRIDE + K];
+        bool any = cz != 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) any = any || (c[k] != 0.f);
+        float* dst = G + q * D;
+        if (!any) {                                   // pixel never sampled: G row is zero, nothing for gWc
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) dst[j * 64 + lane] = 0.f;
+            continue;
+        }
+        const float* zq = Z + q * D;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nj) {
+                const int col = j * 64 + lane;
+                const float z = zq[col];
+                float a = cz * z;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    a = fmaf(c[k], wsm[k * D + col], a);
+                    gw[k][j] = fmaf(c[k], z, gw[k][j]);
+                }
+                dst[col] = a;
+            }
+    }
+    __syncthreads();
+    float* red = wsm;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nj) red[wid * D + j * 64 + lane] = gw[k][j];
+            __syncthreads();
+            for (int col = threadIdx.x; col < D; col += blockDim.x)
+                part_w[((long)blockIdx.x * K + k) * D + col] =
+                    (red[col] + red[D + col]) + (red[2 * D + col] + red[3 * D + col]);
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace gx
+
+extern "C" {
+
+int gx_lowrank_stride(void) { return gx::LR_STRIDE; }
+
+// scores (rows, K) and rnorm (rows) straight from the projected-pixel table (zhat is not written).
+int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
+                         const float* Wc, const float* bias, int K, float* rnorm, float* scores, void* stream) {
+    if (!Z || !picks || !Wc || !rnorm || !scores || B <= 0 || HW <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
+    if (K < 1 || K > 15 || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
+    const long rows = (long)B * rows_per_img;
+    long nb = (rows + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    const int kp = K <= 8 ? 8 : 16;
+    const size_t lds = (size_t)kp * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z, HW,
+                           D, picks, maps, rows_per_img, rows, Wc, bias, K, rnorm, scores);
+    else
+        hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z, HW,
+                           D, picks, maps, rows_per_img, rows, Wc, bias, K, rnorm, scores);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// C [B*HW][16] += per-row coefficients (float atomics); gb = beta*gb + colsum(dS).
+// workspace >= 1024*K floats.
+int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
+                         int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
+                         float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || rows_per_img <= 0 || K < 1 || K > 15)
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)1024 * K * sizeof(float)) return GX_ERR_WORKSPACE;
+    const long rows = (long)B * rows_per_img;
+    long nb = (rows + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(gx::proto_bwd_lowrank_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores, rnorm,
+                       bias, HW, K, picks, maps, rows_per_img, rows, C, workspace);
+    GX_CHECK_LAUNCH();
+    gx::launch_partial_reduce(workspace, (int)nb, K, 1.f, beta, gb, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// G (npix, D) = C[:, :K] Wc + C[:, K] .* Z ; gWc = beta*gWc + C[:, :K]^T Z.   D % 64 == 0, D <= 512.
+// workspace >= gx_proto_small_workspace_bytes(K, D).
+int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int D, const float* Wc, int K, float* G,
+                            float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > 15 || (D & 63) || D > 512) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_proto_small_workspace_bytes(K, D)) return GX_ERR_WORKSPACE;
+    long nb = (npix + 3) / 4;
+    if (nb > GX_PS_BLOCKS) nb = GX_PS_BLOCKS;
+    const int kp = K <= 8 ? 8 : 16;
+    size_t lds = (size_t)kp * D * sizeof(float);
+    if (lds < (size_t)4 * D * sizeof(float)) lds = (size_t)4 * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, C, Z,
+                           npix, D, Wc, K, G, workspace);
+    else
+        hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, C,
+                           Z, npix, D, Wc, K, G, workspace);
+    GX_CHECK_LAUNCH();
+    gx::launch_partial_reduce(workspace, (int)nb, K * D, 1.f, beta, gWc, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // extern "C"

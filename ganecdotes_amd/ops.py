@@ -194,6 +194,51 @@ def proto_bwd_small_(ds, zhat, rnorm, picks, maps, wc, g, gwc, gb, beta):
                "gx_proto_bwd_small")
 
 
+def lowrank_ok(k, d):
+    return k <= 15 and d % 256 == 0 and d <= 512
+
+
+def proto_fwd_lowrank(z, picks, maps, wc, bias):
+    """scores (B*N, K), rnorm (B*N) from the projected-pixel table (zhat is never written)."""
+    _chk(z, wc, bias)
+    b, h, w, d = z.shape
+    n, k = picks.shape[1], wc.shape[0]
+    rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
+    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device)
+    _lib.check(lib().gx_proto_fwd_lowrank(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(wc), _p(bias), k, _p(rn),
+                                          _p(sc), _stream()), "gx_proto_fwd_lowrank")
+    return rn, sc
+
+
+def lowrank_coeffs(b, hw, device):
+    """zeroed coefficient grid C (B*HW, stride)"""
+    return torch.zeros(b * hw, lib().gx_lowrank_stride(), dtype=torch.float32, device=device)
+
+
+def proto_bwd_lowrank_(ds, scores, rnorm, bias, picks, maps, coeffs, hw, gb, beta):
+    _chk(ds, scores, rnorm, bias, coeffs, gb)
+    k = ds.shape[1]
+    b = picks.shape[0]
+    ws = workspace("lowrank_b", 1024 * k * 4, ds.device)
+    _lib.check(lib().gx_proto_bwd_lowrank(_p(ds), _p(scores), _p(rnorm), _p(bias), b, hw, k, _p(picks), picks.shape[1],
+                                          _p(maps), _p(coeffs), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
+               "gx_proto_bwd_lowrank")
+
+
+def proto_lowrank_finish(coeffs, z, wc, gwc, beta):
+    """G (B,H,W,D) rebuilt from the coefficient grid; gwc = beta*gwc + C^T Z."""
+    _chk(coeffs, z, wc, gwc)
+    b, h, w, d = z.shape
+    k = wc.shape[0]
+    L = lib()
+    g = torch.empty_like(z)
+    wsb = L.gx_proto_small_workspace_bytes(k, d)
+    ws = workspace("protosmall", wsb, z.device)
+    _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), b * h * w, d, _p(wc), k, _p(g), _p(gwc), beta, _p(ws), wsb,
+                                         _stream()), "gx_proto_lowrank_finish")
+    return g
+
+
 # ------------------------------------------------------------------------------------- generator pieces
 def pixel_norm(x):
     _chk(x)

@@ -323,15 +323,24 @@ class SwAVClustering(object):
         aux = {}
         mode = sa.get('projection_mode', 'pyramid')
         small = sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D)
+        lowrank = mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D)
         if mode == 'pyramid':
             with self._timed("pyramid_fwd"):
                 pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
                 Zt = [p.project(Wp) for p in pyr]                              # (B, H, W, D) per view
-            Gt = [torch.zeros_like(z) for z in Zt]
+            if lowrank:
+                Ct = [ops.lowrank_coeffs(B, hw * hw, dev) for _ in Zt]         # (B*HW, 16) coefficient grids
+            else:
+                Gt = [torch.zeros_like(z) for z in Zt]
         for pno in range(P):
             picks = pb.picks[pno]
             X, Zh, Rn, Sc = [], [], [], []
             for v, (ts, maps, _) in enumerate(views):
+                if lowrank:
+                    with self._timed("proto_fwd_lowrank"):
+                        rn, sc = ops.proto_fwd_lowrank(Zt[v], picks, maps, Wc, bc)
+                    Zh.append(None); Rn.append(rn); Sc.append(sc)
+                    continue
                 if mode == 'pyramid' and small:
                     with self._timed("proto_fwd_small"):
                         z, rn, sc = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc)
@@ -373,6 +382,11 @@ class SwAVClustering(object):
             # S6: backward (gradients accumulate over views and patches)
             for v in range(2):
                 beta = 0.0 if first_acc else 1.0
+                if lowrank:
+                    with self._timed("proto_bwd_lowrank"):
+                        ops.proto_bwd_lowrank_(dS[v], Sc[v], Rn[v], bc, picks, views[v][1], Ct[v], hw * hw, gb, beta)
+                    first_acc = False
+                    continue
                 if mode == 'pyramid' and small:
                     with self._timed("proto_bwd_small"):
                         ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
@@ -391,6 +405,9 @@ class SwAVClustering(object):
                 first_acc = False
             del X, Zh, Rn, Sc, dS
         if mode == 'pyramid':
+            if lowrank:
+                with self._timed("lowrank_finish"):
+                    Gt = [ops.proto_lowrank_finish(Ct[v], Zt[v], Wc, gWc, 0.0 if v == 0 else 1.0) for v in range(2)]
             with self._timed("pyramid_bwd"):
                 for v in range(2):
                     pyr[v].backward(Gt[v], gWp, accumulate=(v > 0))

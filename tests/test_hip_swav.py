@@ -238,6 +238,46 @@ def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path):
     assert (out["pyramid"][3] == out["panel"][3]).float().mean() > 0.999
 
 
+def test_small_prototype_paths_agree(gpu, tmp_path):
+    """D=256, K=8 on a 512-channel generator: the generic GEMM chain, the fused small-prototype
+    kernels and the low-rank coefficient path give the same loss, gradients and update."""
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.generator import Generator
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.manual_seed(5)
+    np.random.seed(5)
+    g = Generator(32, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)
+    g = g.eval().to(gpu)
+
+    class C:
+        num_latents_for_mean, truncation, latent_dim = 128, 0.7, 512
+    imgs = [draw_image(512, 7, 3, 32 * 32, 3) for _ in range(3)]
+    ml = g.mean_latent(128)
+    out = {}
+    for tag, kw in (("generic", dict(small_proto_kernels=False, lowrank_proto=False)),
+                    ("small", dict(small_proto_kernels=True, lowrank_proto=False)),
+                    ("lowrank", dict(small_proto_kernels=True, lowrank_proto=True))):
+        a = toy_args(hlen=512 * 7, nclasses=256, nprototypes=8, patch_size=700, num_patches=3,
+                     sinkhorn_scope="global", temperature=0.1, **kw)
+        a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.05)
+        sw = SwAVClustering(model=g, model_config=C, out_dir=None, device="cuda", **a)
+        sw.mean_latent = ml
+        torch.manual_seed(11)
+        sw.build_heads()
+        l1 = sw.train_step(imgs).item()
+        l2 = sw.train_step(imgs).item()
+        out[tag] = (l1, l2, [x.clone() for x in sw._grads], [x.clone() for x in sw._params()])
+    for tag in ("small", "lowrank"):
+        np.testing.assert_allclose(out[tag][:2], out["generic"][:2], rtol=1e-4)
+        for a_, b_ in zip(out[tag][2], out["generic"][2]):
+            assert rel(a_, b_) < 1e-3, tag
+        for a_, b_ in zip(out[tag][3], out["generic"][3]):
+            assert rel(a_, b_) < 1e-4, tag
+
+
 def test_no_cpu_fallback(tmp_path):
     from ganecdotes_amd.generator import Generator
     g = Generator(32, 16, 2, channels=MINI)
