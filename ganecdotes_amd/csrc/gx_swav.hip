@@ -695,7 +695,41 @@ int gx_larc_sgd(float* p, const float* g, float* buf, long n, const float* norms
 }
 
 // ---- 'image' marginals: hist[bins] = normalised torch.histc(x, bins)+1e-9 with h[0]=h[1] ----
-// scratch: 2 uints (min,max ordered encodings)
+// Three stages so that the sharded form can all-reduce between them (SURVEY par. 8e): data range
+// (MIN/MAX), raw bin counts (SUM), then the marginal.  scratch: 2 uints (ordered encodings).
+int gx_hist_range(const float* x, long n, unsigned* scratch, float* lohi, void* stream) {
+    if (!x || !scratch || !lohi || n <= 0) return GX_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0xFF, 4, s) != hipSuccess) return GX_ERR_LAUNCH;        // min <- +max
+    if (hipMemsetAsync(scratch + 1, 0, 4, s) != hipSuccess) return GX_ERR_LAUNCH;       // max <- lowest
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, x, n, scratch);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sk_ord_decode_kernel, dim3(1), dim3(64), 0, s, scratch, 2, lohi);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// hist[bins] (+)= counts of x in `bins` equal bins over [lohi[0], lohi[1]] (torch.histc binning)
+int gx_hist_counts(const float* x, long n, const float* lohi, int bins, float* hist, unsigned* scratch, void* stream) {
+    if (!x || !lohi || !hist || !scratch || n <= 0 || bins <= 0) return GX_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sk_ord_encode_kernel, dim3(1), dim3(64), 0, s, lohi, 2, scratch);
+    GX_CHECK_LAUNCH();
+    if (hipMemsetAsync(hist, 0, (size_t)bins * 4, s) != hipSuccess) return GX_ERR_LAUNCH;
+    long want = (n + 255) / 256;
+    const int nb = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(histc_kernel, dim3(nb), dim3(256), 0, s, x, n, scratch, bins, hist);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// h += 1e-9 ; h[0] = h[1] ; h /= sum(h)
+int gx_hist_finish(float* hist, int bins, void* stream) {
+    if (!hist || bins <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(hist_marginal_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, hist, bins);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream) {
     if (!x || !hist || !scratch || n <= 0 || bins <= 0) return GX_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;

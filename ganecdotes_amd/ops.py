@@ -515,11 +515,24 @@ class Sinkhorn:
         return q
 
 
-def hist_marginal(x, bins):
+def hist_marginal(x, bins, reduce=None):
+    """normalised torch.histc(x, bins)+1e-9 with h[0]=h[1]; with `reduce` the data range and the
+    bin counts are all-reduced over the ranks (x = this rank's part of the norm maps)."""
     _chk(x)
+    L = lib()
     hist = torch.empty(bins, dtype=torch.float32, device=x.device)
     scratch = torch.empty(2, dtype=torch.int32, device=x.device)
-    _lib.check(lib().gx_hist_marginal(_p(x), x.numel(), bins, _p(hist), _p(scratch), _stream()), "gx_hist_marginal")
+    if reduce is None:
+        _lib.check(L.gx_hist_marginal(_p(x), x.numel(), bins, _p(hist), _p(scratch), _stream()), "gx_hist_marginal")
+        return hist
+    lohi = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.check(L.gx_hist_range(_p(x), x.numel(), _p(scratch), _p(lohi), _stream()), "gx_hist_range")
+    lohi[0].neg_()                      # one MAX all-reduce for both ends: (-min, max)
+    reduce(lohi, "max")
+    lohi[0].neg_()
+    _lib.check(L.gx_hist_counts(_p(x), x.numel(), _p(lohi), bins, _p(hist), _p(scratch), _stream()), "gx_hist_counts")
+    reduce(hist, "sum")
+    _lib.check(L.gx_hist_finish(_p(hist), bins, _stream()), "gx_hist_finish")
     return hist
 
 

@@ -273,12 +273,15 @@ class SwAVClustering(object):
         self._reduce_fn(t, op)
 
     # ------------------------------------------------------------------------------------- one step
-    def _marginals(self, img, k, nrows):
+    def _marginals(self, img, k, nrows, shared=False):
         """'image' source pdf (swav_clustering.py:523-532): r from a K-bin, c from an nrows-bin
         histogram of the whole norm map."""
-        if self.world > 1:
-            raise NotImplementedError("source_pdf='image' is single-rank in this round")
-        return ops.hist_marginal(img, k), ops.hist_marginal(img, nrows)
+        red = self._reduce if (self.world > 1 and shared) else None
+        r = ops.hist_marginal(img, k, red)
+        c = ops.hist_marginal(img, nrows * (self.world if shared else 1), red)
+        if red is not None:             # this rank's rows of the global per-sample marginal
+            c = c[self.rank * nrows:(self.rank + 1) * nrows].contiguous()
+        return r, c
 
     def _split_k(self, m, n, k):
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
@@ -369,7 +372,7 @@ class SwAVClustering(object):
                     r = c = None
                     if imgs is not None:
                         img = imgs[v] if scope == 'global' else imgs[v][r0 // N:r0 // N + 1]
-                        r, c = self._marginals(img.contiguous(), K, r1 - r0)
+                        r, c = self._marginals(img.contiguous(), K, r1 - r0, shared=(scope == 'global'))
                     nglob = (r1 - r0) * (self.world if scope == 'global' else 1)
                     s = ops.Sinkhorn(Sc[v][r0:r1], self.eps, self.niters, r=r, c=c, c_uniform=1.0 / nglob,
                                      tag=f"sk{v}")

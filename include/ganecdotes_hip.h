@@ -181,6 +181,11 @@ int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int 
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);
+/* the same in three stages for the sharded form: range (all_reduce MIN/MAX of lohi) -> counts
+ * (all_reduce SUM of hist) -> finish */
+int gx_hist_range(const float* x, long n, unsigned* scratch, float* lohi, void* stream);
+int gx_hist_counts(const float* x, long n, const float* lohi, int bins, float* hist, unsigned* scratch, void* stream);
+int gx_hist_finish(float* hist, int bins, void* stream);
 
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).

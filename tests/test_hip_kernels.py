@@ -130,6 +130,31 @@ def test_sinkhorn_image_pdf(ops, tag):
     assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
 
 
+def test_hist_marginal_sharded_equals_single(ops):
+    torch.manual_seed(14)
+    x = torch.rand(4, 32, 32) * 5 + 0.3
+    whole = ops.hist_marginal(dev(x), 300).cpu()
+    parts = [dev(x[:2]), dev(x[2:])]
+    import threading
+    barrier, slots, outs = threading.Barrier(2), [None, None], [None, None]
+
+    def run(rank):
+        def reduce(t, op):
+            torch.cuda.synchronize()
+            slots[rank] = t.clone()
+            barrier.wait()
+            st = torch.stack(slots)
+            red = st.max(0)[0] if op == "max" else st.sum(0)
+            barrier.wait()
+            t.copy_(red)
+        outs[rank] = ops.hist_marginal(parts[rank], 300, reduce).cpu()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].numpy(), whole.numpy(), rtol=1e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("n,k,eps", [(2000, 8, 0.005), (777, 16, 0.003), (500, 1000, 0.01), (64, 5000, 0.005)])
 def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
     from oracle import swav_ref as S

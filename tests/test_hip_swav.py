@@ -198,9 +198,12 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
-def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path):
-    """Full-width 64x64 generator (512-channel taps, hlen cutting the last tap): the pyramid
-    projection and the reference-shaped panel GEMM give the same loss / gradients / predictions."""
+@pytest.mark.parametrize("hlen", [512 * 8 + 300, 512 * 7])
+def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path, hlen):
+    """Full-width 64x64 generator (512-channel taps): the pyramid projection and the
+    reference-shaped panel GEMM give the same loss / gradients / predictions.  hlen cuts inside the
+    last tap, or drops the whole finest level (the car-512 case: a true 512^2 generator has
+    sum(C) = 5504 > hlen = 5376, so its two native-resolution taps are never used)."""
     from ganecdotes_amd.draws import draw_image
     from ganecdotes_amd.generator import Generator
     from ganecdotes_amd.swav_clustering import SwAVClustering
@@ -214,7 +217,6 @@ def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path):
 
     class C:
         num_latents_for_mean, truncation, latent_dim = 128, 0.7, 512
-    hlen = 512 * 8 + 300                                   # cuts inside the last 64x64 tap
     out = {}
     imgs = [draw_image(512, 9, 4, 64 * 64, 2) for _ in range(2)]
     wlat = g.style(torch.randn(1, 512, device="cuda"))
