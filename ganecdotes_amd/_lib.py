@@ -77,6 +77,12 @@ SIGNATURES = {
     "gx_swapped_ce_workspace_bytes": (c_sz, []),
     "gx_swapped_ce": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p,
                             c_sz, c_p]),
+    "gx_col_stats_workspace_bytes": (c_sz, [c_i]),
+    "gx_col_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_bn_lrelu_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p]),
+    "gx_bn_lrelu_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "gx_simclr_ntxent": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "gx_row_div": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_sumsq_workspace_bytes": (c_sz, []),
     "gx_sumsq": (c_i, [c_p, c_l, c_p, c_p, c_sz, c_p]),
     "gx_larc_sgd": (c_i, [c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_i, c_i, c_p]),

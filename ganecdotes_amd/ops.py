@@ -551,6 +551,57 @@ def swapped_ce(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_b
     return loss_out
 
 
+# ------------------------------------------------------------------------------------- SimCLR head
+def col_stats(x):
+    """(mean, biased var) over the rows of x (rows, D)"""
+    _chk(x)
+    rows, d = x.shape
+    L = lib()
+    mean = torch.empty(d, dtype=torch.float32, device=x.device)
+    var = torch.empty(d, dtype=torch.float32, device=x.device)
+    wsb = L.gx_col_stats_workspace_bytes(d)
+    ws = workspace("colstats", wsb, x.device)
+    _lib.check(L.gx_col_stats(_p(x), rows, d, _p(mean), _p(var), _p(ws), wsb, _stream()), "gx_col_stats")
+    return mean, var
+
+
+def bn_lrelu_fwd(x, mean, var, gamma, beta, eps=1e-5, slope=0.01, want_xhat=True):
+    _chk(x, mean, var, gamma, beta)
+    a = torch.empty_like(x)
+    xhat = torch.empty_like(x) if want_xhat else None
+    _lib.check(lib().gx_bn_lrelu_fwd(_p(x), x.shape[0], x.shape[1], _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
+                                     _p(a), _p(xhat), _stream()), "gx_bn_lrelu_fwd")
+    return a, xhat
+
+
+def bn_lrelu_bwd(da, xhat, var, gamma, beta, eps=1e-5, slope=0.01):
+    _chk(da, xhat, var, gamma, beta)
+    n, d = da.shape
+    dx = torch.empty_like(da)
+    dg = torch.empty(d, dtype=torch.float32, device=da.device)
+    db = torch.empty(d, dtype=torch.float32, device=da.device)
+    _lib.check(lib().gx_bn_lrelu_bwd(_p(da), _p(xhat), n, d, _p(var), _p(gamma), _p(beta), eps, slope, _p(dx), _p(dg),
+                                     _p(db), _stream()), "gx_bn_lrelu_bwd")
+    return dx, dg, db
+
+
+def simclr_ntxent(out, temperature, want_grad=True):
+    """loss (1,) and d loss / d out of the reference's inline SimCLR loss on out (2b, D)"""
+    _chk(out)
+    n, d = out.shape
+    loss = torch.empty(1, dtype=torch.float32, device=out.device)
+    dout = torch.empty_like(out) if want_grad else None
+    _lib.check(lib().gx_simclr_ntxent(_p(out), n, d, float(temperature), _p(loss), _p(dout), _stream()),
+               "gx_simclr_ntxent")
+    return loss, dout
+
+
+def row_div_(z, nrm):
+    _chk(z, nrm)
+    _lib.check(lib().gx_row_div(_p(z), z.shape[0], z.shape[1], _p(nrm), _stream()), "gx_row_div")
+    return z
+
+
 # ------------------------------------------------------------------------------------- optimizer
 def sumsq(x, out):
     """out[0] = sum(x^2) (deterministic)."""

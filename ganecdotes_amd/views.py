@@ -1,0 +1,138 @@
+"""View creation shared by the SwAV and SimCLR preprocessors (reference:
+hfc_with_swav/swav_clustering.py:574-656, lib/oneshot/image_augmentor.py:8-104): batch staging
+through pinned memory, latent perturbation, the batched NHWC generator forward and the
+rotate/flip index maps."""
+import torch
+
+from . import ops
+
+
+class PreparedBatch:
+    """Device-side form of a batch of ImageDraws: staged through pinned host memory and copied
+    on a side stream, so drawing / uploading step i+1 overlaps the kernels of step i."""
+    __slots__ = ("n", "z", "map_noise", "mix", "xforms", "picks", "ready", "_keep")
+
+
+class ViewMixin(object):
+    """Needs self.model / mean_latent / truncation / perturb_args / device, `self._hlen` and
+    `_pick_spec() -> (pixels per patch, patches, 'host'|'device')`."""
+
+    def _timed(self, tag, flops=0.0, nbytes=0.0):
+        """HIP-event bracket of a phase of the step (active only when ops.PROFILE is a dict)."""
+        return ops.record("phase:" + tag, flops, nbytes)
+
+    def create_pixel_feature_vectors(self, features, pred=False):
+        """API-compatibility shim of swav_clustering.py:108-130: returns the materialised
+        (B, hlen, H, W) stack through the gather kernel with the identity pick list."""
+        taps = [f.permute(0, 2, 3, 1).contiguous() for f in features]
+        ts = ops.TapSet(taps)
+        hw = ts.size * ts.size
+        picks = torch.arange(hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
+        x = ops.gather_taps(ts, picks, self._hlen)
+        return x.reshape(ts.B, ts.size, ts.size, -1).permute(0, 3, 1, 2)
+
+    def prepare_batch(self, images):
+        """Pack a list of ImageDraws into two pinned staging buffers (floats, int32 picks) and
+        upload them with non-blocking copies on a side stream."""
+        if isinstance(images, PreparedBatch):
+            return images
+        B, S, nl = len(images), self.model.style_dim, self.model.n_latent
+        hw = self.model.size * self.model.size
+        N, npatch, psrc = self._pick_spec()
+        N = hw if (N is None or N >= hw) else N
+        P = len(images[0].picks)
+        dev_picks = (P == 0 and psrc == 'device')
+        nf = B * S + 2 * (2 * B * S) + 2 * (B * nl * 2)
+        if not hasattr(self, "_staging"):
+            self._staging, self._stage_i, self._copy_stream = {}, 0, torch.cuda.Stream(device=self.device)
+        key = (nf, P * B * N)
+        ring = self._staging.setdefault(key, [])
+        if len(ring) < 3:
+            ring.append([torch.empty(nf, dtype=torch.float32).pin_memory(),
+                         torch.empty(max(1, P * B * N), dtype=torch.int32).pin_memory(), None])
+            slot = ring[-1]
+        else:
+            slot = ring[self._stage_i % 3]
+            self._stage_i += 1
+            if slot[2] is not None:
+                slot[2].synchronize()              # its previous upload has been consumed
+        hf, hi, _ = slot
+        o = 0
+        hf[o:o + B * S].view(B, S).copy_(torch.cat([im.z for im in images], 0)); o += B * S
+        for v in range(2):
+            hf[o:o + 2 * B * S].view(2 * B, S).copy_(torch.cat([im.views[v].map_noise for im in images], 0))
+            o += 2 * B * S
+        for v in range(2):
+            mix = hf[o:o + B * nl * 2].view(B, nl, 2)
+            mix.zero_()
+            for b, im in enumerate(images):
+                vd = im.views[v]
+                sig = float(self.perturb_args['perturb_std'][vd.layer_no])
+                mix[b, 2 * vd.layer_no, 0] = sig
+                mix[b, 2 * vd.layer_no + 1, 1] = sig
+            o += B * nl * 2
+        if P:
+            hi.view(P, B, N).copy_(torch.stack([torch.stack([im.picks[p][:N] for im in images]) for p in range(P)]))
+        pb = PreparedBatch()
+        pb.n = B
+        with torch.cuda.stream(self._copy_stream):
+            df = hf.to(self.device, non_blocking=True)
+            di = hi.to(self.device, non_blocking=True)
+            pb.ready = torch.cuda.Event()
+            pb.ready.record()
+        slot[2] = pb.ready
+        o = 0
+        pb.z = df[o:o + B * S].view(B, S); o += B * S
+        pb.map_noise = []
+        for v in range(2):
+            pb.map_noise.append(df[o:o + 2 * B * S].view(2 * B, S)); o += 2 * B * S
+        pb.mix = []
+        for v in range(2):
+            pb.mix.append(df[o:o + B * nl * 2].view(B, nl, 2)); o += B * nl * 2
+        pb.picks = di[:P * B * N].view(P, B, N) if P else None
+        if dev_picks:
+            # picks = first N of a uniform random permutation of the H*W pixels, per image and
+            # patch, drawn on the device generator (one batched argsort of uniform keys)
+            with torch.cuda.stream(self._copy_stream):
+                keys = torch.rand(npatch * B, hw, device=self.device)
+                pb.picks = keys.argsort(dim=1)[:, :N].to(torch.int32).reshape(npatch, B, N).contiguous()
+                pb.ready = torch.cuda.Event()
+                pb.ready.record()
+            slot[2] = pb.ready
+        pb.xforms = [[(im.views[v].angle, im.views[v].flip) for im in images] for v in range(2)]
+        pb._keep = (df, di)
+        return pb
+
+    def _view_latents(self, w, map_noise, mix):
+        """Latents of the feature-producing forward for a batch of images and ONE view each
+        (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents;
+        map_noise (2B,S); mix (B, n_latent, 2) = sigma at the two perturbed latents:
+        lat[b, 2l+j] = (1-sigma) lat + sigma style(noise_j)."""
+        n_latent = self.model.n_latent
+        lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation))
+        lat = lat.unsqueeze(1).repeat(1, n_latent, 1)
+        nw = self.model.style(map_noise).reshape(w.shape[0], 2, -1)
+        keep = 1.0 - mix.sum(dim=2, keepdim=True)
+        return lat * keep + torch.einsum('blj,bjs->bls', mix, nw)
+
+    def make_views(self, images):
+        """Both views of a batch (list of ImageDraws or PreparedBatch) ->
+        per view (TapSet, maps or None, image)."""
+        pb = self.prepare_batch(images)
+        torch.cuda.current_stream().wait_event(pb.ready)
+        w = self.model.style(pb.z)
+        out = []
+        for v in range(2):
+            lat = self._view_latents(w, pb.map_noise[v], pb.mix[v])
+            img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
+                                    input_is_latent=True, randomize_noise=False)
+            ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
+            maps = None
+            if any(a is not None for a, _ in pb.xforms[v]):
+                hw = ts.size
+                maps = torch.empty(pb.n, hw * hw, dtype=torch.int32, device=self.device)
+                for b, (a, f) in enumerate(pb.xforms[v]):
+                    ops.rotflip_map(a or 0.0, f, hw, hw, self.device, out=maps[b])
+            out.append((ts, maps, img))
+        return out
+

@@ -197,6 +197,22 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
                   float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* ---- SimCLR baseline head (baseline/hfc_with_simclr/simclr_clustering.py) -----------------------
+ * gx_col_stats      BatchNorm1d batch statistics (train mode)                      :150
+ * gx_bn_lrelu_fwd   BatchNorm1d + LeakyReLU(0.01)                                   :150-151
+ * gx_bn_lrelu_bwd   their backward over the n = 2*batch samples                    (autograd, :270)
+ * gx_simclr_ntxent  the inline loss over the first n feature rows + d loss/d out   :224-264
+ * gx_row_div        z /= max(|x|, 1e-12): F.normalize(hfeat, dim=1) folded after the projection :191, :387 */
+size_t gx_col_stats_workspace_bytes(int D);
+int gx_col_stats(const float* x, long rows, int D, float* mean, float* var, float* workspace, size_t workspace_bytes,
+                 void* stream);
+int gx_bn_lrelu_fwd(const float* x, long rows, int D, const float* mean, const float* var, const float* gamma,
+                    const float* beta, float eps, float slope, float* a, float* xhat, void* stream);
+int gx_bn_lrelu_bwd(const float* da, const float* xhat, int n, int D, const float* var, const float* gamma,
+                    const float* beta, float eps, float slope, float* dx, float* dgamma, float* dbeta, void* stream);
+int gx_simclr_ntxent(const float* out, int n, int D, float temperature, float* loss, float* dout, void* stream);
+int gx_row_div(float* z, long rows, int D, const float* nrm, void* stream);
+
 /* ---- optimizer: apex LARC(clip=False) around SGD(momentum)   swav_clustering.py:286-292 ------ */
 size_t gx_sumsq_workspace_bytes(void);
 int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t workspace_bytes, void* stream);

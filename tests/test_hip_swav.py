@@ -288,3 +288,65 @@ def test_no_cpu_fallback(tmp_path):
     from ganecdotes_amd.swav_clustering import SwAVClustering
     with pytest.raises(RuntimeError):
         SwAVClustering(model=g, model_config=Cfg, out_dir=str(tmp_path), device="cpu", **toy_args())
+
+
+# ------------------------------------------------------------------------------------- SimCLR (config 5)
+def test_simclr_head_kernels_vs_autograd(gpu):
+    from ganecdotes_amd import ops
+    from oracle import simclr_ref as C
+    torch.manual_seed(31)
+    n, d = 40, 64
+    h1 = torch.randn(n, d)
+    gamma, beta = torch.rand(d) + 0.5, 0.1 * torch.randn(d)
+    w2 = torch.randn(d, d) / 8
+    h1r = h1.clone().requires_grad_(True)
+    gr, br, w2r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    mean = h1r.mean(0)
+    var = h1r.var(0, unbiased=False)
+    a_ref = torch.nn.functional.leaky_relu((h1r - mean) * torch.rsqrt(var + 1e-5) * gr + br, 0.01)
+    out_ref = a_ref @ w2r.t()
+    loss_ref = C.ntxent_feature_rows(out_ref, n // 2, 0.7)
+    loss_ref.backward()
+    d_ = lambda t: t.cuda().contiguous()
+    m, v = ops.col_stats(d_(h1))
+    a, xhat = ops.bn_lrelu_fwd(d_(h1), m, v, d_(gamma), d_(beta))
+    out = ops.gemm(a, d_(w2), False, True)
+    loss, dout = ops.simclr_ntxent(out, 0.7)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    gw2 = ops.gemm(dout, a, True, False)
+    da = ops.gemm(dout, d_(w2), False, False)
+    dh1, dg, db = ops.bn_lrelu_bwd(da, xhat, v, d_(gamma), d_(beta))
+    assert rel(gw2, w2r.grad) < 1e-4 and rel(dh1, h1r.grad) < 1e-3
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+def test_simclr_pretrain_golden_gv12(gpu, tmp_path):
+    from ganecdotes_amd.simclr_clustering import SimCLRClustering
+    d = load_golden("gv12_simclr")
+    g = mini_gen(golden_sd(d), gpu)
+    args = dict(num_iters=2, batch_size=3, patch_size=30, hf_interp="nearest", trust_coeff=0.01,
+                train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=8, hlen=56, epoch_print_freq=1,
+                max_masks=4, use_larc=False, transforms=False, cpu_reference_rng=True)
+    sim = SimCLRClustering(model=g, model_config=Cfg, out_dir=str(tmp_path), device="cuda", simclr_args=args,
+                           perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None,
+                                             perturb_std=[1.0] * 3))
+    torch.manual_seed(42)
+    np.random.seed(42)
+    z = torch.randn(64, 16)                               # the reference constructor's mean_latent draw
+    sim.mean_latent = g.style(z.cuda()).mean(0, keepdim=True)
+    sim.pretrain(None)
+    np.testing.assert_allclose([l.item() for l in sim.loss_history], d["losses"], rtol=1e-3)
+    sdp = sim.projection.state_dict()
+    for key in ("0.weight", "1.weight", "1.bias", "3.weight", "1.running_mean", "1.running_var"):
+        assert rel(sdp[key], T(d["proj_" + key])) < 2e-3, key
+    assert int(sdp["1.num_batches_tracked"]) == 2
+    sim.mean_latent = T(d["mean_latent"]).cuda()
+    for key in ("0.weight", "1.weight", "1.bias", "3.weight"):
+        sdp[key].copy_(T(d["proj_" + key]).cuda())
+    preds, labels = sim.predict_simclr_codes(T(d["pred_w"]).cuda())
+    assert preds.shape == d["preds"].shape
+    assert rel(preds, T(d["preds"])) < 1e-3
+    assert (labels.cpu().numpy() == d["labels"]).mean() > 0.99
+    assert rel(sim.projection[1].running_mean, T(d["proj_after_predict_1.running_mean"])) < 2e-3
+    proj = torch.load(tmp_path / "projection.pt", weights_only=False)
+    assert proj(torch.zeros(4, 56, device="cuda")).shape == (4, 8)

@@ -202,3 +202,25 @@ def test_larc_restatement():
     bufs2 = S.larc_sgd_step([p], [g], bufs, lr=0.01, momentum=0.9, trust=0.01)
     scale2 = 0.01 * p1.norm() / (g.norm() + 1e-8)
     close(bufs2[0], (0.9 * bufs[0] + scale2 * g).numpy(), rtol=1e-6)
+
+
+def test_gv12_simclr_trajectory_and_predict():
+    from oracle import simclr_ref as C
+    d = load_golden("gv12_simclr")
+    sd = golden_sd(d)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    losses, p, ml = C.pretrain_reference_order(
+        sd, 16, num_latents_for_mean=64, psi=0.7, n_perturb_layers=3, num_iters=2, batch=3, hlen=56, nclasses=8,
+        temperature=1.0, lr=0.01, momentum=0.9, trust=0.01, use_larc=False, transforms=False)
+    np.testing.assert_allclose(losses, d["losses"], rtol=1e-4)
+    close(p["w1"], d["proj_0.weight"], rtol=1e-4, atol=1e-6)
+    close(p["gamma"], d["proj_1.weight"], rtol=1e-4, atol=1e-6)
+    close(p["beta"], d["proj_1.bias"], rtol=1e-3, atol=1e-6)
+    close(p["w2"], d["proj_3.weight"], rtol=1e-4, atol=1e-6)
+    close(p["running_mean"], d["proj_1.running_mean"], rtol=1e-4, atol=1e-6)
+    close(p["running_var"], d["proj_1.running_var"], rtol=1e-4, atol=1e-6)
+    close(ml, d["mean_latent"], rtol=1e-5, atol=1e-6)
+    preds, labels = C.predict_simclr_codes(sd, T(d["pred_w"]), ml, 0.7, p, 56)
+    close(preds, d["preds"], rtol=1e-3, atol=1e-4)
+    assert (labels.numpy() == d["labels"]).mean() > 0.99

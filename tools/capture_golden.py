@@ -103,7 +103,7 @@ def _install_placeholders():
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 class _Logger:
@@ -439,6 +439,34 @@ def main():
         preds, labels = sw.predict_swav_codes(wlat)
     save("gv11_predict", w=_np(wlat), mean_latent=_np(sw.mean_latent), preds=_np(preds),
          labels=_np(labels))
+
+    # ---------------------------------------------------------------- GV12
+    # two iterations of the reference's own SimCLRClustering.pretrain() (baseline config 5),
+    # batch_size=3 pixel pairs, rotation/flip disabled, LARC pass-through, seed 42.  The loss is
+    # inline in pretrain() (simclr_clustering.py:224-264), so the trajectory + final weights pin it.
+    from baseline.hfc_with_simclr import simclr_clustering as SIM
+    g12 = mini_generator(112)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    sim_args = dict(num_iters=2, batch_size=3, patch_size=30, hf_interp="nearest", trust_coeff=0.01,
+                    train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=8, hlen=56,
+                    epoch_print_freq=1, max_masks=4)
+    sim = SIM.SimCLRClustering(model=g12, model_config=_Cfg,
+                               perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None,
+                                                 perturb_std=[1.0] * 3),
+                               simclr_args=sim_args, logger=_Logger(), train=True, out_dir=tmp, device="cpu",
+                               tb=Writer(), layer_hf_dim=None)
+    sim.pretrain(None)
+    out = {f"sd_{k_}": _np(v) for k_, v in g12.state_dict().items()}
+    out.update({f"proj_{k_}": _np(v) for k_, v in sim.projection.state_dict().items()})
+    out["losses"] = np.asarray([s_[1] for s_ in sim.writer.scalars], np.float64)
+    torch.manual_seed(1120)
+    wl = g12.style(torch.randn(1, 16))
+    preds, labels = sim.predict_simclr_codes(wl)
+    out.update(dict(pred_w=_np(wl), mean_latent=_np(sim.mean_latent), preds=_np(preds), labels=_np(labels)))
+    out.update({f"proj_after_predict_{k_}": _np(v) for k_, v in sim.projection.state_dict().items()
+                if "running" in k_})
+    save("gv12_simclr", **out)
 
     print("done")
 
