@@ -197,8 +197,17 @@ def main():
                                   "algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
                 "gemm_f32_kernel": "gx::gemm_f32_kernel (pyramid projection / prototype / gradient GEMMs on fp32 "
                                    "MFMA; algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile):
+            for k, t in json.load(open(tfile)).items():
+                if name in k and "<true>" in k or (name in k and "modconv" not in name and "true, true" in k):
+                    traffic = t["hbm_bytes_per_launch"]
+                    break
         roof = dict(bound="mfma", achieved=ach / 1e12, peak=PEAK_F32_MFMA / 1e12, unit="TFLOP/s",
-                    frac=ach / PEAK_F32_MFMA, traffic=None, kernel=what,
+                    frac=ach / PEAK_F32_MFMA, traffic=traffic, kernel=what,
                     launches_per_step=v["launches_per_step"],
                     avg_launch_ms=v["ms_per_step"] / v["launches_per_step"],
                     gflop_per_launch=v["flops_per_step"] / v["launches_per_step"] / 1e9,

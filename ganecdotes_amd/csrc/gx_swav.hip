@@ -553,7 +553,10 @@ int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta
 // ---- Sinkhorn ----------------------------------------------------------------------------
 #define GX_SK_BLOCKS 512
 // workspace layout (4-byte words): [0, K) cmax (ordered-uint), [K, 2K) u, [2K, 2K + BLOCKS*K) partials
-size_t gx_sinkhorn_workspace_bytes(int K) { return (size_t)(2 * (size_t)K + (size_t)GX_SK_BLOCKS * K) * sizeof(float); }
+#define GX_SK_SMALL_BLOCKS 1024   // single-rank small-K path: two partial buffers of this many blocks
+size_t gx_sinkhorn_workspace_bytes(int K) {
+    return (size_t)(4 * (size_t)K + (size_t)2 * GX_SK_SMALL_BLOCKS * K) * sizeof(float);
+}
 float* gx_sinkhorn_u(float* workspace, int K) { return workspace + K; }
 
 static int sk_blocks(long rows, int team) {
@@ -986,16 +989,14 @@ int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int 
     if (!workspace || workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int team = gx::pick_team(K);
-    int nb = sk_blocks(rows, team);
-    if (nb > 250) nb = 250;                                     // two partial buffers must fit the workspace
+    const long tpb = 256 / team;
+    long nbl = (rows + tpb - 1) / tpb;
+    const int nb = (int)(nbl < GX_SK_SMALL_BLOCKS ? nbl : GX_SK_SMALL_BLOCKS);
     int kx = 1;
     while (kx < 64 && kx < K) kx <<= 1;
     unsigned* cmax = (unsigned*)workspace;                      // [K]
     float* labuf = workspace + K;                               // [2][K]  (the "u" slot is not used here)
     float* part = workspace + 3 * (size_t)K;                    // [2][nb][K]  (fits: 2K + BLOCKS*K >= 3K + 2*nb*K? checked below)
-    if ((size_t)3 * K + (size_t)2 * nb * K > (size_t)2 * K + (size_t)GX_SK_BLOCKS * K) {
-        return GX_ERR_WORKSPACE;
-    }
     if (hipMemsetAsync(cmax, 0, (size_t)K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
     hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb), dim3(256), 0, st, S, rows, K, ld, team, cmax);
     GX_CHECK_LAUNCH();

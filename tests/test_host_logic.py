@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.load()
     assert b"gfx950" in L.gx_version()
-    assert L.gx_sinkhorn_workspace_bytes(8) == (16 + 512 * 8) * 4
+    assert L.gx_sinkhorn_workspace_bytes(8) == (32 + 2048 * 8) * 4
     assert L.gx_gemm_f32_workspace_bytes(512, 5376, 8) == 8 * 512 * 5376 * 4
 
 
