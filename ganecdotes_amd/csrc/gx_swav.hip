@@ -3,6 +3,7 @@
 // [b][y][x][c]) so that a sampled pixel is ONE contiguous C_l*4-byte read per tap; the sampled
 // panel X is (rows, hlen) row-major; scores are (rows, K) row-major.
 #include "gx_common.h"
+#include "gx_bigk.h"
 
 namespace gx {
 
@@ -537,11 +538,23 @@ int gx_row_argmax(const float* z, long rows, int D, long ld, long long* labels, 
 
 // ---- column sums (db of the prototype bias): out = alpha*colsum(x) + beta*out ----
 #define GX_RED_BLOCKS 256
-size_t gx_colsum_workspace_bytes(int K) { return (size_t)GX_RED_BLOCKS * K * sizeof(float); }
+#define GX_COLSUM_BLOCKS 1024
+size_t gx_colsum_workspace_bytes(int K) { return (size_t)GX_COLSUM_BLOCKS * K * sizeof(float); }
 int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta, float* out, float* workspace,
               size_t workspace_bytes, void* stream) {
     if (!x || !out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_colsum_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    if (bigk_ok(K)) {                       // many columns: wave-per-row streaming kernel
+        const int nbk = bigk_blocks(rows, GX_COLSUM_BLOCKS);
+        const size_t lds = (size_t)2 * K * sizeof(float);
+        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLSUM>), dim3(nbk), dim3(256), lds,
+                                                        (hipStream_t)stream, x, rows, K, ld, 0.f, nullptr, nullptr,
+                                                        nullptr, 0.f, nullptr, workspace, nullptr));
+        GX_CHECK_LAUNCH();
+        launch_partial_reduce(workspace, nbk, K, alpha, beta, out, (hipStream_t)stream);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     const int nb = (int)((rows < GX_RED_BLOCKS) ? rows : GX_RED_BLOCKS);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, K, ld, workspace);
     GX_CHECK_LAUNCH();
@@ -571,6 +584,15 @@ int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspa
     if (!S || !workspace || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if (workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     if (hipMemsetAsync(workspace, 0, (size_t)K * 4, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
+    if (bigk_ok(K)) {
+        const int nbk = bigk_blocks(rows, 2040);
+        const size_t lds = (size_t)2 * K * sizeof(float);
+        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
+                                                        (hipStream_t)stream, S, rows, K, ld, 0.f, nullptr, nullptr,
+                                                        nullptr, 0.f, nullptr, nullptr, (unsigned*)workspace));
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     const int nb = (int)(rows < 256 ? rows : 256);
     hipLaunchKernelGGL(sk_colmax_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, S, rows, K, ld,
                        (unsigned*)workspace);
@@ -607,6 +629,24 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     float* part = u + K;
     const size_t lds = (size_t)2 * K * sizeof(float);
     if (lds > 160 * 1024) return GX_ERR_BAD_ARG;
+    if (bigk_ok(K)) {
+        const int nbk = bigk_blocks(rows, 2040);           // partial area holds 2048*K floats
+        if (first) {
+            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
+                                                            (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
+                                                            (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
+                                                            nullptr));
+        } else {
+            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), dim3(nbk), dim3(256), lds,
+                                                            (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
+                                                            (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
+                                                            nullptr));
+        }
+        GX_CHECK_LAUNCH();
+        launch_partial_reduce(part, nbk, K, 1.f, 0.f, u, (hipStream_t)stream);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     if (first)
         hipLaunchKernelGGL((sk_pass_kernel<true>), dim3(nb), dim3(256), lds, (hipStream_t)stream, S, rows, K, ld, team,
                            1.f / eps, (const unsigned*)workspace, la, c, c_uniform, lb_out, part);
@@ -654,7 +694,7 @@ int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, cons
 
 // ---- swapped-prediction CE forward + d(scores) ---------------------------------------------
 // loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0]
-size_t gx_swapped_ce_workspace_bytes(void) { return (size_t)GX_SK_BLOCKS * sizeof(float); }
+size_t gx_swapped_ce_workspace_bytes(void) { return (size_t)2048 * sizeof(float); }
 int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
                   const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
                   float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
@@ -662,6 +702,18 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
     if (!Ss || !St || !la_s || !la_t || !loss_out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if ((dSs == nullptr) != (dSt == nullptr) || (dSs && ldd < K)) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_swapped_ce_workspace_bytes()) return GX_ERR_WORKSPACE;
+    if (bigk_ok(K)) {
+        const int nbk = bigk_blocks(rows, 2040);
+        const size_t lds = (size_t)2 * K * sizeof(float);
+        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((swapped_ce_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
+                                                        (hipStream_t)stream, Ss, St, rows, K, ld, 1.f / eps,
+                                                        1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd,
+                                                        workspace));
+        GX_CHECK_LAUNCH();
+        launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     const int team = pick_team(K);
     const int nb = sk_blocks(rows, team);
     hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Ss, St, rows, K, ld, team,
