@@ -544,7 +544,7 @@ int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta
               size_t workspace_bytes, void* stream) {
     if (!x || !out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_colsum_workspace_bytes(K)) return GX_ERR_WORKSPACE;
-    if (bigk_ok(K)) {                       // many columns: wave-per-row streaming kernel
+    if (bigk_ok(K) && bigk_aligned(x, ld)) {   // many columns: wave-per-row streaming kernel
         const int nbk = bigk_blocks(rows, GX_COLSUM_BLOCKS);
         const size_t lds = (size_t)2 * K * sizeof(float);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLSUM>), dim3(nbk), dim3(256), lds,
@@ -584,7 +584,7 @@ int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspa
     if (!S || !workspace || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if (workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     if (hipMemsetAsync(workspace, 0, (size_t)K * 4, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
-    if (bigk_ok(K)) {
+    if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = (size_t)2 * K * sizeof(float);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
@@ -629,7 +629,7 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     float* part = u + K;
     const size_t lds = (size_t)2 * K * sizeof(float);
     if (lds > 160 * 1024) return GX_ERR_BAD_ARG;
-    if (bigk_ok(K)) {
+    if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);           // partial area holds 2048*K floats
         if (first) {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
@@ -702,7 +702,7 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
     if (!Ss || !St || !la_s || !la_t || !loss_out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if ((dSs == nullptr) != (dSt == nullptr) || (dSs && ldd < K)) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_swapped_ce_workspace_bytes()) return GX_ERR_WORKSPACE;
-    if (bigk_ok(K)) {
+    if (bigk_ok(K) && bigk_aligned(Ss, ld) && bigk_aligned(St, ld) && (!dSs || (bigk_aligned(dSs, ldd) && bigk_aligned(dSt, ldd)))) {
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = (size_t)2 * K * sizeof(float);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((swapped_ce_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
