@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--prototypes", type=int, default=8)
     ap.add_argument("--scope", default="global", choices=["global", "image"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,13 +115,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))   # the box's CPU share
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         group = dist.group.WORLD
 
     from ganecdotes_amd.swav_clustering import SwAVClustering
