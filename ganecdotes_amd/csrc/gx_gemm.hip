@@ -8,9 +8,6 @@
 //   S6 dWp             = dz^T X                  (TN, split-K)
 // Reference op chain: hfc_with_swav/swav_clustering.py:171-175 and autograd of it (:459).
 #include "gx_mfma.h"
-#ifndef GX_PRIO_EXPERIMENT
-#define GX_PRIO_EXPERIMENT 0
-#endif
 
 namespace gx {
 
@@ -43,7 +40,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
-    if (GX_PRIO_EXPERIMENT && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(2);
     f32x16 acc[2][2];
     zero_acc(acc);
     f32x4 ra[4], rb[4];
