@@ -1,0 +1,238 @@
+"""BASELINE.json's configurations at their FULL sizes (256^2 x 5376 channels x 20 000 pixels;
+512^2 for car) on a real MI355X:
+
+  * one whole optimizer step of the ffhq-256 / K=8 workload against the CPU oracle on the same
+    draws (one image, one patch: what the oracle finishes in seconds on the box's host cores);
+  * the car-512 generator + all-pixel projection + cluster map against the oracle;
+  * size-independent properties at the bench batch (16 images): the pyramid projection and its
+    backward are exact adjoints, the Sinkhorn codes carry the prescribed sample marginal, the
+    generator is batch-independent, predict is idempotent and the step is reproducible.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ganecdotes_amd import ops
+    ops.lib()
+    return torch.device("cuda")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def full_generator(size, seed=42):
+    from ganecdotes_amd.generator import Generator
+    torch.manual_seed(seed)
+    g = Generator(size, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)            # the checkpoint-free init is 0: exercise the noise path
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    return g.eval(), sd
+
+
+class Cfg:
+    num_latents_for_mean, truncation, latent_dim = 128, 0.7, 512
+
+
+def ffhq_args(batch, nproto, num_patches=5, pick_source="device", **over):
+    swav = dict(num_epochs=1, num_samples=1, num_patches=num_patches, sampling_method="random", patch_size=20000,
+                hf_interp="nearest", warmup_epochs=1, start_warmup=0.01, use_scheduler=False, base_lr=0.01,
+                final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9), projn_nw="linear",
+                temperature=0.01, nprototypes=nproto, nclasses=512, hlen=5376, add_local_loss=False,
+                plot_test_images=False, epoch_print_freq=5, max_masks=4, batch_size=batch,
+                sinkhorn_scope="global", pick_source=pick_source)
+    swav.update(over)
+    return dict(perturb_args=dict(truncation=0.7, n_layers=6, n_samples=1, layer_no=None, perturb_std=[1.0] * 6),
+                swav_args=swav, sinkhorn_args=dict(source_pdf="uniform", niters=10, eps=0.005))
+
+
+# --------------------------------------------------------------------------- full-size step vs oracle
+def test_ffhq256_full_size_step_vs_oracle(gpu):
+    """ffhq-256, 13 taps / 5376 channels, 20 000 sampled pixels, D=512, K=8, T=0.01, eps=0.005
+    (configs[1] at batch 1, one patch): loss, the three gradients and the LARC update against the
+    oracle on identical draws."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(256)
+    g = g.to(gpu)
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
+                        **ffhq_args(1, 8, num_patches=1, pick_source="host"))
+    torch.manual_seed(5)
+    np.random.seed(5)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 128, 512)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(512, 13, 6, 256 * 256, 1, transforms=True)]
+    loss = sw.train_step(images)
+    oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                             ops.rotflip_map(v.angle, v.flip, 256, 256, "cuda").cpu().long())
+                                 for v in im.views], im.picks) for im in images]
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=5376,
+        patch_size=20000, num_patches=1, temperature=0.01, eps=0.005, niters=10, source_pdf="uniform",
+        sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)          # north_star: 1e-3 relative fp32
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < 2e-3
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-4
+
+
+def test_car512_generator_and_cluster_map_vs_oracle(gpu):
+    """configs[3] shape: a 512^2 generator (15 taps, sum C = 5504 > hlen = 5376: the two
+    native-resolution taps fall outside the descriptor) -> image, taps, projection of all 262 144
+    pixels and the argmax cluster map against the oracle."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(512, seed=9)
+    g = g.to(gpu)
+    a = ffhq_args(1, 16)
+    a["perturb_args"] = dict(truncation=0.7, n_layers=7, n_samples=1, layer_no=None, perturb_std=[1.0] * 7)
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", **a)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 64, 512)
+        w = S.G.mapping(torch.randn(1, 512), sd)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    proj_w = sw.projection[0].weight.data.cpu().clone()
+    with torch.no_grad():
+        img_ref, taps_ref, _ = S.G.generator_forward(w, sd, truncation=0.7, truncation_latent=ml,
+                                                     input_is_latent=True)
+    img, taps = g([w.cuda()], truncation=0.7, truncation_latent=ml.cuda(), input_is_latent=True,
+                  randomize_noise=False)
+    assert len(taps) == 15 and taps[-1].shape == (1, 64, 512, 512)
+    assert rel(img, img_ref) < 1e-4
+    for a_, b_ in zip(taps, taps_ref):
+        assert rel(a_, b_) < 1e-4
+    del img_ref, taps_ref
+    preds_ref, labels_ref = S.predict_swav_codes(sd, w, ml, 0.7, proj_w, 5376)
+    preds, labels = sw.predict_swav_codes(w.cuda())
+    assert preds.shape == (1, 512, 512, 512) and labels.shape == (1, 512, 512)
+    assert rel(preds, preds_ref) < 1e-4
+    agree = (labels.cpu() == labels_ref).float().mean().item()
+    assert agree > 0.995, agree
+    # idempotence: no atomics anywhere on the predict path
+    preds2, labels2 = sw.predict_swav_codes(w.cuda())
+    assert torch.equal(preds, preds2) and torch.equal(labels, labels2)
+
+
+# --------------------------------------------------------------------------- properties at the bench batch
+@pytest.fixture(scope="module")
+def bench_state(gpu):
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    g, _ = full_generator(256)
+    g = g.to(gpu)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    ml = g.mean_latent(128)
+
+    def make(nproto, batch=16, **over):
+        sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
+                            **ffhq_args(batch, nproto, **over))
+        sw.mean_latent = ml
+        torch.manual_seed(77)
+        sw.build_heads()
+        return sw
+    return g, ml, make
+
+
+def test_pyramid_projection_adjoint_at_batch16(gpu, bench_state):
+    """<project(W), G> == <W, backward(G)> over 16 x 256^2 pixels x 512 dims: the table
+    projection and the gradient route (sum-pool + TN GEMMs) are exact adjoints of each other."""
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.pyramid import Pyramid
+    g, ml, _ = bench_state
+    torch.manual_seed(3)
+    w = g.style(torch.randn(16, 512, device="cuda"))
+    _, feats = g([w], truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+    ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
+    pyr = Pyramid(ts, 5376)
+    wp = torch.randn(512, 5376, device="cuda") / 73.0
+    z = pyr.project(wp)
+    assert z.shape == (16, 256, 256, 512)
+    # linearity in W
+    z2 = pyr.project(2.5 * wp)
+    assert rel(z2, 2.5 * z) < 1e-5
+    del z2
+    gz = torch.randn_like(z)
+    lhs = float((z.double() * gz.double()).sum())
+    gw = torch.empty_like(wp)
+    pyr.backward(gz, gw, accumulate=False)
+    rhs = float((wp.double() * gw.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    # accumulate=True adds
+    pyr.backward(gz, gw, accumulate=True)
+    rhs2 = float((wp.double() * gw.double()).sum())
+    assert abs(rhs2 - 2 * rhs) <= 1e-4 * abs(2 * rhs)
+
+
+def test_generator_is_batch_independent(gpu, bench_state):
+    """Image b of a 16-image batch equals the same latent run alone (weights are shared by the
+    batch, styles live in the A operand): same taps to fp32 rounding of split-K order."""
+    g, ml, _ = bench_state
+    torch.manual_seed(4)
+    w = g.style(torch.randn(16, 512, device="cuda"))
+    kw = dict(truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+    img, taps = g([w], **kw)
+    taps = [t.clone() for t in taps]
+    img = img.clone()
+    for b in (0, 9, 15):
+        img1, taps1 = g([w[b:b + 1]], **kw)
+        assert rel(img1, img[b:b + 1]) < 2e-5
+        for a_, b_ in zip(taps1, taps):
+            assert rel(a_, b_[b:b + 1]) < 2e-5
+
+
+@pytest.mark.parametrize("nproto", [8, 16, 5000])
+def test_bench_step_properties(gpu, bench_state, nproto):
+    """configs[1] (K=8, batch 16), configs[2]'s per-rank shape (K=16) and the reference's own
+    K=5000: codes are a transport plan with the prescribed per-sample marginal, the loss is
+    the swapped cross-entropy of those codes (recomputed in fp64 with torch on the device), and
+    the step is reproducible."""
+    g, ml, make = bench_state
+    batch = 16 if nproto <= 16 else 4
+    sw = make(nproto, batch=batch, num_patches=1)
+    torch.manual_seed(10)
+    np.random.seed(10)
+    images = sw.draw_batch(batch)
+    torch.manual_seed(20)                       # device picks are drawn from the torch generator
+    loss, aux = sw.train_step(images, return_aux=True)
+    rows = batch * 20000
+    for tag in "st":
+        q = aux[f"q_{tag}"].double()
+        assert q.shape == (rows, nproto) and bool((q >= 0).all())
+        # the last Sinkhorn half-iteration normalises every sample's row to c = 1/rows, and the
+        # reference then multiplies by rows (swav_clustering.py:571) -> rows sum to 1
+        assert float((q.sum(1) - 1).abs().max()) < 1e-4
+        col = q.sum(0) / rows
+        assert abs(float(col.sum()) - 1) < 1e-6
+        assert float((col * nproto - 1).abs().max()) < 0.2, float((col * nproto - 1).abs().max())
+    ps = torch.log_softmax(aux["scores_s"].double() / 0.01, 1)
+    pt = torch.log_softmax(aux["scores_t"].double() / 0.01, 1)
+    want = -0.5 * ((aux["q_t"].double() * ps).sum(1).mean() + (aux["q_s"].double() * pt).sum(1).mean())
+    np.testing.assert_allclose(loss.item(), float(want), rtol=1e-4)
+    # reproducibility from the same state and draws (float atomics reorder sums only)
+    g0 = [x.clone() for x in sw._grads]
+    sw2 = make(nproto, batch=batch, num_patches=1)
+    torch.manual_seed(20)
+    loss2 = sw2.train_step(images)
+    np.testing.assert_allclose(loss2.item(), loss.item(), rtol=1e-5)
+    for a_, b_ in zip(sw2._grads, g0):
+        assert rel(a_, b_) < 1e-4
