@@ -947,9 +947,14 @@ int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float*
 // column sums must be all-reduced between passes.)
 namespace gx {
 
-__global__ void sk_colmax_small_kernel(const float* __restrict__ S, long rows, int K, long ld, int team,
+// blockIdx.y = problem: the (view, patch) score matrices of one step are independent Sinkhorn
+// problems of one shape, so they run as ONE launch per iteration (S, r, c, cmax, la and the
+// partial sums are strided by problem).
+__global__ void sk_colmax_small_kernel(const float* __restrict__ S, long sprob, long rows, int K, long ld, int team,
                                        unsigned* __restrict__ cmax) {
     __shared__ unsigned smax[64];
+    S += (long)blockIdx.y * sprob;
+    cmax += (long)blockIdx.y * K;
     if (threadIdx.x < 64) smax[threadIdx.x] = 0u;
     __syncthreads();
     const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
@@ -985,21 +990,31 @@ __device__ __forceinline__ void sk_fold_update(const float* __restrict__ upart_p
 }
 
 // it == 0: u_k = sum_n exp((S_nk - cmax_k)/eps).  it >= 1: fold the update of pass it-1, then sweep.
-__global__ void sk_pass_small_kernel(const float* __restrict__ S, long rows, int K, long ld, int team, int kx,
-                                     float inv_eps, int it, const unsigned* __restrict__ cmax,
-                                     const float* __restrict__ r, const float* __restrict__ c, float c_uniform,
-                                     const float* __restrict__ upart_prev, int nblk_prev,
+// Per-problem strides: S sprob, r rstride, c cstride, cmax/la K, partial sums gridDim.x * K.
+__global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, long rows, int K, long ld, int team,
+                                     int kx, float inv_eps, int it, const unsigned* __restrict__ cmax,
+                                     const float* __restrict__ r, long rstride, const float* __restrict__ c,
+                                     long cstride, float c_uniform, const float* __restrict__ upart_prev,
                                      const float* __restrict__ la_prev, float* __restrict__ la_cur,
                                      float* __restrict__ upart) {
     __shared__ float las[64], uacc[64], red[256];
+    const long y = blockIdx.y;
+    S += y * sprob;
+    cmax += y * K;
+    if (r) r += y * rstride;
+    if (c) c += y * cstride;
+    upart_prev += y * gridDim.x * K;
+    upart += y * gridDim.x * K;
+    la_prev += y * K;
+    la_cur += y * K;
     if (threadIdx.x < 64) uacc[threadIdx.x] = 0.f;
     if (it == 0) {
         if (threadIdx.x < K) las[threadIdx.x] = -ord2f(cmax[threadIdx.x]) * inv_eps;
         __syncthreads();
     } else {
-        sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
+        sk_fold_update(upart_prev, gridDim.x, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
     }
-    if (blockIdx.x == 0 && threadIdx.x < K && la_cur) la_cur[threadIdx.x] = las[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < K) la_cur[threadIdx.x] = las[threadIdx.x];
     const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
     const long nrow_iters = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
     float ul = 0.f;                                           // this lane's column (k = tl) partial: K <= team
@@ -1021,51 +1036,67 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long rows, int
     if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
 }
 
+// grid = nprob blocks
 __global__ void sk_finish_small_kernel(const float* __restrict__ upart_prev, int nblk_prev, int K, int kx,
                                        const float* __restrict__ la_prev, const unsigned* __restrict__ cmax,
-                                       int first_update, float inv_eps, const float* __restrict__ r,
+                                       int first_update, float inv_eps, const float* __restrict__ r, long rstride,
                                        float* __restrict__ la_out) {
     __shared__ float las[64], red[256];
-    sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, first_update != 0, inv_eps, r, las, red);
-    if (threadIdx.x < K) la_out[threadIdx.x] = las[threadIdx.x];
+    const long y = blockIdx.x;
+    sk_fold_update(upart_prev + y * nblk_prev * K, nblk_prev, K, kx, la_prev + y * K, cmax + y * K, first_update != 0,
+                   inv_eps, r ? r + y * rstride : nullptr, las, red);
+    if (threadIdx.x < K) la_out[y * K + threadIdx.x] = las[threadIdx.x];
 }
 
 }  // namespace gx
 
 extern "C" {
-// Single-rank Sinkhorn for K <= 64 (same result as gx_sinkhorn; niters + 2 launches).
-// Workspace: gx_sinkhorn_workspace_bytes(K).
-int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
-                      const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream) {
-    if (!S || !la || rows <= 0 || K <= 0 || K > 64 || ld < K || eps <= 0.f || niters < 1) return GX_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+// Single-rank Sinkhorn for K <= 64 over `nprob` independent, equally shaped problems (problem i:
+// scores S + i*sprob, prototype marginal r + i*rstride or uniform, sample marginal c + i*cstride or
+// uniform 1/rows; result la + i*K).  niters + 2 launches for the whole batch; same result per
+// problem as gx_sinkhorn.  Workspace: nprob * gx_sinkhorn_workspace_bytes(K).
+int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, int K, long ld, float eps, int niters,
+                            const float* r, long rstride, const float* c, long cstride, float* la,
+                            float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S || !la || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || K > 64 || ld < K || eps <= 0.f ||
+        niters < 1 || (nprob > 1 && sprob < 0))
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)nprob * gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int team = gx::pick_team(K);
     const long tpb = 256 / team;
     long nbl = (rows + tpb - 1) / tpb;
-    const int nb = (int)(nbl < GX_SK_SMALL_BLOCKS ? nbl : GX_SK_SMALL_BLOCKS);
+    long cap = 4096 / nprob;                                    // ~2 waves of blocks over the whole batch
+    cap = cap < 64 ? 64 : (cap > GX_SK_SMALL_BLOCKS ? GX_SK_SMALL_BLOCKS : cap);
+    const int nb = (int)(nbl < cap ? nbl : cap);
     int kx = 1;
     while (kx < 64 && kx < K) kx <<= 1;
-    unsigned* cmax = (unsigned*)workspace;                      // [K]
-    float* labuf = workspace + K;                               // [2][K]  (the "u" slot is not used here)
-    float* part = workspace + 3 * (size_t)K;                    // [2][nb][K]  (fits: 2K + BLOCKS*K >= 3K + 2*nb*K? checked below)
-    if (hipMemsetAsync(cmax, 0, (size_t)K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
-    hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb), dim3(256), 0, st, S, rows, K, ld, team, cmax);
+    const size_t PK = (size_t)nprob * K;
+    unsigned* cmax = (unsigned*)workspace;                      // [nprob][K]
+    float* labuf = workspace + PK;                              // [2][nprob][K]
+    float* part = workspace + 3 * PK;                           // [2][nprob][nb][K]
+    if (hipMemsetAsync(cmax, 0, PK * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
+    hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, cmax);
     GX_CHECK_LAUNCH();
     const float c_uniform = 1.f / (float)rows;
     for (int it = 0; it < niters; ++it) {
-        float* up_prev = part + (size_t)((it + 1) & 1) * nb * K;
-        float* up_cur = part + (size_t)(it & 1) * nb * K;
-        hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb), dim3(256), 0, st, S, rows, K, ld, team, kx, 1.f / eps, it,
-                           cmax, r, c, c_uniform, up_prev, nb, labuf + (size_t)((it + 1) & 1) * K,
-                           labuf + (size_t)(it & 1) * K, up_cur);
+        float* up_prev = part + (size_t)((it + 1) & 1) * nb * PK;
+        float* up_cur = part + (size_t)(it & 1) * nb * PK;
+        hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
+                           1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev,
+                           labuf + (size_t)((it + 1) & 1) * PK, labuf + (size_t)(it & 1) * PK, up_cur);
         GX_CHECK_LAUNCH();
     }
     const int last = niters - 1;
-    hipLaunchKernelGGL(gx::sk_finish_small_kernel, dim3(1), dim3(256), 0, st, part + (size_t)(last & 1) * nb * K, nb, K,
-                       kx, labuf + (size_t)(last & 1) * K, cmax, niters == 1 ? 1 : 0, 1.f / eps, r, la);
+    hipLaunchKernelGGL(gx::sk_finish_small_kernel, dim3(nprob), dim3(256), 0, st, part + (size_t)(last & 1) * nb * PK,
+                       nb, K, kx, labuf + (size_t)(last & 1) * PK, cmax, niters == 1 ? 1 : 0, 1.f / eps, r, rstride, la);
     GX_CHECK_LAUNCH();
     return GX_OK;
+}
+// One problem (see gx_sinkhorn_small_batch).  Workspace: gx_sinkhorn_workspace_bytes(K).
+int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
+                      const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream) {
+    return gx_sinkhorn_small_batch(S, 1, 0, rows, K, ld, eps, niters, r, 0, c, 0, la, workspace, workspace_bytes, stream);
 }
 }  // extern "C"
 

@@ -168,14 +168,14 @@ def proto_small_ok(k, d):
     return k <= 16 and d % 256 == 0 and d <= 512
 
 
-def proto_fwd_small(z, picks, maps, wc, bias):
-    """Fused row gather + normalise + scores for K <= 16 prototypes."""
-    _chk(z, wc, bias)
+def proto_fwd_small(z, picks, maps, wc, bias, out=None):
+    """Fused row gather + normalise + scores for K <= 16 prototypes (scores into `out` if given)."""
+    _chk(z, wc, bias, out)
     b, h, w, d = z.shape
     n, k = picks.shape[1], wc.shape[0]
     zhat = torch.empty(b * n, d, dtype=torch.float32, device=z.device)
     rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
-    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device)
+    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device) if out is None else out
     _lib.check(lib().gx_proto_fwd_small(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(wc), _p(bias), k, _p(zhat),
                                         _p(rn), _p(sc), _stream()), "gx_proto_fwd_small")
     return zhat, rn, sc
@@ -198,13 +198,13 @@ def lowrank_ok(k, d):
     return k <= 15 and d % 256 == 0 and d <= 512
 
 
-def proto_fwd_lowrank(z, picks, maps, wc, bias):
+def proto_fwd_lowrank(z, picks, maps, wc, bias, out=None):
     """scores (B*N, K), rnorm (B*N) from the projected-pixel table (zhat is never written)."""
-    _chk(z, wc, bias)
+    _chk(z, wc, bias, out)
     b, h, w, d = z.shape
     n, k = picks.shape[1], wc.shape[0]
     rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
-    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device)
+    sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device) if out is None else out
     _lib.check(lib().gx_proto_fwd_lowrank(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(wc), _p(bias), k, _p(rn),
                                           _p(sc), _stream()), "gx_proto_fwd_lowrank")
     return rn, sc
@@ -455,17 +455,23 @@ class Sinkhorn:
     Sharded: pass `reduce(tensor, op)` that all-reduces in place over the ranks ('max' for the K
     column maxima, 'sum' for the K column sums) and c_uniform = 1/rows_global."""
 
-    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="sk"):
+    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="sk", la=None):
         _chk(scores, r, c)
         self.S = scores
         self.rows, self.K = scores.shape
         self.eps, self.niters = float(eps), int(niters)
         self.r, self.c = r, c
         self.c_uniform = 1.0 / self.rows if c_uniform is None else float(c_uniform)
-        L = lib()
-        self.wsb = L.gx_sinkhorn_workspace_bytes(self.K)
-        self.ws = workspace(tag, self.wsb, scores.device)
-        self.la = torch.empty(self.K, dtype=torch.float32, device=scores.device)
+        self.tag = tag
+        self.wsb = lib().gx_sinkhorn_workspace_bytes(self.K)
+        self._ws = None
+        self.la = torch.empty(self.K, dtype=torch.float32, device=scores.device) if la is None else la
+
+    @property
+    def ws(self):
+        if self._ws is None:
+            self._ws = workspace(self.tag, self.wsb, self.S.device)
+        return self._ws
 
     def run(self, reduce=None):
         L, S, K = lib(), self.S, self.K
@@ -487,8 +493,8 @@ class Sinkhorn:
         _lib.check(lib().gx_sinkhorn_colmax(_p(S), self.rows, self.K, S.stride(0), _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_colmax")
 
-    def cmax_get(self):
-        cm = torch.empty(self.K, dtype=torch.float32, device=self.S.device)
+    def cmax_get(self, out=None):
+        cm = torch.empty(self.K, dtype=torch.float32, device=self.S.device) if out is None else out
         _lib.check(lib().gx_sinkhorn_cmax_get(_p(self.ws), self.K, _p(cm), _stream()), "gx_sinkhorn_cmax_get")
         return cm
 
@@ -504,8 +510,9 @@ class Sinkhorn:
     def colsums(self):
         return self.ws[self.K:2 * self.K]
 
-    def update(self, first):
-        _lib.check(lib().gx_sinkhorn_update(_p(self.colsums()), _p(self.r), self.K, int(first), _p(self.ws), self.eps,
+    def update(self, first, u=None):
+        u = self.colsums() if u is None else u
+        _lib.check(lib().gx_sinkhorn_update(_p(u), _p(self.r), self.K, int(first), _p(self.ws), self.eps,
                                             _p(self.la), _stream()), "gx_sinkhorn_update")
 
     def codes(self):
@@ -513,6 +520,53 @@ class Sinkhorn:
         _lib.check(lib().gx_sinkhorn_codes(_p(self.S), self.rows, self.K, self.S.stride(0), self.eps, _p(self.la),
                                            _p(q), q.stride(0), _stream()), "gx_sinkhorn_codes")
         return q
+
+
+class SinkhornBatch:
+    """`nprob` independent, equally shaped Sinkhorn problems — the 2 views x patches (x images for
+    the per-image scope) score matrices of one optimizer step — solved together.
+
+    scores (nprob, rows, K) contiguous; r (nprob, K) / c (nprob, rows) or None (uniform).
+    One rank, K <= 64: ONE launch per Sinkhorn iteration for the whole batch.  Sharded: the same
+    per-problem kernels as `Sinkhorn`, but ONE all-reduce of nprob*K values per exchange
+    (sharded.run_sinkhorn_group) instead of one per problem.  self[i] is problem i's state."""
+
+    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="skb"):
+        _chk(scores, r, c)
+        if scores.dim() != 3:
+            raise RuntimeError("SinkhornBatch: scores must be (nprob, rows, K)")
+        self.S = scores
+        self.nprob, self.rows, self.K = scores.shape
+        self.eps, self.niters = float(eps), int(niters)
+        self.r, self.c = r, c
+        self.c_uniform = 1.0 / self.rows if c_uniform is None else float(c_uniform)
+        self.tag = tag
+        self.la = torch.empty(self.nprob, self.K, dtype=torch.float32, device=scores.device)
+        self.probs = [Sinkhorn(scores[i], eps, niters, r=None if r is None else r[i], c=None if c is None else c[i],
+                               c_uniform=self.c_uniform, tag=f"{tag}.{i}", la=self.la[i])
+                      for i in range(self.nprob)]
+
+    def __getitem__(self, i):
+        return self.probs[i]
+
+    def run(self, reduce=None):
+        if reduce is None and self.c_uniform == 1.0 / self.rows and self.K <= 64 and self.rows >= 4096:
+            L = lib()
+            wsb = self.nprob * L.gx_sinkhorn_workspace_bytes(self.K)
+            ws = workspace(self.tag, wsb, self.S.device)
+            _lib.check(L.gx_sinkhorn_small_batch(
+                _p(self.S), self.nprob, self.S.stride(0), self.rows, self.K, self.S.stride(1), self.eps, self.niters,
+                _p(self.r), 0 if self.r is None else self.r.stride(0), _p(self.c),
+                0 if self.c is None else self.c.stride(0), _p(self.la), _p(ws), wsb, _stream()),
+                "gx_sinkhorn_small_batch")
+            return self
+        if reduce is None:
+            for p in self.probs:
+                p.run()
+            return self
+        from .sharded import run_sinkhorn_group
+        run_sinkhorn_group(self.probs, self.niters, reduce)
+        return self
 
 
 def hist_marginal(x, bins, reduce=None):

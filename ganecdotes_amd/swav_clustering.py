@@ -216,78 +216,105 @@ class SwAVClustering(ViewMixin):
                 Ct = [ops.lowrank_coeffs(B, hw * hw, dev) for _ in Zt]         # (B*HW, 16) coefficient grids
             else:
                 Gt = [torch.zeros_like(z) for z in Zt]
-        for pno in range(P):
-            picks = pb.picks[pno]
-            X, Zh, Rn, Sc = [], [], [], []
-            for v, (ts, maps, _) in enumerate(views):
-                if lowrank:
-                    with self._timed("proto_fwd_lowrank"):
-                        rn, sc = ops.proto_fwd_lowrank(Zt[v], picks, maps, Wc, bc)
-                    Zh.append(None); Rn.append(rn); Sc.append(sc)
-                    continue
-                if mode == 'pyramid' and small:
-                    with self._timed("proto_fwd_small"):
-                        z, rn, sc = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc)
-                    Zh.append(z); Rn.append(rn); Sc.append(sc)
-                    continue
-                if mode == 'pyramid':
-                    with self._timed("gather_rows"):
-                        z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
-                else:
-                    with self._timed("gather"):
-                        x = ops.gather_taps(ts, picks, hlen, maps)             # (B*N, hlen)
-                    with self._timed("proj_fwd"):
-                        z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
-                    rn = ops.row_l2_normalize_(z)                              # z -> z_hat
-                    X.append(x)
-                sc = ops.gemm(z, Wc, False, True, col_bias=bc)                 # (B*N, K)
-                Zh.append(z); Rn.append(rn); Sc.append(sc)
-            dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
+        # 'image' source pdf: the marginals depend on the view (and image), not on the patch
+        marg = None
+        if imgs is not None:
             if scope == 'global':
-                groups = [(0, rows)]
+                marg = [self._marginals(imgs[v].contiguous(), K, rows, shared=True) for v in range(2)]
+                r_one = torch.stack([m[0] for m in marg])                       # (2, K)
+                c_one = torch.stack([m[1] for m in marg])                       # (2, rows)
             else:
-                groups = [(b * N, (b + 1) * N) for b in range(B)]
-            for (r0, r1) in groups:
-                sk = []
+                marg = [[self._marginals(imgs[v][b:b + 1].contiguous(), K, N) for b in range(B)] for v in range(2)]
+                r_one = torch.stack([torch.stack([m[0] for m in mv]) for mv in marg])   # (2, B, K)
+                c_one = torch.stack([torch.stack([m[1] for m in mv]) for mv in marg])   # (2, B, N)
+        ngroups = 1 if scope == 'global' else B                  # Sinkhorn problems per (patch, view)
+        grows = rows // ngroups
+        nglob = grows * (self.world if scope == 'global' else 1)
+        # The pyramid path holds only (rows, K) scores per patch, so all patches go through ONE
+        # batched Sinkhorn (as many as fit 16 GB of scores); the panel path keeps a (rows, hlen)
+        # descriptor panel per view alive until its backward, so it goes patch by patch.
+        pgroup = max(1, min(P, int(16e9 // (8.0 * rows * K)))) if mode == 'pyramid' else 1
+        for p0 in range(0, P, pgroup):
+            pnos = list(range(p0, min(P, p0 + pgroup)))
+            G = len(pnos)
+            Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)
+            keep = []
+            for gi, pno in enumerate(pnos):
+                picks = pb.picks[pno]
+                X, Zh, Rn = [], [], []
+                for v, (ts, maps, _) in enumerate(views):
+                    sc = Sc_all[gi, v]
+                    if lowrank:
+                        with self._timed("proto_fwd_lowrank"):
+                            rn, _ = ops.proto_fwd_lowrank(Zt[v], picks, maps, Wc, bc, out=sc)
+                        Zh.append(None); Rn.append(rn)
+                        continue
+                    if mode == 'pyramid' and small:
+                        with self._timed("proto_fwd_small"):
+                            z, rn, _ = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc, out=sc)
+                        Zh.append(z); Rn.append(rn)
+                        continue
+                    if mode == 'pyramid':
+                        with self._timed("gather_rows"):
+                            z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
+                    else:
+                        with self._timed("gather"):
+                            x = ops.gather_taps(ts, picks, hlen, maps)             # (B*N, hlen)
+                        with self._timed("proj_fwd"):
+                            z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
+                        rn = ops.row_l2_normalize_(z)                              # z -> z_hat
+                        X.append(x)
+                    ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)              # (B*N, K)
+                    Zh.append(z); Rn.append(rn)
+                keep.append((X, Zh, Rn))
+            # S4: every (patch, view[, image]) problem of the group in one batched Sinkhorn
+            r_all = c_all = None
+            if marg is not None:
+                r_all = r_one.unsqueeze(0).expand(G, *r_one.shape).reshape(G * 2 * ngroups, K).contiguous()
+                c_all = c_one.unsqueeze(0).expand(G, *c_one.shape).reshape(G * 2 * ngroups, grows).contiguous()
+            with self._timed("sinkhorn"):
+                skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
+                                        c=c_all, c_uniform=1.0 / nglob)
+                skb.run(self._reduce if (scope == 'global' and self.world > 1) else None)
+            for gi, pno in enumerate(pnos):
+                picks = pb.picks[pno]
+                X, Zh, Rn = keep[gi]
+                Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
+                dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
+                for g in range(ngroups):
+                    r0, r1 = g * grows, (g + 1) * grows
+                    sk = [skb[(gi * 2 + v) * ngroups + g] for v in range(2)]
+                    ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
+                    if return_aux and pno == 0 and g == 0:
+                        aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
+                                   q_s=sk[0].codes(), q_t=sk[1].codes())
+                # S6: backward (gradients accumulate over views and patches)
                 for v in range(2):
-                    r = c = None
-                    if imgs is not None:
-                        img = imgs[v] if scope == 'global' else imgs[v][r0 // N:r0 // N + 1]
-                        r, c = self._marginals(img.contiguous(), K, r1 - r0, shared=(scope == 'global'))
-                    nglob = (r1 - r0) * (self.world if scope == 'global' else 1)
-                    s = ops.Sinkhorn(Sc[v][r0:r1], self.eps, self.niters, r=r, c=c, c_uniform=1.0 / nglob,
-                                     tag=f"sk{v}")
-                    s.run(self._reduce if (scope == 'global' and self.world > 1) else None)
-                    sk.append(s)
-                ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
-                if return_aux and pno == 0 and r0 == 0:
-                    aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
-                               q_s=sk[0].codes(), q_t=sk[1].codes())
-            # S6: backward (gradients accumulate over views and patches)
-            for v in range(2):
-                beta = 0.0 if first_acc else 1.0
-                if lowrank:
-                    with self._timed("proto_bwd_lowrank"):
-                        ops.proto_bwd_lowrank_(dS[v], Sc[v], Rn[v], bc, picks, views[v][1], Ct[v], hw * hw, gb, beta)
+                    beta = 0.0 if first_acc else 1.0
+                    if lowrank:
+                        with self._timed("proto_bwd_lowrank"):
+                            ops.proto_bwd_lowrank_(dS[v], Sc[v], Rn[v], bc, picks, views[v][1], Ct[v], hw * hw, gb, beta)
+                        first_acc = False
+                        continue
+                    if mode == 'pyramid' and small:
+                        with self._timed("proto_bwd_small"):
+                            ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
+                        first_acc = False
+                        continue
+                    ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
+                    ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
+                    dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)
+                    if mode == 'pyramid':
+                        with self._timed("scatter_rows"):
+                            ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])
+                    else:
+                        ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
+                        with self._timed("proj_dW"):
+                            ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
                     first_acc = False
-                    continue
-                if mode == 'pyramid' and small:
-                    with self._timed("proto_bwd_small"):
-                        ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
-                    first_acc = False
-                    continue
-                ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
-                ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
-                dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)
-                if mode == 'pyramid':
-                    with self._timed("scatter_rows"):
-                        ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])
-                else:
-                    ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
-                    with self._timed("proj_dW"):
-                        ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
-                first_acc = False
-            del X, Zh, Rn, Sc, dS
+                keep[gi] = None
+                del X, Zh, Rn, Sc, dS
+            del keep, Sc_all, skb
         if mode == 'pyramid':
             if lowrank:
                 with self._timed("lowrank_finish"):

@@ -178,6 +178,13 @@ int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters
 int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
                       const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream);
                       /* same result for K <= 64 on one rank: one launch per iteration */
+/* `nprob` independent, equally shaped problems in one launch per iteration: the 2 views x
+ * num_patches score matrices of one optimizer step (the reference runs them one after another,
+ * swav_clustering.py:389-406).  Problem i: S + i*sprob, r + i*rstride, c + i*cstride -> la + i*K.
+ * Workspace: nprob * gx_sinkhorn_workspace_bytes(K). */
+int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, int K, long ld, float eps, int niters,
+                            const float* r, long rstride, const float* c, long cstride, float* la,
+                            float* workspace, size_t workspace_bytes, void* stream);
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);

@@ -26,7 +26,7 @@ class TorchSinkhornKernels:
     def colmax(self):
         self.cmax = self.S.max(0)[0]
 
-    def cmax_get(self):
+    def cmax_get(self, out=None):
         return self.cmax.clone()
 
     def cmax_set(self, cm):
@@ -43,9 +43,10 @@ class TorchSinkhornKernels:
     def colsums(self):
         return self.u
 
-    def update(self, first):
+    def update(self, first, u=None):
+        u = self.u if u is None else u
         base = -self.cmax / self.eps if first else self.la
-        self.la = base + float(np.log(1.0 / self.K)) - torch.log(self.u)
+        self.la = base + float(np.log(1.0 / self.K)) - torch.log(u)
 
     def codes(self):
         return torch.softmax(self.S / self.eps + self.la, dim=1)
@@ -74,6 +75,48 @@ def _worker(rank, world, port, scores, eps, out):
     out[rank] = (lo, hi, q.numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+class CountingReduce:
+    def __init__(self, group):
+        self.fn, self.calls = sharded.make_reduce(group), 0
+
+    def __call__(self, t, op):
+        self.calls += 1
+        self.fn(t, op)
+
+
+def _group_worker(rank, world, port, problems, eps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharded.shard_range(problems[0].shape[0], rank, world)
+    ks = [TorchSinkhornKernels(sc[lo:hi].clone(), eps, sc.shape[0]) for sc in problems]
+    red = CountingReduce(dist.group.WORLD)
+    sharded.run_sinkhorn_group(ks, 10, red)
+    out[rank] = (lo, hi, [k.codes().numpy() for k in ks], red.calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grouped_sharded_sinkhorn_shares_the_exchanges():
+    """A step's independent problems (views x patches) exchange together: 1 + niters
+    collectives for the whole group, each problem's codes equal to its own 1-rank run."""
+    from oracle import swav_ref as S
+    torch.manual_seed(6)
+    n, k, eps = 257, 8, 0.02
+    problems = [0.3 * torch.randn(n, k) for _ in range(3)]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_group_worker, args=(2, _free_port(), problems, eps, out), nprocs=2, join=True)
+    assert out[0][3] == 11 and out[1][3] == 11
+    for i, sc in enumerate(problems):
+        ref = S.sinkhorn_knopp(sc, eps, 10, fp64=True).numpy()
+        q = np.zeros_like(ref)
+        for r in range(2):
+            lo, hi, qs, _ = out[r]
+            q[lo:hi] = qs[i]
+        assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
 
 
 def test_shard_range_covers_everything():

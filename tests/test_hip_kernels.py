@@ -196,6 +196,57 @@ def test_sinkhorn_small_fused_path(ops, n, k, eps, pdf):
         assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
 
 
+@pytest.mark.parametrize("nprob,n,k,pdf", [(10, 20000, 8, "uniform"), (3, 4100, 16, "image"), (4, 5000, 40, "uniform"),
+                                           (2, 300, 12, "uniform"), (2, 4200, 80, "uniform")])
+def test_sinkhorn_batch_equals_per_problem(ops, nprob, n, k, pdf):
+    """SinkhornBatch (one launch per iteration over all problems when K <= 64, rows >= 4096;
+    per-problem kernels otherwise) == each problem solved alone; and with a (faked 2-rank)
+    reduce the grouped exchange gives the 1-rank codes of the concatenation."""
+    torch.manual_seed(nprob * n + k)
+    eps = 0.005
+    s = dev(0.3 * torch.nn.functional.normalize(torch.randn(nprob, n, 16), dim=2) @
+            torch.nn.functional.normalize(torch.randn(k, 16), dim=1).t())
+    r = c = None
+    if pdf == "image":
+        imgs = [dev(torch.rand(1, 64, 64) * 2 + 0.1) for _ in range(nprob)]
+        r = torch.stack([ops.hist_marginal(im, k) for im in imgs])
+        c = torch.stack([ops.hist_marginal(im, n) for im in imgs])
+    skb = ops.SinkhornBatch(s, eps, 10, r=r, c=c).run()
+    for i in range(nprob):
+        one = ops.Sinkhorn(s[i], eps, 10, r=None if r is None else r[i], c=None if c is None else c[i],
+                           tag="one").run()
+        np.testing.assert_allclose(skb[i].codes().cpu().numpy(), one.codes().cpu().numpy(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(skb.la[i].cpu().numpy(), one.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if pdf == "uniform":
+        # two "ranks" hold the two halves of every problem; the fake reduce sums / maxes the pair
+        h = n // 2
+        halves = [ops.SinkhornBatch(s[:, :h].contiguous(), eps, 10, c_uniform=1.0 / n, tag="ha"),
+                  ops.SinkhornBatch(s[:, h:].contiguous(), eps, 10, c_uniform=1.0 / n, tag="hb")]
+        calls = []
+
+        def lockstep():
+            """drive both rank states through run_sinkhorn_group's schedule with a shared exchange"""
+            A, Bk = halves[0].probs, halves[1].probs
+            for kk in A + Bk:
+                kk.colmax()
+            cm = torch.maximum(torch.stack([kk.cmax_get() for kk in A]), torch.stack([kk.cmax_get() for kk in Bk]))
+            calls.append("max")
+            for i2 in range(nprob):
+                A[i2].cmax_set(cm[i2]); Bk[i2].cmax_set(cm[i2])
+            for it in range(10):
+                for kk in A + Bk:
+                    kk.sweep(it == 0)
+                u = torch.stack([kk.colsums() for kk in A]) + torch.stack([kk.colsums() for kk in Bk])
+                calls.append("sum")
+                for i2 in range(nprob):
+                    A[i2].update(it == 0, u=u[i2]); Bk[i2].update(it == 0, u=u[i2])
+        lockstep()
+        assert len(calls) == 11
+        for i in range(nprob):
+            q = torch.cat([halves[0][i].codes(), halves[1][i].codes()]).cpu().numpy()
+            np.testing.assert_allclose(q, skb[i].codes().cpu().numpy(), rtol=5e-4, atol=1e-7)
+
+
 def test_sinkhorn_sharded_equals_single(ops):
     """W-rank result == 1-rank result on the concatenated pixels (ranks faked)."""
     torch.manual_seed(11)
