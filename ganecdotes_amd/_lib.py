@@ -33,7 +33,8 @@ SIGNATURES = {
     "gx_proto_fwd_small": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_bwd_small": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,
                                  c_p]),
-    "gx_lowrank_stride": (c_i, []),
+    "gx_lowrank_stride": (c_i, [c_i]),
+    "gx_gather_scores": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_fwd_lowrank": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_proto_bwd_lowrank": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz, c_p]),

@@ -1358,7 +1358,9 @@ int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, i
 // (gWc[k] = sum_rows dS_k zhat = sum_q C[q][k] Z[q] with the same coefficients).
 namespace gx {
 
-constexpr int LR_STRIDE = 16;          // coefficient slots per pixel: K <= 15 prototype slots + 1
+constexpr int LR_MAXK = 16;            // low-rank path: K <= 16 prototypes
+// coefficient slots per pixel: K prototype slots + 1, padded to a float4 multiple (16 for K <= 15, 20 for K = 16)
+__host__ __device__ constexpr int lr_stride(int K) { return (K + 1 + 3) & ~3; }
 
 // scores[row][k] = rn * <Z[q], Wc_k> + b_k ; rnorm[row] = rn.  One wave per row.
 template <int KP>
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
     const float myb = (owner && bias) ? bias[myk] : 0.f;
     for (long row = wave0; row < rows; row += nwave) {
         const int b = (int)(row / rows_per_img);
-        int pix = picks[row];
+        int pix = picks ? picks[row] : (int)(row - (long)b * rows_per_img);   // no picks: the whole table, in order
         if (maps) pix = maps[(long)b * HW + pix];
         float p[KP];
 #pragma unroll
@@ -1407,26 +1409,46 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
     }
 }
 
+// Sampled rows of the all-pixel score table: scores[row][:] = T[q][:], rnorm[row] = rnT[q] with
+// q = map(pick(row)); a pixel rotated out of the frame (q < 0) has a zero descriptor: score = bias,
+// rnorm = 1/1e-12 like F.normalize's eps clamp.  One thread per (row, k).
+__global__ void gather_scores_kernel(const float* __restrict__ T, const float* __restrict__ rnT,
+                                     const float* __restrict__ bias, int HW, int K, const int* __restrict__ picks,
+                                     const int* __restrict__ maps, int rows_per_img, long rows,
+                                     float* __restrict__ scores, float* __restrict__ rnorm) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * K) return;
+    const long row = idx / K;
+    const int k = (int)(idx - row * K);
+    const int b = (int)(row / rows_per_img);
+    int pix = picks[row];
+    if (maps) pix = maps[(long)b * HW + pix];
+    const long q = (long)b * HW + pix;
+    scores[idx] = pix >= 0 ? T[q * K + k] : (bias ? bias[k] : 0.f);
+    if (k == 0) rnorm[row] = pix >= 0 ? rnT[q] : 1e12f;
+}
+
 // One THREAD per row: coefficient scatter + per-block partial of gb.
 __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const float* __restrict__ scores,
                                          const float* __restrict__ rnorm, const float* __restrict__ bias, int HW, int K,
                                          const int* __restrict__ picks, const int* __restrict__ maps, int rows_per_img,
                                          long rows, float* __restrict__ C, float* __restrict__ part_b) {
-    __shared__ float sb[LR_STRIDE];
-    if (threadIdx.x < LR_STRIDE) sb[threadIdx.x] = 0.f;
+    __shared__ float sb[LR_MAXK];
+    const int ls = lr_stride(K);
+    if (threadIdx.x < LR_MAXK) sb[threadIdx.x] = 0.f;
     __syncthreads();
-    float gb[LR_STRIDE - 1];
+    float gb[LR_MAXK];
 #pragma unroll
-    for (int k = 0; k < LR_STRIDE - 1; ++k) gb[k] = 0.f;
+    for (int k = 0; k < LR_MAXK; ++k) gb[k] = 0.f;
     for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long)gridDim.x * blockDim.x) {
         const int b = (int)(row / rows_per_img);
         int pix = picks[row];
         if (maps) pix = maps[(long)b * HW + pix];
         const float rn = rnorm[row];
         float dot = 0.f;
-        float* dst = C + ((long)b * HW + (pix >= 0 ? pix : 0)) * LR_STRIDE;
+        float* dst = C + ((long)b * HW + (pix >= 0 ? pix : 0)) * ls;
 #pragma unroll
-        for (int k = 0; k < LR_STRIDE - 1; ++k)
+        for (int k = 0; k < LR_MAXK; ++k)
             if (k < K) {
                 const float d = dS[row * K + k];
                 gb[k] += d;
@@ -1436,7 +1458,7 @@ __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const flo
         if (pix >= 0) atomicAdd(dst + K, -rn * rn * dot);
     }
 #pragma unroll
-    for (int k = 0; k < LR_STRIDE - 1; ++k)
+    for (int k = 0; k < LR_MAXK; ++k)
         if (k < K) {
             const float s = gx_wave_sum(gb[k]);
             if ((threadIdx.x & 63) == 0) atomicAdd(&sb[k], s);
@@ -1457,6 +1479,7 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nj = D >> 6;
     const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wid;
     const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    const int ls = lr_stride(K);
     float gw[KP][8];
 #pragma unroll
     for (int k = 0; k < KP; ++k)
@@ -1465,8 +1488,8 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
     for (long q = wave0; q < npix; q += nwave) {
         float c[KP];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) c[k] = k < K ? C[q * LR_STRIDE + k] : 0.f;
-        const float cz = C[q * LR_STRIDE + K];
+        for (int k = 0; k < KP; ++k) c[k] = k < K ? C[q * ls + k] : 0.f;
+        const float cz = C[q * ls + K];
         bool any = cz != 0.f;
 #pragma unroll
         for (int k = 0; k < KP; ++k) any = any || (c[k] != 0.f);
@@ -1513,13 +1536,14 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
 
 extern "C" {
 
-int gx_lowrank_stride(void) { return gx::LR_STRIDE; }
+int gx_lowrank_stride(int K) { return gx::lr_stride(K); }
 
 // scores (rows, K) and rnorm (rows) straight from the projected-pixel table (zhat is not written).
 int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
                          const float* Wc, const float* bias, int K, float* rnorm, float* scores, void* stream) {
-    if (!Z || !picks || !Wc || !rnorm || !scores || B <= 0 || HW <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
-    if (K < 1 || K > 15 || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
+    if (!Z || !Wc || !rnorm || !scores || B <= 0 || HW <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
+    if (!picks && (rows_per_img != HW || maps)) return GX_ERR_BAD_ARG;      // no picks: every pixel, in order
+    if (K < 1 || K > gx::LR_MAXK || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
     const long rows = (long)B * rows_per_img;
     long nb = (rows + 3) / 4;
     if (nb > 2048) nb = 2048;
@@ -1535,12 +1559,25 @@ int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks,
     return GX_OK;
 }
 
-// C [B*HW][16] += per-row coefficients (float atomics); gb = beta*gb + colsum(dS).
+// Rows of the all-pixel score table (gx_proto_fwd_lowrank with picks == NULL) for one patch.
+int gx_gather_scores(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
+                     const int* picks, int rows_per_img, const int* maps, float* scores, float* rnorm, void* stream) {
+    if (!table || !rn_table || !picks || !scores || !rnorm || B <= 0 || HW <= 0 || K <= 0 || rows_per_img <= 0)
+        return GX_ERR_BAD_ARG;
+    const long rows = (long)B * rows_per_img;
+    hipLaunchKernelGGL(gx::gather_scores_kernel, dim3((unsigned)gx_cdiv(rows * K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       table, rn_table, bias, HW, K, picks, maps, rows_per_img, rows, scores, rnorm);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// C [B*HW][gx_lowrank_stride(K)] += per-row coefficients (float atomics); gb = beta*gb + colsum(dS).
 // workspace >= 1024*K floats.
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream) {
-    if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || rows_per_img <= 0 || K < 1 || K > 15)
+    if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || rows_per_img <= 0 || K < 1 ||
+        K > gx::LR_MAXK)
         return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < (size_t)1024 * K * sizeof(float)) return GX_ERR_WORKSPACE;
     const long rows = (long)B * rows_per_img;
@@ -1558,7 +1595,8 @@ int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnor
 // workspace >= gx_proto_small_workspace_bytes(K, D).
 int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int D, const float* Wc, int K, float* G,
                             float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream) {
-    if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > 15 || (D & 63) || D > 512) return GX_ERR_BAD_ARG;
+    if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > gx::LR_MAXK || (D & 63) || D > 512)
+        return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_proto_small_workspace_bytes(K, D)) return GX_ERR_WORKSPACE;
     long nb = (npix + 3) / 4;
     if (nb > GX_PS_BLOCKS) nb = GX_PS_BLOCKS;

@@ -195,14 +195,15 @@ def proto_bwd_small_(ds, zhat, rnorm, picks, maps, wc, g, gwc, gb, beta):
 
 
 def lowrank_ok(k, d):
-    return k <= 15 and d % 256 == 0 and d <= 512
+    return k <= 16 and d % 256 == 0 and d <= 512
 
 
 def proto_fwd_lowrank(z, picks, maps, wc, bias, out=None):
-    """scores (B*N, K), rnorm (B*N) from the projected-pixel table (zhat is never written)."""
+    """scores (B*N, K), rnorm (B*N) from the projected-pixel table (zhat is never written).
+    picks=None: the score / rnorm tables of every pixel in order (B*HW rows)."""
     _chk(z, wc, bias, out)
     b, h, w, d = z.shape
-    n, k = picks.shape[1], wc.shape[0]
+    n, k = (h * w if picks is None else picks.shape[1]), wc.shape[0]
     rn = torch.empty(b * n, dtype=torch.float32, device=z.device)
     sc = torch.empty(b * n, k, dtype=torch.float32, device=z.device) if out is None else out
     _lib.check(lib().gx_proto_fwd_lowrank(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(wc), _p(bias), k, _p(rn),
@@ -210,9 +211,21 @@ def proto_fwd_lowrank(z, picks, maps, wc, bias, out=None):
     return rn, sc
 
 
-def lowrank_coeffs(b, hw, device):
-    """zeroed coefficient grid C (B*HW, stride)"""
-    return torch.zeros(b * hw, lib().gx_lowrank_stride(), dtype=torch.float32, device=device)
+def gather_scores(table, rn_table, bias, picks, maps, hw, out=None):
+    """one patch's rows of the all-pixel score table: scores (B*N, K), rnorm (B*N)"""
+    _chk(table, rn_table, bias, out)
+    b, n = picks.shape
+    k = table.shape[1]
+    rn = torch.empty(b * n, dtype=torch.float32, device=table.device)
+    sc = torch.empty(b * n, k, dtype=torch.float32, device=table.device) if out is None else out
+    _lib.check(lib().gx_gather_scores(_p(table), _p(rn_table), _p(bias), b, hw, k, _p(picks), n, _p(maps), _p(sc),
+                                      _p(rn), _stream()), "gx_gather_scores")
+    return rn, sc
+
+
+def lowrank_coeffs(b, hw, k, device):
+    """zeroed coefficient grid C (B*HW, stride(K))"""
+    return torch.zeros(b * hw, lib().gx_lowrank_stride(k), dtype=torch.float32, device=device)
 
 
 def proto_bwd_lowrank_(ds, scores, rnorm, bias, picks, maps, coeffs, hw, gb, beta):

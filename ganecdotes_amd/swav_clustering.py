@@ -213,7 +213,9 @@ class SwAVClustering(ViewMixin):
                 pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
                 Zt = [p.project(Wp) for p in pyr]                              # (B, H, W, D) per view
             if lowrank:
-                Ct = [ops.lowrank_coeffs(B, hw * hw, dev) for _ in Zt]         # (B*HW, 16) coefficient grids
+                Ct = [ops.lowrank_coeffs(B, hw * hw, K, dev) for _ in Zt]      # (B*HW, K+1 padded) coefficient grids
+                with self._timed("score_table"):                               # every pixel's scores, once per view
+                    Tab = [ops.proto_fwd_lowrank(z, None, None, Wc, bc) for z in Zt]
             else:
                 Gt = [torch.zeros_like(z) for z in Zt]
         # 'image' source pdf: the marginals depend on the view (and image), not on the patch
@@ -245,8 +247,7 @@ class SwAVClustering(ViewMixin):
                 for v, (ts, maps, _) in enumerate(views):
                     sc = Sc_all[gi, v]
                     if lowrank:
-                        with self._timed("proto_fwd_lowrank"):
-                            rn, _ = ops.proto_fwd_lowrank(Zt[v], picks, maps, Wc, bc, out=sc)
+                        rn, _ = ops.gather_scores(Tab[v][1], Tab[v][0], bc, picks, maps, hw * hw, out=sc)
                         Zh.append(None); Rn.append(rn)
                         continue
                     if mode == 'pyramid' and small:

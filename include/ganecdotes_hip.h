@@ -128,15 +128,20 @@ int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, i
                        int rows_per_img, const int* maps, const float* Wc, int K, float* G, float* gWc, float* gb,
                        float beta, float* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- low-rank prototype backward (K <= 15): per-row gradient = K+1 coefficients per pixel ----------
+/* ---- low-rank prototype backward (K <= 16): per-row gradient = K+1 coefficients per pixel ----------
  * dz(row) = sum_k (rn dS_k) Wc_k - (rn^2 <zhat, dS Wc>) Z[q]  lies in span{Wc, Z[q]} (DESIGN.md par. 4.3):
- * gx_proto_fwd_lowrank     scores, rnorm from Z rows (zhat never written)
+ * gx_proto_fwd_lowrank     scores, rnorm from Z rows (zhat never written); picks == NULL (rows_per_img
+ *                          == HW, maps == NULL): the score table of EVERY pixel, computed once per view
+ * gx_gather_scores         one patch's sampled rows of that table (the 5 patches of a step re-sample
+ *                          the same 65 536 pixels: swav_clustering.py:160-171 gathers 2 KB rows 5 times)
  * gx_proto_bwd_lowrank     C[q][0..K] += coefficients (36-B atomics per row instead of 2 KB), gb
  * gx_proto_lowrank_finish  once per view: G = C[:, :K] Wc + C[:, K] .* Z ; gWc (+)= C[:, :K]^T Z
- * C is [B*HW][gx_lowrank_stride()] floats, zeroed by the caller each step. */
-int gx_lowrank_stride(void);
+ * C is [B*HW][gx_lowrank_stride(K)] floats, zeroed by the caller each step. */
+int gx_lowrank_stride(int K);
 int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
                          const float* Wc, const float* bias, int K, float* rnorm, float* scores, void* stream);
+int gx_gather_scores(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
+                     const int* picks, int rows_per_img, const int* maps, float* scores, float* rnorm, void* stream);
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream);

@@ -240,9 +240,11 @@ def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path, hlen):
     assert (out["pyramid"][3] == out["panel"][3]).float().mean() > 0.999
 
 
-def test_small_prototype_paths_agree(gpu, tmp_path):
-    """D=256, K=8 on a 512-channel generator: the generic GEMM chain, the fused small-prototype
-    kernels and the low-rank coefficient path give the same loss, gradients and update."""
+@pytest.mark.parametrize("nproto", [8, 16, 11])
+def test_small_prototype_paths_agree(gpu, tmp_path, nproto):
+    """D=256, K=8 / 16 (BASELINE configs[1] / [2]) / 11 on a 512-channel generator: the generic GEMM
+    chain, the fused small-prototype kernels and the low-rank coefficient path (score table of
+    every pixel + per-patch gathers) give the same loss, gradients and update."""
     from ganecdotes_amd.draws import draw_image
     from ganecdotes_amd.generator import Generator
     from ganecdotes_amd.swav_clustering import SwAVClustering
@@ -262,7 +264,7 @@ def test_small_prototype_paths_agree(gpu, tmp_path):
     for tag, kw in (("generic", dict(small_proto_kernels=False, lowrank_proto=False)),
                     ("small", dict(small_proto_kernels=True, lowrank_proto=False)),
                     ("lowrank", dict(small_proto_kernels=True, lowrank_proto=True))):
-        a = toy_args(hlen=512 * 7, nclasses=256, nprototypes=8, patch_size=700, num_patches=3,
+        a = toy_args(hlen=512 * 7, nclasses=256, nprototypes=nproto, patch_size=700, num_patches=3,
                      sinkhorn_scope="global", temperature=0.1, **kw)
         a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.05)
         sw = SwAVClustering(model=g, model_config=C, out_dir=None, device="cuda", **a)
