@@ -37,7 +37,8 @@ SIGNATURES = {
     "gx_gather_scores": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_fwd_lowrank": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_proto_bwd_lowrank": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
-    "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    "gx_upsample2_add_scores": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),

@@ -16,6 +16,9 @@
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+namespace gx {
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+}  // namespace gx
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int gx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -25,8 +25,6 @@ constexpr int LDM = 128 + 4;          // MC image row stride (floats)
 constexpr int TILE_FLOATS = 128 * LDK;  // 4608 >= BK*LDM (4224): one operand, one buffer
 constexpr int GEMM_THREADS = 256;
 
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-
 // Load up to 4 consecutive floats; `nvalid` = how many of them exist.
 __device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec_ok) {
     if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const f32x4*>(p);

@@ -1428,106 +1428,200 @@ __global__ void gather_scores_kernel(const float* __restrict__ T, const float* _
     if (k == 0) rnorm[row] = pix >= 0 ? rnT[q] : 1e12f;
 }
 
-// One THREAD per row: coefficient scatter + per-block partial of gb.
+// One TEAM of 16 (K <= 15) or 32 lanes per row, lane tl owning coefficient tl: a row's K+1 float
+// atomics leave as ONE wave instruction over contiguous addresses (a 64-B line per row) instead
+// of K+1 instructions of 64 scattered lines each.  Also the per-block partial of gb.
 __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const float* __restrict__ scores,
                                          const float* __restrict__ rnorm, const float* __restrict__ bias, int HW, int K,
                                          const int* __restrict__ picks, const int* __restrict__ maps, int rows_per_img,
                                          long rows, float* __restrict__ C, float* __restrict__ part_b) {
     __shared__ float sb[LR_MAXK];
     const int ls = lr_stride(K);
+    const int team = (K + 1 <= 16) ? 16 : 32;
+    const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
     if (threadIdx.x < LR_MAXK) sb[threadIdx.x] = 0.f;
     __syncthreads();
-    float gb[LR_MAXK];
-#pragma unroll
-    for (int k = 0; k < LR_MAXK; ++k) gb[k] = 0.f;
-    for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(row / rows_per_img);
-        int pix = picks[row];
-        if (maps) pix = maps[(long)b * HW + pix];
-        const float rn = rnorm[row];
-        float dot = 0.f;
-        float* dst = C + ((long)b * HW + (pix >= 0 ? pix : 0)) * ls;
-#pragma unroll
-        for (int k = 0; k < LR_MAXK; ++k)
-            if (k < K) {
-                const float d = dS[row * K + k];
-                gb[k] += d;
-                dot = fmaf(d, scores[row * K + k] - (bias ? bias[k] : 0.f), dot);
-                if (pix >= 0) atomicAdd(dst + k, rn * d);
+    const float myb = (bias && tl < K) ? bias[tl] : 0.f;
+    float gbl = 0.f;
+    const long niter = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    for (long it = 0; it < niter; ++it) {
+        const long row = (it * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows;
+        float d = 0.f, sc = 0.f, rn = 0.f;
+        long q = -1;
+        if (live) {
+            const int b = (int)(row / rows_per_img);
+            int pix = picks[row];
+            if (maps) pix = maps[(long)b * HW + pix];
+            q = pix >= 0 ? (long)b * HW + pix : -1;
+            rn = rnorm[row];
+            if (tl < K) {
+                d = dS[row * K + tl];
+                sc = scores[row * K + tl] - myb;
             }
-        if (pix >= 0) atomicAdd(dst + K, -rn * rn * dot);
-    }
-#pragma unroll
-    for (int k = 0; k < LR_MAXK; ++k)
-        if (k < K) {
-            const float s = gx_wave_sum(gb[k]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&sb[k], s);
         }
+        const float dot = gx_team_sum(d * sc, team);
+        gbl += d;
+        if (q >= 0 && tl <= K) atomicAdd(C + q * ls + tl, tl < K ? rn * d : -rn * rn * dot);
+    }
+    for (int o = team; o < 64; o <<= 1) gbl += __shfl_xor(gbl, o, 64);
+    if ((threadIdx.x & 63) < team && tl < K) atomicAdd(&sb[tl], gbl);
     __syncthreads();
     if (threadIdx.x < K) part_b[(long)blockIdx.x * K + threadIdx.x] = sb[threadIdx.x];
 }
 
-// Dense finish, one wave per pixel: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of
-// gWc[k] += C[q][k] Z[q].  Lane l owns columns j*64 + l.
-template <int KP>
+// Dense finish: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of gWc[k] += C[q][k] Z[q].
+// One wave per group of 4 pixels (8 row loads in flight per lane); lane l owns the float4 columns
+// (i*64 + l)*4.  POOL: the group is the 2x2 block under coarse pixel `g` and its sum is written to
+// Gpool[g] — the first sum-pooling step of the pyramid backward, while the rows are in registers.
+template <int KP, bool POOL>
 __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* __restrict__ C, const float* __restrict__ Z,
-                                                                   long npix, int D, const float* __restrict__ Wc, int K,
-                                                                   float* __restrict__ G, float* __restrict__ part_w) {
+                                                                   long npix, int rc, int D, const float* __restrict__ Wc,
+                                                                   int K, float* __restrict__ G, float* __restrict__ Gpool,
+                                                                   float* __restrict__ part_w) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D]
     for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nj = D >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nv = D >> 8;
     const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wid;
     const long nwave = (long)gridDim.x * (blockDim.x >> 6);
-    const int ls = lr_stride(K);
-    float gw[KP][8];
+    const int ls = lr_stride(K), rf = 2 * rc;
+    const long ngroups = POOL ? npix / 4 : (npix + 3) / 4;
+    f32x4 gw[KP][2];
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
+    for (int k = 0; k < KP; ++k) gw[k][0] = gw[k][1] = zero4();
+    for (long g = wave0; g < ngroups; g += nwave) {
+        long pq[4];
+        if (POOL) {
+            const long per = (long)rc * rc;
+            const long b = g / per, rem = g - b * per;
+            const long cy = rem / rc, cx = rem - cy * rc;
+            pq[0] = (b * rf + 2 * cy) * rf + 2 * cx;
+            pq[1] = pq[0] + 1; pq[2] = pq[0] + rf; pq[3] = pq[2] + 1;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gw[k][j] = 0.f;
-    for (long q = wave0; q < npix; q += nwave) {
-        float c[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) c[k] = k < K ? C[q * ls + k] : 0.f;
-        const float cz = C[q * ls + K];
-        bool any = cz != 0.f;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) any = any || (c[k] != 0.f);
-        float* dst = G + q * D;
-        if (!any) {                                   // pixel never sampled: G row is zero, nothing for gWc
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nj) dst[j * 64 + lane] = 0.f;
-            continue;
+            for (int j = 0; j < 4; ++j) pq[j] = g * 4 + j;
         }
-        const float* zq = Z + q * D;
+        float cv[4];
+        f32x4 z[4][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < nj) {
-                const int col = j * 64 + lane;
-                const float z = zq[col];
-                float a = cz * z;
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = pq[j] < npix;
+            cv[j] = (ok && lane < ls) ? C[pq[j] * ls + lane] : 0.f;
 #pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    a = fmaf(c[k], wsm[k * D + col], a);
-                    gw[k][j] = fmaf(c[k], z, gw[k][j]);
-                }
-                dst[col] = a;
+            for (int i = 0; i < 2; ++i)
+                z[j][i] = (ok && i < nv) ? *reinterpret_cast<const f32x4*>(Z + pq[j] * D + (i * 64 + lane) * 4) : zero4();
+        }
+        f32x4 pool[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (pq[j] >= npix) continue;
+            float* dst = G + pq[j] * D;
+            if (__ballot(cv[j] != 0.f) == 0ull) {      // pixel never sampled: zero row, nothing for gWc
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (i < nv) *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = zero4();
+                continue;
             }
+            float c[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) c[k] = __shfl(cv[j], k, 64);
+            const float cz = __shfl(cv[j], K, 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nv) {
+                    f32x4 a = cz * z[j][i];
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
+                        a += c[k] * w;
+                        gw[k][i] += c[k] * z[j][i];
+                    }
+                    *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = a;
+                    pool[i] += a;
+                }
+        }
+        if (POOL) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nv) *reinterpret_cast<f32x4*>(Gpool + g * D + (i * 64 + lane) * 4) = pool[i];
+        }
     }
     __syncthreads();
-    float* red = wsm;
+    float* red = wsm;                                  // [4 waves][D]  (KP >= 4)
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (k < K) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nj) red[wid * D + j * 64 + lane] = gw[k][j];
+            for (int i = 0; i < 2; ++i)
+                if (i < nv) *reinterpret_cast<f32x4*>(red + wid * D + (i * 64 + lane) * 4) = gw[k][i];
             __syncthreads();
             for (int col = threadIdx.x; col < D; col += blockDim.x)
                 part_w[((long)blockIdx.x * K + k) * D + col] =
                     (red[col] + red[D + col]) + (red[2 * D + col] + red[3 * D + col]);
             __syncthreads();
+        }
+    }
+}
+
+// Finest pyramid level of the low-rank path: fine += upsample2(coarse) AND the score / rnorm tables
+// of the finished rows in the same pass.  One wave per coarse pixel = 2x2 block of fine pixels:
+// one coarse row + four fine rows in flight per lane.
+template <int KP>
+__global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* __restrict__ coarse, float* __restrict__ fine,
+                                                                   long ncoarse, int rc, int D,
+                                                                   const float* __restrict__ Wc,
+                                                                   const float* __restrict__ bias, int K,
+                                                                   float* __restrict__ rn_table,
+                                                                   float* __restrict__ sc_table) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] (rows >= K are zero)
+    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nv = D >> 8, rf = 2 * rc;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    const int myk = ps_lane_k<KP>(lane);
+    const bool owner = ps_lane_owner<KP>(lane) && myk < K;
+    const float myb = (owner && bias) ? bias[myk] : 0.f;
+    const long per = (long)rc * rc;
+    for (long g = wave0; g < ncoarse; g += nwave) {
+        const long b = g / per, rem = g - b * per;
+        const long cy = rem / rc, cx = rem - cy * rc;
+        long pq[4];
+        pq[0] = (b * rf + 2 * cy) * rf + 2 * cx;
+        pq[1] = pq[0] + 1; pq[2] = pq[0] + rf; pq[3] = pq[2] + 1;
+        f32x4 c[2], z[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            c[i] = i < nv ? *reinterpret_cast<const f32x4*>(coarse + g * D + (i * 64 + lane) * 4) : zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                z[j][i] = i < nv ? *reinterpret_cast<const f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) : zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float p[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) p[k] = 0.f;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nv) {
+                    const f32x4 v = z[j][i] + c[i];
+                    *reinterpret_cast<f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) = v;
+                    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
+                        p[k] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                    }
+                }
+            ss = gx_wave_sum(ss);
+            const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            const float sc = ps_reduce<KP>(p, lane);
+            if (owner) sc_table[pq[j] * K + myk] = fmaf(sc, rn, myb);
+            if (lane == 0) rn_table[pq[j]] = rn;
         }
     }
 }
@@ -1581,7 +1675,7 @@ int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnor
         return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < (size_t)1024 * K * sizeof(float)) return GX_ERR_WORKSPACE;
     const long rows = (long)B * rows_per_img;
-    long nb = (rows + 255) / 256;
+    long nb = (rows + 15) / 16;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(gx::proto_bwd_lowrank_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores, rnorm,
                        bias, HW, K, picks, maps, rows_per_img, rows, C, workspace);
@@ -1591,26 +1685,51 @@ int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnor
     return GX_OK;
 }
 
-// G (npix, D) = C[:, :K] Wc + C[:, K] .* Z ; gWc = beta*gWc + C[:, :K]^T Z.   D % 64 == 0, D <= 512.
+// G (npix, D) = C[:, :K] Wc + C[:, K] .* Z ; gWc = beta*gWc + C[:, :K]^T Z.   D in {256, 512}.
+// Gpool != NULL: the pixels are B images of (2rc x 2rc) and Gpool (B*rc*rc, D) receives the 2x2
+// sum-pooled G (what gx_sumpool2 would compute from G).  rc is ignored when Gpool == NULL.
 // workspace >= gx_proto_small_workspace_bytes(K, D).
-int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int D, const float* Wc, int K, float* G,
-                            float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream) {
-    if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > gx::LR_MAXK || (D & 63) || D > 512)
+int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, int D, const float* Wc, int K, float* G,
+                            float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
+                            void* stream) {
+    if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > gx::LR_MAXK || (D & 255) || D > 512)
         return GX_ERR_BAD_ARG;
+    if (Gpool && (rc <= 0 || npix % (4L * rc * rc) != 0)) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_proto_small_workspace_bytes(K, D)) return GX_ERR_WORKSPACE;
-    long nb = (npix + 3) / 4;
+    long nb = (npix + 15) / 16;
     if (nb > GX_PS_BLOCKS) nb = GX_PS_BLOCKS;
     const int kp = K <= 8 ? 8 : 16;
-    size_t lds = (size_t)kp * D * sizeof(float);
-    if (lds < (size_t)4 * D * sizeof(float)) lds = (size_t)4 * D * sizeof(float);
-    if (kp == 8)
-        hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, C, Z,
-                           npix, D, Wc, K, G, workspace);
-    else
-        hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, C,
-                           Z, npix, D, Wc, K, G, workspace);
+    const size_t lds = (size_t)kp * D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define GX_FINISH(KP, POOL)                                                                                         \
+    hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<KP, POOL>), dim3((int)nb), dim3(256), lds, st, C, Z, npix, rc, \
+                       D, Wc, K, G, Gpool, workspace)
+    if (kp == 8) { if (Gpool) GX_FINISH(8, true); else GX_FINISH(8, false); }
+    else         { if (Gpool) GX_FINISH(16, true); else GX_FINISH(16, false); }
+#undef GX_FINISH
     GX_CHECK_LAUNCH();
-    gx::launch_partial_reduce(workspace, (int)nb, K * D, 1.f, beta, gWc, (hipStream_t)stream);
+    gx::launch_partial_reduce(workspace, (int)nb, K * D, 1.f, beta, gWc, st);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// fine (B, 2rc, 2rc, D) += upsample2(coarse (B, rc, rc, D)); rn_table (B*4rc^2), sc_table (B*4rc^2, K)
+// = what gx_proto_fwd_lowrank(picks = NULL) gives on the finished table.  D in {256, 512}, K <= 16.
+int gx_upsample2_add_scores(const float* coarse, float* fine, int B, int rc, int D, const float* Wc, const float* bias,
+                            int K, float* rn_table, float* sc_table, void* stream) {
+    if (!coarse || !fine || !Wc || !rn_table || !sc_table || B <= 0 || rc <= 0) return GX_ERR_BAD_ARG;
+    if (K < 1 || K > gx::LR_MAXK || (D & 255) || D > 512) return GX_ERR_BAD_ARG;
+    const long ncoarse = (long)B * rc * rc;
+    long nb = (ncoarse + 3) / 4;
+    if (nb > 4096) nb = 4096;
+    const int kp = K <= 8 ? 8 : 16;
+    const size_t lds = (size_t)kp * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, coarse,
+                           fine, ncoarse, rc, D, Wc, bias, K, rn_table, sc_table);
+    else
+        hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, coarse,
+                           fine, ncoarse, rc, D, Wc, bias, K, rn_table, sc_table);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -238,18 +238,37 @@ def proto_bwd_lowrank_(ds, scores, rnorm, bias, picks, maps, coeffs, hw, gb, bet
                "gx_proto_bwd_lowrank")
 
 
-def proto_lowrank_finish(coeffs, z, wc, gwc, beta):
-    """G (B,H,W,D) rebuilt from the coefficient grid; gwc = beta*gwc + C^T Z."""
+def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False):
+    """G (B,H,W,D) rebuilt from the coefficient grid; gwc = beta*gwc + C^T Z.
+    want_pool: also return sumpool2(G) (B,H/2,W/2,D), produced in the same pass."""
     _chk(coeffs, z, wc, gwc)
     b, h, w, d = z.shape
     k = wc.shape[0]
     L = lib()
     g = torch.empty_like(z)
+    pool = None
+    if want_pool:
+        if h != w or h % 2:
+            raise RuntimeError("proto_lowrank_finish: pooled output needs a square, even-sized table")
+        pool = torch.empty(b, h // 2, w // 2, d, dtype=torch.float32, device=z.device)
     wsb = L.gx_proto_small_workspace_bytes(k, d)
     ws = workspace("protosmall", wsb, z.device)
-    _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), b * h * w, d, _p(wc), k, _p(g), _p(gwc), beta, _p(ws), wsb,
-                                         _stream()), "gx_proto_lowrank_finish")
-    return g
+    _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), b * h * w, h // 2, d, _p(wc), k, _p(g), _p(pool), _p(gwc),
+                                         beta, _p(ws), wsb, _stream()), "gx_proto_lowrank_finish")
+    return (g, pool) if want_pool else g
+
+
+def upsample2_add_scores_(coarse, fine, wc, bias):
+    """fine (B,2r,2r,D) += upsample2(coarse (B,r,r,D)) and, in the same pass, the prototype score
+    table (B*4r^2, K) and 1/||row|| table (B*4r^2) of the finished rows."""
+    _chk(coarse, fine, wc, bias)
+    b, r, _, d = coarse.shape
+    k = wc.shape[0]
+    rn = torch.empty(b * 4 * r * r, dtype=torch.float32, device=fine.device)
+    sc = torch.empty(b * 4 * r * r, k, dtype=torch.float32, device=fine.device)
+    _lib.check(lib().gx_upsample2_add_scores(_p(coarse), _p(fine), b, r, d, _p(wc), _p(bias), k, _p(rn), _p(sc),
+                                             _stream()), "gx_upsample2_add_scores")
+    return rn, sc
 
 
 # ------------------------------------------------------------------------------------- generator pieces

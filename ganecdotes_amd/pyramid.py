@@ -32,10 +32,13 @@ class Pyramid:
         if any(b != 2 * a for a, b in zip(self.res, self.res[1:])) or self.res[-1] != self.size:
             raise RuntimeError("pyramid projection needs taps at successive powers of two")
 
-    def project(self, wp):
-        """wp (D, hlen) -> Z (B, H, W, D): the projection of every pixel's descriptor."""
+    def project(self, wp, score_head=None):
+        """wp (D, hlen) -> Z (B, H, W, D): the projection of every pixel's descriptor.
+        score_head=(Wc, bias) with K <= 16: the last upsample-add also emits the prototype score
+        table of every pixel; returns (Z, (rn_table, score_table))."""
         d = wp.shape[0]
         prev = None
+        tables = None
         for r, taps in zip(self.res, self.levels):
             p = torch.empty(self.B * r * r, d, dtype=torch.float32, device=wp.device)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
@@ -50,12 +53,20 @@ class Pyramid:
                     ops.gemm(t[:, :cu], wp[:, off:off + cu], False, True, out=p, beta=0.0 if i == 0 else 1.0)
             p = p.reshape(self.B, r, r, d)
             if prev is not None:
-                ops.upsample2_add_(prev, p)
+                if score_head is not None and r == self.res[-1]:
+                    tables = ops.upsample2_add_scores_(prev, p, *score_head)
+                else:
+                    ops.upsample2_add_(prev, p)
             prev = p
+        if score_head is not None:
+            if tables is None:                       # single-level pyramid: no upsample pass to ride on
+                tables = ops.proto_fwd_lowrank(prev, None, None, *score_head)
+            return prev, tables
         return prev
 
-    def backward(self, g, gwp, accumulate):
-        """g (B, H, W, D) = d loss / d Z -> gwp (D, hlen) (+)= sum over taps of G_level^T tap."""
+    def backward(self, g, gwp, accumulate, g_pooled=None):
+        """g (B, H, W, D) = d loss / d Z -> gwp (D, hlen) (+)= sum over taps of G_level^T tap.
+        g_pooled: sumpool2(g) if the caller already has it."""
         first = not accumulate
         touched = set()
         for r, taps in zip(reversed(self.res), reversed(self.levels)):
@@ -70,7 +81,7 @@ class Pyramid:
                          split_k=split)
                 touched.add((off, cu))
             if r != self.res[0]:
-                g = ops.sumpool2(g)
+                g = g_pooled if (g_pooled is not None and r == self.res[-1]) else ops.sumpool2(g)
         if first:      # columns of hlen not covered by any tap cannot exist (sum C >= hlen); nothing to zero
             pass
         return gwp

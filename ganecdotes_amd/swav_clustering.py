@@ -211,11 +211,13 @@ class SwAVClustering(ViewMixin):
         if mode == 'pyramid':
             with self._timed("pyramid_fwd"):
                 pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
-                Zt = [p.project(Wp) for p in pyr]                              # (B, H, W, D) per view
+                if lowrank:      # the finest upsample-add also emits every pixel's scores (rn table, score table)
+                    Zt, Tab = zip(*[p.project(Wp, score_head=(Wc, bc)) for p in pyr])
+                else:
+                    Zt = [p.project(Wp) for p in pyr]                          # (B, H, W, D) per view
             if lowrank:
                 Ct = [ops.lowrank_coeffs(B, hw * hw, K, dev) for _ in Zt]      # (B*HW, K+1 padded) coefficient grids
-                with self._timed("score_table"):                               # every pixel's scores, once per view
-                    Tab = [ops.proto_fwd_lowrank(z, None, None, Wc, bc) for z in Zt]
+                Gt = [None, None]
             else:
                 Gt = [torch.zeros_like(z) for z in Zt]
         # 'image' source pdf: the marginals depend on the view (and image), not on the patch
@@ -317,12 +319,16 @@ class SwAVClustering(ViewMixin):
                 del X, Zh, Rn, Sc, dS
             del keep, Sc_all, skb
         if mode == 'pyramid':
+            Gp = [None, None]
             if lowrank:
                 with self._timed("lowrank_finish"):
-                    Gt = [ops.proto_lowrank_finish(Ct[v], Zt[v], Wc, gWc, 0.0 if v == 0 else 1.0) for v in range(2)]
+                    pool = len(pyr[0].res) > 1
+                    for v in range(2):
+                        out = ops.proto_lowrank_finish(Ct[v], Zt[v], Wc, gWc, 0.0 if v == 0 else 1.0, want_pool=pool)
+                        Gt[v], Gp[v] = out if pool else (out, None)
             with self._timed("pyramid_bwd"):
                 for v in range(2):
-                    pyr[v].backward(Gt[v], gWp, accumulate=(v > 0))
+                    pyr[v].backward(Gt[v], gWp, accumulate=(v > 0), g_pooled=Gp[v])
             del Zt, Gt
         if self.world > 1:
             sharded.allreduce_flat(list(self._grads) + [loss], self.dist_group)

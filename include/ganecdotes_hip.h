@@ -136,6 +136,7 @@ int gx_proto_bwd_small(const float* dS, const float* zhat, const float* rnorm, i
  *                          the same 65 536 pixels: swav_clustering.py:160-171 gathers 2 KB rows 5 times)
  * gx_proto_bwd_lowrank     C[q][0..K] += coefficients (36-B atomics per row instead of 2 KB), gb
  * gx_proto_lowrank_finish  once per view: G = C[:, :K] Wc + C[:, K] .* Z ; gWc (+)= C[:, :K]^T Z
+ *                          (+ the first 2x2 sum-pooling of G for the pyramid backward)
  * C is [B*HW][gx_lowrank_stride(K)] floats, zeroed by the caller each step. */
 int gx_lowrank_stride(int K);
 int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
@@ -145,8 +146,13 @@ int gx_gather_scores(const float* table, const float* rn_table, const float* bia
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream);
-int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int D, const float* Wc, int K, float* G,
-                            float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream);
+int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, int D, const float* Wc, int K, float* G,
+                            float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
+                            void* stream);   /* Gpool != NULL: also the 2x2 sum-pooled G (B*rc*rc, D) */
+/* finest pyramid level + score table in one pass: fine += upsample2(coarse); rn_table, sc_table as
+ * gx_proto_fwd_lowrank(picks = NULL) on the result */
+int gx_upsample2_add_scores(const float* coarse, float* fine, int B, int rc, int D, const float* Wc, const float* bias,
+                            int K, float* rn_table, float* sc_table, void* stream);
 
 /* ---- projection / prototype helpers ---------------------------------------------------------
  * gx_row_l2_normalize   F.normalize(p=2, dim=1) in place, rnorm out     swav_clustering.py:174
