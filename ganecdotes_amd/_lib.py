@@ -21,6 +21,8 @@ c_sz = ctypes.c_size_t
 # name -> (restype, argtypes); must list every symbol of include/ganecdotes_hip.h
 SIGNATURES = {
     "gx_version": (ctypes.c_char_p, []),
+    "gx_set_gemm_mode": (c_i, [c_i]),
+    "gx_get_gemm_mode": (c_i, []),
     "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "gx_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p,
                           c_sz, c_p]),

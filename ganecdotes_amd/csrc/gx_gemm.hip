@@ -7,7 +7,12 @@
 //   S6 dz_hat          = dS Wc                   (NN)
 //   S6 dWp             = dz^T X                  (TN, split-K)
 // Reference op chain: hfc_with_swav/swav_clustering.py:171-175 and autograd of it (:459).
-#include "gx_mfma.h"
+#include "gx_mfma_x6.h"
+#include <cstdlib>
+
+#ifndef GX_DEFAULT_GEMM_MODE
+#define GX_DEFAULT_GEMM_MODE 0
+#endif
 
 namespace gx {
 
@@ -25,6 +30,33 @@ struct GemmArgs {
     // K1 is a multiple of BK (K1 == K when unused).  Non-transposed A only.
     const float* A2; long lda2; int K1;
 };
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
+                                              int lane) {
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
+    const long ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + acc_col(wc, nt, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + acc_row(wr, mt, r, lane);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mt][nt][r];
+                    if (!to_slab) {
+                        v *= g.alpha;
+                        if (g.row_scale) v *= g.row_scale[row];
+                        if (g.col_bias) v += g.col_bias[col];
+                        if (g.beta != 0.f) v += g.beta * out[(long)row * ldo + col];
+                    }
+                    out[(long)row * ldo + col] = v;
+                }
+            }
+        }
+}
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
 // VEC: every operand is 16-B aligned with ld % 4 == 0 and (MC operands) M/N % 4 == 0, K % 4 == 0.
@@ -74,29 +106,57 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    const bool to_slab = g.slab != nullptr;
-    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
-    const long ldo = to_slab ? g.N : g.ldc;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = n0 + acc_col(wc, nt, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + acc_row(wr, mt, r, lane);
-                if (row < g.M && col < g.N) {
-                    float v = acc[mt][nt][r];
-                    if (!to_slab) {
-                        v *= g.alpha;
-                        if (g.row_scale) v *= g.row_scale[row];
-                        if (g.col_bias) v += g.col_bias[col];
-                        if (g.beta != 0.f) v += g.beta * out[(long)row * ldo + col];
-                    }
-                    out[(long)row * ldo + col] = v;
-                }
-            }
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane);
+}
+
+// The same contraction on the bf16 matrix cores (gx_mfma_x6.h): 128 x 128 x 16 tiles, every operand
+// element split into three bf16 on its way into LDS, six MFMA products per fp32 product.
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
+    constexpr bool A_KC = !TA, B_KC = TB;
+    __shared__ __attribute__((aligned(16))) char lds[4 * X_TILE_BYTES];   // A0 B0 A1 B1
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    f32x4 ra[2], rb[2];
+
+    auto load_a = [&](int k0) {
+        const bool second = !TA && k0 >= g.K1;
+        x6_load_tile<A_KC, VEC>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M, second ? k0 - g.K1 : k0,
+                                second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, tid);
+    };
+    const int nkt = (kend - kbeg + XK - 1) / XK;
+    if (nkt > 0) {
+        load_a(kbeg);
+        x6_load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
+        x6_store_tile<A_KC>(lds, ra, tid);
+        x6_store_tile<B_KC>(lds + X_TILE_BYTES, rb, tid);
+    }
+    __syncthreads();
+    for (int t = 0; t < nkt; ++t) {
+        char* As = lds + (t & 1) * 2 * X_TILE_BYTES;
+        char* Bs = As + X_TILE_BYTES;
+        const bool more = (t + 1 < nkt);
+        if (more) {   // next tile's global loads fly under this tile's MFMAs (a deeper, two-tile prefetch was slower)
+            load_a(kbeg + (t + 1) * XK);
+            x6_load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * XK, kend, rb, tid);
         }
+        x6_mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
+        if (more) {
+            char* An = lds + ((t + 1) & 1) * 2 * X_TILE_BYTES;
+            x6_store_tile<A_KC>(An, ra, tid);
+            x6_store_tile<B_KC>(An + X_TILE_BYTES, rb, tid);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane);
 }
 
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
@@ -116,6 +176,16 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int sp
         if (beta != 0.f) v += beta * *c;
         *c = v;
     }
+}
+
+// 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); 1: bf16x6 on the bf16 MFMA.
+static int g_gemm_mode = -1;
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("GX_GEMM_MODE");
+        g_gemm_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : GX_DEFAULT_GEMM_MODE;
+    }
+    return g_gemm_mode;
 }
 
 static int launch_gemm(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
@@ -143,9 +213,12 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         g.slab = workspace;
     }
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
+    const bool x6 = gemm_mode() == 1;
 #define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
     do {                                                                                                       \
-        if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g);      \
+        if (x6 && g.vec_ok) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, true>), grid, block, 0, stream, g);  \
+        else if (x6) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, false>), grid, block, 0, stream, g);        \
+        else if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, g);              \
     } while (0)
     if (!transA && transB) GX_LAUNCH_GEMM(false, true);
@@ -168,6 +241,16 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 }  // namespace gx
 
 extern "C" {
+
+// Contraction engine of gx_gemm_f32 / gx_gemm_f32_cat: 0 = exact-fp32 MFMA, 1 = bf16x6 (fp32-level
+// error on the 16x faster bf16 matrix cores).  Returns the previous mode.  Env GX_GEMM_MODE=0|1 sets
+// the initial value.
+int gx_set_gemm_mode(int mode) {
+    const int prev = gx::gemm_mode();
+    if (mode == 0 || mode == 1) gx::g_gemm_mode = mode;
+    return prev;
+}
+int gx_get_gemm_mode(void) { return gx::gemm_mode(); }
 
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k) {
     return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;

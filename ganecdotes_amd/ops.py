@@ -72,6 +72,15 @@ def workspace(tag, nbytes, device):
 
 
 # ------------------------------------------------------------------------------------- GEMM
+def set_gemm_mode(mode):
+    """0: exact-fp32 MFMA; 1: bf16x6 on the bf16 matrix cores.  Returns the previous mode."""
+    return lib().gx_set_gemm_mode(int(mode))
+
+
+def get_gemm_mode():
+    return lib().gx_get_gemm_mode()
+
+
 def _chk2d(*ts):
     """2-D fp32 HIP tensors with unit inner stride (row-strided views such as W[:, a:b] are fine)."""
     for t in ts:

@@ -39,6 +39,13 @@ const char* gx_version(void);
  * 1: [K][M].  transB=0: B is [K][N] (ldb), 1: [N][K].  split_k>1 needs a workspace of
  * gx_gemm_f32_workspace_bytes() and sums the K-slices in a fixed order.
  * Replaces: F.linear / autograd matmuls of swav_clustering.py:171-175, :459. */
+/* Contraction engine behind gx_gemm_f32 / gx_gemm_f32_cat (and the modulated conv):
+ *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32; bitwise an fmaf chain, 157 TFLOP/s peak)
+ *   1  "bf16x6": every fp32 operand element split into three bf16 (exactly), six bf16 MFMA products
+ *      per fp32 product, fp32 accumulate — fp32-level error at 1/6 of the 2.5 PFLOP/s bf16 peak.
+ * gx_set_gemm_mode returns the previous mode; env GX_GEMM_MODE=0|1 sets the initial one. */
+int gx_set_gemm_mode(int mode);
+int gx_get_gemm_mode(void);
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k);
 int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                 float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,

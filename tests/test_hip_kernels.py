@@ -81,6 +81,73 @@ def test_gemm_big_ffhq_shape(ops):
     assert rel_err(out, x.double() @ w.double().t()) < 3e-6
 
 
+# ------------------------------------------------------------------------------------- GEMM on the bf16 cores
+@pytest.fixture
+def x6(ops):
+    prev = ops.set_gemm_mode(1)
+    yield
+    ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (200, 72, 100), (1, 512, 512), (333, 129, 37), (64, 8, 516),
+                                   (260, 260, 16), (129, 4, 8)])
+def test_gemm_x6_layouts(ops, x6, ta, tb, m, n, k):
+    """bf16x6 engine (three-way bf16 split, six MFMA products): every layout / ragged edge"""
+    torch.manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(k, m) if ta else torch.randn(m, k)
+    b = torch.randn(n, k) if tb else torch.randn(k, n)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    out = ops.gemm(dev(a), dev(b), ta, tb)
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_gemm_x6_accuracy(ops):
+    """fp32-level error: against fp64 the bf16x6 engine is no worse than the exact-fp32 MFMA engine
+    on the projection shape (K = 5376) and on badly scaled operands; A = I reproduces B bit for bit
+    (h + m + l == x exactly); split-K, epilogue and the concatenated-A form work on it."""
+    torch.manual_seed(21)
+    x = torch.randn(1024, 5376)
+    w = torch.randn(512, 5376) / 73.0
+    ref = x.double() @ w.double().t()
+    prev = ops.set_gemm_mode(0)
+    try:
+        e32 = rel_err(ops.gemm(dev(x), dev(w), False, True), ref)
+        ops.set_gemm_mode(1)
+        ex6 = rel_err(ops.gemm(dev(x), dev(w), False, True), ref)
+        assert ex6 < 1.5 * e32 + 5e-8, (ex6, e32)
+        # 12 orders of magnitude of dynamic range inside one reduction
+        scale = torch.exp(torch.linspace(-14, 14, 5376))
+        xs, ws = x * scale, w / scale
+        ex6s = rel_err(ops.gemm(dev(xs), dev(ws), False, True), ref)
+        ops.set_gemm_mode(0)
+        e32s = rel_err(ops.gemm(dev(xs), dev(ws), False, True), ref)
+        assert ex6s < 1.5 * e32s + 5e-8, (ex6s, e32s)
+        ops.set_gemm_mode(1)
+        n = 160
+        b = torch.randn(n, n)
+        assert torch.equal(ops.gemm(dev(torch.eye(n)), dev(b), False, False).cpu(), b)
+        assert torch.equal(ops.gemm(dev(torch.eye(n)), dev(b), False, True).cpu(), b.t().contiguous())
+        assert torch.equal(ops.gemm(dev(torch.eye(n)), dev(b), True, False).cpu(), b)
+        # epilogue + split-K
+        m, nn, k = 300, 200, 5000
+        a, bb = torch.randn(k, m), torch.randn(k, nn)
+        rs, cb, c0 = torch.rand(m) + 0.5, torch.randn(nn), torch.randn(m, nn)
+        want = 0.7 * rs[:, None].double() * (a.t().double() @ bb.double()) + cb.double() + 0.3 * c0.double()
+        for sk in (1, 4, 7):
+            out = dev(c0.clone())
+            ops.gemm(dev(a), dev(bb), True, False, out=out, alpha=0.7, beta=0.3, row_scale=dev(rs), col_bias=dev(cb),
+                     split_k=sk)
+            assert rel_err(out, want) < 3e-6
+        # [A1 | A2] concatenated along K
+        a1, a2, wc = torch.randn(500, 128), torch.randn(500, 96), torch.randn(64, 224)
+        out = torch.empty(500, 64, device="cuda")
+        ops.gemm_cat(dev(a1), dev(a2), dev(wc), out)
+        assert rel_err(out, torch.cat([a1, a2], 1).double() @ wc.double().t()) < 2e-6
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 # ------------------------------------------------------------------------------------- Sinkhorn
 def _sk_cases():
     d = load_golden("gv7_sinkhorn")
