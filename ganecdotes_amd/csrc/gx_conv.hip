@@ -14,7 +14,9 @@
 // GEMMs (one per output parity class, 4+2+2+1 taps) writing the (2H+1)^2 pre-blur image,
 // followed by one fused FIR-blur + demod + noise + bias + act pass (upfirdn2d mode 1,
 // upfirdn2d_kernel.cu:114-215 semantics).
-#include "gx_mfma.h"
+#include "gx_mfma_x6.h"
+
+extern "C" int gx_get_gemm_mode(void);      // gx_gemm.hip: 0 = exact-fp32 MFMA, 1 = bf16x6
 
 namespace gx {
 
@@ -125,10 +127,92 @@ __device__ __forceinline__ void conv_mainloop(const ConvArgs& g, const ConvSub& 
     }
 }
 
+// The same main loop on the bf16 matrix cores (gx_mfma_x6.h): 16-channel chunks, the thread stages
+// rows (tid >> 2) + 64 i (i < 2) of the pixel tile and of the weight tile, channels 4 (tid & 3) .. +3;
+// the modulated activation and the weight are split into three bf16 planes on their way into LDS.
+template <bool VEC, int NT>
+__device__ __forceinline__ void conv_mainloop_x6(const ConvArgs& g, const ConvSub& sb, char* lds, f32x16 (&acc)[2][2],
+                                                 const long (&pix_off)[4], const int (&soff)[4],
+                                                 const unsigned (&tapmask)[4], int n0, int cc0, int ncc, int tid,
+                                                 int wr, int wc, int lane) {
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(g.in, VEC ? g.in_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(g.style ? g.style : g.in, (VEC && g.style) ? g.style_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
+    const int kq = (tid & 3) * 4;
+    long toff[NT], wb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        toff[t] = ((long)sb.dy[t] * g.IW + sb.dx[t]) * g.Cin;
+        wb[t] = (long)sb.tw[t] * g.Cout * g.Cin;
+    }
+    unsigned rowok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rowok[i] = (n0 + (tid >> 2) + 64 * i) < g.Cout;
+    f32x4 ra[2], rw[2], st[2];
+
+    auto load_style = [&](int cc) {
+        const int ci = cc * XK + kq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!g.style) { st[i] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
+            if (VEC) st[i] = buf_load4(rs_st, (unsigned)((soff[i] + ci) * 4) | oob_mask(ci < g.Cin));
+            else st[i] = ci < g.Cin ? load4(g.style + soff[i] + ci, g.Cin - ci, false) : zero4();
+        }
+    };
+    auto load_ab = [&](int cc, int tap, long to, long wbt) {
+        const int ci = cc * XK + kq;
+        const bool cok = ci < g.Cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+            if (VEC) ra[i] = buf_load4(rs_in, (unsigned)((pix_off[i] + to + ci) * 4) | oob_mask(ok));
+            else ra[i] = ok ? load4(g.in + pix_off[i] + to + ci, g.Cin - ci, false) : zero4();
+            const long wo = wbt + (long)(n0 + (tid >> 2) + 64 * i) * g.Cin + ci;
+            const bool wok = rowok[i] && cok;
+            if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)(wo * 4) | oob_mask(wok));
+            else rw[i] = wok ? load4(g.wt + wo, g.Cin - ci, false) : zero4();
+        }
+    };
+    auto stage = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] *= st[i];
+        x6_store_tile<true>(dst, ra, tid);
+        x6_store_tile<true>(dst + X_TILE_BYTES, rw, tid);
+    };
+
+    if (ncc > 0) {
+        load_style(cc0);
+        load_ab(cc0, 0, toff[0], wb[0]);
+        stage(lds);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int cc = cc0; cc < cc0 + ncc; ++cc) {
+        const bool last_cc = (cc + 1 == cc0 + ncc);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            char* As = lds + buf * 2 * X_TILE_BYTES;
+            const bool wrap = (tap + 1 == NT);
+            const bool more = !(wrap && last_cc);
+            if (more) load_ab(wrap ? cc + 1 : cc, wrap ? 0 : tap + 1, toff[wrap ? 0 : tap + 1], wb[wrap ? 0 : tap + 1]);
+            x6_mfma_ktile<true, true>(As, As + X_TILE_BYTES, acc, wr, wc, lane);
+            if (more) {
+                if (wrap) load_style(cc + 1);
+                stage(lds + (buf ^ 1) * 2 * X_TILE_BYTES);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+}
+
 // VEC: in / wt / style 16-B aligned and Cin % 4 == 0 (every real layer); otherwise the scalar path.
-template <bool VEC>
+// X6: contraction on the bf16 matrix cores (three-way split, gx_mfma_x6.h) instead of the fp32 MFMA.
+template <bool VEC, bool X6>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+    constexpr int CK = X6 ? XK : BK;                              // channels per k-tile
+    constexpr int NR = X6 ? 2 : 4;                                // pixel rows a thread stages
+    __shared__ __attribute__((aligned(16))) char lds_raw[X6 ? 4 * X_TILE_BYTES : 4 * TILE_FLOATS * 4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     // sub-problem from the block id range; XCD-aware remap INSIDE the sub-problem so that every
     // XCD gets an equal share of each class (classes differ 4x in work per tile)
@@ -151,9 +235,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     unsigned tapmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned m = (unsigned)m0 + (tid >> 3) + 32 * i;
+        const unsigned m = (unsigned)m0 + (X6 ? (tid >> 2) + 64 * i : (tid >> 3) + 32 * i);
         pix_off[i] = 0; soff[i] = 0; tapmask[i] = 0;
-        if (m < Mtot) {
+        if (i < NR && m < Mtot) {
             const unsigned b = m / ohw, rem = m - b * ohw;
             const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
             pix_off[i] = (((long)b * g.IH + oy) * g.IW + ox) * g.Cin;
@@ -165,19 +249,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
         }
     }
     // split-K over channel chunks
-    const int ncc_all = (g.Cin + BK - 1) / BK;
+    const int ncc_all = (g.Cin + CK - 1) / CK;
     const int cps = (ncc_all + g.splits - 1) / g.splits;
     const int cc0 = blockIdx.y * cps;
     const int ncc = max(0, min(ncc_all, cc0 + cps) - cc0);
 
     f32x16 acc[2][2];
     zero_acc(acc);
+#define GX_CONV_LOOP(NT_)                                                                                       \
+    do {                                                                                                      \
+        if (X6) conv_mainloop_x6<VEC, NT_>(g, sb, lds_raw, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); \
+        else conv_mainloop<VEC, NT_>(g, sb, reinterpret_cast<float*>(lds_raw), acc, pix_off, soff, tapmask, n0, cc0,  \
+                                     ncc, tid, wr, wc, lane);                                                 \
+    } while (0)
     switch (ntaps) {
-        case 9: conv_mainloop<VEC, 9>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
-        case 4: conv_mainloop<VEC, 4>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
-        case 2: conv_mainloop<VEC, 2>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
-        default: conv_mainloop<VEC, 1>(g, sb, lds, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); break;
+        case 9: GX_CONV_LOOP(9); break;
+        case 4: GX_CONV_LOOP(4); break;
+        case 2: GX_CONV_LOOP(2); break;
+        default: GX_CONV_LOOP(1); break;
     }
+#undef GX_CONV_LOOP
 
     // ---- epilogue.  A lane's 16 rows of an MFMA tile are m = base + (r&3) + 8*(r>>2): decode the
     // base once, then walk the rows with carries instead of 64 integer divisions per lane.
@@ -466,7 +557,7 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         g.sub[i].tile_base = base;
         g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, BM);
         base += g.sub[i].tiles_m * g.tiles_n;
-        const int kt = gx_cdiv(g.Cin, BK);                     // split-K granularity = channel chunks
+        const int kt = gx_cdiv(g.Cin, BK);                     // split-K granularity = channel chunks (>= this many in either engine)
         min_kt = kt < min_kt ? kt : min_kt;
         if ((long)g.B * g.sub[i].OH * g.sub[i].OW >= (1L << 31)) return GX_ERR_BAD_ARG;
     }
@@ -478,8 +569,11 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         else g.slab = slab;
     }
     dim3 grid(g.ntile, g.splits);
-    if (g.vec_ok) hipLaunchKernelGGL(modconv_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
-    else hipLaunchKernelGGL(modconv_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
+    const bool x6 = gx_get_gemm_mode() == 1;
+    if (x6 && g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+    else if (x6) hipLaunchKernelGGL((modconv_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+    else if (g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL((modconv_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, stream, g);
     GX_CHECK_LAUNCH();
     if (g.splits > 1) {
         const long total = (long)g.B * g.outH * g.outW * g.Cout;

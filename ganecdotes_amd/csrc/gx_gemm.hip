@@ -11,7 +11,7 @@
 #include <cstdlib>
 
 #ifndef GX_DEFAULT_GEMM_MODE
-#define GX_DEFAULT_GEMM_MODE 0
+#define GX_DEFAULT_GEMM_MODE 1      // bf16x6; 0 = exact-fp32 MFMA (env GX_GEMM_MODE / gx_set_gemm_mode)
 #endif
 
 namespace gx {

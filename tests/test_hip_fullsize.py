@@ -57,10 +57,19 @@ def ffhq_args(batch, nproto, num_patches=5, pick_source="device", **over):
 
 
 # --------------------------------------------------------------------------- full-size step vs oracle
-def test_ffhq256_full_size_step_vs_oracle(gpu):
+@pytest.fixture(params=[1, 0], ids=["bf16x6", "f32mfma"])
+def engine(request, gpu):
+    """both contraction engines (GEMMs and modulated convs): bf16x6 (default) and exact-fp32 MFMA"""
+    from ganecdotes_amd import ops
+    prev = ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(prev)
+
+
+def test_ffhq256_full_size_step_vs_oracle(gpu, engine):
     """ffhq-256, 13 taps / 5376 channels, 20 000 sampled pixels, D=512, K=8, T=0.01, eps=0.005
     (configs[1] at batch 1, one patch): loss, the three gradients and the LARC update against the
-    oracle on identical draws."""
+    oracle on identical draws — on either contraction engine."""
     from oracle import swav_ref as S
     from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
@@ -93,7 +102,7 @@ def test_ffhq256_full_size_step_vs_oracle(gpu):
         assert rel(got, want) < 1e-4
 
 
-def test_car512_generator_and_cluster_map_vs_oracle(gpu):
+def test_car512_generator_and_cluster_map_vs_oracle(gpu, engine):
     """configs[3] shape: a 512^2 generator (15 taps, sum C = 5504 > hlen = 5376: the two
     native-resolution taps fall outside the descriptor) -> image, taps, projection of all 262 144
     pixels and the argmax cluster map against the oracle."""

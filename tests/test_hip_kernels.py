@@ -22,6 +22,14 @@ def ops():
     return O
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+def engine(request, ops):
+    """both contraction engines: exact-fp32 MFMA and bf16x6 (the default)"""
+    prev = ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(prev)
+
+
 def dev(x):
     if isinstance(x, np.ndarray):
         x = T(x)
@@ -36,7 +44,7 @@ def rel_err(a, b):
 # ------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (200, 72, 100), (1, 512, 512), (333, 129, 37), (64, 8, 516)])
-def test_gemm_layouts(ops, ta, tb, m, n, k):
+def test_gemm_layouts(ops, engine, ta, tb, m, n, k):
     torch.manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(k, m) if ta else torch.randn(m, k)
     b = torch.randn(n, k) if tb else torch.randn(k, n)
@@ -45,7 +53,7 @@ def test_gemm_layouts(ops, ta, tb, m, n, k):
     assert rel_err(out, ref) < 2e-6
 
 
-def test_gemm_asymmetric_identity(ops):
+def test_gemm_asymmetric_identity(ops, engine):
     # A = I with an ASYMMETRIC B catches a transposed C write
     n = 160
     b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) * 1e-3
@@ -55,7 +63,7 @@ def test_gemm_asymmetric_identity(ops):
     assert torch.equal(out.cpu(), b.t().contiguous())
 
 
-def test_gemm_epilogue_and_splitk(ops):
+def test_gemm_epilogue_and_splitk(ops, engine):
     torch.manual_seed(3)
     m, n, k = 300, 200, 5000
     a, b = torch.randn(k, m), torch.randn(k, n)
@@ -72,7 +80,7 @@ def test_gemm_epilogue_and_splitk(ops):
     assert rel_err(out, ref32) < 1e-5
 
 
-def test_gemm_big_ffhq_shape(ops):
+def test_gemm_big_ffhq_shape(ops, engine):
     # ffhq projection shape at reduced rows: (N, 5376) x (512, 5376)^T
     torch.manual_seed(5)
     x = torch.randn(1000, 5376)
@@ -424,7 +432,7 @@ def test_gather_rotflip_batch(ops):
         np.testing.assert_allclose(img[i].numpy(), S.norm_map(stack)[0].numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_gemm_cat_and_strided_views(ops):
+def test_gemm_cat_and_strided_views(ops, engine):
     torch.manual_seed(8)
     m, k1, k2, n = 300, 64, 40, 72
     a1, a2 = torch.randn(m, k1), torch.randn(m, k2 + 8)
@@ -555,7 +563,7 @@ def _style(ops, style, mod_w, mod_b):
     return s
 
 
-def test_modconv_golden_gv2(ops):
+def test_modconv_golden_gv2(ops, engine):
     d = load_golden("gv2_modconv")
     kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
     for tag in ("plain", "up", "rgb"):
@@ -575,7 +583,7 @@ def test_modconv_golden_gv2(ops):
         assert rel_err(y.permute(0, 3, 1, 2), ref) < 5e-6, tag
 
 
-def test_styled_conv_and_torgb_golden_gv3(ops):
+def test_styled_conv_and_torgb_golden_gv3(ops, engine):
     d = load_golden("gv3_layers")
     kf = dev(torch.flip(T(d["up_sd_conv.blur.kernel"]), [0, 1]))
     for tag in ("plain", "up"):
@@ -611,7 +619,7 @@ def test_mapping_pieces_golden_gv3(ops):
     assert rel_err(y, T(d["el_y"])) < 1e-5
 
 
-def test_modconv_ffhq_shapes(ops):
+def test_modconv_ffhq_shapes(ops, engine):
     """A real-width layer (512->512 @ 16x16, batch 2) against the oracle."""
     from oracle import stylegan2_ref as G
     torch.manual_seed(21)
