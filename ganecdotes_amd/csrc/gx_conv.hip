@@ -15,6 +15,7 @@
 // followed by one fused FIR-blur + demod + noise + bias + act pass (upfirdn2d mode 1,
 // upfirdn2d_kernel.cu:114-215 semantics).
 #include "gx_mfma_x6.h"
+#include <cstdlib>
 
 extern "C" int gx_get_gemm_mode(void);      // gx_gemm.hip: 0 = exact-fp32 MFMA, 1 = bf16x6
 
@@ -45,6 +46,65 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
+
+// Epilogue of a wave's (32 MT) x 64 accumulator sub-tile whose first row (output pixel index within
+// the sub-problem) is row0 and first output channel col0.  A lane's 16 rows of an MFMA tile are
+// m = base + (r&3) + 8*(r>>2): decode the base once, then walk the rows with carries instead of 64
+// integer divisions per lane.
+template <int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& g, const ConvSub& sb, f32x16 (&acc)[MT][2], unsigned row0,
+                                              int col0, int lane) {
+    const int OH = sb.OH, OW = sb.OW;
+    const unsigned ohw = (unsigned)OH * (unsigned)OW;
+    const unsigned Mtot = (unsigned)g.B * ohw;
+    const bool to_slab = g.slab != nullptr;
+    float* outp = to_slab ? g.slab + (long)blockIdx.y * g.B * g.outH * g.outW * g.Cout : g.out;
+    const float nw = (!to_slab && g.noise && g.noise_w) ? *g.noise_w : 0.f;
+    int co[2]; bool cok[2]; float bias_c[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        co[nt] = col0 + nt * 32 + (lane & 31);
+        cok[nt] = co[nt] < g.Cout;
+        bias_c[nt] = (!to_slab && g.bias && cok[nt]) ? g.bias[co[nt]] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned mbase = row0 + mt * 32 + 4 * (lane >> 5);
+        unsigned b = mbase / ohw, rem = mbase - b * ohw;
+        int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+        int prev = 0, bcur = -1;
+        float dm[2] = {1.f, 1.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int delta = (r & 3) + 8 * (r >> 2);
+            ox += delta - prev; prev = delta;
+            while (ox >= OW) { ox -= OW; ++oy; }
+            while (oy >= OH) { oy -= OH; ++b; }
+            if (mbase + delta >= Mtot) continue;
+            const int y = oy * g.ymul + sb.yadd, x = ox * g.xmul + sb.xadd;
+            const long pix = ((long)b * g.outH + y) * g.outW + x;
+            float nz = 0.f;
+            if (!to_slab) {
+                if (g.noise) nz = nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x];
+                if (g.demod && (int)b != bcur) {
+                    bcur = (int)b;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) dm[nt] = cok[nt] ? g.demod[(long)b * g.Cout + co[nt]] : 1.f;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (!cok[nt]) continue;
+                float v = acc[mt][nt][r];
+                if (!to_slab) {
+                    v = fmaf(v, dm[nt], nz + bias_c[nt]);
+                    if (g.act) v = lrelu_sqrt2(v);
+                }
+                outp[pix * g.Cout + co[nt]] = v;
+            }
+        }
+    }
+}
 
 // Main loop of one output tile for a sub-problem with NT taps (compile-time: the tap loop is
 // unrolled, so per-tap offsets live in SGPRs and nothing is fetched from the argument block inside
@@ -270,55 +330,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     }
 #undef GX_CONV_LOOP
 
-    // ---- epilogue.  A lane's 16 rows of an MFMA tile are m = base + (r&3) + 8*(r>>2): decode the
-    // base once, then walk the rows with carries instead of 64 integer divisions per lane.
-    const bool to_slab = g.slab != nullptr;
-    float* outp = to_slab ? g.slab + (long)blockIdx.y * g.B * g.outH * g.outW * g.Cout : g.out;
-    const float nw = (!to_slab && g.noise && g.noise_w) ? *g.noise_w : 0.f;
-    int co[2]; bool cok[2]; float bias_c[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        co[nt] = n0 + acc_col(wc, nt, lane);
-        cok[nt] = co[nt] < g.Cout;
-        bias_c[nt] = (!to_slab && g.bias && cok[nt]) ? g.bias[co[nt]] : 0.f;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const unsigned mbase = (unsigned)m0 + acc_row(wr, mt, 0, lane);
-        unsigned b = mbase / ohw, rem = mbase - b * ohw;
-        int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
-        int prev = 0, bcur = -1;
-        float dm[2] = {1.f, 1.f};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int delta = (r & 3) + 8 * (r >> 2);
-            ox += delta - prev; prev = delta;
-            while (ox >= OW) { ox -= OW; ++oy; }
-            while (oy >= OH) { oy -= OH; ++b; }
-            if (mbase + delta >= Mtot) continue;
-            const int y = oy * g.ymul + sb.yadd, x = ox * g.xmul + sb.xadd;
-            const long pix = ((long)b * g.outH + y) * g.outW + x;
-            float nz = 0.f;
-            if (!to_slab) {
-                if (g.noise) nz = nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x];
-                if (g.demod && (int)b != bcur) {
-                    bcur = (int)b;
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) dm[nt] = cok[nt] ? g.demod[(long)b * g.Cout + co[nt]] : 1.f;
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (!cok[nt]) continue;
-                float v = acc[mt][nt][r];
-                if (!to_slab) {
-                    v = fmaf(v, dm[nt], nz + bias_c[nt]);
-                    if (g.act) v = lrelu_sqrt2(v);
-                }
-                outp[pix * g.Cout + co[nt]] = v;
-            }
-        }
-    }
+    conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // Split-K tail: out = epilogue(sum_s slab[s]) over the whole NHWC output (fixed order).
@@ -552,6 +564,7 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
     g.wt_bytes = (unsigned)wtb;
     g.style_bytes = (unsigned)((size_t)g.B * g.Cin * 4);
     g.tiles_n = gx_cdiv(g.Cout, BN);
+    const bool x6 = gx_get_gemm_mode() == 1;
     int base = 0, min_kt = 1 << 30;
     for (int i = 0; i < g.nsub; ++i) {
         g.sub[i].tile_base = base;
@@ -569,7 +582,6 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         else g.slab = slab;
     }
     dim3 grid(g.ntile, g.splits);
-    const bool x6 = gx_get_gemm_mode() == 1;
     if (x6 && g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
     else if (x6) hipLaunchKernelGGL((modconv_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
     else if (g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, stream, g);

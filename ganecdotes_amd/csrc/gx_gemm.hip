@@ -31,19 +31,20 @@ struct GemmArgs {
     const float* A2; long lda2; int K1;
 };
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
-                                              int lane) {
+// Accumulators of a wave's (32 MT) x (32 NT) sub-tile whose first row / column in C is (row0, col0).
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane) {
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
     const long ldo = to_slab ? g.N : g.ldc;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = n0 + acc_col(wc, nt, lane);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + nt * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + acc_row(wr, mt, r, lane);
+                const int row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M && col < g.N) {
                     float v = acc[mt][nt][r];
                     if (!to_slab) {
@@ -56,6 +57,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                 }
             }
         }
+}
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
+                                              int lane) {
+    gemm_epilogue_t<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
@@ -159,6 +164,85 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
     gemm_epilogue(g, acc, m0, n0, wr, wc, lane);
 }
 
+// Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
+// split arithmetic, the LDS round trip and a barrier that the 4-wave kernel above strings in series
+// with it (its MFMA pipe is busy 55 % of the time).  Here a workgroup of 512 threads owns a 256 x 128
+// tile and its waves have fixed roles:
+//   waves 0-3  consumers, 2 x 2, each a 128 x 64 sub-tile: 12 fragment reads + 48 MFMAs per k-tile,
+//              nothing else;
+//   waves 4-7  producers: global loads two k-tiles ahead (two register sets), exact three-way bf16
+//              split, LDS stores into the slot the consumers left one barrier ago.
+// One barrier per k-tile, two LDS slots: between barriers t and t+1 the consumers read slot t&1
+// while the producers fill slot (t+1)&1.  One producer and one consumer wave share each SIMD, so
+// the split arithmetic issues in the gaps of the other wave's MFMAs.
+constexpr int WS_BM = 256, WS_BN = 128, WS_THREADS = 512;
+constexpr int WS_SLOT = XImg<WS_BM>::BYTES + XImg<WS_BN>::BYTES;          // 25344 + 13056 B
+
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
+    constexpr bool A_KC = !TA, B_KC = TB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * WS_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * WS_BM, n0 = tn * WS_BN;
+    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nkt = (kend - kbeg + XK - 1) / XK;
+    char* slot0 = lds;
+    char* slot1 = lds + WS_SLOT;
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int p = tid - 256;
+        f32x4 ra0[4], rb0[2], ra1[4], rb1[2];
+        auto load_tiles = [&](int t, f32x4 (&ra)[4], f32x4 (&rb)[2]) {     // tiles past kend load as zeros
+            const int k0 = kbeg + t * XK;
+            const bool second = !TA && k0 >= g.K1;
+            x6_load_tile<A_KC, VEC, WS_BM>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M,
+                                           second ? k0 - g.K1 : k0,
+                                           second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, p);
+            x6_load_tile<B_KC, VEC, WS_BN>(g.B, g.ldb, n0, g.N, k0, kend, rb, p);
+        };
+        auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
+            x6_store_tile<A_KC, WS_BM>(slot, ra, p);
+            x6_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p);
+        };
+        load_tiles(0, ra0, rb0);
+        load_tiles(1, ra1, rb1);
+        if (nkt > 0) stage(slot0, ra0, rb0);
+        __syncthreads();                                             // barrier 0: tile 0 visible
+        for (int t = 0; t < nkt; t += 2) {
+            load_tiles(t + 2, ra0, rb0);
+            if (t + 1 < nkt) stage(slot1, ra1, rb1);
+            __syncthreads();                                         // barrier t+1
+            if (t + 1 >= nkt) break;
+            load_tiles(t + 3, ra1, rb1);
+            if (t + 2 < nkt) stage(slot0, ra0, rb0);
+            __syncthreads();                                         // barrier t+2
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    const int wr = wid >> 1, wc = wid & 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    __syncthreads();                                                 // barrier 0
+    for (int t = 0; t < nkt; ++t) {
+        const char* slot = (t & 1) ? slot1 : slot0;
+        x6_mfma_tile<A_KC, B_KC, 4, 2, WS_BM, WS_BN>(slot, slot + XImg<WS_BM>::BYTES, acc, wr * 128, wc * 64, lane);
+        __syncthreads();                                             // barrier t+1
+    }
+    gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int splits, float* __restrict__ C,
                                           int M, int N, long ldc, float alpha, float beta,
@@ -201,7 +285,11 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     g.vec_ok = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
                (lda2 % 4 == 0) && lda < (1 << 22) && ldb < (1 << 22) && lda2 < (1 << 22) && (K % 4 == 0) && (g.K1 % 4 == 0) && (!transA || M % 4 == 0) &&
                (transB || N % 4 == 0);
-    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
+    const bool x6 = gemm_mode() == 1;
+    // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
+    // to amortise a tile's prologue / epilogue, which nothing overlaps there
+    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= 768 && !getenv("GX_X6_NO_WS");
+    g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
     if (split_k > ktiles) split_k = ktiles;
@@ -213,10 +301,11 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         g.slab = workspace;
     }
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
-    const bool x6 = gemm_mode() == 1;
 #define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
     do {                                                                                                       \
-        if (x6 && g.vec_ok) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, true>), grid, block, 0, stream, g);  \
+        if (ws && g.vec_ok) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, true>), grid, dim3(WS_THREADS), 0, stream, g); \
+        else if (ws) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, false>), grid, dim3(WS_THREADS), 0, stream, g); \
+        else if (x6 && g.vec_ok) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, true>), grid, block, 0, stream, g);  \
         else if (x6) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, false>), grid, block, 0, stream, g);        \
         else if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, g);              \

@@ -29,10 +29,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XK = 16;                              // fp32 k per tile = one 32x32x16 MFMA step
 constexpr int X_KC_ROW = 32;                        // bytes per row of a KC plane
-constexpr int X_KC_PLANE = 128 * X_KC_ROW;          // 4096 B
-constexpr int X_MC_ROWW = 136;                      // words per k-pair row of an MC plane
-constexpr int X_MC_PLANE = 8 * X_MC_ROWW * 4;       // 4352 B
-constexpr int X_TILE_BYTES = 3 * X_MC_PLANE;        // one operand, one buffer (13056 B; the KC image is 12288 B)
+// Images of R rows (R = 128: one operand of the 128 x 128 tile; R = 256: the A operand of the
+// wave-specialised 256 x 128 tile), filled by 256 threads.
+template <int R> struct XImg {
+    static constexpr int KC_PLANE = R * X_KC_ROW;             // R = 128: 4096 B
+    static constexpr int MC_ROWW = R + 8;                     // words per k-pair row
+    static constexpr int MC_PLANE = 8 * MC_ROWW * 4;          // R = 128: 4352 B
+    static constexpr int BYTES = 3 * MC_PLANE;                // one image (the KC form is smaller)
+    static constexpr int NV = R / 64;                         // float4 per thread per tile
+};
+constexpr int X_TILE_BYTES = XImg<128>::BYTES;      // 13056 B
 // byte offset of the 16-B half `half` of row `row` inside a KC plane
 __device__ __forceinline__ int x_kc_off(int row, int half) { return row * X_KC_ROW + ((half ^ ((row >> 3) & 1)) << 4); }
 
@@ -40,122 +46,139 @@ __device__ __forceinline__ int x_kc_off(int row, int half) { return row * X_KC_R
 // Each remainder is exact in fp32 (it is a multiple of the ulp of x below the rounding point).
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
-#ifdef GX_X6_FAKE_SPLIT      // timing experiment only (wrong results): no remainder arithmetic
-    m = h; l = h; return;
-#endif
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
     const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
     l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
 }
 
-// Global -> registers for one 128 x 16 operand tile (2 float4 per thread).
-//  KC: element (row, k) at P[row*ld + k]: thread -> rows (tid>>2) + 64 i, k = 4 (tid&3) .. +3.
-//  MC: element (row, k) at P[k*ld + row]: thread -> rows 4 (tid&31) .. +3, k = 2 (tid>>5) + i.
+// Global -> registers for one R x 16 operand tile (R/64 float4 per thread, 256 threads, t = 0..255).
+//  KC: element (row, k) at P[row*ld + k]: v[i] = row (t>>2) + 64 i, k = 4 (t&3) .. +3.
+//  MC: element (row, k) at P[k*ld + row]: v[2j+i] = rows 4 (t&31) + 128 j .. +3, k = 2 (t>>5) + i.
 //  VEC as in load_tile.
-template <bool KC, bool VEC>
+template <bool KC, bool VEC, int R = 128>
 __device__ __forceinline__ void x6_load_tile(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
-                                             int kend, f32x4 (&v)[2], int tid) {
+                                             int kend, f32x4 (&v)[R / 64], int t) {
+    constexpr int NV = R / 64;
     if (VEC) {
         const unsigned uld = (unsigned)ld;
         if (KC) {
-            const int nv = min(128, nrows - row0), kv = min(XK, kend - k0);
+            const int nv = min(R, nrows - row0), kv = min(XK, kend - k0);
             const unsigned nbytes = (nv > 0 && kv > 0) ? ((unsigned)(nv - 1) * uld + (unsigned)kv) * 4u : 0u;
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(P + (long)row0 * ld + k0, nbytes);
-            const unsigned kk = (tid & 3) * 4;
+            const unsigned kk = (t & 3) * 4;
             const unsigned km = oob_mask((int)kk < kv);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned r = (tid >> 2) + 64 * i;
+            for (int i = 0; i < NV; ++i) {
+                const unsigned r = (t >> 2) + 64 * i;
                 v[i] = buf_load4(rs, ((r * uld + kk) * 4u) | km);
             }
         } else {
-            const int kv = min(XK, kend - k0), mv = min(128, nrows - row0);
+            const int kv = min(XK, kend - k0), mv = min(R, nrows - row0);
             const unsigned nbytes = (kv > 0 && mv > 0) ? ((unsigned)(kv - 1) * uld + (unsigned)mv) * 4u : 0u;
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(P + (long)k0 * ld + row0, nbytes);
-            const unsigned mm = (tid & 31) * 4;
-            const unsigned km = oob_mask((int)mm < mv);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned kr = 2 * (tid >> 5) + i;
-                v[i] = buf_load4(rs, ((kr * uld + mm) * 4u) | km);
+            for (int j = 0; j < NV / 2; ++j) {
+                const unsigned mm = (t & 31) * 4 + 128 * j;
+                const unsigned km = oob_mask((int)mm < mv);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned kr = 2 * (t >> 5) + i;
+                    v[2 * j + i] = buf_load4(rs, ((kr * uld + mm) * 4u) | km);
+                }
             }
         }
         return;
     }
     if (KC) {
-        const int k = k0 + (tid & 3) * 4;
+        const int k = k0 + (t & 3) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = row0 + (tid >> 2) + 64 * i;
+        for (int i = 0; i < NV; ++i) {
+            const int row = row0 + (t >> 2) + 64 * i;
             v[i] = (row < nrows && k < kend) ? load4(P + (long)row * ld + k, kend - k, false) : zero4();
         }
     } else {
-        const int m = row0 + (tid & 31) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kr = k0 + 2 * (tid >> 5) + i;
-            v[i] = (kr < kend && m < nrows) ? load4(P + (long)kr * ld + m, nrows - m, false) : zero4();
+        for (int j = 0; j < NV / 2; ++j) {
+            const int m = row0 + (t & 31) * 4 + 128 * j;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kr = k0 + 2 * (t >> 5) + i;
+                v[2 * j + i] = (kr < kend && m < nrows) ? load4(P + (long)kr * ld + m, nrows - m, false) : zero4();
+            }
         }
     }
 }
 
 // registers -> the three bf16 planes of one operand image
-template <bool KC>
-__device__ __forceinline__ void x6_store_tile(char* __restrict__ S, const f32x4 (&v)[2], int tid) {
+template <bool KC, int R = 128>
+__device__ __forceinline__ void x6_store_tile(char* __restrict__ S, const f32x4 (&v)[R / 64], int t) {
+    constexpr int NV = R / 64;
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             unsigned h[2], m[2], l[2];
             split3(v[i][0], v[i][1], h[0], m[0], l[0]);
             split3(v[i][2], v[i][3], h[1], m[1], l[1]);
-            char* p = S + x_kc_off((tid >> 2) + 64 * i, (tid >> 1) & 1) + (tid & 1) * 8;
+            char* p = S + x_kc_off((t >> 2) + 64 * i, (t >> 1) & 1) + (t & 1) * 8;
             *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[1]};
-            *reinterpret_cast<u32x2*>(p + X_KC_PLANE) = (u32x2){m[0], m[1]};
-            *reinterpret_cast<u32x2*>(p + 2 * X_KC_PLANE) = (u32x2){l[0], l[1]};
+            *reinterpret_cast<u32x2*>(p + XImg<R>::KC_PLANE) = (u32x2){m[0], m[1]};
+            *reinterpret_cast<u32x2*>(p + 2 * XImg<R>::KC_PLANE) = (u32x2){l[0], l[1]};
         }
     } else {
-        unsigned h[4], m[4], l[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split3(v[0][e], v[1][e], h[e], m[e], l[e]);      // (k, k+1) of one m
-        char* p = S + ((tid >> 5) * X_MC_ROWW + (tid & 31) * 4) * 4;
-        *reinterpret_cast<u32x4*>(p) = (u32x4){h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<u32x4*>(p + X_MC_PLANE) = (u32x4){m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<u32x4*>(p + 2 * X_MC_PLANE) = (u32x4){l[0], l[1], l[2], l[3]};
+        for (int j = 0; j < NV / 2; ++j) {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[2 * j][e], v[2 * j + 1][e], h[e], m[e], l[e]);   // (k, k+1) of one m
+            char* p = S + ((t >> 5) * XImg<R>::MC_ROWW + (t & 31) * 4 + 128 * j) * 4;
+            *reinterpret_cast<u32x4*>(p) = (u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(p + XImg<R>::MC_PLANE) = (u32x4){m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(p + 2 * XImg<R>::MC_PLANE) = (u32x4){l[0], l[1], l[2], l[3]};
+        }
     }
 }
 
-template <bool KC>
+template <bool KC, int R = 128>
 __device__ __forceinline__ bf16x8 x6_frag(const char* __restrict__ S, int plane, int row, int h) {
-    if (KC) return *reinterpret_cast<const bf16x8*>(S + plane * X_KC_PLANE + x_kc_off(row, h));
-    const unsigned* W = reinterpret_cast<const unsigned*>(S + plane * X_MC_PLANE) + 4 * h * X_MC_ROWW + row;
+    if (KC) return *reinterpret_cast<const bf16x8*>(S + plane * XImg<R>::KC_PLANE + x_kc_off(row, h));
+    const unsigned* W = reinterpret_cast<const unsigned*>(S + plane * XImg<R>::MC_PLANE) + 4 * h * XImg<R>::MC_ROWW + row;
     u32x4 w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = W[j * X_MC_ROWW];
+    for (int j = 0; j < 4; ++j) w[j] = W[j * XImg<R>::MC_ROWW];
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// One 16-deep k-tile for this wave's 64 x 64 sub-tile: 4 MFMA tiles x 6 products, smallest terms first.
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void x6_mfma_ktile(const char* __restrict__ As, const char* __restrict__ Bs,
-                                              f32x16 (&acc)[2][2], int wr, int wc, int lane) {
+// One 16-deep k-tile for a wave's (32 MT) x (32 NT) sub-tile at rows a_row0 / b_row0 of the images:
+// MT x NT MFMA tiles x 6 products, smallest terms first.
+template <bool A_KC, bool B_KC, int MT, int NT, int RA, int RB>
+__device__ __forceinline__ void x6_mfma_tile(const char* __restrict__ As, const char* __restrict__ Bs,
+                                             f32x16 (&acc)[MT][NT], int a_row0, int b_row0, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[MT][3], b[NT][3];
+    // fragment reads in the order the products consume them (l*h first), so the first MFMAs can
+    // issue when a third of the reads have landed
+    constexpr int PA[3] = {2, 0, 1}, PB[3] = {0, 2, 1};
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int q = 0; q < 3; ++q) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            a[t][p] = x6_frag<A_KC>(As, p, wr * 64 + t * 32 + r, h);
-            b[t][p] = x6_frag<B_KC>(Bs, p, wc * 64 + t * 32 + r, h);
-        }
+        for (int t = 0; t < MT; ++t) a[t][PA[q]] = x6_frag<A_KC, RA>(As, PA[q], a_row0 + t * 32 + r, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t][PB[q]] = x6_frag<B_KC, RB>(Bs, PB[q], b_row0 + t * 32 + r, h);
+    }
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][TA[t]], b[nt][TB[t]], acc[mt][nt], 0, 0, 0);
+}
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void x6_mfma_ktile(const char* __restrict__ As, const char* __restrict__ Bs,
+                                              f32x16 (&acc)[2][2], int wr, int wc, int lane) {
+    x6_mfma_tile<A_KC, B_KC, 2, 2, 128, 128>(As, Bs, acc, wr * 64, wc * 64, lane);
 }
 
 }  // namespace gx
