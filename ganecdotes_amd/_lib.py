@@ -75,6 +75,10 @@ SIGNATURES = {
     "gx_sinkhorn_small": (c_i, [c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_small_batch": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_sz,
                                       c_p]),
+    "gx_sinkhorn_small_batch_colmax": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_p, c_sz, c_p, c_p]),
+    "gx_sinkhorn_small_batch_pass": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_f, c_p, c_p, c_p,
+                                           c_sz, c_p, c_p]),
+    "gx_sinkhorn_small_batch_finish": (c_i, [c_i, c_i, c_f, c_i, c_p, c_l, c_p, c_p, c_p, c_p]),
     "gx_sinkhorn_codes": (c_i, [c_p, c_l, c_i, c_l, c_f, c_p, c_p, c_l, c_p]),
     "gx_hist_marginal": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
     "gx_hist_range": (c_i, [c_p, c_l, c_p, c_p, c_p]),

@@ -177,6 +177,8 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, long rows, in
 __global__ void partial_reduce_kernel(const float* __restrict__ part, int nblk, int K, float alpha, float beta,
                                       float* __restrict__ out, int kx) {
     __shared__ float red[256];
+    part += (long)blockIdx.y * nblk * K;                          // blockIdx.y = problem (batched callers)
+    out += (long)blockIdx.y * K;
     const int tx = threadIdx.x % kx, ty = threadIdx.x / kx, ny = blockDim.x / kx;
     const int k = blockIdx.x * kx + tx;
     float s = 0.f;
@@ -995,7 +997,7 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, lo
                                      int kx, float inv_eps, int it, const unsigned* __restrict__ cmax,
                                      const float* __restrict__ r, long rstride, const float* __restrict__ c,
                                      long cstride, float c_uniform, const float* __restrict__ upart_prev,
-                                     const float* __restrict__ la_prev, float* __restrict__ la_cur,
+                                     int nblk_prev, const float* __restrict__ la_prev, float* __restrict__ la_cur,
                                      float* __restrict__ upart) {
     __shared__ float las[64], uacc[64], red[256];
     const long y = blockIdx.y;
@@ -1003,7 +1005,7 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, lo
     cmax += y * K;
     if (r) r += y * rstride;
     if (c) c += y * cstride;
-    upart_prev += y * gridDim.x * K;
+    upart_prev += y * nblk_prev * K;                  // nblk_prev = 1: already reduced (and all-reduced) sums
     upart += y * gridDim.x * K;
     la_prev += y * K;
     la_cur += y * K;
@@ -1012,7 +1014,7 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, lo
         if (threadIdx.x < K) las[threadIdx.x] = -ord2f(cmax[threadIdx.x]) * inv_eps;
         __syncthreads();
     } else {
-        sk_fold_update(upart_prev, gridDim.x, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
+        sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
     }
     if (blockIdx.x == 0 && threadIdx.x < K) la_cur[threadIdx.x] = las[threadIdx.x];
     const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
@@ -1083,7 +1085,7 @@ int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, in
         float* up_prev = part + (size_t)((it + 1) & 1) * nb * PK;
         float* up_cur = part + (size_t)(it & 1) * nb * PK;
         hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
-                           1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev,
+                           1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev, nb,
                            labuf + (size_t)((it + 1) & 1) * PK, labuf + (size_t)(it & 1) * PK, up_cur);
         GX_CHECK_LAUNCH();
     }
@@ -1097,6 +1099,84 @@ int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, in
 int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int niters, const float* r,
                       const float* c, float* la, float* workspace, size_t workspace_bytes, void* stream) {
     return gx_sinkhorn_small_batch(S, 1, 0, rows, K, ld, eps, niters, r, 0, c, 0, la, workspace, workspace_bytes, stream);
+}
+
+// ---- the same batch, staged for row-sharded scores (one rank holds `rows` of each problem): the
+// host all-reduces the nprob*K column maxima once (MAX) and the nprob*K column sums after every
+// pass (SUM); 2 launches + 1 collective per iteration for the WHOLE batch.
+//   colmax : local column maxima as floats -> cmax_out [nprob*K]
+//   pass   : it == 0 takes the all-reduced maxima cmax_in; it >= 1 the all-reduced sums u_prev of
+//            pass it-1 (folds the la update), sweeps, and leaves this rank's sums in u_out [nprob*K];
+//            c_uniform = 1 / (rows over all ranks)
+//   finish : last la update from the all-reduced sums of the last pass -> la [nprob*K]
+static int sk_batch_geometry(int nprob, long rows, int K, int* team, int* nb, int* kx) {
+    *team = gx::pick_team(K);
+    const long tpb = 256 / *team;
+    long nbl = (rows + tpb - 1) / tpb;
+    long cap = 4096 / nprob;
+    cap = cap < 64 ? 64 : (cap > GX_SK_SMALL_BLOCKS ? GX_SK_SMALL_BLOCKS : cap);
+    *nb = (int)(nbl < cap ? nbl : cap);
+    *kx = 1;
+    while (*kx < 64 && *kx < K) *kx <<= 1;
+    return 0;
+}
+int gx_sinkhorn_small_batch_colmax(const float* S, int nprob, long sprob, long rows, int K, long ld, float* workspace,
+                                   size_t workspace_bytes, float* cmax_out, void* stream) {
+    if (!S || !cmax_out || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || K > 64 || ld < K) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)nprob * gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int team, nb, kx;
+    sk_batch_geometry(nprob, rows, K, &team, &nb, &kx);
+    const size_t PK = (size_t)nprob * K;
+    if (hipMemsetAsync(workspace, 0, PK * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
+    hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team,
+                       (unsigned*)workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gx::sk_ord_decode_kernel, dim3(gx_cdiv((long)PK, 256)), dim3(256), 0, st,
+                       (const unsigned*)workspace, (int)PK, cmax_out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_sinkhorn_small_batch_pass(const float* S, int nprob, long sprob, long rows, int K, long ld, float eps, int it,
+                                 const float* r, long rstride, const float* c, long cstride, float c_uniform,
+                                 const float* cmax_in, const float* u_prev, float* workspace, size_t workspace_bytes,
+                                 float* u_out, void* stream) {
+    if (!S || !u_out || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || K > 64 || ld < K || eps <= 0.f || it < 0 ||
+        (it == 0 && !cmax_in) || (it > 0 && !u_prev))
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)nprob * gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int team, nb, kx;
+    sk_batch_geometry(nprob, rows, K, &team, &nb, &kx);
+    const size_t PK = (size_t)nprob * K;
+    unsigned* cmax = (unsigned*)workspace;
+    float* labuf = workspace + PK;
+    float* part = workspace + 3 * PK;
+    if (it == 0) {
+        hipLaunchKernelGGL(gx::sk_ord_encode_kernel, dim3(gx_cdiv((long)PK, 256)), dim3(256), 0, st, cmax_in, (int)PK, cmax);
+        GX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
+                       1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, u_prev ? u_prev : part, 1,
+                       labuf + (size_t)((it + 1) & 1) * PK, labuf + (size_t)(it & 1) * PK, part);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gx::partial_reduce_kernel, dim3((K + kx - 1) / kx, nprob), dim3(256), 0, st, part, nb, K, 1.f, 0.f,
+                       u_out, kx);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_sinkhorn_small_batch_finish(int nprob, int K, float eps, int niters, const float* r, long rstride,
+                                   const float* u_last, const float* workspace, float* la, void* stream) {
+    if (!u_last || !workspace || !la || nprob <= 0 || K <= 0 || K > 64 || niters < 1 || eps <= 0.f) return GX_ERR_BAD_ARG;
+    int kx = 1;
+    while (kx < 64 && kx < K) kx <<= 1;
+    const size_t PK = (size_t)nprob * K;
+    const int last = niters - 1;
+    hipLaunchKernelGGL(gx::sk_finish_small_kernel, dim3(nprob), dim3(256), 0, (hipStream_t)stream, u_last, 1, K, kx,
+                       workspace + PK + (size_t)(last & 1) * PK, (const unsigned*)workspace, niters == 1 ? 1 : 0, 1.f / eps,
+                       r, rstride, la);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
 }
 }  // extern "C"
 

@@ -605,8 +605,34 @@ class SinkhornBatch:
             for p in self.probs:
                 p.run()
             return self
+        if self.K <= 64 and self.rows >= 4096:
+            return self._run_sharded_small(reduce)
         from .sharded import run_sinkhorn_group
         run_sinkhorn_group(self.probs, self.niters, reduce)
+        return self
+
+    def _run_sharded_small(self, reduce):
+        """Row-sharded batch, K <= 64: batched kernels, 1 MAX + niters SUM all-reduces of nprob*K floats."""
+        L = lib()
+        wsb = self.nprob * L.gx_sinkhorn_workspace_bytes(self.K)
+        ws = workspace(self.tag, wsb, self.S.device)
+        S, n, K = self.S, self.nprob, self.K
+        rs = 0 if self.r is None else self.r.stride(0)
+        cs = 0 if self.c is None else self.c.stride(0)
+        cm = torch.empty(n, K, dtype=torch.float32, device=S.device)
+        u = [torch.empty(n, K, dtype=torch.float32, device=S.device) for _ in range(2)]
+        _lib.check(L.gx_sinkhorn_small_batch_colmax(_p(S), n, S.stride(0), self.rows, K, S.stride(1), _p(ws), wsb, _p(cm),
+                                                    _stream()), "gx_sinkhorn_small_batch_colmax")
+        reduce(cm, "max")
+        for it in range(self.niters):
+            _lib.check(L.gx_sinkhorn_small_batch_pass(
+                _p(S), n, S.stride(0), self.rows, K, S.stride(1), self.eps, it, _p(self.r), rs, _p(self.c), cs,
+                self.c_uniform, _p(cm), _p(u[(it + 1) & 1]) if it > 0 else None, _p(ws), wsb, _p(u[it & 1]), _stream()),
+                "gx_sinkhorn_small_batch_pass")
+            reduce(u[it & 1], "sum")
+        _lib.check(L.gx_sinkhorn_small_batch_finish(n, K, self.eps, self.niters, _p(self.r), rs,
+                                                    _p(u[(self.niters - 1) & 1]), _p(ws), _p(self.la), _stream()),
+                   "gx_sinkhorn_small_batch_finish")
         return self
 
 

@@ -203,6 +203,18 @@ int gx_sinkhorn_small(const float* S, long rows, int K, long ld, float eps, int 
 int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, int K, long ld, float eps, int niters,
                             const float* r, long rstride, const float* c, long cstride, float* la,
                             float* workspace, size_t workspace_bytes, void* stream);
+/* The same batch with the scores row-sharded over ranks (sinkhorn_scope='global' on N GPUs): the
+ * host all-reduces cmax_out (MAX) once and u_out (SUM) after every pass — 2 launches + 1 collective
+ * of nprob*K floats per iteration for the whole batch.  pass: it == 0 takes the reduced maxima,
+ * it >= 1 the reduced sums of pass it-1; c_uniform = 1 / (rows over all ranks). */
+int gx_sinkhorn_small_batch_colmax(const float* S, int nprob, long sprob, long rows, int K, long ld, float* workspace,
+                                   size_t workspace_bytes, float* cmax_out, void* stream);
+int gx_sinkhorn_small_batch_pass(const float* S, int nprob, long sprob, long rows, int K, long ld, float eps, int it,
+                                 const float* r, long rstride, const float* c, long cstride, float c_uniform,
+                                 const float* cmax_in, const float* u_prev, float* workspace, size_t workspace_bytes,
+                                 float* u_out, void* stream);
+int gx_sinkhorn_small_batch_finish(int nprob, int K, float eps, int niters, const float* r, long rstride,
+                                   const float* u_last, const float* workspace, float* la, void* stream);
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);

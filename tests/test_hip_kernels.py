@@ -322,6 +322,52 @@ def test_sinkhorn_batch_equals_per_problem(ops, nprob, n, k, pdf):
             np.testing.assert_allclose(q, skb[i].codes().cpu().numpy(), rtol=5e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("nprob,n,k,pdf", [(10, 20000, 8, "uniform"), (4, 9000, 16, "image"), (2, 600, 12, "uniform")])
+def test_sinkhorn_batch_two_ranks_equal_one(ops, nprob, n, k, pdf):
+    """SinkhornBatch.run(reduce) on two row-shards (two threads standing in for two ranks, the
+    reduce exchanging through host memory) == the 1-rank batch on the concatenation; the batched
+    sharded path makes 1 + niters exchanges for the whole batch."""
+    import threading
+    torch.manual_seed(nprob + n + k)
+    eps = 0.005
+    s = dev(0.3 * torch.nn.functional.normalize(torch.randn(nprob, n, 16), dim=2) @
+            torch.nn.functional.normalize(torch.randn(k, 16), dim=1).t())
+    r = c = None
+    if pdf == "image":
+        imgs = [dev(torch.rand(1, 64, 64) * 2 + 0.1) for _ in range(nprob)]
+        r = torch.stack([ops.hist_marginal(im, k) for im in imgs])
+        c = torch.stack([ops.hist_marginal(im, n) for im in imgs])
+    whole = ops.SinkhornBatch(s, eps, 10, r=r, c=c, tag="whole").run()
+    h = n // 2
+    spans = [(0, h), (h, n)]
+    barrier, slots, outs, calls = threading.Barrier(2), [None, None], [None, None], [0, 0]
+
+    def run(rank):
+        lo, hi = spans[rank]
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            def reduce(t, op):
+                calls[rank] += 1
+                torch.cuda.current_stream().synchronize()
+                slots[rank] = t.clone()
+                barrier.wait()
+                st = torch.stack(slots)
+                red = st.max(0)[0] if op == "max" else st.sum(0)
+                barrier.wait()
+                t.copy_(red)
+            part = ops.SinkhornBatch(s[:, lo:hi].contiguous(), eps, 10, r=r, c=None if c is None else c[:, lo:hi].contiguous(),
+                                     c_uniform=1.0 / n, tag=f"rank{rank}").run(reduce)
+            outs[rank] = [part[i].codes().cpu() for i in range(nprob)]
+            stream.synchronize()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert calls == [11, 11]
+    for i in range(nprob):
+        q = torch.cat([outs[0][i], outs[1][i]]).numpy()
+        np.testing.assert_allclose(q, whole[i].codes().cpu().numpy(), rtol=5e-4, atol=1e-7)
+
+
 def test_sinkhorn_sharded_equals_single(ops):
     """W-rank result == 1-rank result on the concatenated pixels (ranks faked)."""
     torch.manual_seed(11)
