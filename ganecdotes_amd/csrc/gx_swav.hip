@@ -1200,8 +1200,13 @@ __device__ __forceinline__ float ps_reduce(float (&v)[KP], int lane) {
         const bool hi = (lane & o) != 0;
 #pragma unroll
         for (int i = 0; i < half; ++i) {
-            const float keep = hi ? v[half + i] : v[i];
-            const float send = hi ? v[i] : v[half + i];
+            // read both elements as opaque scalars first: otherwise the compiler turns `hi ? v[a] : v[b]`
+            // into v[hi ? a : b], a run-time index into the register array, and lowers it to a 16-step
+            // compare/select chain per access (480 v_cndmask per reduction instead of 30)
+            float lo_v = v[i], hi_v = v[half + i];
+            asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+            const float keep = hi ? hi_v : lo_v;
+            const float send = hi ? lo_v : hi_v;
             v[i] = keep + __shfl_xor(send, o, 64);
         }
         o >>= 1;
@@ -1551,25 +1556,27 @@ __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const flo
 }
 
 // Dense finish: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of gWc[k] += C[q][k] Z[q].
-// One wave per group of 4 pixels (8 row loads in flight per lane); lane l owns the float4 columns
-// (i*64 + l)*4.  POOL: the group is the 2x2 block under coarse pixel `g` and its sum is written to
-// Gpool[g] — the first sum-pooling step of the pyramid backward, while the rows are in registers.
+// blockIdx.y = 256-column slab of the D columns; one wave per group of 4 pixels (4 row slabs of 1 KB
+// in flight per lane), lane l owns the float4 columns slab + 4 l.  POOL: the group is the 2x2 block
+// under coarse pixel `g` and its sum is written to Gpool[g] — the first sum-pooling step of the
+// pyramid backward, while the rows are in registers.
 template <int KP, bool POOL>
 __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* __restrict__ C, const float* __restrict__ Z,
                                                                    long npix, int rc, int D, const float* __restrict__ Wc,
                                                                    int K, float* __restrict__ G, float* __restrict__ Gpool,
                                                                    float* __restrict__ part_w) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D]
-    for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][256] (this slab of Wc)
+    const int cb = blockIdx.y * 256;
+    for (int i = threadIdx.x; i < KP * 256; i += blockDim.x) wsm[i] = (i >> 8) < K ? Wc[(long)(i >> 8) * D + cb + (i & 255)] : 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nv = D >> 8;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = cb + lane * 4;
     const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wid;
     const long nwave = (long)gridDim.x * (blockDim.x >> 6);
     const int ls = lr_stride(K), rf = 2 * rc;
     const long ngroups = POOL ? npix / 4 : (npix + 3) / 4;
-    f32x4 gw[KP][2];
+    f32x4 gw[KP];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) gw[k][0] = gw[k][1] = zero4();
+    for (int k = 0; k < KP; ++k) gw[k] = zero4();
     for (long g = wave0; g < ngroups; g += nwave) {
         long pq[4];
         if (POOL) {
@@ -1583,62 +1590,47 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
             for (int j = 0; j < 4; ++j) pq[j] = g * 4 + j;
         }
         float cv[4];
-        f32x4 z[4][2];
+        f32x4 z[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = pq[j] < npix;
             cv[j] = (ok && lane < ls) ? C[pq[j] * ls + lane] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                z[j][i] = (ok && i < nv) ? *reinterpret_cast<const f32x4*>(Z + pq[j] * D + (i * 64 + lane) * 4) : zero4();
+            z[j] = ok ? *reinterpret_cast<const f32x4*>(Z + pq[j] * D + col) : zero4();
         }
-        f32x4 pool[2] = {zero4(), zero4()};
+        // coefficients as wave-uniform scalars (lane k of cv[j] holds C[q_j][k]); a never-sampled pixel has
+        // all-zero coefficients and simply yields a zero row.  A prototype float4 is read from LDS once
+        // for the four rows.
+        f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = __shfl(cv[j], K, 64) * z[j];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[j]), k));
+                a[j] += c * w;
+                gw[k] += c * z[j];
+            }
+        }
+        f32x4 pool = zero4();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (pq[j] >= npix) continue;
-            float* dst = G + pq[j] * D;
-            if (__ballot(cv[j] != 0.f) == 0ull) {      // pixel never sampled: zero row, nothing for gWc
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (i < nv) *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = zero4();
-                continue;
-            }
-            float c[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) c[k] = __shfl(cv[j], k, 64);
-            const float cz = __shfl(cv[j], K, 64);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nv) {
-                    f32x4 a = cz * z[j][i];
-#pragma unroll
-                    for (int k = 0; k < KP; ++k) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
-                        a += c[k] * w;
-                        gw[k][i] += c[k] * z[j][i];
-                    }
-                    *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = a;
-                    pool[i] += a;
-                }
+            if (pq[j] < npix) *reinterpret_cast<f32x4*>(G + pq[j] * D + col) = a[j];
+            pool += a[j];
         }
-        if (POOL) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nv) *reinterpret_cast<f32x4*>(Gpool + g * D + (i * 64 + lane) * 4) = pool[i];
-        }
+        if (POOL) *reinterpret_cast<f32x4*>(Gpool + g * D + col) = pool;
     }
     __syncthreads();
-    float* red = wsm;                                  // [4 waves][D]  (KP >= 4)
+    float* red = wsm;                                  // [4 waves][256]  (KP >= 4)
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (k < K) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nv) *reinterpret_cast<f32x4*>(red + wid * D + (i * 64 + lane) * 4) = gw[k][i];
+            *reinterpret_cast<f32x4*>(red + wid * 256 + lane * 4) = gw[k];
             __syncthreads();
-            for (int col = threadIdx.x; col < D; col += blockDim.x)
-                part_w[((long)blockIdx.x * K + k) * D + col] =
-                    (red[col] + red[D + col]) + (red[2 * D + col] + red[3 * D + col]);
+            for (int c2 = threadIdx.x; c2 < 256; c2 += blockDim.x)
+                part_w[((long)blockIdx.x * K + k) * D + cb + c2] =
+                    (red[c2] + red[256 + c2]) + (red[512 + c2] + red[768 + c2]);
             __syncthreads();
         }
     }
@@ -1679,27 +1671,41 @@ __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 z[j][i] = i < nv ? *reinterpret_cast<const f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) : zero4();
+        // finished rows (stored), their squared norms, and the K dot products of all four pixels:
+        // a prototype float4 is read from LDS once and used for the four rows
+        float p[4][KP], ss[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float p[KP];
+            ss[j] = 0.f;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) p[k] = 0.f;
-            float ss = 0.f;
+            for (int k = 0; k < KP; ++k) p[j][k] = 0.f;
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nv) {
-                    const f32x4 v = z[j][i] + c[i];
-                    *reinterpret_cast<f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) = v;
-                    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        for (int i = 0; i < 2; ++i)
+            if (i < nv) {                       // (no `break`: the loop must unroll, or z[.][i] is indexed at run time)
+                f32x4 v[4];
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
-                        p[k] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = z[j][i] + c[i];
+                    *reinterpret_cast<f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) = v[j];
+                    ss[j] += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
                 }
-            ss = gx_wave_sum(ss);
-            const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-            const float sc = ps_reduce<KP>(p, lane);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * D + (i * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        p[j][k] += v[j][0] * w[0] + v[j][1] * w[1] + v[j][2] * w[2] + v[j][3] * w[3];
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sj = gx_wave_sum(ss[j]);
+            const float rn = 1.f / fmaxf(sqrtf(sj), 1e-12f);
+            float pj[KP];                                 // a 1-D copy keeps the accumulators in registers
+#pragma unroll
+            for (int k = 0; k < KP; ++k) pj[k] = p[j][k];
+            const float sc = ps_reduce<KP>(pj, lane);
             if (owner) sc_table[pq[j] * K + myk] = fmaf(sc, rn, myb);
             if (lane == 0) rn_table[pq[j]] = rn;
         }
@@ -1779,11 +1785,11 @@ int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, i
     long nb = (npix + 15) / 16;
     if (nb > GX_PS_BLOCKS) nb = GX_PS_BLOCKS;
     const int kp = K <= 8 ? 8 : 16;
-    const size_t lds = (size_t)kp * D * sizeof(float);
+    const size_t lds = (size_t)kp * 256 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define GX_FINISH(KP, POOL)                                                                                         \
-    hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<KP, POOL>), dim3((int)nb), dim3(256), lds, st, C, Z, npix, rc, \
-                       D, Wc, K, G, Gpool, workspace)
+    hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<KP, POOL>), dim3((int)nb, D / 256), dim3(256), lds, st, C, Z, \
+                       npix, rc, D, Wc, K, G, Gpool, workspace)
     if (kp == 8) { if (Gpool) GX_FINISH(8, true); else GX_FINISH(8, false); }
     else         { if (Gpool) GX_FINISH(16, true); else GX_FINISH(16, false); }
 #undef GX_FINISH
