@@ -366,6 +366,45 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
     if (lane == 0) demod[idx] = scale * rsqrtf(scale * scale * a + 1e-8f);
 }
 
+// ---- all layers of a generator forward at once -----------------------------------------------
+// style_pick: S_all [B*n_latent][total] (every latent through every layer's affine, one GEMM) ->
+// packed per-layer styles: layer j occupies out[B*off_j .. B*(off_j+cin_j)) as [B][cin_j].
+// table rows: {latent index, column offset, cin}.
+__global__ void style_pick_kernel(const float* __restrict__ S_all, int B, int n_latent, int total,
+                                  const int* __restrict__ table, int nlayer, float* __restrict__ out) {
+    const long n = (long)B * total;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i enumerates the packed output: find the layer whose slab [B*off, B*(off+cin)) holds i
+        int j = 0;
+        while (j + 1 < nlayer && i >= (long)B * table[3 * (j + 1) + 1]) ++j;
+        const int idx = table[3 * j], off = table[3 * j + 1], cin = table[3 * j + 2];
+        const long r = i - (long)B * off;
+        const int b = (int)(r / cin), c = (int)(r - (long)b * cin);
+        out[i] = S_all[((long)b * n_latent + idx) * total + off + c];
+    }
+}
+// demod_batch: one wave per (layer, b, co).  table rows: {style offset (= column offset), cin, cout,
+// wsq offset, demod offset (in units of B rows: out index = B*doff + b*cout + co)}; scale[j] floats.
+__global__ void demod_batch_kernel(const float* __restrict__ s_packed, const float* __restrict__ wsq_all, int B,
+                                   const int* __restrict__ table, const float* __restrict__ scale, int nconv,
+                                   long total_waves, float* __restrict__ demod) {
+    const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= total_waves) return;
+    int j = 0;
+    while (j + 1 < nconv && w >= (long)B * table[5 * (j + 1) + 4]) ++j;
+    const int soff = table[5 * j], cin = table[5 * j + 1], cout = table[5 * j + 2], woff = table[5 * j + 3],
+              doff = table[5 * j + 4];
+    const long r = w - (long)B * doff;
+    const int b = (int)(r / cout), co = (int)(r - (long)b * cout), lane = threadIdx.x & 63;
+    const float* s = s_packed + (long)B * soff + (long)b * cin;
+    const float* wq = wsq_all + woff + (long)co * cin;
+    float a = 0.f;
+    for (int ci = lane; ci < cin; ci += 64) { const float sv = s[ci]; a = fmaf(sv * sv, wq[ci], a); }
+    a = gx_wave_sum(a);
+    const float sc = scale[j];
+    if (lane == 0) demod[w] = sc * rsqrtf(sc * sc * a + 1e-8f);
+}
+
 // Blur of the (2H+1)^2 transposed-conv image with pad (1,1) + StyledConv epilogue:
 //   out[b,y,x,c] = act( demod[b,c] * sum_{fy,fx} kf[fy][fx] * T[b, y+fy-1, x+fx-1, c] + nw*noise + bias[c] )
 // kf is the FLIPPED 4x4 FIR (upfirdn2d correlates with the flipped kernel, model.py:88).
@@ -608,6 +647,30 @@ int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float s
     if (!s || !wsq || !demod || B <= 0 || Cin <= 0 || Cout <= 0) return GX_ERR_BAD_ARG;
     hipLaunchKernelGGL(demod_kernel, dim3(gx_cdiv((long)B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, s, wsq, B,
                        Cin, Cout, scale, demod);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// Per-layer styles of one generator forward, gathered from the all-latents x all-layers affine GEMM.
+int gx_style_pick(const float* S_all, int B, int n_latent, int total, const int* table, int nlayer, float* out,
+                  void* stream) {
+    if (!S_all || !table || !out || B <= 0 || n_latent <= 0 || total <= 0 || nlayer <= 0) return GX_ERR_BAD_ARG;
+    const long n = (long)B * total;
+    long want = (n + 255) / 256;
+    hipLaunchKernelGGL(style_pick_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, S_all,
+                       B, n_latent, total, table, nlayer, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// demod' of every styled conv of one generator forward (gx_demod per layer, one launch).
+// total_rows = sum_j cout_j; demod holds B*total_rows floats, layer j at B*doff_j as [B][cout_j].
+int gx_demod_batch(const float* s_packed, const float* wsq_all, int B, const int* table, const float* scale, int nconv,
+                   int total_rows, float* demod, void* stream) {
+    if (!s_packed || !wsq_all || !table || !scale || !demod || B <= 0 || nconv <= 0 || total_rows <= 0)
+        return GX_ERR_BAD_ARG;
+    const long waves = (long)B * total_rows;
+    hipLaunchKernelGGL(demod_batch_kernel, dim3(gx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, s_packed, wsq_all,
+                       B, table, scale, nconv, waves, demod);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -30,6 +30,27 @@ __global__ void rotflip_map_kernel(int* __restrict__ map, int H, int W, float cs
     map[p] = src;
 }
 
+// The maps of a whole view batch in one launch: blockIdx.y = image, per-image (cos, sin, flip) by value.
+constexpr int RF_MAX = 64;
+struct RotFlipBatch { float cs[RF_MAX], sn[RF_MAX]; int flip[RF_MAX]; };
+__global__ void rotflip_map_batch_kernel(int* __restrict__ maps, int H, int W, RotFlipBatch rf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= H * W) return;
+    const float cs = rf.cs[b], sn = rf.sn[b];
+    const int y = p / W, x = p - y * W;
+    const int xr = rf.flip[b] ? (W - 1 - x) : x;
+    const float bx = (float)xr - 0.5f * (float)W + 0.5f;
+    const float by = (float)y - 0.5f * (float)H + 0.5f;
+    const float gxn = __fdiv_rn(__fadd_rn(__fmul_rn(bx, cs), __fmul_rn(by, sn)), 0.5f * (float)W);
+    const float gyn = __fdiv_rn(__fadd_rn(__fmul_rn(bx, -sn), __fmul_rn(by, cs)), 0.5f * (float)H);
+    const float ix = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(gxn, 1.f), (float)W), -1.f), 0.5f);
+    const float iy = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(gyn, 1.f), (float)H), -1.f), 0.5f);
+    const float rx = nearbyintf(ix), ry = nearbyintf(iy);
+    int src = -1;
+    if (rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1)) src = (int)ry * W + (int)rx;
+    maps[(long)b * H * W + p] = src;
+}
+
 // ===================================================================== S1 + S1b + S2: gather
 constexpr int MAX_TAPS = 16;
 struct TapList {
@@ -470,6 +491,23 @@ int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stre
     hipLaunchKernelGGL(rotflip_map_kernel, dim3(gx_cdiv((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                        map, H, W, cs, sn, flip);
     GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// maps [n][H*W]: image i rotated by angles_deg[i] (host array) then flipped if flips[i] (host array)
+int gx_rotflip_map_batch(const float* angles_deg, const int* flips, int n, int H, int W, int* maps, void* stream) {
+    if (!angles_deg || !flips || !maps || n <= 0 || H <= 0 || W <= 0) return GX_ERR_BAD_ARG;
+    for (int i0 = 0; i0 < n; i0 += RF_MAX) {
+        const int m = n - i0 < RF_MAX ? n - i0 : RF_MAX;
+        RotFlipBatch rf;
+        for (int i = 0; i < m; ++i) {
+            const double rot = -(double)angles_deg[i0 + i] * 3.14159265358979323846 / 180.0;
+            rf.cs[i] = (float)cos(rot); rf.sn[i] = (float)sin(rot); rf.flip[i] = flips[i0 + i] ? 1 : 0;
+        }
+        hipLaunchKernelGGL(rotflip_map_batch_kernel, dim3(gx_cdiv((long)H * W, 256), m), dim3(256), 0, (hipStream_t)stream,
+                           maps + (long)i0 * H * W, H, W, rf);
+        GX_CHECK_LAUNCH();
+    }
     return GX_OK;
 }
 

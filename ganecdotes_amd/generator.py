@@ -170,6 +170,41 @@ class Generator(nn.Module):
         for i, m in enumerate(self.to_rgbs):
             rgb(m, f"to_rgbs.{i}")
         d["const"] = self.input.input.detach().permute(0, 2, 3, 1).contiguous()     # (1,4,4,C)
+        # every layer's style affine as ONE GEMM (weights stacked along the output columns), and the
+        # per-layer slices / demod inputs as tables for gx_style_pick / gx_demod_batch
+        layers = [("conv1", self.conv1, 0, True), ("to_rgb1", self.to_rgb1, 1, False)]
+        i = 1
+        for blk in range(len(self.to_rgbs)):
+            layers.append((f"convs.{2 * blk}", self.convs[2 * blk], i, True))
+            layers.append((f"convs.{2 * blk + 1}", self.convs[2 * blk + 1], i + 1, True))
+            layers.append((f"to_rgbs.{blk}", self.to_rgbs[blk], i + 2, False))
+            i += 2
+        dev = self.input.input.device
+        ws, bs, pick, dtab, dscale, wsq = [], [], [], [], [], []
+        off = doff = woff = 0
+        for key, m, idx, styled in layers:
+            w = m.conv.modulation.weight.detach()
+            cin = w.shape[0]
+            ws.append(w); bs.append(m.conv.modulation.bias.detach())
+            pick += [idx, off, cin]
+            d[key + ".soff"] = (off, cin)
+            if styled:
+                cout = d[key + ".wsq"].shape[0]
+                dtab += [off, cin, cout, woff, doff]
+                dscale.append(d[key + ".scale"])
+                wsq.append(d[key + ".wsq"].reshape(-1))
+                d[key + ".doff"] = (doff, cout)
+                doff += cout; woff += cout * cin
+            off += cin
+        d["mod.W"] = torch.cat(ws).contiguous()
+        d["mod.b"] = torch.cat(bs).contiguous()
+        d["mod.pick"] = torch.tensor(pick, dtype=torch.int32, device=dev)
+        d["mod.nlayer"] = len(layers)
+        d["mod.dtab"] = torch.tensor(dtab, dtype=torch.int32, device=dev)
+        d["mod.dscale"] = torch.tensor(dscale, dtype=torch.float32, device=dev)
+        d["mod.wsq"] = torch.cat(wsq).contiguous()
+        d["mod.nconv"] = len(dscale)
+        d["mod.drows"] = doff
         self._derived = d
         return d
 
@@ -194,29 +229,41 @@ class Generator(nn.Module):
         return self.style(z)
 
     # ------------------------------------------------------------------ layers
-    def _affine(self, m, lat):
-        w = m.conv.modulation.weight.detach()
-        return ops.gemm(lat, w, False, True, alpha=1.0 / math.sqrt(w.shape[1]),
-                        col_bias=m.conv.modulation.bias.detach())
+    def _styles(self, latent, d):
+        """(packed styles, packed demod') of every layer for latent (B, n_latent, S): one GEMM of all
+        latents through all affines (EqualLinear, model.py:155-169 inside ModulatedConv2d :239), one
+        pick, one demod launch."""
+        bsz, nl, sd = latent.shape
+        s_all = ops.gemm(latent.reshape(bsz * nl, sd), d["mod.W"], False, True, alpha=1.0 / math.sqrt(sd),
+                         col_bias=d["mod.b"])
+        sp = ops.style_pick(s_all, bsz, nl, d["mod.pick"], d["mod.nlayer"])
+        dm = ops.demod_batch(sp, d["mod.wsq"], bsz, d["mod.dtab"], d["mod.dscale"], d["mod.nconv"], d["mod.drows"])
+        return sp, dm
 
-    def _styled(self, m, key, x, lat, noise, d):
-        s = self._affine(m, lat)
-        dm = ops.demod(s, d[key + ".wsq"], d[key + ".scale"])
+    @staticmethod
+    def _slab(packed, bsz, span):
+        off, n = span
+        return packed[bsz * off:bsz * (off + n)].view(bsz, n)
+
+    def _styled(self, m, key, x, sp, dmp, noise, d):
+        bsz = x.shape[0]
+        s = self._slab(sp, bsz, d[key + ".soff"])
+        dm = self._slab(dmp, bsz, d[key + ".doff"])
         nw = m.noise.weight.detach()
         b = m.activate.bias.detach()
         if m.upsample:
             return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True)
         return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True)
 
-    def _rgb(self, m, key, x, lat, skip, d):
-        s = self._affine(m, lat)
+    def _rgb(self, m, key, x, sp, skip, d):
+        s = self._slab(sp, x.shape[0], d[key + ".soff"])
         return ops.torgb(x, d[key + ".w3"], s, d[key + ".scale"], d[key + ".bias"], skip, d.get(key + ".kf"))
 
     def synthesis(self, latent, noise):
         """latent (B, n_latent, S) -> (image (B,3,size,size) or None, [NHWC taps])."""
         d = self._prepare()
         bsz = latent.shape[0]
-        lat = [latent[:, i].contiguous() for i in range(self.n_latent)]
+        sp, dmp = self._styles(latent.contiguous(), d)
 
         def nz(i, res):
             if noise[i] is None:
@@ -224,19 +271,17 @@ class Generator(nn.Module):
             return noise[i].contiguous()
 
         x = d["const"].expand(bsz, -1, -1, -1).contiguous()
-        x = self._styled(self.conv1, "conv1", x, lat[0], nz(0, 4), d)
+        x = self._styled(self.conv1, "conv1", x, sp, dmp, nz(0, 4), d)
         taps = [x]
-        skip = self._rgb(self.to_rgb1, "to_rgb1", x, lat[1], None, d) if self.want_image else None
-        i = 1
+        skip = self._rgb(self.to_rgb1, "to_rgb1", x, sp, None, d) if self.want_image else None
         for blk in range(len(self.to_rgbs)):
             res = 2 ** (blk + 3)
-            x = self._styled(self.convs[2 * blk], f"convs.{2 * blk}", x, lat[i], nz(2 * blk + 1, res), d)
+            x = self._styled(self.convs[2 * blk], f"convs.{2 * blk}", x, sp, dmp, nz(2 * blk + 1, res), d)
             taps.append(x)
-            x = self._styled(self.convs[2 * blk + 1], f"convs.{2 * blk + 1}", x, lat[i + 1], nz(2 * blk + 2, res), d)
+            x = self._styled(self.convs[2 * blk + 1], f"convs.{2 * blk + 1}", x, sp, dmp, nz(2 * blk + 2, res), d)
             taps.append(x)
             if self.want_image:
-                skip = self._rgb(self.to_rgbs[blk], f"to_rgbs.{blk}", x, lat[i + 2], skip, d)
-            i += 2
+                skip = self._rgb(self.to_rgbs[blk], f"to_rgbs.{blk}", x, sp, skip, d)
         return skip, taps
 
     # ------------------------------------------------------------------ reference call signature

@@ -303,6 +303,25 @@ def lerp_rows(w, base, psi):
     return out
 
 
+def style_pick(s_all, b, n_latent, table, nlayer):
+    """per-layer styles (packed: layer j at [b*off_j, b*(off_j+cin_j)) as (b, cin_j)) from the
+    all-latents x all-layers affine output s_all (b*n_latent, total)"""
+    _chk(s_all)
+    total = s_all.shape[1]
+    out = torch.empty(b * total, dtype=torch.float32, device=s_all.device)
+    _lib.check(lib().gx_style_pick(_p(s_all), b, n_latent, total, _p(table), nlayer, _p(out), _stream()), "gx_style_pick")
+    return out
+
+
+def demod_batch(s_packed, wsq_all, b, table, scale, nconv, total_rows):
+    """demod' of every styled conv of a forward in one launch (packed like style_pick's output)"""
+    _chk(s_packed, wsq_all, scale)
+    out = torch.empty(b * total_rows, dtype=torch.float32, device=s_packed.device)
+    _lib.check(lib().gx_demod_batch(_p(s_packed), _p(wsq_all), b, _p(table), _p(scale), nconv, total_rows, _p(out),
+                                    _stream()), "gx_demod_batch")
+    return out
+
+
 def demod(s, wsq, scale):
     _chk(s, wsq)
     b, cin = s.shape
@@ -390,6 +409,15 @@ def rotflip_map(angle_deg, flip, h, w, device, out=None):
     if out is None:
         out = torch.empty(h * w, dtype=torch.int32, device=device)
     _lib.check(lib().gx_rotflip_map(float(angle_deg), int(bool(flip)), h, w, _p(out), _stream()), "gx_rotflip_map")
+    return out
+
+
+def rotflip_map_batch(angles, flips, h, w, out):
+    """out (n, h*w) int32: one launch for the maps of a whole view batch (None angle = 0 degrees)"""
+    n = len(angles)
+    a = (ctypes.c_float * n)(*[float(x or 0.0) for x in angles])
+    f = (ctypes.c_int * n)(*[int(bool(x)) for x in flips])
+    _lib.check(lib().gx_rotflip_map_batch(a, f, n, h, w, _p(out), _stream()), "gx_rotflip_map_batch")
     return out
 
 

@@ -103,15 +103,17 @@ class ViewMixin(object):
         pb._keep = (df, di)
         return pb
 
-    def _view_latents(self, w, map_noise, mix):
+    def _view_latents(self, w, map_noise, mix, nw=None):
         """Latents of the feature-producing forward for a batch of images and ONE view each
         (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents;
-        map_noise (2B,S); mix (B, n_latent, 2) = sigma at the two perturbed latents:
-        lat[b, 2l+j] = (1-sigma) lat + sigma style(noise_j)."""
+        map_noise (2B,S) (or nw = its mapping, if the caller already has it); mix (B, n_latent, 2) =
+        sigma at the two perturbed latents:  lat[b, 2l+j] = (1-sigma) lat + sigma style(noise_j)."""
         n_latent = self.model.n_latent
         lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation))
         lat = lat.unsqueeze(1).repeat(1, n_latent, 1)
-        nw = self.model.style(map_noise).reshape(w.shape[0], 2, -1)
+        if nw is None:
+            nw = self.model.style(map_noise)
+        nw = nw.reshape(w.shape[0], 2, -1)
         keep = 1.0 - mix.sum(dim=2, keepdim=True)
         return lat * keep + torch.einsum('blj,bjs->bls', mix, nw)
 
@@ -120,10 +122,13 @@ class ViewMixin(object):
         per view (TapSet, maps or None, image)."""
         pb = self.prepare_batch(images)
         torch.cuda.current_stream().wait_event(pb.ready)
-        w = self.model.style(pb.z)
+        n = pb.n
+        # the latents and both views' perturbation noises go through the mapping network together
+        allw = self.model.style(torch.cat([pb.z, pb.map_noise[0], pb.map_noise[1]]))
+        w = allw[:n]
         out = []
         for v in range(2):
-            lat = self._view_latents(w, pb.map_noise[v], pb.mix[v])
+            lat = self._view_latents(w, None, pb.mix[v], nw=allw[n + 2 * n * v:n + 2 * n * (v + 1)])
             img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
                                     input_is_latent=True, randomize_noise=False)
             ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
@@ -131,8 +136,6 @@ class ViewMixin(object):
             if any(a is not None for a, _ in pb.xforms[v]):
                 hw = ts.size
                 maps = torch.empty(pb.n, hw * hw, dtype=torch.int32, device=self.device)
-                for b, (a, f) in enumerate(pb.xforms[v]):
-                    ops.rotflip_map(a or 0.0, f, hw, hw, self.device, out=maps[b])
+                ops.rotflip_map_batch([a for a, _ in pb.xforms[v]], [f for _, f in pb.xforms[v]], hw, hw, maps)
             out.append((ts, maps, img))
         return out
-

@@ -74,6 +74,14 @@ int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1
 int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream);
 int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream);
 int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream);
+/* One generator forward's per-layer work in single launches (the reference runs one EqualLinear per
+ * ModulatedConv2d, model.py:239-243): gx_style_pick gathers every layer's style from ONE affine GEMM
+ * of all latents x all layers; gx_demod_batch is gx_demod for all styled convs;
+ * table layouts: see csrc/gx_conv.hip. */
+int gx_style_pick(const float* S_all, int B, int n_latent, int total, const int* table, int nlayer, float* out,
+                  void* stream);
+int gx_demod_batch(const float* s_packed, const float* wsq_all, int B, const int* table, const float* scale, int nconv,
+                   int total_rows, float* demod, void* stream);
 int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float scale, float* demod, void* stream);
 size_t gx_modconv_slab_bytes(int B, int outH, int outW, int Cout);   /* optional split-K scratch (small layers) */
 int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
@@ -102,6 +110,8 @@ int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* str
  *                                                  swav_clustering.py:108-130, :160-167
  * gx_row_sumsq / gx_norm_map   per-pixel L2 norm map of the stack   swav_clustering.py:361-362 */
 int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stream);
+/* the maps of a whole view batch in one launch (angles / flips are host arrays of n entries) */
+int gx_rotflip_map_batch(const float* angles_deg, const int* flips, int n, int H, int W, int* maps, void* stream);
 int gx_gather_taps(int ntaps, const float* const* tap_ptrs /*host array of device ptrs*/, const int* tap_channels /*host*/,
                    const int* tap_res /*host*/, int B, int H, int W, int hlen, const int* picks, int rows_per_img,
                    const int* maps, float* X, long ldx, void* stream);
