@@ -1,6 +1,7 @@
 """The oracle (CPU restatement) against the golden vectors captured from the
 reference's own functions (tools/capture_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden_sd, load_golden
@@ -224,3 +225,37 @@ def test_gv12_simclr_trajectory_and_predict():
     preds, labels = C.predict_simclr_codes(sd, T(d["pred_w"]), ml, 0.7, p, 56)
     close(preds, d["preds"], rtol=1e-3, atol=1e-4)
     assert (labels.numpy() == d["labels"]).mean() > 0.99
+
+
+# ------------------------------------------------------------------------------------- GV13: one-shot head
+@pytest.mark.parametrize("size", ["XXS", "XS"])
+def test_oneshot_head_finetune_golden_gv13(size):
+    from oracle import oneshot_ref as O
+    d = load_golden("gv13_oneshot")
+    feats, labels = torch.from_numpy(d[f"{size}_feats"]), torch.from_numpy(d[f"{size}_labels"])
+    plan = O.segmentor_plan(size, 16, 5)
+    keys = sorted((k for k in d if k.startswith(f"{size}_init_")),
+                  key=lambda k: (int(k.split("layers.")[1].split(".")[0]), "bias" in k))
+    params = [torch.from_numpy(d[k]) for k in keys]
+    assert [tuple(p.shape) for p in params[::2]] == [(b, a, 3, 3) for a, b, _, _ in plan]
+    np.testing.assert_allclose(O.segmentor_forward(feats, params, plan).numpy(), d[f"{size}_out0"], rtol=1e-5, atol=1e-6)
+    losses, final = O.finetune(feats, labels, params, plan, epochs=len(d[f"{size}_losses"]), lr=float(d["lr"]),
+                               beta1=float(d["beta1"]), beta2=float(d["beta2"]), step_size=int(d["step_size"]),
+                               gamma=float(d["gamma"]))
+    np.testing.assert_allclose(losses, d[f"{size}_losses"], rtol=1e-5)
+    for k, p in zip(keys, final):
+        np.testing.assert_allclose(p.numpy(), d[k.replace("_init_", "_final_")], rtol=1e-4, atol=1e-6)
+    pred = O.segmentor_forward(feats, final, plan).max(1)[1].numpy()
+    assert (pred == d[f"{size}_pred"]).mean() > 0.995
+
+
+def test_iou_metrics_golden_gv13():
+    from oracle import oneshot_ref as O
+    d = load_golden("gv13_oneshot")
+    classes = ["background", "a", "b", "c"]
+    gt, pred = d["met_gt"], d["met_pred"]
+    mi = {c: O.mask_iou(gt, pred, i) for i, c in enumerate(classes)}
+    np.testing.assert_allclose([mi[c] for c in classes], d["met_mask_iou"], rtol=1e-12)
+    np.testing.assert_allclose(O.weighted_iou(gt, mi, classes), float(d["met_w_iou"]), rtol=1e-12)
+    np.testing.assert_allclose(O.bin_iou(gt, pred), float(d["met_bin_iou"]), rtol=1e-12)
+    assert O.mask_iou(np.zeros((4, 4)), np.zeros((4, 4)), 3) == float(d["met_empty_iou"]) == 0
