@@ -20,6 +20,13 @@ c_sz = ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol of include/ganecdotes_hip.h
 SIGNATURES = {
+    "gx_head_pad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "gx_head_act_mask": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "gx_head_act_mask_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "gx_head_softmax_ce": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_head_adam": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "gx_head_argmax": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "gx_confusion": (c_i, [c_p, c_p, c_l, c_i, c_p, c_p]),
     "gx_version": (ctypes.c_char_p, []),
     "gx_set_gemm_mode": (c_i, [c_i]),
     "gx_get_gemm_mode": (c_i, []),

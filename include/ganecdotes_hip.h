@@ -32,6 +32,23 @@ extern "C" {
 #define GX_ERR_WORKSPACE (-3)
 #define GX_ERR_LAUNCH (-4)
 
+/* ---- one-shot fine-tune head and its scoring (SURVEY.md par. 8f rank 1) -------------------------
+ * OneShotSegmentor (hfc_with_swav/swav_clustering.py:697-758) trained by OneShotPipeline.run_trainer
+ * (src/one_shot_pipeline.py:533-581) and scored by run_tests (:595-886) + lib/metrics/segmentation.py.
+ * Activations are zero-padded flat NHWC [B][H+2P][W+2P][C] (P = largest dilation): a dilated 3x3 tap is
+ * a row shift, so conv forward / dW / dX are nine gx_gemm_f32 calls each on row-offset views; these
+ * entry points are the glue: padding, bias-activation-mask and its backward, nn.CrossEntropyLoss + its
+ * gradient (softmax_ce workspace: 1024 floats), torch.optim.Adam, argmax, confusion matrix [C][C]. */
+int gx_head_pad(const float* in, int B, int H, int W, int C, int P, float* out, void* stream);
+int gx_head_act_mask(float* y, int B, int H, int W, int C, int P, int act, void* stream);
+int gx_head_act_mask_bwd(float* dy, const float* y, int B, int H, int W, int C, int P, int act, void* stream);
+int gx_head_softmax_ce(const float* logits, const long long* labels, int B, int H, int W, int C, int P, float* dlogits,
+                       float* loss_out, float* workspace, size_t workspace_bytes, void* stream);
+int gx_head_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 int step, void* stream);
+int gx_head_argmax(const float* logits, int B, int H, int W, int C, int P, long long* pred, void* stream);
+int gx_confusion(const long long* gt, const long long* pred, long n, int C, unsigned long long* conf, void* stream);
+
 const char* gx_version(void);
 
 /* ---- dense fp32-MFMA GEMM -------------------------------------------------------------------

@@ -1,12 +1,14 @@
 """Slim orchestrator with the reference's contract (src/one_shot_pipeline.py:33-465):
 `OneShotPipeline(out_dir, exp_name, model, segmentor, trainer, tester, mode, inputs, custom,
 device, num_test_samples)`, `load_model`, `load_segmentor`, `load_trainer`,
-`run_pipeline(blocks_to_run)`.  It drives ONLY the accelerated path: generator load,
-`preprocessor.preprocess` (SwAV pretrain) and `predict_swav_codes`; the one-shot fine-tune,
-IoU test loop, plotting and the GUI are outside this build (SURVEY.md par. 8f).
+`run_pipeline(blocks_to_run)`, `run_trainer`, `run_tests`.  It drives the accelerated path: generator
+load, `preprocessor.preprocess` (SwAV pretrain), `predict_swav_codes`, the one-shot fine-tune of the
+head (`run_trainer`, reference :466-581) and the IoU test loop (`run_tests`, :595-886) — all on HIP
+(ganecdotes_amd/oneshot.py).  Plotting, tensorboard images and the labelling GUI are outside this build.
 
-`synthetic=True` (opt-in extra): random-init generator under seed 42 and random latents,
-because no checkpoints / latents / labels exist offline (reference: checkpoints/ is empty).
+`synthetic=True` (opt-in extra): random-init generator under seed 42, random latents and a synthetic
+label partition, because no checkpoints / latents / labels exist offline (reference: checkpoints/ is
+empty) — the loop is exercised, the IoU numbers mean nothing.
 """
 import os
 import time
@@ -86,19 +88,58 @@ class OneShotPipeline(object):
         self.trainer_config = load_config(self.configs['trainer'], 'trainer_config')
 
     # -------------------------------------------------------------------------
-    def run_pipeline(self, blocks_to_run=('setup', 'train')):
+    def _load_samples(self):
+        """test latents / labels (src/one_shot_pipeline.py:356-384): `latents.pt` is either a tensor or a
+        (latents, noises) tuple; labels may be a numpy array, are scaled by 255 when stored in [0, 1), and
+        LSUN-car labels (384 rows) are centred in a square canvas."""
+        if self.synthetic:
+            n = (self.num_test_samples or 4) + 1
+            torch.manual_seed(1234)
+            self.test_latents = self.model.style(torch.randn(n, self.model_config.latent_dim, device=self.device))
+            size, k = self.model.size, len(self.model_config.classes)
+            yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+            lab = ((xx * k) // size + (yy * k) // size) % k              # synthetic partition: NOT ground truth
+            self.test_labels = lab.unsqueeze(0).repeat(n, 1, 1).float()
+            self.one_shot_ind = 0
+            return
+        lat = torch.load(self.model_config.sample_latents)
+        self.test_latents = (lat[0] if isinstance(lat, (tuple, list)) else lat).to(self.device)
+        lab = torch.load(self.model_config.sample_labels)
+        if not isinstance(lab, torch.Tensor):
+            lab = torch.from_numpy(lab)
+        if lab.max() < 1:
+            lab = lab * 255
+        if self.model_str.find('p-car') != -1:
+            full = torch.zeros(lab.shape[0], lab.shape[2], lab.shape[2])
+            full[:, 256 - 192:256 + 192, :] = lab.clone()
+            lab = full
+        self.test_labels = lab
+        self.one_shot_ind = self.model_config.one_shot_ind
+
+    def _resize_labels(self, lab, size):
+        """transforms.Resize(image_size, interpolation=NEAREST) of the reference (:562-563), as an index"""
+        if lab.shape[-1] == size and lab.shape[-2] == size:
+            return lab
+        return torch.nn.functional.interpolate(lab[:, None].float(), size=(size, size), mode="nearest")[:, 0]
+
+    def run_pipeline(self, blocks_to_run=('setup', 'train', 'test')):
         if 'setup' in blocks_to_run:
-            if self.synthetic:
-                z = torch.randn(1, self.model_config.latent_dim).to(self.device)
-                self.one_shot_latent = self.model.style(z)
-            else:
-                lat = torch.load(self.model_config.sample_latents)
-                lat = lat[0] if isinstance(lat, tuple) else lat
-                self.one_shot_latent = lat[self.model_config.one_shot_ind].to(self.device)
+            self._load_samples()
+            ind = self.one_shot_ind
+            self.one_shot_latent = self.test_latents[ind]
+            self.one_shot_label = self.test_labels[ind:ind + 1]
+            if self.num_test_samples is None:
+                self.num_test_samples = self.test_latents.shape[0]
+            self.num_test_samples = min(self.num_test_samples, self.test_latents.shape[0])
         if 'train' in blocks_to_run:
             self.run_trainer()
+        if 'test' in blocks_to_run:
+            self.run_tests()
 
     def run_trainer(self):
+        """(:466-581) pretrain / load the clustering model, take the code map of the labelled latent and
+        fine-tune the head on it with the trainer config (Adam + CrossEntropyLoss, StepLR per epoch)."""
+        from ganecdotes_amd.oneshot import OneShotHead
         kw = dict(self.seg_config.hfc_prep_args)
         self.preprocessor = self.preprocessor(model=self.model, model_config=self.model_config,
                                               out_dir=self.out_dir, logger=self.logger,
@@ -106,8 +147,41 @@ class OneShotPipeline(object):
                                               **({'dist_group': self.dist_group} if self.dist_group else {}), **kw)
         if self.seg_config.train_hfc:
             self.preprocessor.preprocess(self.one_shot_latent)
-        predict = getattr(self.preprocessor, 'predict_swav_codes', None) or self.preprocessor.predict_simclr_codes
-        self.one_shot_features, self.one_shot_clusters = predict(self.one_shot_latent.reshape(1, -1))
+        self._predict = getattr(self.preprocessor, 'predict_swav_codes', None) or self.preprocessor.predict_simclr_codes
+        self.one_shot_features, self.one_shot_clusters = self._predict(self.one_shot_latent.reshape(1, -1))
+        self.one_shot_features = self.one_shot_features.detach().clone()
         torch.save(self.one_shot_clusters.cpu(), os.path.join(self.out_dir, 'cluster_map.pt'))
-        self.logger.info(f"cluster map {tuple(self.one_shot_clusters.shape)} saved; one-shot fine-tune / IoU "
-                         f"test loop are not part of this build")
+        tc = self.trainer_config
+        self.head = OneShotHead(**self.seg_config.seg_args, n_class=len(self.model_config.classes), device=self.device)
+        size = self.one_shot_features.shape[-1]
+        label = self._resize_labels(self.one_shot_label, size).to(self.device, torch.long)
+        t0 = time.time()
+        self.head_losses = self.head.fit(self.one_shot_features.permute(0, 2, 3, 1), label, num_epochs=tc.num_epochs,
+                                         lr=tc.lr, beta1=tc.beta1, beta2=tc.beta2, **tc.scheduler_args,
+                                         print_freq=tc.print_freq, logger=self.logger)
+        self.segmentor = self.head.to_module()          # the torch module the reference keeps (and moves to CPU, :610)
+        self.logger.info(f'******* Training Complete ({time.time() - t0:.1f}s, final loss {self.head_losses[-1]:.4f}) ********')
+
+    def run_tests(self):
+        """(:595-886) predictions of the fine-tuned head on the test latents, label_predictions.pt and the
+        IoU block (per-class mask IoU, area-weighted IoU, binary IoU)."""
+        from ganecdotes_amd.oneshot import run_tests
+
+        class _Prep:                                    # run_tests only needs predict_swav_codes-shaped access
+            predict_swav_codes = staticmethod(lambda lat: self._predict(lat))
+        n = self.num_test_samples
+        self.test_dir = os.path.join(self.out_dir, 'tests')
+        os.makedirs(self.test_dir, exist_ok=True)
+        size = self.one_shot_features.shape[-1]
+        labels = self._resize_labels(self.test_labels[:n], size)
+        pred, self.results = run_tests(_Prep, self.head, self.test_latents[:n], labels, self.model_config.classes)
+        torch.save(pred, os.path.join(self.test_dir, 'label_predictions.pt'))
+        classes = self.model_config.classes
+        mean_iou = {c: float(sum(m[c] for m in self.results['mask_iou']) / n) for c in classes}
+        self.results['mean_mask_iou'] = mean_iou
+        self.results['mIoU'] = float(sum(mean_iou.values()) / len(classes))
+        self.logger.info(f"mask IoU per class: {mean_iou}")
+        self.logger.info(f"mIoU {self.results['mIoU']:.4f} | weighted IoU {sum(self.results['w_iou']) / n:.4f} | "
+                         f"binary IoU (last sample) {self.results['bin_iou']:.4f}"
+                         + ("   [synthetic labels: not a quality measure]" if self.synthetic else ""))
+        return self.results
