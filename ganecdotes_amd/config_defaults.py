@@ -60,12 +60,15 @@ def stylegan_model(subdir, ckpt, classes, one_shot_ind=0, image_size=256, latent
                 sample_images=ldir + "/images/", one_shot_ind=one_shot_ind, classes=list(classes))
 
 
-def baggan_model(subdir, classes, one_shot_ind=0):
-    """pidray-* models use the BagGAN generator, which is outside this build (SURVEY par. 8f rank 3):
-    the config exists so the registry is complete; loading it raises NotImplementedError."""
+def baggan_model(subdir, classes, one_shot_ind=0, truncation=0.95):
+    """pidray-* models: the BagGAN generator (ganecdotes_amd/baggan.py).  `model_path` is where the
+    reference's BagGANHQ finds the generator (models/baggan/config/config_pidray_unlabeled.py:12-28, load_epoch
+    740: `G_net_e_740_i_0.pth`); `gen_args` are its generator_params (:80-86)."""
     base = ROOT_DIR + "/checkpoints/baggan/" + subdir
     return dict(config_path=ROOT_DIR + "/models/baggan/config/config_pidray_unlabeled.py",
-                num_latents_for_mean=4096, truncation=0.7, image_size=256, latent_dim=512, is_baggan=True,
-                gen_args=dict(size=256, style_dim=512, n_mlp=8),
+                model_path=ROOT_DIR + "/checkpoints/baggan/pidray_baggan_presaved/models/expt_v4.0.1/G_net_e_740_i_0.pth",
+                num_latents_for_mean=4096, truncation=truncation, image_size=256, latent_dim=512, is_baggan=True,
+                gen_args=dict(latent_dims=(512, 512), img_resolution=256, mlp_layers=8, mlp_lr=0.01, img_chls=3,
+                              fir_filter=[1, 3, 3, 1], res2chlmap=None),
                 sample_latents=base + "/latents.pt", sample_labels=base + "/labels.pt",
                 sample_images=base + "/images/", one_shot_ind=one_shot_ind, classes=list(classes))

@@ -53,12 +53,13 @@ class OneShotPipeline(object):
     # -------------------------------------------------------------------------
     def load_model(self):
         self.model_config = load_config(self.configs['model'], 'model_config')
-        if self.model_config.is_baggan:
-            raise NotImplementedError("BagGAN (pidray-*) generators are outside this build (SURVEY.md par. 8f)")
-        self.model = Generator(**self.model_config.gen_args)
+        gen_cls = Generator
+        if self.model_config.is_baggan:               # pidray-*: BagGANHQ(...).generator.module (reference :150-154)
+            from models.baggan.models import StyleGANGenerator as gen_cls
+        self.model = gen_cls(**self.model_config.gen_args)
         if self.synthetic:
             torch.manual_seed(42)
-            self.model = Generator(**self.model_config.gen_args)
+            self.model = gen_cls(**self.model_config.gen_args)
             for n, p in self.model.named_parameters():
                 if n.endswith("noise.weight"):
                     p.data.fill_(0.1)

@@ -109,6 +109,28 @@ def test_generator_full_width_vs_oracle(gpu):
         assert rel(a, b) < 5e-5
 
 
+def test_baggan_generator_golden_gv14(gpu):
+    """pidray-* models: the reference BagGAN StyleGANGenerator's mapping, image and
+    7 feature taps, loaded from its own state_dict through the key translation"""
+    from models.baggan.models import StyleGANGenerator
+    d = load_golden("gv14_baggan")
+    ref = {k[3:]: T(v) for k, v in d.items() if k.startswith("sd_")}
+    g = StyleGANGenerator(latent_dims=(16, 16), img_resolution=32, mlp_layers=2, _channels={4: 16, 8: 16, 16: 8, 32: 8})
+    g.load_state_dict(ref)
+    g = g.eval().to(gpu)
+    w, ml = T(d["w"]).cuda(), T(d["mean_latent"]).cuda()
+    assert rel(g.style(T(d["z"]).cuda()), T(d["w"])) < 1e-5
+    img, taps = g([w], truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+    assert rel(img, T(d["img"])) < 2e-5
+    assert len(taps) == 7
+    for i, t in enumerate(taps):
+        assert rel(t, T(d[f"tap_{i}"])) < 2e-5, i
+    imgz, tapsz = g([T(d["z"]).cuda()], randomize_noise=False, truncation_latent=ml)
+    assert rel(imgz, T(d["img_z"])) < 2e-5 and rel(tapsz[-1], T(d["tap_z_last"])) < 2e-5
+    _, lat = g([w], return_latents=True, truncation=0.7, truncation_latent=ml, input_is_latent=True)
+    assert rel(lat, T(d["latent"])) < 1e-6
+
+
 # ------------------------------------------------------------------------------------- views
 def test_views_golden_gv9(gpu, tmp_path):
     from ganecdotes_amd.draws import ImageDraws, ViewDraws

@@ -127,3 +127,26 @@ def test_plugin_exports_and_generator_state_dict_keys():
     seg = base.segmentor(512, 8, 'XXS')
     assert [type(l).__name__ for l in seg.layers] == ['Conv2d']
     assert len(base.segmentor(512, 8, 'XS').layers) == 5
+
+
+def test_baggan_generator_speaks_the_reference_keys():
+    """pidray-* models: state_dict keys of the HIP BagGAN generator == the reference StyleGANGenerator's
+    (GV14 fixture), checkpoints round-trip through the key translation, and the pidray configs build it."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from models.baggan.models import StyleGANGenerator
+    d = load_golden("gv14_baggan")
+    ref = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd_")}
+    g = StyleGANGenerator(latent_dims=(16, 16), img_resolution=32, mlp_layers=2, _channels={4: 16, 8: 16, 16: 8, 32: 8})
+    assert set(g.state_dict().keys()) == set(ref.keys())
+    res = g.load_state_dict(ref)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in g.state_dict().items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+        np.testing.assert_array_equal(v.numpy(), ref[k].numpy())
+    from configs import mapper
+    from lib.util.util import load_config
+    m = load_config(mapper.models['pidray-256'], 'model_config')
+    assert m.is_baggan and m.truncation == 0.9 and m.gen_args['img_resolution'] == 256
+    assert load_config(mapper.models['pidray-hammer-256'], 'model_config').truncation == 0.95

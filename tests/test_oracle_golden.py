@@ -259,3 +259,23 @@ def test_iou_metrics_golden_gv13():
     np.testing.assert_allclose(O.weighted_iou(gt, mi, classes), float(d["met_w_iou"]), rtol=1e-12)
     np.testing.assert_allclose(O.bin_iou(gt, pred), float(d["met_bin_iou"]), rtol=1e-12)
     assert O.mask_iou(np.zeros((4, 4)), np.zeros((4, 4)), 3) == float(d["met_empty_iou"]) == 0
+
+
+# ------------------------------------------------------------------------------------- GV14: BagGAN generator
+def test_baggan_generator_golden_gv14():
+    from oracle import baggan_ref as B
+    d = load_golden("gv14_baggan")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd_")}
+    z, w, ml = (torch.from_numpy(d[k]) for k in ("z", "w", "mean_latent"))
+    with torch.no_grad():
+        np.testing.assert_allclose(B.mapping(z, sd).numpy(), d["w"], rtol=1e-5, atol=1e-6)
+        img, taps, lat = B.generator_forward(w, sd, truncation=0.7, truncation_latent=ml, input_is_latent=True)
+    np.testing.assert_allclose(img.numpy(), d["img"], rtol=1e-4, atol=1e-5)
+    assert len(taps) == 7
+    for i, t in enumerate(taps):
+        np.testing.assert_allclose(t.numpy(), d[f"tap_{i}"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lat.numpy(), d["latent"], rtol=1e-6)
+    with torch.no_grad():
+        imgz, tapsz, _ = B.generator_forward(z, sd)
+    np.testing.assert_allclose(imgz.numpy(), d["img_z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tapsz[-1].numpy(), d["tap_z_last"], rtol=1e-4, atol=1e-5)

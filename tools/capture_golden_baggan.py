@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GV14: golden vectors for the BagGAN generator forward (pidray-* models).
+
+Runs only in the build container; imports the reference's models/baggan/models.py at run time and
+writes plain arrays.  The reference's StyleGANGenerator always takes its widths from the module global
+DEFAULT_RES_TO_CHANNEL_MAP (a passed res2chlmap is ignored by its constructor, models.py:121-122), so
+the capture process shrinks that global — in memory, for this run only — to get a fixture-sized model:
+{4: 16, 8: 16, 16: 8, 32: 8}.  Captured: the state_dict (reference key names), mapping output, and
+image + 7 feature taps for (a) W latents with truncation and registered noise, (b) Z latents.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from capture_golden import REF, _install_placeholders, _np   # noqa: E402
+
+
+def main():
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    _install_placeholders()
+    sys.path.insert(0, REF)
+    import matplotlib
+    matplotlib.use("agg")
+    import torch
+    torch.set_num_threads(4)
+    from models.baggan import models as BM
+    BM.DEFAULT_RES_TO_CHANNEL_MAP = {4: 16, 8: 16, 16: 8, 32: 8}
+    torch.manual_seed(1400)
+    g = BM.StyleGANGenerator(latent_dims=(16, 16), img_resolution=32, mlp_layers=2, mlp_lr=0.01, img_chls=1,
+                             fir_filter=[1, 3, 3, 1], res2chlmap=None).eval()
+    with torch.no_grad():
+        for n, p in g.named_parameters():        # exercise the paths whose init is zero / one
+            if n.endswith("noise_block.weight"):
+                p.fill_(0.1)
+            if n.endswith("activation.bias") or n.endswith("x_to_img_init.bias") or ".bias" in n and "x_to_img" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    arrs = {f"sd_{k}": _np(v) for k, v in g.state_dict().items()}
+    torch.manual_seed(1401)
+    z = torch.randn(2, 16)
+    with torch.no_grad():
+        w = g.style(z)
+        ml = g.mean_latent(64)
+        img, feats = g([w], truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+        arrs.update(z=_np(z), w=_np(w), mean_latent=_np(ml), img=_np(img))
+        for i, f in enumerate(feats):
+            arrs[f"tap_{i}"] = _np(f)
+        imgz, featsz = g([z], randomize_noise=False, truncation_latent=ml)
+        arrs["img_z"] = _np(imgz)
+        arrs["tap_z_last"] = _np(featsz[-1])
+        _, lat = g([w], return_latents=True, truncation=0.7, truncation_latent=ml, input_is_latent=True,
+                   randomize_noise=False)
+        arrs["latent"] = _np(lat)
+    path = os.path.join(out_dir, "gv14_baggan.npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, len(arrs), "arrays;", sorted(k for k in arrs if k.startswith("sd_"))[:60])
+
+
+if __name__ == "__main__":
+    main()
