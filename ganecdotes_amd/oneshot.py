@@ -89,7 +89,8 @@ class OneShotHead:
     def _range(self, rows, s):
         """row range [lo, hi) the GEMMs run over: it covers every row whose taps stay in the buffer,
         [s, rows - s), widened to multiples of 4 rows (16-B vector loads of the m-contiguous GEMM
-        operands); the few extra rows are border rows (masked to zero) and read at most 3 guard rows."""
+        operands); the few extra rows are border rows (masked to zero), read at most 3 guard rows and
+        never reach past the buffer (hi <= rows - s + 3 <= rows because s >= 3)."""
         lo = s & ~3
         hi = lo + ((rows - s - lo + 3) & ~3)
         return lo, hi
@@ -125,8 +126,6 @@ class OneShotHead:
                 ops.gemm(x[g + lo + sh:g + hi + sh], self.W[i][tap], False, True, out=yst[g + lo:g + hi],
                          beta=0.0 if tap == 0 else 1.0, col_bias=self.b[i] if tap == 0 else None)
             _lib.check(lib().gx_head_act_mask(_p(y), b, h, w, cout, self.P, int(act), _stream()), "gx_head_act_mask")
-            if hi > rows:
-                yst[g + rows:].zero_()           # rows past the image written by the widened range
             acts.append((yst, y))
             x = yst
         return acts
@@ -145,8 +144,6 @@ class OneShotHead:
             if i != len(self.plan) - 1:          # through the LeakyReLU + border mask that follow layer i
                 _lib.check(lib().gx_head_act_mask_bwd(_p(dy), _p(acts[i][1]), b, h, w, cout, self.P, int(act), _stream()),
                            "gx_head_act_mask_bwd")
-                if hi > rows:
-                    dyst[g + rows:].zero_()
             dw = torch.empty(9, cout, cin, dtype=torch.float32, device=self.device)
             split = int(max(1, min(256, (hi - lo) // 2048)))
             for tap in range(9):
