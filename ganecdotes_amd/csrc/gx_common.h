@@ -23,23 +23,51 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int gx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Cross-lane exchange inside a row of 16 lanes by DPP (one VALU instruction, no LDS round trip, unlike
+// ds_bpermute behind __shfl_xor).  For a commutative reduction any pairing that joins two already
+// reduced, disjoint groups will do: xor 1 and xor 2 are quad permutes, the 8-lane step pairs lane i
+// with 7 - i (row_half_mirror) and the 16-lane step lane i with 15 - i (row_mirror).
+template <int CTRL>
+__device__ __forceinline__ float gx_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int GX_DPP_XOR1 = 0xB1, GX_DPP_XOR2 = 0x4E, GX_DPP_HALF_MIRROR = 0x141, GX_DPP_MIRROR = 0x140;
+
 __device__ __forceinline__ float gx_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += gx_dpp<GX_DPP_XOR1>(v);
+    v += gx_dpp<GX_DPP_XOR2>(v);
+    v += gx_dpp<GX_DPP_HALF_MIRROR>(v);
+    v += gx_dpp<GX_DPP_MIRROR>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float gx_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, gx_dpp<GX_DPP_XOR1>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_XOR2>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_MIRROR>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
-// reductions over a power-of-two team of consecutive lanes (team <= 64)
+// reductions over a power-of-two team of consecutive lanes (team <= 64); every lane gets the result
 __device__ __forceinline__ float gx_team_sum(float v, int team) {
-    for (int o = team >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (team >= 2) v += gx_dpp<GX_DPP_XOR1>(v);
+    if (team >= 4) v += gx_dpp<GX_DPP_XOR2>(v);
+    if (team >= 8) v += gx_dpp<GX_DPP_HALF_MIRROR>(v);
+    if (team >= 16) v += gx_dpp<GX_DPP_MIRROR>(v);
+    if (team >= 32) v += __shfl_xor(v, 16, 64);
+    if (team >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float gx_team_max(float v, int team) {
-    for (int o = team >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (team >= 2) v = fmaxf(v, gx_dpp<GX_DPP_XOR1>(v));
+    if (team >= 4) v = fmaxf(v, gx_dpp<GX_DPP_XOR2>(v));
+    if (team >= 8) v = fmaxf(v, gx_dpp<GX_DPP_HALF_MIRROR>(v));
+    if (team >= 16) v = fmaxf(v, gx_dpp<GX_DPP_MIRROR>(v));
+    if (team >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (team >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
