@@ -56,6 +56,11 @@ SIGNATURES = {
     "gx_rotflip_map_batch": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_demod": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "gx_modconv_slab_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gx_conv_weight_planes_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gx_split_conv_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "gx_modconv_fwd_p": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_sz,
+                               c_p]),
+    "gx_modconv_up_convt_p": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gx_modconv_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_sz,
                              c_p]),
     "gx_modconv_up_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

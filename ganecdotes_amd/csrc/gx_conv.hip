@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 extern "C" int gx_get_gemm_mode(void);      // gx_gemm.hip: 0 = exact-fp32 MFMA, 1 = bf16x6
+extern "C" size_t gx_conv_weight_planes_bytes(int taps, int Cout, int Cin);
 
 namespace gx {
 
@@ -30,6 +31,8 @@ struct ConvSub {                               // one implicit-GEMM sub-problem 
 struct ConvArgs {
     const float* in; int B, IH, IW, Cin;      // NHWC input
     const float* wt;                           // [9 or 1][Cout][Cin]
+    const unsigned short* wtp;                 // optional pre-split weights (gx_split_conv_weights), bf16x6 engine
+    int wtp_ncc; unsigned wtp_bytes;           // 16-channel chunks per (tap, Cout tile); extent for the buffer descriptor
     const float* style;                        // [B][Cin] modulation or nullptr
     int nsub; ConvSub sub[4];                  // 1 (plain conv) or 4 (parity classes of the stride-2 transposed conv)
     float* out; int outH, outW, Cout;          // NHWC output tensor
@@ -190,7 +193,9 @@ __device__ __forceinline__ void conv_mainloop(const ConvArgs& g, const ConvSub& 
 // The same main loop on the bf16 matrix cores (gx_mfma_x6.h): 16-channel chunks, the thread stages
 // rows (tid >> 2) + 64 i (i < 2) of the pixel tile and of the weight tile, channels 4 (tid & 3) .. +3;
 // the modulated activation and the weight are split into three bf16 planes on their way into LDS.
-template <bool VEC, int NT>
+// WP: the weight tile comes pre-split (three bf16 planes in HBM, made once per model by gx_split_bf16x3):
+// a thread copies 16 B per plane straight into the LDS image (row tid >> 1, half tid & 1), no arithmetic.
+template <bool VEC, int NT, bool WP>
 __device__ __forceinline__ void conv_mainloop_x6(const ConvArgs& g, const ConvSub& sb, char* lds, f32x16 (&acc)[2][2],
                                                  const long (&pix_off)[4], const int (&soff)[4],
                                                  const unsigned (&tapmask)[4], int n0, int cc0, int ncc, int tid,
@@ -198,6 +203,10 @@ __device__ __forceinline__ void conv_mainloop_x6(const ConvArgs& g, const ConvSu
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(g.in, VEC ? g.in_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_st = make_rsrc(g.style ? g.style : g.in, (VEC && g.style) ? g.style_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(g.wt, VEC ? g.wt_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(reinterpret_cast<const float*>(g.wtp ? (const void*)g.wtp : (const void*)g.wt),
+                                                   WP ? g.wtp_bytes : 0u);
+    const int wp_ntn = (g.Cout + 127) >> 7;
+    u32x4 rwp[3];
     const int kq = (tid & 3) * 4;
     long toff[NT], wb[NT];
 #pragma unroll
@@ -227,17 +236,31 @@ __device__ __forceinline__ void conv_mainloop_x6(const ConvArgs& g, const ConvSu
             const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
             if (VEC) ra[i] = buf_load4(rs_in, (unsigned)((pix_off[i] + to + ci) * 4) | oob_mask(ok));
             else ra[i] = ok ? load4(g.in + pix_off[i] + to + ci, g.Cin - ci, false) : zero4();
+            if (WP) continue;
             const long wo = wbt + (long)(n0 + (tid >> 2) + 64 * i) * g.Cin + ci;
             const bool wok = rowok[i] && cok;
             if (VEC) rw[i] = buf_load4(rs_wt, (unsigned)(wo * 4) | oob_mask(wok));
             else rw[i] = wok ? load4(g.wt + wo, g.Cin - ci, false) : zero4();
+        }
+        if (WP) {      // block (tap, Cout tile, chunk): 3 planes x 4 KB, copied linearly
+            const unsigned blk = (unsigned)(((sb.tw[tap] * wp_ntn + (n0 >> 7)) * g.wtp_ncc + cc) * 3) * 4096u;
+            const unsigned m = oob_mask(cc < g.wtp_ncc);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rwp[p] = __builtin_bit_cast(u32x4, buf_load4(rs_wp, (blk + p * 4096u + (unsigned)tid * 16u) | m));
         }
     };
     auto stage = [&](char* dst) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) ra[i] *= st[i];
         x6_store_tile<true>(dst, ra, tid);
-        x6_store_tile<true>(dst + X_TILE_BYTES, rw, tid);
+        if (WP) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<u32x4*>(dst + X_TILE_BYTES + p * XImg<128>::KC_PLANE + tid * 16) = rwp[p];
+        } else {
+            x6_store_tile<true>(dst + X_TILE_BYTES, rw, tid);
+        }
     };
 
     if (ncc > 0) {
@@ -318,7 +341,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
     zero_acc(acc);
 #define GX_CONV_LOOP(NT_)                                                                                       \
     do {                                                                                                      \
-        if (X6) conv_mainloop_x6<VEC, NT_>(g, sb, lds_raw, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); \
+        if (X6 && VEC && g.wtp) conv_mainloop_x6<VEC, NT_, true>(g, sb, lds_raw, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); \
+        else if (X6) conv_mainloop_x6<VEC, NT_, false>(g, sb, lds_raw, acc, pix_off, soff, tapmask, n0, cc0, ncc, tid, wr, wc, lane); \
         else conv_mainloop<VEC, NT_>(g, sb, reinterpret_cast<float*>(lds_raw), acc, pix_off, soff, tapmask, n0, cc0,  \
                                      ncc, tid, wr, wc, lane);                                                 \
     } while (0)
@@ -364,6 +388,30 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
     for (int ci = lane; ci < Cin; ci += 64) { const float sv = s[(long)b * Cin + ci]; a = fmaf(sv * sv, wsq[(long)co * Cin + ci], a); }
     a = gx_wave_sum(a);
     if (lane == 0) demod[idx] = scale * rsqrtf(scale * scale * a + 1e-8f);
+}
+
+// Pre-split conv weights for the bf16x6 engine, stored in the order the kernel consumes them: for every
+// (tap, 128-row Cout tile, 16-channel chunk) one 12 KB block = the three bf16 planes (h, m, l with
+// w = h + m + l exactly) of that weight tile, each plane already in the LDS image layout (32-B rows with
+// the half-swap swizzle).  A workgroup copies a block linearly: thread t moves bytes [16 t, 16 t + 16) of each plane.
+__global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps, int Cout, int Cin, int ntn, int ncc,
+                                          unsigned short* __restrict__ planes) {
+    const long total = (long)taps * ntn * ncc * 128 * 16;          // padded element count
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
+        long blk = i >> 11;
+        const int cc = (int)(blk % ncc); blk /= ncc;
+        const int tn = (int)(blk % ntn); const int tap = (int)(blk / ntn);
+        const int co = tn * 128 + row, ci = cc * 16 + k;
+        const float x = (co < Cout && ci < Cin) ? wt[((long)tap * Cout + co) * Cin + ci] : 0.f;
+        unsigned h, m, l;
+        split3(x, 0.f, h, m, l);
+        unsigned short* base = planes + ((((long)tap * ntn + tn) * ncc + cc) * 3) * 2048;      // 2048 bf16 per plane
+        const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
+        base[off] = (unsigned short)(h & 0xffffu);
+        base[2048 + off] = (unsigned short)(m & 0xffffu);
+        base[4096 + off] = (unsigned short)(l & 0xffffu);
+    }
 }
 
 // ---- all layers of a generator forward at once -----------------------------------------------
@@ -601,6 +649,10 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
                inb < 0xFFFFFFF0ull && wtb < 0xFFFFFFF0ull;
     g.in_bytes = (unsigned)inb;
     g.wt_bytes = (unsigned)wtb;
+    g.wtp_ncc = gx_cdiv(g.Cin, 16);
+    const size_t wpb = gx_conv_weight_planes_bytes(wtaps, g.Cout, g.Cin);
+    if (g.wtp && (((uintptr_t)g.wtp & 15) || wpb >= 0xFFFFFFF0ull)) g.wtp = nullptr;
+    g.wtp_bytes = (unsigned)wpb;
     g.style_bytes = (unsigned)((size_t)g.B * g.Cin * 4);
     g.tiles_n = gx_cdiv(g.Cout, BN);
     const bool x6 = gx_get_gemm_mode() == 1;
@@ -651,6 +703,22 @@ int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float s
     return GX_OK;
 }
 
+// Pre-split (frozen) conv weights wt [taps][Cout][Cin] for the bf16x6 engine; `planes` holds
+// gx_conv_weight_planes_bytes(taps, Cout, Cin) bytes (tiled, see split_conv_weights_kernel).
+size_t gx_conv_weight_planes_bytes(int taps, int Cout, int Cin) {
+    return (size_t)taps * gx_cdiv(Cout, 128) * gx_cdiv(Cin, 16) * 3 * 4096;
+}
+int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned short* planes, void* stream) {
+    if (!wt || !planes || taps <= 0 || Cout <= 0 || Cin <= 0) return GX_ERR_BAD_ARG;
+    const int ntn = gx_cdiv(Cout, 128), ncc = gx_cdiv(Cin, 16);
+    const long total = (long)taps * ntn * ncc * 2048;
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       wt, taps, Cout, Cin, ntn, ncc, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
 // Per-layer styles of one generator forward, gathered from the all-latents x all-layers affine GEMM.
 int gx_style_pick(const float* S_all, int B, int n_latent, int total, const int* table, int nlayer, float* out,
                   void* stream) {
@@ -683,12 +751,16 @@ int gx_demod_batch(const float* s_packed, const float* wsq_all, int B, const int
 // (0 bytes / NULL is allowed: the layer then runs unsplit).
 size_t gx_modconv_slab_bytes(int B, int outH, int outW, int Cout) { return conv_slab_bytes(B, outH, outW, Cout, 16); }
 
-int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
-                   const float* demod, const float* noise, long noise_bstride, const float* noise_w,
-                   const float* bias, int act, float* out, float* slab, size_t slab_bytes, void* stream) {
+// wt_planes (optional, may be NULL): gx_split_bf16x3(wt) — used by the bf16x6 engine instead of splitting
+// the weight tile in every workgroup.
+int gx_modconv_fwd_p(const float* x, int B, int H, int W, int Cin, const float* wt, const unsigned short* wt_planes,
+                     int ksize, int Cout, const float* s, const float* demod, const float* noise, long noise_bstride,
+                     const float* noise_w, const float* bias, int act, float* out, float* slab, size_t slab_bytes,
+                     void* stream) {
     if (!x || !wt || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3))
         return GX_ERR_BAD_ARG;
     ConvArgs g{};
+    g.wtp = wt_planes;
     g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
     g.nsub = 1;
     ConvSub& sb = g.sub[0];
@@ -703,6 +775,12 @@ int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt
     g.ymul = 1; g.xmul = 1;
     g.demod = demod; g.noise = noise; g.noise_bstride = noise_bstride; g.noise_w = noise_w; g.bias = bias; g.act = act;
     return launch_conv(g, slab, slab_bytes, (hipStream_t)stream);
+}
+int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,
+                   const float* demod, const float* noise, long noise_bstride, const float* noise_w,
+                   const float* bias, int act, float* out, float* slab, size_t slab_bytes, void* stream) {
+    return gx_modconv_fwd_p(x, B, H, W, Cin, wt, nullptr, ksize, Cout, s, demod, noise, noise_bstride, noise_w, bias, act,
+                            out, slab, slab_bytes, stream);
 }
 
 // Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur
@@ -729,10 +807,11 @@ int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* k
 
 // Stage 1: conv_transpose2d(stride 2, pad 0) of the modulated input as four implicit GEMMs (one
 // per output parity class) -> T [B][2H+1][2W+1][Cout] (raw sums, no demod).
-int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
-                        float* T, float* slab, size_t slab_bytes, void* stream) {
+int gx_modconv_up_convt_p(const float* x, int B, int H, int W, int Cin, const float* wt, const unsigned short* wt_planes,
+                          int Cout, const float* s, float* T, float* slab, size_t slab_bytes, void* stream) {
     if (!x || !wt || !T || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return GX_ERR_BAD_ARG;
     ConvArgs g{};
+    g.wtp = wt_planes;
     g.in = x; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = s;
     g.nsub = 4;
     for (int py = 0; py < 2; ++py)
@@ -752,6 +831,11 @@ int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const floa
     g.ymul = 2; g.xmul = 2;
     g.demod = nullptr; g.noise = nullptr; g.noise_w = nullptr; g.bias = nullptr; g.act = 0;
     return launch_conv(g, slab, slab_bytes, (hipStream_t)stream);
+}
+
+int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
+                        float* T, float* slab, size_t slab_bytes, void* stream) {
+    return gx_modconv_up_convt_p(x, B, H, W, Cin, wt, nullptr, Cout, s, T, slab, slab_bytes, stream);
 }
 
 int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,

@@ -150,6 +150,8 @@ class Generator(nn.Module):
             w = m.conv.weight.detach()[0]                                  # (Cout, Cin, k, k)
             cout, cin, k, _ = w.shape
             d[key + ".wt"] = w.permute(2, 3, 0, 1).reshape(k * k, cout, cin).contiguous()
+            # the generator is frozen on this path: split the weights into bf16 planes once (bf16x6 engine)
+            d[key + ".wtp"] = ops.split_conv_weights(d[key + ".wt"]) if w.is_cuda else None
             d[key + ".wsq"] = w.pow(2).sum(dim=(2, 3)).contiguous()
             d[key + ".scale"] = 1.0 / math.sqrt(cin * k * k)
             if hasattr(m.conv, "blur"):
@@ -252,8 +254,8 @@ class Generator(nn.Module):
         nw = m.noise.weight.detach()
         b = m.activate.bias.detach()
         if m.upsample:
-            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True)
-        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True)
+            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=d[key + ".wtp"])
+        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True, wt_planes=d[key + ".wtp"])
 
     def _rgb(self, m, key, x, sp, skip, d):
         s = self._slab(sp, x.shape[0], d[key + ".soff"])

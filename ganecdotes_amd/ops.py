@@ -350,8 +350,18 @@ def _conv_slab(L, b, oh, ow, cout, device):
     return workspace("convslab", nbytes, device), nbytes
 
 
-def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True):
-    """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin)."""
+def split_conv_weights(wt):
+    """bf16x6 planes of frozen conv weights wt (taps, Cout, Cin), tiled for the conv kernel (int16 buffer)"""
+    _chk(wt)
+    taps, cout, cin = wt.shape
+    L = lib()
+    planes = torch.empty(L.gx_conv_weight_planes_bytes(taps, cout, cin) // 2, dtype=torch.int16, device=wt.device)
+    _lib.check(L.gx_split_conv_weights(_p(wt), taps, cout, cin, _p(planes), _stream()), "gx_split_conv_weights")
+    return planes
+
+
+def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=None):
+    """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin); wt_planes = split_conv_weights(wt) (optional)."""
     _chk(x, wt, s, dmod, noise_w, bias)
     b, h, w, cin = x.shape
     cout = wt.shape[1]
@@ -360,13 +370,13 @@ def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True):
     L = lib()
     slab, sbytes = _conv_slab(L, b, h, w, cout, x.device)
     with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
-        _lib.check(L.gx_modconv_fwd(_p(x), b, h, w, cin, _p(wt), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
-                                    _p(noise_w), _p(bias), int(act), _p(out), _p(slab), sbytes, _stream()),
-                   "gx_modconv_fwd")
+        _lib.check(L.gx_modconv_fwd_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
+                                      _p(noise_w), _p(bias), int(act), _p(out), _p(slab), sbytes, _stream()),
+                   "gx_modconv_fwd_p")
     return out
 
 
-def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True):
+def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=None):
     """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC."""
     _chk(x, wt, s, dmod, kf, noise_w, bias)
     b, h, w, cin = x.shape
@@ -377,8 +387,8 @@ def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True):
     out = torch.empty(b, 2 * h, 2 * w, cout, dtype=torch.float32, device=x.device)
     slab, sbytes = _conv_slab(L, b, 2 * h + 1, 2 * w + 1, cout, x.device)
     with record("modconv_kernel", 2.0 * b * h * w * cin * cout * 9):
-        _lib.check(L.gx_modconv_up_convt(_p(x), b, h, w, cin, _p(wt), cout, _p(s), _p(scratch), _p(slab), sbytes,
-                                         _stream()), "gx_modconv_up_convt")
+        _lib.check(L.gx_modconv_up_convt_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), cout, _p(s), _p(scratch), _p(slab),
+                                           sbytes, _stream()), "gx_modconv_up_convt_p")
     tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
     with record("blur_act_kernel", 0.0, tbytes):
         _lib.check(L.gx_blur_act_fwd(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,

@@ -110,7 +110,18 @@ int gx_modconv_up_fwd(const float* x, int B, int H, int W, int Cin, const float*
                       const float* noise_w, const float* bias, int act, float* T, float* out, float* slab,
                       size_t slab_bytes, void* stream);
 int gx_modconv_up_convt(const float* x, int B, int H, int W, int Cin, const float* wt, int Cout, const float* s,
-                        float* T, float* slab, size_t slab_bytes, void* stream);   /* stage 1: transposed conv -> T */
+                        float* T, float* slab, size_t slab_bytes, void* stream);
+/* bf16x6 engine: conv weights pre-split once per (frozen) model into three bf16 planes, tiled in the order
+ * the kernel copies them into LDS (gx_split_conv_weights; gx_conv_weight_planes_bytes bytes); the _p
+ * forms take them (NULL = split the fp32 weight tile in every workgroup). */
+size_t gx_conv_weight_planes_bytes(int taps, int Cout, int Cin);
+int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned short* planes, void* stream);
+int gx_modconv_fwd_p(const float* x, int B, int H, int W, int Cin, const float* wt, const unsigned short* wt_planes,
+                     int ksize, int Cout, const float* s, const float* demod, const float* noise, long noise_bstride,
+                     const float* noise_w, const float* bias, int act, float* out, float* slab, size_t slab_bytes,
+                     void* stream);
+int gx_modconv_up_convt_p(const float* x, int B, int H, int W, int Cin, const float* wt, const unsigned short* wt_planes,
+                          int Cout, const float* s, float* T, float* slab, size_t slab_bytes, void* stream);   /* stage 1: transposed conv -> T */
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                     const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                     float* out, void* stream);                         /* stage 2: blur + epilogue */

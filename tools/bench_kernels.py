@@ -41,9 +41,11 @@ def bench_conv(B=16):
         nw = torch.full((1,), 0.1, device="cuda")
         bias = torch.randn(cout, device="cuda")
         if up:
-            fn = lambda: ops.modconv_up(x, wt, s, dm, kf, nz, nw, bias, True)
+            wp = ops.split_conv_weights(wt) if __import__('os').environ.get('GX_NO_PLANES') is None else None
+            fn = lambda: ops.modconv_up(x, wt, s, dm, kf, nz, nw, bias, True, wt_planes=wp)
         else:
-            fn = lambda: ops.modconv(x, wt, 3, s, dm, nz, nw, bias, True)
+            wp = ops.split_conv_weights(wt) if __import__('os').environ.get('GX_NO_PLANES') is None else None
+            fn = lambda: ops.modconv(x, wt, 3, s, dm, nz, nw, bias, True, wt_planes=wp)
         ms = timeit(fn)
         fl = 2.0 * B * res * res * cin * cout * 9
         print(f"conv{'_up' if up else '   '} res={res:4d} {cin:4d}->{cout:4d}  {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
