@@ -113,8 +113,9 @@ class SimCLRClustering(ViewMixin):
         bsz, hlen = sa['batch_size'], self._hlen
         w1, gamma, beta, w2 = self._params()
         bn = self.projection[1]
-        views = self.make_views([image])
-        pb_picks = self.prepare_batch([image]).picks[0]                        # (1, bsz) int32
+        pb = self.prepare_batch([image])
+        views = self.make_views(pb)                                            # acquires pb on this stream
+        pb_picks = pb.picks[0]                                                 # (1, bsz) int32
         xs = []
         for ts, maps, _ in views:
             x = ops.gather_taps(ts, pb_picks, hlen, maps)                      # (bsz, hlen)

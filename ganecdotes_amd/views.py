@@ -12,6 +12,18 @@ class PreparedBatch:
     on a side stream, so drawing / uploading step i+1 overlaps the kernels of step i."""
     __slots__ = ("n", "z", "map_noise", "mix", "xforms", "picks", "ready", "_keep")
 
+    def acquire(self):
+        """Make the batch usable on the CURRENT stream: wait for the side-stream upload, and tell the
+        caching allocator that this stream reads the side-stream-owned buffers — otherwise their memory
+        returns to the side stream's pool the moment Python drops them and the NEXT batch's upload /
+        key sort overwrites picks that kernels already queued on this stream have yet to read (a host
+        running many steps ahead turned that into out-of-range pixel indices)."""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready)
+        for t in tuple(self._keep) + ((self.picks,) if self.picks is not None else ()):
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
+
 
 class ViewMixin(object):
     """Needs self.model / mean_latent / truncation / perturb_args / device, `self._hlen` and
@@ -121,7 +133,7 @@ class ViewMixin(object):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->
         per view (TapSet, maps or None, image)."""
         pb = self.prepare_batch(images)
-        torch.cuda.current_stream().wait_event(pb.ready)
+        pb.acquire()
         n = pb.n
         # the latents and both views' perturbation noises go through the mapping network together
         allw = self.model.style(torch.cat([pb.z, pb.map_noise[0], pb.map_noise[1]]))

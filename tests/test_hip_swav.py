@@ -304,6 +304,30 @@ def test_small_prototype_paths_agree(gpu, tmp_path, nproto):
             assert rel(a_, b_) < 1e-4, tag
 
 
+def test_host_running_ahead_keeps_batches_intact(gpu, tmp_path):
+    """60 optimizer steps queued without a host sync, device-drawn picks: the side-stream-owned staging /
+    pick buffers of batch i must not be recycled for batch i+1 while kernels of step i are still queued
+    (PreparedBatch.acquire records the consuming stream); the run matches the same run synced every step."""
+    d = load_golden("gv10_pretrain")
+    g = mini_gen(golden_sd(d), gpu)
+    ml = g.mean_latent(64)
+    out = []
+    for sync in (False, True):
+        sw = make_swav(g, gpu, tmp_path, pick_source="device", batch_size=4, sinkhorn_scope="global")
+        sw.mean_latent = ml
+        torch.manual_seed(77)
+        np.random.seed(77)
+        sw.build_heads()
+        losses = []
+        for _ in range(60):
+            losses.append(sw.train_step(sw.draw_batch(4)))
+            if sync:
+                torch.cuda.synchronize()
+        out.append(torch.cat(losses).cpu().numpy())
+    assert np.isfinite(out[0]).all()
+    np.testing.assert_allclose(out[0], out[1], rtol=2e-3)
+
+
 def test_no_cpu_fallback(tmp_path):
     from ganecdotes_amd.generator import Generator
     g = Generator(32, 16, 2, channels=MINI)
