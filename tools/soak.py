@@ -1,17 +1,32 @@
-import sys, torch, numpy as np
-sys.path.insert(0, ".")
-import bench
-from ganecdotes_amd.swav_clustering import SwAVClustering
+#!/usr/bin/env python3
+"""Soak run: many optimizer steps queued back to back with no host sync (the host runs far ahead of the GPU),
+then one read-back.  usage: soak.py [steps] [prototypes] [batch] [scope] [source_pdf]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                                    # noqa: E402
+from ganecdotes_amd.swav_clustering import SwAVClustering      # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+scope = sys.argv[4] if len(sys.argv) > 4 else "global"
+pdf = sys.argv[5] if len(sys.argv) > 5 else "uniform"
 dev = torch.device("cuda", 0)
 g = bench.build_generator(256, dev)
-wl = bench.workload(16, 8)
+wl = bench.workload(batch, k, scope=scope)
+wl["sinkhorn_args"]["source_pdf"] = pdf
 sw = SwAVClustering(model=g, model_config=bench.ModelCfg, out_dir=None, device=dev, **wl)
-torch.manual_seed(42); np.random.seed(42)
+torch.manual_seed(42)
+np.random.seed(42)
 sw.build_heads()
-losses = []
-for i in range(150):
-    losses.append(sw.train_step(sw.draw_batch(16)))
+losses = [sw.train_step(sw.draw_batch(batch)) for _ in range(steps)]
 l = torch.cat(losses).cpu().numpy()
-print("finite", np.isfinite(l).all(), "first", l[:5], "last", l[-5:], "min", l.min(), "max", l.max())
 w = sw.projection[0].weight.data
-print("Wp finite", bool(torch.isfinite(w).all()), float(w.abs().max()))
+print(f"K={k} B={batch} scope={scope} pdf={pdf}: finite={bool(np.isfinite(l).all())} loss {l[0]:.4f} -> {l[-1]:.4f} "
+      f"(min {l.min():.4f}); Wp finite={bool(torch.isfinite(w).all())}; "
+      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
