@@ -16,7 +16,8 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return 0 (GX_OK) or a negative GX_ERR_* code; the Python wrapper raises RuntimeError,
  *     mirroring TORCH_CHECK -> RuntimeError of the reference boundary (upfirdn2d.cpp:9-15);
- *   - thread-safe for distinct streams; no global state;
+ *   - thread-safe for distinct streams; the only process-wide state is the contraction-engine mode
+ *     (gx_set_gemm_mode / env GX_GEMM_MODE), read at launch time;
  *   - feature maps are NHWC ([b][y][x][c]) fp32; matrices row-major fp32; indices int32.
  */
 #ifndef GANECDOTES_HIP_H
