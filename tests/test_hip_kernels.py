@@ -110,6 +110,28 @@ def test_gemm_x6_layouts(ops, x6, ta, tb, m, n, k):
     assert rel_err(out, ref) < 2e-6
 
 
+def test_gemm_random_shapes_both_engines(ops, engine):
+    """40 random (layout, M, N, K, split, ld padding) cases per engine, incl. the wave-specialised
+    form (M > 128, K >= 768) and ragged edges, against fp64"""
+    rng = np.random.RandomState(1234 + engine)
+    for case in range(40):
+        ta, tb = bool(rng.randint(2)), bool(rng.randint(2))
+        m = int(rng.choice([1, 7, 64, 129, 200, 257, 300, 513]))
+        n = int(rng.choice([1, 4, 12, 100, 128, 130, 512]))
+        k = int(rng.choice([3, 16, 100, 256, 800, 1030, 2049]))
+        sk = int(rng.choice([1, 1, 2, 5]))
+        pad_a, pad_b = int(rng.choice([0, 4, 5])), int(rng.choice([0, 4, 7]))
+        a_full = torch.randn((k, m + pad_a) if ta else (m, k + pad_a))
+        b_full = torch.randn((n, k + pad_b) if tb else (k, n + pad_b))
+        a = a_full[:, :m] if ta else a_full[:, :k]
+        b = b_full[:, :k] if tb else b_full[:, :n]
+        ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+        ad, bd = dev(a_full), dev(b_full)
+        out = ops.gemm(ad[:, :m] if ta else ad[:, :k], bd[:, :k] if tb else bd[:, :n], ta, tb, split_k=sk)
+        assert out.shape == (m, n)
+        assert rel_err(out, ref) < 5e-6, (case, ta, tb, m, n, k, sk, pad_a, pad_b)
+
+
 def test_gemm_x6_accuracy(ops):
     """fp32-level error: against fp64 the bf16x6 engine is no worse than the exact-fp32 MFMA engine
     on the projection shape (K = 5376) and on badly scaled operands; A = I reproduces B bit for bit
@@ -685,3 +707,37 @@ def test_modconv_ffhq_shapes(ops, engine):
     y = ops.modconv_up(xd, dev(wt), s, dm, dev(torch.flip(blur, [0, 1])), None, None, None, act=False)
     ref = G.modulated_conv(x, style, w, mod_w, mod_b, upsample=True, blur_kernel=blur)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_modconv_random_shapes_both_engines(ops, engine):
+    """12 random layers per engine (batch, channels incl. non-multiples of 16 / 128, resolution, plain or
+    upsampling, with and without the pre-split weight planes, noise + bias + activation) against the oracle"""
+    from oracle import stylegan2_ref as G
+    rng = np.random.RandomState(77 + engine)
+    blur = G.fir_kernel() * 4
+    for case in range(12):
+        b = int(rng.choice([1, 2, 3]))
+        cin = int(rng.choice([8, 16, 24, 40, 128, 136]))
+        cout = int(rng.choice([8, 12, 64, 128, 132, 200]))
+        h = int(rng.choice([4, 5, 8, 16, 33]))
+        up = bool(rng.randint(2)) and h <= 16
+        planes = bool(rng.randint(2))
+        torch.manual_seed(1000 + case)
+        w = torch.randn(1, cout, cin, 3, 3)
+        mod_w, mod_b = torch.randn(cin, 32), torch.ones(cin)
+        x, style = torch.randn(b, cin, h, h), torch.randn(b, 32)
+        oh = 2 * h if up else h
+        noise, nw, bias = torch.randn(b, 1, oh, oh), torch.tensor([0.3]), 0.1 * torch.randn(cout)
+        wt, wsq = _prep_conv(w)
+        s = _style(ops, style, mod_w, mod_b)
+        dm = ops.demod(s, dev(wsq), 1.0 / math.sqrt(cin * 9))
+        xd, wd = dev(x.permute(0, 2, 3, 1)), dev(wt)
+        wp = ops.split_conv_weights(wd) if planes else None
+        if up:
+            y = ops.modconv_up(xd, wd, s, dm, dev(torch.flip(blur, [0, 1])), dev(noise), dev(nw), dev(bias), True, wt_planes=wp)
+            ref = G.modulated_conv(x, style, w, mod_w, mod_b, upsample=True, blur_kernel=blur)
+        else:
+            y = ops.modconv(xd, wd, 3, s, dm, dev(noise), dev(nw), dev(bias), True, wt_planes=wp)
+            ref = G.modulated_conv(x, style, w, mod_w, mod_b)
+        ref = G.lrelu_bias_scale(ref + nw * noise, bias)
+        assert rel_err(y.permute(0, 3, 1, 2), ref) < 2e-5, (case, b, cin, cout, h, up, planes)
