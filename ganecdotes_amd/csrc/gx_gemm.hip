@@ -288,7 +288,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
-    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= 768 && !getenv("GX_X6_NO_WS");
+    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= 768;
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
