@@ -80,8 +80,9 @@ __global__ void hd_softmax_ce_kernel(const float* __restrict__ logits, const lon
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
         const float lse = mx + logf(se);
-        if (t >= 0 && t < C) lacc += lse - l[t];
-        if (d) for (int c = 0; c < C; ++c) d[c] = (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) * inv_n;
+        const bool valid = t >= 0 && t < C;        // a label outside [0, C) contributes neither loss nor gradient
+        if (valid) lacc += lse - l[t];
+        if (d) for (int c = 0; c < C; ++c) d[c] = valid ? (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) * inv_n : 0.f;
     }
     const float tot = gx_block_sum(lacc, red);
     if (threadIdx.x == 0) loss_part[blockIdx.x] = tot * inv_n;
