@@ -236,8 +236,8 @@ def main():
                        if ops.get_gemm_mode() == 1 else "fp32 MFMA (exact fmaf chains)"),
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
-                               f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = first N of a random permutation drawn on "
-                               f"the device generator",
+                               f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
+                               f"the device generator (= the set randperm[:N] selects)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": float(loss.item())},
         "roofline": roof,

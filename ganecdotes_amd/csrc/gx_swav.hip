@@ -51,6 +51,90 @@ __global__ void rotflip_map_batch_kernel(int* __restrict__ maps, int H, int W, R
     maps[(long)b * H * W + p] = src;
 }
 
+// ===================================================================== S2: random pixel subsets
+// picks[row][0..N) = the indices of the N smallest of HW i.i.d. uniform keys = a uniform random N-subset of
+// the pixels (the set `randperm(HW)[:N]` draws, swav_clustering.py:388-390; its order is irrelevant to the
+// loss) — by a 3-level radix SELECT (11 + 11 + 10 bits of the float bit pattern) and an order-preserving
+// compaction instead of a full sort: 4 reads of the 256 KB key row, indices come out ascending
+// (deterministic, and the later row gathers walk memory forwards).  One workgroup of 1024 threads per row.
+__device__ __forceinline__ void rs_find_bin(const unsigned* hist, int nbins, unsigned need, unsigned* s_bin,
+                                            unsigned* s_below) {
+    // wave 0: lane l owns bins [l*per, (l+1)*per); first bin where the running count reaches `need`
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, per = nbins / 64;
+        unsigned mine = 0;
+        for (int i = 0; i < per; ++i) mine += hist[lane * per + i];
+        unsigned incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        const unsigned excl = incl - mine;
+        if (excl < need && need <= incl) {
+            unsigned run = excl;
+            for (int i = 0; i < per; ++i) {
+                const unsigned c = hist[lane * per + i];
+                if (run + c >= need) { *s_bin = lane * per + i; *s_below = run; break; }
+                run += c;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void random_subset_kernel(const unsigned* __restrict__ keys, int HW, int N,
+                                                             int* __restrict__ picks) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned s_bin, s_below, s_scan[2][16], s_tot[2];
+    const unsigned* k = keys + (long)blockIdx.x * HW;
+    int* out = picks + (long)blockIdx.x * N;
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, need = (unsigned)N, below = 0;
+    // three radix levels: shifts 21, 10, 0 with 11, 11, 10 bits
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+#pragma unroll
+    for (int lv = 0; lv < 3; ++lv) {
+        const int nb = 1 << bits[lv];
+        for (int i = tid; i < 2048; i += 1024) hist[i] = 0u;
+        __syncthreads();
+        const int hs = shifts[lv] + bits[lv];                    // bits above this level
+        for (int i = tid; i < HW; i += 1024) {
+            const unsigned v = k[i];
+            if (lv == 0 || (v >> hs) == prefix) atomicAdd(&hist[(v >> shifts[lv]) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        rs_find_bin(hist, nb, need, &s_bin, &s_below);
+        __syncthreads();
+        prefix = (prefix << bits[lv]) | s_bin;
+        below += s_below;
+        need -= s_below;                                          // still to take inside the chosen bin
+        __syncthreads();
+    }
+    const unsigned T = prefix;                                    // the N-th smallest key; `need` of the keys == T are taken
+    // order-preserving compaction: thread t owns the contiguous index range [t*per, (t+1)*per)
+    const int per = (HW + 1023) / 1024, i0 = tid * per, i1 = min(HW, i0 + per);
+    unsigned nless = 0, ntie = 0;
+    for (int i = i0; i < i1; ++i) { const unsigned v = k[i]; nless += v < T; ntie += v == T; }
+    // block exclusive scans of (nless, ntie)
+    unsigned incl[2] = {nless, ntie};
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl[q], o, 64); if (lane >= o) incl[q] += v; }
+        if (lane == 63) s_scan[q][wv] = incl[q];
+    }
+    __syncthreads();
+    if (tid < 2) {
+        unsigned run = 0;
+        for (int w = 0; w < 16; ++w) { const unsigned c = s_scan[tid][w]; s_scan[tid][w] = run; run += c; }
+        s_tot[tid] = run;
+    }
+    __syncthreads();
+    unsigned pos_less = s_scan[0][wv] + incl[0] - nless, pos_tie = s_scan[1][wv] + incl[1] - ntie;
+    const unsigned total_less = s_tot[0];                         // == below
+    for (int i = i0; i < i1; ++i) {
+        const unsigned v = k[i];
+        if (v < T) out[pos_less++] = i;
+        else if (v == T) { if (pos_tie < need) out[total_less + pos_tie] = i; ++pos_tie; }
+    }
+}
+
 // ===================================================================== S1 + S1b + S2: gather
 constexpr int MAX_TAPS = 16;
 struct TapList {
@@ -508,6 +592,16 @@ int gx_rotflip_map_batch(const float* angles_deg, const int* flips, int n, int H
                            maps + (long)i0 * H * W, H, W, rf);
         GX_CHECK_LAUNCH();
     }
+    return GX_OK;
+}
+
+// picks [rows][N] int32 = indices of the N smallest of the HW uniform fp32 keys (>= 0) of every row:
+// a uniform random N-subset per row (ascending; pixels whose key ties the N-th smallest come last).  HW <= 2^22, 1 <= N <= HW.
+int gx_random_subset_picks(const float* keys, int rows, int HW, int N, int* picks, void* stream) {
+    if (!keys || !picks || rows <= 0 || HW <= 0 || HW > (1 << 22) || N <= 0 || N > HW) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(random_subset_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(keys), HW, N, picks);
+    GX_CHECK_LAUNCH();
     return GX_OK;
 }
 

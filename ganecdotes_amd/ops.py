@@ -422,6 +422,16 @@ def rotflip_map(angle_deg, flip, h, w, device, out=None):
     return out
 
 
+def random_subset_picks(keys, n):
+    """keys (rows, HW) uniform fp32 in [0,1) -> (rows, n) int32: indices of the n smallest keys of every row
+    (a uniform random n-subset in ascending pixel order) — radix select, no sort"""
+    _chk(keys)
+    rows, hw = keys.shape
+    out = torch.empty(rows, n, dtype=torch.int32, device=keys.device)
+    _lib.check(lib().gx_random_subset_picks(_p(keys), rows, hw, n, _p(out), _stream()), "gx_random_subset_picks")
+    return out
+
+
 def rotflip_map_batch(angles, flips, h, w, out):
     """out (n, h*w) int32: one launch for the maps of a whole view batch (None angle = 0 degrees)"""
     n = len(angles)

@@ -103,11 +103,11 @@ class ViewMixin(object):
             pb.mix.append(df[o:o + B * nl * 2].view(B, nl, 2)); o += B * nl * 2
         pb.picks = di[:P * B * N].view(P, B, N) if P else None
         if dev_picks:
-            # picks = first N of a uniform random permutation of the H*W pixels, per image and
-            # patch, drawn on the device generator (one batched argsort of uniform keys)
+            # picks = the pixels the first N entries of a uniform random permutation select, per image and
+            # patch: the N smallest of H*W uniform keys drawn on the device generator (radix select)
             with torch.cuda.stream(self._copy_stream):
                 keys = torch.rand(npatch * B, hw, device=self.device)
-                pb.picks = keys.argsort(dim=1)[:, :N].to(torch.int32).reshape(npatch, B, N).contiguous()
+                pb.picks = ops.random_subset_picks(keys, N).reshape(npatch, B, N)
                 pb.ready = torch.cuda.Event()
                 pb.ready.record()
             slot[2] = pb.ready

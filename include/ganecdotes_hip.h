@@ -138,6 +138,10 @@ int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* str
  *                  picks[row], optional maps[b][H*W] (-1 = zero fill)
  *                                                  swav_clustering.py:108-130, :160-167
  * gx_row_sumsq / gx_norm_map   per-pixel L2 norm map of the stack   swav_clustering.py:361-362 */
+/* the N pixels of a patch: a uniform random N-subset of the HW pixels per row (what randperm(HW)[:N]
+ * selects, swav_clustering.py:388-390), as the indices of the N smallest of HW uniform keys — radix select +
+ * order-preserving compaction, no sort.  keys [rows][HW] fp32 in [0, 1); picks [rows][N] ascending (pixels tying the N-th smallest key last). */
+int gx_random_subset_picks(const float* keys, int rows, int HW, int N, int* picks, void* stream);
 int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stream);
 /* the maps of a whole view batch in one launch (angles / flips are host arrays of n entries) */
 int gx_rotflip_map_batch(const float* angles_deg, const int* flips, int n, int H, int W, int* maps, void* stream);

@@ -741,3 +741,34 @@ def test_modconv_random_shapes_both_engines(ops, engine):
             ref = G.modulated_conv(x, style, w, mod_w, mod_b)
         ref = G.lrelu_bias_scale(ref + nw * noise, bias)
         assert rel_err(y.permute(0, 3, 1, 2), ref) < 2e-5, (case, b, cin, cout, h, up, planes)
+
+
+@pytest.mark.parametrize("rows,hw,n,quant", [(80, 65536, 20000, 0), (3, 1024, 300, 0), (4, 65536, 20000, 64),
+                                             (2, 262144, 20000, 0), (2, 1000, 1000, 8), (5, 4097, 1, 0)])
+def test_random_subset_picks(ops, rows, hw, n, quant):
+    """radix-select picks == the n smallest keys of every row (the set argsort(keys)[:n] selects), distinct,
+    exactly n, in ascending pixel order (keys below the n-th smallest first, then the tied ones) — also with
+    heavily tied keys (quant levels), n == HW and n == 1"""
+    torch.manual_seed(rows * hw + n)
+    keys = torch.rand(rows, hw, device="cuda")
+    if quant:
+        keys = torch.floor(keys * quant) / quant
+    picks = ops.random_subset_picks(keys, n).cpu().long()
+    kc = keys.cpu()
+    for r in range(rows):
+        p = picks[r]
+        assert p.shape == (n,) and int(p.min()) >= 0 and int(p.max()) < hw
+        assert len(torch.unique(p)) == n
+        picked = torch.zeros(hw, dtype=torch.bool)
+        picked[p] = True
+        if n < hw:
+            assert float(kc[r][picked].max()) <= float(kc[r][~picked].min())
+        if not quant:
+            assert torch.equal(torch.sort(p)[0], torch.sort(torch.argsort(kc[r])[:n])[0])
+            assert torch.equal(p[:-1], torch.sort(p[:-1])[0])    # ascending; the n-th smallest key's pixel comes last
+    # uniformity smoke check: every pixel is picked with probability n / hw
+    if rows >= 80:
+        freq = torch.zeros(hw)
+        for r in range(rows):
+            freq[picks[r]] += 1
+        assert abs(float(freq.mean()) / rows - n / hw) < 1e-6
