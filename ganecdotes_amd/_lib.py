@@ -51,6 +51,7 @@ SIGNATURES = {
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
+    "gx_view_latents": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_style_pick": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "gx_demod_batch": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "gx_rotflip_map_batch": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),

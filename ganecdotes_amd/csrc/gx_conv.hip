@@ -414,6 +414,24 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
     }
 }
 
+// Latents of one view of a batch (swav_clustering.py:599-640 + image_augmentor.py:42-53 + the truncation of
+// model.py:594-602): lat[b][l][:] = keep * (m + psi (w_b - m)) + mix[b][l][0] nw[b][0][:] + mix[b][l][1] nw[b][1][:]
+// with keep = 1 - mix[b][l][0] - mix[b][l][1]  (mix is sigma at the two perturbed latents of image b, else 0).
+__global__ void view_latents_kernel(const float* __restrict__ w, const float* __restrict__ mean, float psi,
+                                    const float* __restrict__ nw, const float* __restrict__ mix, int B, int NL, int S,
+                                    float* __restrict__ lat) {
+    const long total = (long)B * NL * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % S);
+        const long bl = i / S;
+        const int b = (int)(bl / NL);
+        const float m0 = mix[bl * 2], m1 = mix[bl * 2 + 1];
+        const float mu = mean[c];
+        const float base = fmaf(psi, w[(long)b * S + c] - mu, mu);
+        lat[i] = (1.f - (m0 + m1)) * base + m0 * nw[((long)b * 2) * S + c] + m1 * nw[((long)b * 2 + 1) * S + c];
+    }
+}
+
 // ---- all layers of a generator forward at once -----------------------------------------------
 // style_pick: S_all [B*n_latent][total] (every latent through every layer's affine, one GEMM) ->
 // packed per-layer styles: layer j occupies out[B*off_j .. B*(off_j+cin_j)) as [B][cin_j].
@@ -715,6 +733,18 @@ int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
                        wt, taps, Cout, Cin, ntn, ncc, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// lat [B][n_latent][S] of one view: truncated w, with the two perturbed latents of every image mixed
+// towards its two mapped noises (w [B][S], mean [S], nw [B][2][S], mix [B][n_latent][2]).
+int gx_view_latents(const float* w, const float* mean, float psi, const float* nw, const float* mix, int B, int n_latent,
+                    int S, float* lat, void* stream) {
+    if (!w || !mean || !nw || !mix || !lat || B <= 0 || n_latent <= 0 || S <= 0) return GX_ERR_BAD_ARG;
+    long want = ((long)B * n_latent * S + 255) / 256;
+    hipLaunchKernelGGL(view_latents_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, w,
+                       mean, psi, nw, mix, B, n_latent, S, lat);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

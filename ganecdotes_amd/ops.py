@@ -303,6 +303,16 @@ def lerp_rows(w, base, psi):
     return out
 
 
+def view_latents(w, mean, psi, nw, mix):
+    """lat (B, n_latent, S): truncated w (B,S) with the perturbed latents mixed towards nw (B,2,S) by mix (B,n_latent,2)"""
+    _chk(w, mean, nw, mix)
+    b, s = w.shape
+    nl = mix.shape[1]
+    lat = torch.empty(b, nl, s, dtype=torch.float32, device=w.device)
+    _lib.check(lib().gx_view_latents(_p(w), _p(mean), psi, _p(nw), _p(mix), b, nl, s, _p(lat), _stream()), "gx_view_latents")
+    return lat
+
+
 def style_pick(s_all, b, n_latent, table, nlayer):
     """per-layer styles (packed: layer j at [b*off_j, b*(off_j+cin_j)) as (b, cin_j)) from the
     all-latents x all-layers affine output s_all (b*n_latent, total)"""

@@ -120,14 +120,10 @@ class ViewMixin(object):
         (swav_clustering.py:599-640, image_augmentor.py:42-53).  w (B,S) mapped latents;
         map_noise (2B,S) (or nw = its mapping, if the caller already has it); mix (B, n_latent, 2) =
         sigma at the two perturbed latents:  lat[b, 2l+j] = (1-sigma) lat + sigma style(noise_j)."""
-        n_latent = self.model.n_latent
-        lat = ops.lerp_rows(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation))
-        lat = lat.unsqueeze(1).repeat(1, n_latent, 1)
         if nw is None:
             nw = self.model.style(map_noise)
-        nw = nw.reshape(w.shape[0], 2, -1)
-        keep = 1.0 - mix.sum(dim=2, keepdim=True)
-        return lat * keep + torch.einsum('blj,bjs->bls', mix, nw)
+        return ops.view_latents(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation),
+                                nw.reshape(w.shape[0], 2, -1).contiguous(), mix.contiguous())
 
     def make_views(self, images):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->

@@ -92,6 +92,10 @@ int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1
 int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream);
 int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream);
 int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream);
+/* the (B, n_latent, S) latents of one view: truncation (model.py:594-602) + the perturbation mix of
+ * image_augmentor.py:42-53 / swav_clustering.py:599-640 in one pass */
+int gx_view_latents(const float* w, const float* mean, float psi, const float* nw, const float* mix, int B, int n_latent,
+                    int S, float* lat, void* stream);
 /* One generator forward's per-layer work in single launches (the reference runs one EqualLinear per
  * ModulatedConv2d, model.py:239-243): gx_style_pick gathers every layer's style from ONE affine GEMM
  * of all latents x all layers; gx_demod_batch is gx_demod for all styled convs;
