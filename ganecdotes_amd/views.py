@@ -134,16 +134,20 @@ class ViewMixin(object):
         # the latents and both views' perturbation noises go through the mapping network together
         allw = self.model.style(torch.cat([pb.z, pb.map_noise[0], pb.map_noise[1]]))
         w = allw[:n]
+        # both views go through the generator as ONE batch of 2B images (the reference runs them one after
+        # the other, swav_clustering.py:340-345: same arithmetic per image, half the launches, and the
+        # low-resolution layers get enough tiles to fill the chip)
+        lat = torch.cat([self._view_latents(w, None, pb.mix[v], nw=allw[n + 2 * n * v:n + 2 * n * (v + 1)])
+                         for v in range(2)])
+        img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
+                                input_is_latent=True, randomize_noise=False)
         out = []
         for v in range(2):
-            lat = self._view_latents(w, None, pb.mix[v], nw=allw[n + 2 * n * v:n + 2 * n * (v + 1)])
-            img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
-                                    input_is_latent=True, randomize_noise=False)
-            ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
+            ts = ops.TapSet([f[v * n:(v + 1) * n].permute(0, 2, 3, 1) for f in feats])
             maps = None
             if any(a is not None for a, _ in pb.xforms[v]):
                 hw = ts.size
                 maps = torch.empty(pb.n, hw * hw, dtype=torch.int32, device=self.device)
                 ops.rotflip_map_batch([a for a, _ in pb.xforms[v]], [f for _, f in pb.xforms[v]], hw, hw, maps)
-            out.append((ts, maps, img))
+            out.append((ts, maps, None if img is None else img[v * n:(v + 1) * n]))
         return out
