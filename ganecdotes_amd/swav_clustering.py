@@ -188,7 +188,7 @@ class SwAVClustering(ViewMixin):
         ops.row_l2_normalize_(Wc, want_rnorm=False)
 
         with self._timed("views"):
-            views = self.make_views(pb)
+            views, ts_all = self.make_views(pb, want_all=True)
         hw = views[0][0].size
         if N is None or N >= hw * hw:
             N = hw * hw
@@ -210,16 +210,23 @@ class SwAVClustering(ViewMixin):
         lowrank = mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D)
         if mode == 'pyramid':
             with self._timed("pyramid_fwd"):
-                pyr = [Pyramid(ts, hlen) for ts, _, _ in views]
+                # ONE pyramid over the 2B images of both views: each level is one GEMM, the table Z_all
+                # (2B, H, W, D) holds view s in [0, B) and view t in [B, 2B)
+                pyr = Pyramid(ts_all, hlen)
+                npx = B * hw * hw
                 if lowrank:      # the finest upsample-add also emits every pixel's scores (rn table, score table)
-                    Zt, Tab = zip(*[p.project(Wp, score_head=(Wc, bc)) for p in pyr])
+                    Z_all, (rn_all, sc_all) = pyr.project(Wp, score_head=(Wc, bc))
+                    Tab = [(rn_all[v * npx:(v + 1) * npx], sc_all[v * npx:(v + 1) * npx]) for v in range(2)]
                 else:
-                    Zt = [p.project(Wp) for p in pyr]                          # (B, H, W, D) per view
+                    Z_all = pyr.project(Wp)
+                Zt = [Z_all[v * B:(v + 1) * B] for v in range(2)]              # (B, H, W, D) per view
             if lowrank:
-                Ct = [ops.lowrank_coeffs(B, hw * hw, K, dev) for _ in Zt]      # (B*HW, K+1 padded) coefficient grids
-                Gt = [None, None]
+                Ct_all = ops.lowrank_coeffs(2 * B, hw * hw, K, dev)            # (2B*HW, K+1 padded) coefficient grid
+                Ct = [Ct_all[v * npx:(v + 1) * npx] for v in range(2)]
+                G_all = None
             else:
-                Gt = [torch.zeros_like(z) for z in Zt]
+                G_all = torch.zeros_like(Z_all)
+                Gt = [G_all[v * B:(v + 1) * B] for v in range(2)]
         # 'image' source pdf: the marginals depend on the view (and image), not on the patch
         marg = None
         if imgs is not None:
@@ -319,17 +326,15 @@ class SwAVClustering(ViewMixin):
                 del X, Zh, Rn, Sc, dS
             del keep, Sc_all, skb
         if mode == 'pyramid':
-            Gp = [None, None]
+            Gp = None
             if lowrank:
                 with self._timed("lowrank_finish"):
-                    pool = len(pyr[0].res) > 1
-                    for v in range(2):
-                        out = ops.proto_lowrank_finish(Ct[v], Zt[v], Wc, gWc, 0.0 if v == 0 else 1.0, want_pool=pool)
-                        Gt[v], Gp[v] = out if pool else (out, None)
+                    pool = len(pyr.res) > 1
+                    out = ops.proto_lowrank_finish(Ct_all, Z_all, Wc, gWc, 0.0, want_pool=pool)
+                    G_all, Gp = out if pool else (out, None)
             with self._timed("pyramid_bwd"):
-                for v in range(2):
-                    pyr[v].backward(Gt[v], gWp, accumulate=(v > 0), g_pooled=Gp[v])
-            del Zt, Gt
+                pyr.backward(G_all, gWp, accumulate=False, g_pooled=Gp)
+            del Zt, Z_all, G_all
         if self.world > 1:
             sharded.allreduce_flat(list(self._grads) + [loss], self.dist_group)
         # S8: LARC + momentum SGD

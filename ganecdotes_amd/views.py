@@ -125,9 +125,10 @@ class ViewMixin(object):
         return ops.view_latents(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation),
                                 nw.reshape(w.shape[0], 2, -1).contiguous(), mix.contiguous())
 
-    def make_views(self, images):
+    def make_views(self, images, want_all=False):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->
-        per view (TapSet, maps or None, image)."""
+        per view (TapSet, maps or None, image); want_all: also the TapSet of the whole 2B-image batch
+        (view s = images [0, B), view t = [B, 2B))."""
         pb = self.prepare_batch(images)
         pb.acquire()
         n = pb.n
@@ -150,4 +151,6 @@ class ViewMixin(object):
                 maps = torch.empty(pb.n, hw * hw, dtype=torch.int32, device=self.device)
                 ops.rotflip_map_batch([a for a, _ in pb.xforms[v]], [f for _, f in pb.xforms[v]], hw, hw, maps)
             out.append((ts, maps, None if img is None else img[v * n:(v + 1) * n]))
+        if want_all:
+            return out, ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
         return out
