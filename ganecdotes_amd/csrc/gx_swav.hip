@@ -431,11 +431,20 @@ __global__ void sk_codes_kernel(const float* __restrict__ S, long rows, int K, l
 // (calculate_swapped_prediction_loss, swav_clustering.py:547-570 with :408-409, and its
 // autograd).  gscale = 1/(N_total * num_patches [* num_images]); loss partial sums are per
 // block (fixed order) and are NOT yet scaled.
+// blockIdx.y = pair (batched form): pair y = (patch y / ngroups, row group y % ngroups); see gx_swapped_ce_batch.
+struct CePairs { int ngroups; long patch_stride, group_stride, la_patch_stride, la_group_stride; };
 __global__ void swapped_ce_kernel(const float* __restrict__ Ss, const float* __restrict__ St, long rows, int K,
                                   long ld, int team, float inv_eps, float inv_T,
                                   const float* __restrict__ las, const float* __restrict__ lat, float gscale,
                                   float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
-                                  float* __restrict__ loss_part) {
+                                  float* __restrict__ loss_part, CePairs pr) {
+    {
+        const long pa = blockIdx.y / pr.ngroups, gr = blockIdx.y % pr.ngroups;
+        const long so = pa * pr.patch_stride + gr * pr.group_stride, lo = pa * pr.la_patch_stride + gr * pr.la_group_stride;
+        Ss += so; St += so; las += lo; lat += lo;
+        if (dSs) { dSs += so; dSt += so; }
+        loss_part += (long)blockIdx.y * gridDim.x;
+    }
     const int tpb = blockDim.x / team;
     const int ti = threadIdx.x / team, tl = threadIdx.x % team;
     float lacc = 0.f;
@@ -851,9 +860,35 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
     const int team = pick_team(K);
     const int nb = sk_blocks(rows, team);
     hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Ss, St, rows, K, ld, team,
-                       1.f / eps, 1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd, workspace);
+                       1.f / eps, 1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd, workspace,
+                       CePairs{1, 0, 0, 0, 0});
     GX_CHECK_LAUNCH();
     launch_partial_reduce(workspace, nb, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// Every (patch, row group) pair of a step in one launch (K <= 64, contiguous rows: ld == K).  Scores S_all
+// [npatch][2 views][rows_per_patch][K] with row groups of `rows` rows (ngroups per patch: 1 for the global
+// Sinkhorn scope, B for the per-image one); la_all [(patch*2 + view)*ngroups + group][K] (SinkhornBatch order);
+// dS_all like S_all.  loss_out[0] = loss_scale * sum + loss_beta * loss_out[0].
+// workspace >= npatch * ngroups * 512 floats.
+int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
+                        float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
+                        float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S_all || !la_all || !loss_out || npatch <= 0 || ngroups <= 0 || rows <= 0 || K <= 0 || K > 64 ||
+        rows * ngroups != rows_per_patch || (long)npatch * ngroups > 65535)
+        return GX_ERR_BAD_ARG;
+    const int team = pick_team(K);
+    const int nb = sk_blocks(rows, team);
+    const long npair = (long)npatch * ngroups;
+    if (!workspace || workspace_bytes < (size_t)npair * nb * sizeof(float)) return GX_ERR_WORKSPACE;
+    const long vs = rows_per_patch * K;                       // view stride
+    CePairs pr{ngroups, 2 * vs, rows * K, (long)2 * ngroups * K, (long)K};
+    hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb, (unsigned)npair), dim3(256), 0, (hipStream_t)stream, S_all, S_all + vs,
+                       rows, K, (long)K, team, 1.f / eps, 1.f / temperature, la_all, la_all + (long)ngroups * K, grad_scale,
+                       dS_all, dS_all ? dS_all + vs : nullptr, (long)K, workspace, pr);
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(workspace, (int)(npair * nb), 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1687,6 +1722,65 @@ __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const flo
     if (threadIdx.x < K) part_b[(long)blockIdx.x * K + threadIdx.x] = sb[threadIdx.x];
 }
 
+// The whole step at once (low-rank path, both views in one 2B-image batch): row r enumerates
+// (patch p, view v, image b, sample n); its pixel is map(picks[p][b][n]) of image v*B + b.
+__device__ __forceinline__ long lr_row_pixel(long r, int B, int N, int HW, const int* __restrict__ picks,
+                                             const int* __restrict__ maps) {
+    const int n = (int)(r % N);
+    const long t = r / N;
+    const int b = (int)(t % B), v = (int)((t / B) & 1);
+    const long p = t / (2 * B);
+    const int img = v * B + b;
+    int pix = picks[(p * B + b) * N + n];
+    if (maps) pix = maps[(long)img * HW + pix];
+    return pix >= 0 ? (long)img * HW + pix : -1;
+}
+__global__ void gather_scores_batch_kernel(const float* __restrict__ T, const float* __restrict__ rnT,
+                                           const float* __restrict__ bias, int B, int HW, int K, int N,
+                                           const int* __restrict__ picks, const int* __restrict__ maps, long rows,
+                                           float* __restrict__ scores, float* __restrict__ rnorm) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * K) return;
+    const long r = idx / K;
+    const int k = (int)(idx - r * K);
+    const long q = lr_row_pixel(r, B, N, HW, picks, maps);
+    scores[idx] = q >= 0 ? T[q * K + k] : (bias ? bias[k] : 0.f);
+    if (k == 0) rnorm[r] = q >= 0 ? rnT[q] : 1e12f;
+}
+__global__ void proto_bwd_lowrank_batch_kernel(const float* __restrict__ dS, const float* __restrict__ scores,
+                                               const float* __restrict__ rnorm, const float* __restrict__ bias, int B,
+                                               int HW, int K, int N, const int* __restrict__ picks,
+                                               const int* __restrict__ maps, long rows, float* __restrict__ C,
+                                               float* __restrict__ part_b) {
+    __shared__ float sb[LR_MAXK];
+    const int ls = lr_stride(K);
+    const int team = (K + 1 <= 16) ? 16 : 32;
+    const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
+    if (threadIdx.x < LR_MAXK) sb[threadIdx.x] = 0.f;
+    __syncthreads();
+    const float myb = (bias && tl < K) ? bias[tl] : 0.f;
+    float gbl = 0.f;
+    const long niter = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
+    for (long it = 0; it < niter; ++it) {
+        const long row = (it * gridDim.x + blockIdx.x) * tpb + ti;
+        const bool live = row < rows;
+        float d = 0.f, sc = 0.f, rn = 0.f;
+        long q = -1;
+        if (live) {
+            q = lr_row_pixel(row, B, N, HW, picks, maps);
+            rn = rnorm[row];
+            if (tl < K) { d = dS[row * K + tl]; sc = scores[row * K + tl] - myb; }
+        }
+        const float dot = gx_team_sum(d * sc, team);
+        gbl += d;
+        if (q >= 0 && tl <= K) atomicAdd(C + q * ls + tl, tl < K ? rn * d : -rn * rn * dot);
+    }
+    for (int o = team; o < 64; o <<= 1) gbl += __shfl_xor(gbl, o, 64);
+    if ((threadIdx.x & 63) < team && tl < K) atomicAdd(&sb[tl], gbl);
+    __syncthreads();
+    if (threadIdx.x < K) part_b[(long)blockIdx.x * K + threadIdx.x] = sb[threadIdx.x];
+}
+
 // Dense finish: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of gWc[k] += C[q][k] Z[q].
 // blockIdx.y = 256-column slab of the D columns; one wave per group of 4 pixels (4 row slabs of 1 KB
 // in flight per lane), lane l owns the float4 columns slab + 4 l.  POOL: the group is the 2x2 block
@@ -1879,6 +1973,40 @@ int gx_gather_scores(const float* table, const float* rn_table, const float* bia
     const long rows = (long)B * rows_per_img;
     hipLaunchKernelGGL(gx::gather_scores_kernel, dim3((unsigned)gx_cdiv(rows * K, 256)), dim3(256), 0, (hipStream_t)stream,
                        table, rn_table, bias, HW, K, picks, maps, rows_per_img, rows, scores, rnorm);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// All patches and both views of a step in one launch: tables over the 2B-image batch (view v = images
+// [v*B, (v+1)*B)), picks [npatch][B][N], maps [2B][HW] or NULL; rows are ordered (patch, view, image, sample),
+// i.e. scores is [npatch][2][B*N][K].
+int gx_gather_scores_batch(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
+                           const int* picks, int npatch, int N, const int* maps, float* scores, float* rnorm,
+                           void* stream) {
+    if (!table || !rn_table || !picks || !scores || !rnorm || B <= 0 || HW <= 0 || K <= 0 || npatch <= 0 || N <= 0)
+        return GX_ERR_BAD_ARG;
+    const long rows = (long)npatch * 2 * B * N;
+    hipLaunchKernelGGL(gx::gather_scores_batch_kernel, dim3((unsigned)gx_cdiv(rows * K, 256)), dim3(256), 0,
+                       (hipStream_t)stream, table, rn_table, bias, B, HW, K, N, picks, maps, rows, scores, rnorm);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// the matching coefficient scatter: C [2B*HW][gx_lowrank_stride(K)] += ..., gb = beta*gb + colsum(dS).
+// workspace >= 1024*K floats.
+int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
+                               int K, const int* picks, int npatch, int N, const int* maps, float* C, float* gb,
+                               float beta, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || npatch <= 0 || N <= 0 || K < 1 ||
+        K > gx::LR_MAXK)
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)1024 * K * sizeof(float)) return GX_ERR_WORKSPACE;
+    const long rows = (long)npatch * 2 * B * N;
+    long nb = (rows + 15) / 16;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(gx::proto_bwd_lowrank_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores,
+                       rnorm, bias, B, HW, K, N, picks, maps, rows, C, workspace);
+    GX_CHECK_LAUNCH();
+    gx::launch_partial_reduce(workspace, (int)nb, K, 1.f, beta, gb, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -232,6 +232,40 @@ def gather_scores(table, rn_table, bias, picks, maps, hw, out=None):
     return rn, sc
 
 
+def gather_scores_batch(table, rn_table, bias, picks, maps, b, hw, out):
+    """all patches x both views: out (P, 2, B*N, K) scores, returns rnorm (P, 2, B*N); tables over the 2B batch"""
+    _chk(table, rn_table, bias, out)
+    p, pb, n = picks.shape
+    k = table.shape[1]
+    rn = torch.empty(p, 2, b * n, dtype=torch.float32, device=table.device)
+    _lib.check(lib().gx_gather_scores_batch(_p(table), _p(rn_table), _p(bias), b, hw, k, _p(picks), p, n, _p(maps), _p(out),
+                                            _p(rn), _stream()), "gx_gather_scores_batch")
+    return rn
+
+
+def proto_bwd_lowrank_batch_(ds, scores, rnorm, bias, picks, maps, coeffs, b, hw, gb, beta):
+    _chk(ds, scores, rnorm, bias, coeffs, gb)
+    p, pb, n = picks.shape
+    k = ds.shape[-1]
+    ws = workspace("lowrank_b", 1024 * k * 4, ds.device)
+    _lib.check(lib().gx_proto_bwd_lowrank_batch(_p(ds), _p(scores), _p(rnorm), _p(bias), b, hw, k, _p(picks), p, n, _p(maps),
+                                                _p(coeffs), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
+               "gx_proto_bwd_lowrank_batch")
+
+
+def swapped_ce_batch(scores, ngroups, skb, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_scores):
+    """scores / d_scores (P, 2, rows_per_patch, K); skb = the SinkhornBatch over its (P*2*ngroups) problems"""
+    _chk(scores, d_scores, loss_out)
+    p, _, rpp, k = scores.shape
+    rows = rpp // ngroups
+    wsb = p * ngroups * 512 * 4
+    ws = workspace("ce_batch", wsb, scores.device)
+    _lib.check(lib().gx_swapped_ce_batch(_p(scores), p, ngroups, rpp, rows, k, skb.eps, temperature, _p(skb.la), grad_scale,
+                                         _p(d_scores), loss_scale, loss_beta, _p(loss_out), _p(ws), wsb, _stream()),
+               "gx_swapped_ce_batch")
+    return loss_out
+
+
 def lowrank_coeffs(b, hw, k, device):
     """zeroed coefficient grid C (B*HW, stride(K))"""
     return torch.zeros(b * hw, lib().gx_lowrank_stride(k), dtype=torch.float32, device=device)

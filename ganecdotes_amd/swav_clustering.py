@@ -216,13 +216,17 @@ class SwAVClustering(ViewMixin):
                 npx = B * hw * hw
                 if lowrank:      # the finest upsample-add also emits every pixel's scores (rn table, score table)
                     Z_all, (rn_all, sc_all) = pyr.project(Wp, score_head=(Wc, bc))
-                    Tab = [(rn_all[v * npx:(v + 1) * npx], sc_all[v * npx:(v + 1) * npx]) for v in range(2)]
                 else:
                     Z_all = pyr.project(Wp)
                 Zt = [Z_all[v * B:(v + 1) * B] for v in range(2)]              # (B, H, W, D) per view
             if lowrank:
+                maps_all = None
+                if views[0][1] is not None or views[1][1] is not None:        # (2B, HW) rotate / flip index maps
+                    ident = None
+                    if views[0][1] is None or views[1][1] is None:
+                        ident = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+                    maps_all = torch.cat([m if m is not None else ident for m in (views[0][1], views[1][1])])
                 Ct_all = ops.lowrank_coeffs(2 * B, hw * hw, K, dev)            # (2B*HW, K+1 padded) coefficient grid
-                Ct = [Ct_all[v * npx:(v + 1) * npx] for v in range(2)]
                 G_all = None
             else:
                 G_all = torch.zeros_like(Z_all)
@@ -250,15 +254,15 @@ class SwAVClustering(ViewMixin):
             G = len(pnos)
             Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)
             keep = []
-            for gi, pno in enumerate(pnos):
+            batched = lowrank                    # K <= 16: gather / loss / scatter of all patches in single launches
+            if batched:      # every patch and both views in single launches (tables over the 2B-image batch)
+                gpicks = pb.picks[pnos[0]:pnos[-1] + 1].contiguous()
+                Rn_all = ops.gather_scores_batch(sc_all, rn_all, bc, gpicks, maps_all, B, hw * hw, Sc_all)
+            for gi, pno in enumerate(pnos if not batched else []):
                 picks = pb.picks[pno]
                 X, Zh, Rn = [], [], []
                 for v, (ts, maps, _) in enumerate(views):
                     sc = Sc_all[gi, v]
-                    if lowrank:
-                        rn, _ = ops.gather_scores(Tab[v][1], Tab[v][0], bc, picks, maps, hw * hw, out=sc)
-                        Zh.append(None); Rn.append(rn)
-                        continue
                     if mode == 'pyramid' and small:
                         with self._timed("proto_fwd_small"):
                             z, rn, _ = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc, out=sc)
@@ -286,7 +290,18 @@ class SwAVClustering(ViewMixin):
                 skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
                                         c=c_all, c_uniform=1.0 / nglob)
                 skb.run(self._reduce if (scope == 'global' and self.world > 1) else None)
-            for gi, pno in enumerate(pnos):
+            if batched:
+                dS_all = torch.empty_like(Sc_all)
+                ops.swapped_ce_batch(Sc_all, ngroups, skb, T, gscale, loss, gscale, 1.0, dS_all)
+                if return_aux and pnos[0] == 0:
+                    aux.update(scores_s=Sc_all[0, 0, :grows].clone(), scores_t=Sc_all[0, 1, :grows].clone(),
+                               q_s=skb[0].codes(), q_t=skb[ngroups].codes())
+                with self._timed("proto_bwd_lowrank"):
+                    ops.proto_bwd_lowrank_batch_(dS_all, Sc_all, Rn_all, bc, gpicks, maps_all, Ct_all, B, hw * hw, gb,
+                                                 0.0 if first_acc else 1.0)
+                first_acc = False
+                del dS_all, Rn_all
+            for gi, pno in enumerate(pnos if not batched else []):
                 picks = pb.picks[pno]
                 X, Zh, Rn = keep[gi]
                 Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
@@ -301,11 +316,6 @@ class SwAVClustering(ViewMixin):
                 # S6: backward (gradients accumulate over views and patches)
                 for v in range(2):
                     beta = 0.0 if first_acc else 1.0
-                    if lowrank:
-                        with self._timed("proto_bwd_lowrank"):
-                            ops.proto_bwd_lowrank_(dS[v], Sc[v], Rn[v], bc, picks, views[v][1], Ct[v], hw * hw, gb, beta)
-                        first_acc = False
-                        continue
                     if mode == 'pyramid' and small:
                         with self._timed("proto_bwd_small"):
                             ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)

@@ -197,6 +197,14 @@ int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks,
                          const float* Wc, const float* bias, int K, float* rnorm, float* scores, void* stream);
 int gx_gather_scores(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
                      const int* picks, int rows_per_img, const int* maps, float* scores, float* rnorm, void* stream);
+/* the whole step in single launches (both views = one 2B-image batch, all patches; rows ordered
+ * (patch, view, image, sample)): gather, coefficient scatter, and — gx_swapped_ce_batch below — the loss */
+int gx_gather_scores_batch(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
+                           const int* picks, int npatch, int N, const int* maps, float* scores, float* rnorm,
+                           void* stream);
+int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
+                               int K, const int* picks, int npatch, int N, const int* maps, float* C, float* gb,
+                               float beta, float* workspace, size_t workspace_bytes, void* stream);
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream);
@@ -280,6 +288,11 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
                   const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
                   float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
                   void* stream);
+/* every (patch, row group) pair of a step in one launch; S_all / dS_all [npatch][2][rows_per_patch][K],
+ * la_all in SinkhornBatch order; workspace >= npatch * ngroups * 512 floats */
+int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
+                        float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
+                        float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- SimCLR baseline head (baseline/hfc_with_simclr/simclr_clustering.py) -----------------------
  * gx_col_stats      BatchNorm1d batch statistics (train mode)                      :150
