@@ -548,6 +548,97 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 // up2 = upfirdn2d(up=2, pad=(2,1)) with the flipped 4x4 FIR kf (already x4).  Image is planar
 // NCHW (3 channels).  A team of `lp` lanes (lp = min(64, Cin/4), power of two) owns a pixel and
 // reads its Cin floats as float4: one fully coalesced pass over the tap.
+// ToRGB for Cin % 4 == 0, Cin <= 4 * 4 * lp: the lane's slice of the 3 x Cin weight stays in registers and a
+// wave keeps the rows of TG_R pixel groups in flight (the one-group-at-a-time form below reaches 1.8 TB/s).
+constexpr int TG_R = 4;
+__device__ __forceinline__ float torgb_skip(const float* __restrict__ prev, const float* __restrict__ kf, int b, int c,
+                                            int y, int xx, int H, int Wd) {
+    const int ph = H >> 1, pw = Wd >> 1;
+    const float* pp = prev + ((long)b * 3 + c) * ph * pw;
+    float u = 0.f;
+#pragma unroll
+    for (int fy = 0; fy < 4; ++fy) {
+        const int zy = y + fy - 2;
+        if (zy < 0 || zy >= H || (zy & 1)) continue;
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+            const int zx = xx + fx - 2;
+            if (zx < 0 || zx >= Wd || (zx & 1)) continue;
+            u = fmaf(kf[fy * 4 + fx], pp[(zy >> 1) * pw + (zx >> 1)], u);
+        }
+    }
+    return u;
+}
+template <int TG_NI>                 // float4 chunks of a pixel's channels per lane: ceil(Cin / (4 lp))
+__global__ __launch_bounds__(256) void torgb_stream_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                           const float* __restrict__ W, float scale,
+                                                           const float* __restrict__ bias, const float* __restrict__ prev,
+                                                           const float* __restrict__ kf, int B, int H, int Wd, int Cin,
+                                                           int lp, float* __restrict__ img) {
+    const int ppw = 64 / lp, lane = threadIdx.x & 63, tl = lane % lp, sub = lane / lp;
+    constexpr int ni = TG_NI;
+    const long npix = (long)B * H * Wd, hw = (long)H * Wd;
+    const long ngroups = (npix + ppw - 1) / ppw;
+    f32x4 w0[TG_NI], w1[TG_NI], w2[TG_NI];
+#pragma unroll
+    for (int it = 0; it < TG_NI; ++it) {
+        const int ci = (it * lp + tl) * 4;
+        const bool ok = it < ni && ci < Cin;
+        w0[it] = ok ? *reinterpret_cast<const f32x4*>(W + ci) : zero4();
+        w1[it] = ok ? *reinterpret_cast<const f32x4*>(W + Cin + ci) : zero4();
+        w2[it] = ok ? *reinterpret_cast<const f32x4*>(W + 2 * Cin + ci) : zero4();
+    }
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    for (long g0 = wave0 * TG_R; g0 < ngroups; g0 += nwave * TG_R) {
+        f32x4 xv[TG_R][TG_NI];
+        long pix[TG_R];
+#pragma unroll
+        for (int r = 0; r < TG_R; ++r) {
+            pix[r] = (g0 + r) * ppw + sub;
+            const bool live = pix[r] < npix;
+#pragma unroll
+            for (int it = 0; it < TG_NI; ++it) {
+                const int ci = (it * lp + tl) * 4;
+                xv[r][it] = (live && it < ni && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + pix[r] * Cin + ci) : zero4();
+            }
+        }
+        // the skip connection's taps (tiny, cached image of the previous resolution) are fetched now, next to
+        // the row loads, not after the reductions
+        float skipv[TG_R];
+        int oy[TG_R], ox[TG_R], ob[TG_R];
+#pragma unroll
+        for (int r = 0; r < TG_R; ++r) {
+            const bool live = pix[r] < npix;
+            ob[r] = live ? (int)(pix[r] / hw) : 0;
+            const int rem = live ? (int)(pix[r] - (long)ob[r] * hw) : 0;
+            oy[r] = rem / Wd; ox[r] = rem - oy[r] * Wd;
+            skipv[r] = (prev && live && tl < 3) ? torgb_skip(prev, kf, ob[r], tl, oy[r], ox[r], H, Wd) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < TG_R; ++r) {
+            const bool live = pix[r] < npix;
+            const int b = ob[r];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < TG_NI; ++it) {
+                const int ci = (it * lp + tl) * 4;
+                if (it < ni && ci < Cin) {
+                    const f32x4 v = xv[r][it] * *reinterpret_cast<const f32x4*>(s + (long)b * Cin + ci);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a0 = fmaf(v[q], w0[it][q], a0); a1 = fmaf(v[q], w1[it][q], a1); a2 = fmaf(v[q], w2[it][q], a2);
+                    }
+                }
+            }
+            a0 = gx_team_sum(a0, lp); a1 = gx_team_sum(a1, lp); a2 = gx_team_sum(a2, lp);
+            if (live && tl < 3)
+                img[(((long)b * 3 + tl) * H + oy[r]) * Wd + ox[r]] =
+                    (tl == 0 ? a0 : (tl == 1 ? a1 : a2)) * scale + bias[tl] + skipv[r];
+        }
+    }
+}
+
 __global__ void torgb_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ W,
                              float scale, const float* __restrict__ bias, const float* __restrict__ prev,
                              const float* __restrict__ kf, int B, int H, int Wd, int Cin, int lp,
@@ -886,6 +977,17 @@ int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, 
     int lp = 4;                                   // lanes per pixel: >= 4 (three output lanes), <= 64
     while (lp < 64 && lp * 4 < Cin) lp <<= 1;
     const long waves = ((long)B * H * W + (64 / lp) - 1) / (64 / lp);
+    const int ni = (Cin + lp * 4 - 1) / (lp * 4);
+    if ((Cin & 3) == 0 && ni <= 4 && (((uintptr_t)x | (uintptr_t)s | (uintptr_t)w3) & 15) == 0) {
+        long nb = gx_cdiv(gx_cdiv(waves, TG_R), 4);
+        if (nb > 8192) nb = 8192;
+#define GX_TORGB(NI_) hipLaunchKernelGGL((torgb_stream_kernel<NI_>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, \
+                                         s, w3, scale, bias3, prev_img, kf, B, H, W, Cin, lp, img)
+        if (ni == 1) GX_TORGB(1); else if (ni == 2) GX_TORGB(2); else GX_TORGB(4);
+#undef GX_TORGB
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     hipLaunchKernelGGL(torgb_kernel, dim3(gx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, s, w3, scale,
                        bias3, prev_img, kf, B, H, W, Cin, lp, img);
     GX_CHECK_LAUNCH();
