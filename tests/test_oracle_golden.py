@@ -279,3 +279,80 @@ def test_baggan_generator_golden_gv14():
         imgz, tapsz, _ = B.generator_forward(z, sd)
     np.testing.assert_allclose(imgz.numpy(), d["img_z"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(tapsz[-1].numpy(), d["tap_z_last"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ GV15
+def _gv15():
+    return load_golden("gv15_kmeans")
+
+
+def _same_partition(a, b):
+    return len(set(zip(a.tolist(), b.tolist()))) == max(len(set(a.tolist())), len(set(b.tolist())))
+
+
+@pytest.mark.parametrize("tag,kw", [("explicit", {}), ("maxiter2", dict(max_iter=2)), ("far", {})])
+def test_gv15_lloyd_matches_sklearn(tag, kw):
+    """oracle Lloyd (centring, tolerance, E/M step, empty-cluster relocation, final E step) vs sklearn 1.7.2"""
+    from oracle import kmeans_ref as K
+    g = _gv15()
+    init = g["A_init_far"] if tag == "far" else g["A_init"]
+    m = K.kmeans_fit(g["A_x"], init.shape[0], n_init=1, init=init, **kw)
+    assert m["n_iter_"] == int(g[f"A_{tag}_n_iter"])
+    np.testing.assert_array_equal(m["labels_"], g[f"A_{tag}_labels"])
+    np.testing.assert_allclose(m["cluster_centers_"], g[f"A_{tag}_centers"], rtol=0, atol=2e-5)
+    assert abs(m["inertia_"] - float(g[f"A_{tag}_inertia"])) <= 1e-5 * float(g[f"A_{tag}_inertia"])
+
+
+def test_gv15_kmeans_plusplus_stream_matches_sklearn():
+    """seeded greedy k-means++: the same RandomState reproduces sklearn's chosen indices and final clustering"""
+    from oracle import kmeans_ref as K
+    g = _gv15()
+    x = g["A_x"]
+    xc = x - x.mean(axis=0)
+    _, ids = K.kmeans_plusplus(xc, 6, K._row_sumsq(xc), np.random.RandomState(5))
+    np.testing.assert_array_equal(ids, g["A_pp_indices"])
+    for tag, k, n_init, seed in (("pp1", 5, 1, 3), ("pp3", 7, 3, 11)):
+        m = K.kmeans_fit(x, k, n_init=n_init, random_state=seed)
+        np.testing.assert_array_equal(m["labels_"], g[f"A_{tag}_labels"])
+        np.testing.assert_allclose(m["cluster_centers_"], g[f"A_{tag}_centers"], rtol=0, atol=2e-5)
+        assert m["n_iter_"] == int(g[f"A_{tag}_n_iter"])
+    np.testing.assert_array_equal(K.kmeans_predict(_blobs16(), g["A_explicit_centers"]), g["A_pred_labels"])
+
+
+def _blobs16():
+    rng = np.random.RandomState(16)
+    centres = rng.randn(5, 24).astype(np.float32) * 2.0 + 3.0
+    return np.ascontiguousarray(centres[rng.randint(0, 5, 700)] + rng.randn(700, 24).astype(np.float32), np.float32)
+
+
+def test_gv15_reference_hfc_preprocessor():
+    """the reference's HFCPreprocessor.train_hfc_model / predict_hfc_vectors + FlatKMeansHFC on its mini generator"""
+    import torch
+    from oracle import kmeans_ref as K
+    g = _gv15()
+    sd = golden_sd(g)
+    w = torch.from_numpy(g["B_w"])
+    clusters, nl = g["B_clusters"].tolist(), len(g["B_clusters"])
+    torch.manual_seed(int(g["B_seed_train"]))
+    feats, new_list, _, _ = K.train_features(sd, w[0:1], 16, num_latents_for_mean=64, truncation=0.7, n_layers=nl,
+                                             n_samples=int(g["B_n_samples"]), perturb_std=g["B_perturb_std"].tolist())
+    for n in range(nl):
+        np.testing.assert_allclose(feats[n], g[f"B_feat_{n}"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.stack([t.numpy() for t in new_list]), g["B_new_latents"], rtol=1e-5, atol=1e-6)
+    models = K.flat_fit([g[f"B_feat_{n}"] for n in range(nl)], clusters, random_state=0, n_init=2, verbose=0)
+    for n, m in enumerate(models):
+        assert _same_partition(m["labels_"], g[f"B_labels_{n}"])
+        np.testing.assert_array_equal(m["labels_"], g[f"B_labels_{n}"])
+        np.testing.assert_allclose(m["cluster_centers_"], g[f"B_centers_{n}"], rtol=0, atol=1e-5)
+        assert abs(m["inertia_"] - float(g[f"B_inertia_{n}"])) <= 1e-5 * float(g[f"B_inertia_{n}"])
+        # `self.stds = self.means = [None] * n` (hfc_kmeans_clustering.py:54) aliases the two lists: both hold the std
+        np.testing.assert_allclose(m["std"], g[f"B_std_{n}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(g[f"B_mean_{n}"], g[f"B_std_{n}"])
+    torch.manual_seed(int(g["B_seed_predict"]))
+    pf, _ = K.predict_features(sd, w[1:2], 16, num_latents_for_mean=64, truncation=0.7, n_layers=nl)
+    maps, labels = K.flat_predict(pf, [g[f"B_centers_{n}"] for n in range(nl)], int(g["B_out_size"]))
+    for n in range(nl):
+        np.testing.assert_array_equal(labels[n], g[f"B_pred_labels_{n}"])
+    np.testing.assert_array_equal(maps * 2 - 1, g["B_pred_maps"])
+    assert sorted(g["B_saved_files"].tolist()) == ["clusterer_layer_0.sav", "clusterer_layer_1.sav", "clusterer_layer_2.sav",
+                                                   "model_stats.npz"]
