@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libganecdotes_hip.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_simclr.hip", "gx_head.hip"]
+SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_simclr.hip", "gx_head.hip", "gx_kmeans.hip"]
 ARCH = "gfx950"
 
 

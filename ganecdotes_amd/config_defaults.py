@@ -50,6 +50,21 @@ def simclr_segmentor(*, nclasses=512, n_hfc_layers=6):
                 nclasses=nclasses, hfc_prep_args=prep, seg_args=dict(size="XS", in_ch=nclasses))
 
 
+def kmeans_segmentor(*, n_hfc_layers=5, clusters_per_layer=(4, 8, 16, 32, 64), train_hfc=True):
+    """Attributes of the `hfc_kmeans` config (configs/segmentors/hfc_kmeans_config.py:1-75): flat k-means per
+    generator layer, 4 perturbed samples per layer, label maps at 256, the 5-layer 'S' head on sum(K) channels."""
+    clusters = list(clusters_per_layer)
+    prep = dict(
+        perturb_args=dict(truncation=0.7, n_layers=n_hfc_layers, n_samples=4, perturb_std=[1.0] * n_hfc_layers),
+        hfc_algo='hfc_kmeans',
+        hfc_args=dict(kmeans_args=dict(verbose=0),
+                      base_args=dict(out_dir=None, n_layers=n_hfc_layers, clusters_per_layer=clusters, out_size=256,
+                                     presaved=not train_hfc)),
+        hier_encode=False, hle_samples=100, train=train_hfc)
+    return dict(n_layers=13, n_hfc_layers=n_hfc_layers, clusters_per_layer=clusters, train_hfc=train_hfc,
+                hfc_prep_args=prep, seg_args=dict(size='S', in_ch=sum(clusters)))
+
+
 def stylegan_model(subdir, ckpt, classes, one_shot_ind=0, image_size=256, latents_dir=None):
     """Attributes of a standard (non-BagGAN) model config."""
     base = ROOT_DIR + "/checkpoints/standard/"

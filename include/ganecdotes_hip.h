@@ -316,6 +316,46 @@ int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t worksp
 int gx_larc_sgd(float* p, const float* g, float* buf, long n, const float* norms2 /*{sum p^2, sum g^2}*/, float lr,
                 float momentum, float trust, int first_step, int use_larc, void* stream);
 
+/* ---- hfc_kmeans baseline (SURVEY.md par. 8f rank 4) ---------------------------------------------
+ * FlatKMeansHFC (baseline/hfc_kmeans/hfc_kmeans_clustering.py:127-209) = one sklearn.cluster.KMeans per
+ * generator layer on the (pixels, channels) panel of that layer; HFCPreprocessor
+ * (baseline/hfc_kmeans/segmentor.py:66-232) builds the panels and turns labels into one-hot maps.
+ * The per-iteration contractions (scores X.C^T, per-cluster sums onehot^T.X) are gx_gemm_f32 calls; these
+ * entry points are the rest of sklearn's dense float32 path, all with fixed-order reductions:
+ *   gx_kmeans_center_panel   X = [tap1 | tap2] - mean (KMeans.fit: X -= X.mean(0)), xsq = row_norms(X)^2;
+ *                            taps are NHWC levels, i.e. already (pixels, channels) row-major
+ *   gx_kmeans_assign         E step of _update_chunk_dense: label = argmin_k(csq[k] - 2 S[n][k]), first
+ *                            minimum wins; optional one-hot rows (for the sums GEMM), label histogram
+ *                            counts[K] and the number of rows whose label differs from labels_prev
+ *   gx_kmeans_update         _average_centers + _center_shift: centers_new = sums / counts (may alias centers_old),
+ *                            shift2[k] = |new - old|^2, csq[k] = |new|^2
+ *   gx_kmeans_row_dist       |X[n] - centers[labels[n]]|^2 by direct differences (+ their float64 sum):
+ *                            _inertia_dense and the distances of _relocate_empty_clusters_dense
+ *   gx_kmeans_pp_*           greedy k-means++ (_kmeans_plusplus): sample = searchsorted(cumsum_f64(closest),
+ *                            targets) clipped; with G = X.X[cand]^T (rows x T) the squared distances are
+ *                            max(xsq[n] + xsq[cand[t]] - 2 G[n][t], 0); pots[t] = sum_n min(closest, D_t)
+ *                            (closest NULL: sum D_t); commit: closest = min(closest, D_best) (first: D_best)
+ *   gx_kmeans_label_maps     FlatKMeansHFC.predict's one-hot maps of all layers, nearest-resized to
+ *                            out_size, NHWC [B][out][out][sum K], values hi / lo (1 / -1 = the `*2-1`
+ *                            of predict_hfc_vectors, segmentor.py:230) */
+int gx_kmeans_center_panel(const float* tap1, int C1, const float* tap2, int C2, long rows, const float* mean, float* X,
+                           float* xsq, void* stream);
+int gx_kmeans_assign(const float* S, long rows, int K, long ld, const float* csq, const int* labels_prev, int* labels,
+                     float* onehot, long ld_onehot, int* counts, int* nchanged, void* stream);
+int gx_kmeans_update(const float* sums, const int* counts, int K, int C, const float* centers_old, float* centers_new,
+                     float* csq, float* shift2, void* stream);
+int gx_kmeans_row_dist(const float* X, long rows, int C, long ldx, const float* centers, int K, const int* labels,
+                       float* dist, double* total, void* stream);
+size_t gx_kmeans_pp_workspace_bytes(int T);
+int gx_kmeans_pp_pots(const float* G, long rows, int T, long ld, const float* xsq, const int* cand, const float* closest,
+                      double* pots, void* workspace, size_t workspace_bytes, void* stream);
+int gx_kmeans_pp_commit(const float* G, long rows, int T, long ld, const float* xsq, const int* cand, int best, int first,
+                        float* closest, void* stream);
+int gx_kmeans_pp_sample(const float* closest, long rows, const double* targets /*host, T values*/, int T, int* cand,
+                        void* stream);
+int gx_kmeans_label_maps(int nlayers, const int* const* labels /*host array of device ptrs*/, const int* res /*host*/,
+                         const int* K /*host*/, int B, int out_size, float hi, float lo, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

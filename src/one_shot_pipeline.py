@@ -2,7 +2,8 @@
 `OneShotPipeline(out_dir, exp_name, model, segmentor, trainer, tester, mode, inputs, custom,
 device, num_test_samples)`, `load_model`, `load_segmentor`, `load_trainer`,
 `run_pipeline(blocks_to_run)`, `run_trainer`, `run_tests`.  It drives the accelerated path: generator
-load, `preprocessor.preprocess` (SwAV pretrain), `predict_swav_codes`, the one-shot fine-tune of the
+load, `preprocessor.preprocess` (SwAV pretrain) / `train_hfc_model` (k-means), `predict_swav_codes` /
+`predict_hfc_vectors`, the one-shot fine-tune of the
 head (`run_trainer`, reference :466-581) and the IoU test loop (`run_tests`, :595-886) — all on HIP
 (ganecdotes_amd/oneshot.py).  Plotting, tensorboard images and the labelling GUI are outside this build.
 
@@ -82,6 +83,12 @@ class OneShotPipeline(object):
             import baseline.hfc_with_simclr.base as hfc_with_simclr
             self.segmentor = hfc_with_simclr.segmentor
             self.preprocessor = hfc_with_simclr.preprocessor
+        elif self.seg_str == 'hfc_kmeans':               # built here, like the reference (:211-219)
+            import baseline.hfc_kmeans.base as hfc_kmeans
+            self.segmentor = hfc_kmeans.segmentor
+            self.preprocessor = hfc_kmeans.preprocessor(model=self.model, model_config=self.model_config,
+                                                        out_dir=self.out_dir, logger=self.logger,
+                                                        **self.seg_config.hfc_prep_args)
         else:
             raise NotImplementedError(f"method '{self.seg_str}' is outside this build (SURVEY.md par. 8f)")
 
@@ -141,17 +148,24 @@ class OneShotPipeline(object):
         """(:466-581) pretrain / load the clustering model, take the code map of the labelled latent and
         fine-tune the head on it with the trainer config (Adam + CrossEntropyLoss, StepLR per epoch)."""
         from ganecdotes_amd.oneshot import OneShotHead
-        kw = dict(self.seg_config.hfc_prep_args)
-        self.preprocessor = self.preprocessor(model=self.model, model_config=self.model_config,
-                                              out_dir=self.out_dir, logger=self.logger,
-                                              tb=self.summary_writer, device=self.device,
-                                              **({'dist_group': self.dist_group} if self.dist_group else {}), **kw)
-        if self.seg_config.train_hfc:
-            self.preprocessor.preprocess(self.one_shot_latent)
-        self._predict = getattr(self.preprocessor, 'predict_swav_codes', None) or self.preprocessor.predict_simclr_codes
-        self.one_shot_features, self.one_shot_clusters = self._predict(self.one_shot_latent.reshape(1, -1))
-        self.one_shot_features = self.one_shot_features.detach().clone()
-        torch.save(self.one_shot_clusters.cpu(), os.path.join(self.out_dir, 'cluster_map.pt'))
+        if self.seg_str == 'hfc_kmeans':                 # (:484-495) fit the per-layer k-means, take the label maps
+            if self.seg_config.train_hfc:
+                self.preprocessor.train_hfc_model(self.one_shot_latent.reshape(1, -1))
+            self._predict = self.preprocessor.predict_hfc_vectors
+            self.one_shot_features, self.one_shot_clusters = self._predict(self.one_shot_latent.reshape(1, -1))
+            torch.save([l.cpu() for l in self.one_shot_clusters], os.path.join(self.out_dir, 'cluster_map.pt'))
+        else:
+            kw = dict(self.seg_config.hfc_prep_args)
+            self.preprocessor = self.preprocessor(model=self.model, model_config=self.model_config,
+                                                  out_dir=self.out_dir, logger=self.logger,
+                                                  tb=self.summary_writer, device=self.device,
+                                                  **({'dist_group': self.dist_group} if self.dist_group else {}), **kw)
+            if self.seg_config.train_hfc:
+                self.preprocessor.preprocess(self.one_shot_latent)
+            self._predict = getattr(self.preprocessor, 'predict_swav_codes', None) or self.preprocessor.predict_simclr_codes
+            self.one_shot_features, self.one_shot_clusters = self._predict(self.one_shot_latent.reshape(1, -1))
+            self.one_shot_features = self.one_shot_features.detach().clone()
+            torch.save(self.one_shot_clusters.cpu(), os.path.join(self.out_dir, 'cluster_map.pt'))
         tc = self.trainer_config
         self.head = OneShotHead(**self.seg_config.seg_args, n_class=len(self.model_config.classes), device=self.device)
         size = self.one_shot_features.shape[-1]
