@@ -29,6 +29,9 @@ SIGNATURES = {
     "gx_confusion": (c_i, [c_p, c_p, c_l, c_i, c_p, c_p]),
     "gx_kmeans_center_panel": (c_i, [c_p, c_i, c_p, c_i, c_l, c_p, c_p, c_p, c_p]),
     "gx_kmeans_assign": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p]),
+    "gx_kmeans_accumulate_supported": (c_i, [c_i]),
+    "gx_kmeans_accumulate_workspace_bytes": (c_sz, [c_l, c_i, c_i]),
+    "gx_kmeans_accumulate": (c_i, [c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_p, c_sz, c_p]),
     "gx_kmeans_update": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "gx_kmeans_row_dist": (c_i, [c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_kmeans_pp_workspace_bytes": (c_sz, [c_i]),

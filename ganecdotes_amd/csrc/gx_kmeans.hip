@@ -91,6 +91,44 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// M step sums (the `centers_new[label] += X[i]` loop of _update_chunk_dense): every block owns a chunk of
+// rows and a slab of W = blockDim.x columns, keeps K x W accumulators in LDS (thread t only ever touches
+// column t, so no barrier and no atomics are needed; a row's label is wave-uniform) and writes its partial
+// sums; km_reduce_sums_kernel adds the chunks in order.  X is read once.
+__global__ void km_accumulate_kernel(const float* __restrict__ X, long rows, int C, long ldx,
+                                     const int* __restrict__ labels, int K, int rows_per_block,
+                                     float* __restrict__ part) {
+    extern __shared__ float acc[];                       // [K][W]
+    const int W = blockDim.x, t = threadIdx.x;
+    const int col = blockIdx.y * W + t;
+    for (int k = 0; k < K; ++k) acc[k * W + t] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const bool live = col < C;
+    const float* x = X + (live ? col : 0);
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const int l0 = labels[r], l1 = labels[r + 1], l2 = labels[r + 2], l3 = labels[r + 3];
+        const float x0 = x[r * ldx], x1 = x[(r + 1) * ldx], x2 = x[(r + 2) * ldx], x3 = x[(r + 3) * ldx];
+        acc[l0 * W + t] += x0;
+        acc[l1 * W + t] += x1;
+        acc[l2 * W + t] += x2;
+        acc[l3 * W + t] += x3;
+    }
+    for (; r < r1; ++r) acc[labels[r] * W + t] += x[r * ldx];
+    if (live)
+        for (int k = 0; k < K; ++k) part[((long)blockIdx.x * K + k) * C + col] = acc[k * W + t];
+}
+__global__ __launch_bounds__(256) void km_reduce_sums_kernel(const float* __restrict__ part, int nchunk, long kc,
+                                                             float* __restrict__ sums) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kc) return;
+    float a = 0.f;
+    for (int c = 0; c < nchunk; ++c) a += part[(long)c * kc + i];
+    sums[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------------
 // M step tail (_average_centers + _center_shift): new centre k = sums[k] * (1 / count[k]);
 // shift2[k] = |new - old|^2, csq[k] = |new|^2.  One block per centre.  A cluster with count 0 (only
 // possible when relocation was pointless) keeps its centre.
@@ -211,11 +249,12 @@ __global__ __launch_bounds__(1024) void km_pp_sample_kernel(const float* __restr
     for (long i = lo; i < hi; ++i) a += (double)closest[i];
     incl[threadIdx.x] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = 0.0;
-        for (int i = 0; i < 1024; ++i) { run += incl[i]; incl[i] = run; }
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1024 chunk sums
+        const double add = (int)threadIdx.x >= off ? incl[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        incl[threadIdx.x] += add;
+        __syncthreads();
     }
-    __syncthreads();
     const double before = threadIdx.x ? incl[threadIdx.x - 1] : 0.0;
     const double after = incl[threadIdx.x];
     for (int t = 0; t < T; ++t) {
@@ -282,6 +321,43 @@ int gx_kmeans_assign(const float* S, long rows, int K, long ld, const float* csq
     if (nchanged && hipMemsetAsync(nchanged, 0, sizeof(int), s) != hipSuccess) return GX_ERR_LAUNCH;
     hipLaunchKernelGGL(gx::km_assign_kernel, dim3(gx_cdiv(rows, 16)), dim3(256), 0, s, S, rows, K, ld, csq, labels_prev,
                        labels, onehot, ld_onehot, counts, nchanged);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// slab width (threads per block) for K clusters so that K x W floats fit 64 KB of LDS; 0: K too large
+static int km_acc_width(int K) { return K <= 64 ? 256 : K <= 128 ? 128 : K <= 256 ? 64 : 0; }
+static void km_acc_geometry(long rows, int K, int C, int* W, int* nslab, int* rpb, int* nchunk) {
+    *W = km_acc_width(K);
+    *nslab = *W ? gx_cdiv(C, *W) : 0;
+    int want = *nslab ? 512 / *nslab : 1;                 // about two blocks per CU in total
+    if (want < 1) want = 1;
+    long per = (rows + want - 1) / want;
+    if (per < 64) per = 64;
+    per = (per + 3) & ~3L;
+    *rpb = (int)per;
+    *nchunk = gx_cdiv(rows, per);
+}
+int gx_kmeans_accumulate_supported(int K) { return km_acc_width(K) != 0; }
+size_t gx_kmeans_accumulate_workspace_bytes(long rows, int K, int C) {
+    int W, nslab, rpb, nchunk;
+    km_acc_geometry(rows, K, C, &W, &nslab, &rpb, &nchunk);
+    return W ? (size_t)nchunk * K * C * sizeof(float) : 0;
+}
+int gx_kmeans_accumulate(const float* X, long rows, int C, long ldx, const int* labels, int K, float* sums,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !labels || !sums || rows <= 0 || C <= 0 || K <= 0 || ldx < C) return GX_ERR_BAD_ARG;
+    int W, nslab, rpb, nchunk;
+    km_acc_geometry(rows, K, C, &W, &nslab, &rpb, &nchunk);
+    if (!W) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_kmeans_accumulate_workspace_bytes(rows, K, C)) return GX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gx::km_accumulate_kernel, dim3(nchunk, nslab), dim3(W), (size_t)K * W * sizeof(float), s, X, rows, C,
+                       ldx, labels, K, rpb, (float*)workspace);
+    GX_CHECK_LAUNCH();
+    const long kc = (long)K * C;
+    hipLaunchKernelGGL(gx::km_reduce_sums_kernel, dim3(gx_cdiv(kc, 256)), dim3(256), 0, s, (const float*)workspace, nchunk, kc,
+                       sums);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -149,7 +149,11 @@ class KMeans:
         cen = [c0.contiguous().clone(), torch.empty_like(c0)]
         lab = [torch.empty(rows, dtype=torch.int32, device=dev) for _ in range(2)]
         S = torch.empty(rows, k, dtype=torch.float32, device=dev)
-        onehot = torch.empty(rows, k, dtype=torch.float32, device=dev)
+        direct = bool(L.gx_kmeans_accumulate_supported(k))       # else: sums = onehot^T . X on the GEMM engine
+        onehot = None if direct else torch.empty(rows, k, dtype=torch.float32, device=dev)
+        if direct:
+            wsb = L.gx_kmeans_accumulate_workspace_bytes(rows, k, C)
+            ws = workspace("kmeans_acc", wsb, dev)
         sums = torch.empty(k, C, dtype=torch.float32, device=dev)
         stat = torch.zeros(2 * k + 1, dtype=torch.int32, device=dev)     # label histogram | rows that changed | shift^2
         counts, nchanged, shift2 = stat[:k], stat[k:k + 1], stat[k + 1:].view(torch.float32)
@@ -161,7 +165,11 @@ class KMeans:
             cur = lab[i & 1]
             self._scores(X, cen[0], S)
             self._assign(S, csq, prev, cur, onehot, counts, nchanged)
-            ops.gemm(onehot, X, True, False, out=sums, split_k=split)
+            if direct:
+                _lib.check(L.gx_kmeans_accumulate(_p(X), rows, C, X.stride(0), _p(cur), k, _p(sums), _p(ws), wsb, _stream()),
+                           "gx_kmeans_accumulate")
+            else:
+                ops.gemm(onehot, X, True, False, out=sums, split_k=split)
             for attempt in range(2):
                 _lib.check(L.gx_kmeans_update(_p(sums), _p(counts), k, C, _p(cen[0]), _p(cen[1]), _p(csq), _p(shift2),
                                               _stream()), "gx_kmeans_update")

@@ -327,6 +327,9 @@ int gx_larc_sgd(float* p, const float* g, float* buf, long n, const float* norms
  *   gx_kmeans_assign         E step of _update_chunk_dense: label = argmin_k(csq[k] - 2 S[n][k]), first
  *                            minimum wins; optional one-hot rows (for the sums GEMM), label histogram
  *                            counts[K] and the number of rows whose label differs from labels_prev
+ *   gx_kmeans_accumulate     M step sums, `centers_new[label] += X[i]`: one pass over X with per-block LDS
+ *                            accumulators (K <= 256: gx_kmeans_accumulate_supported), chunk partials added in
+ *                            a fixed order — no atomics; larger K: onehot^T.X through gx_gemm_f32
  *   gx_kmeans_update         _average_centers + _center_shift: centers_new = sums / counts (may alias centers_old),
  *                            shift2[k] = |new - old|^2, csq[k] = |new|^2
  *   gx_kmeans_row_dist       |X[n] - centers[labels[n]]|^2 by direct differences (+ their float64 sum):
@@ -342,6 +345,10 @@ int gx_kmeans_center_panel(const float* tap1, int C1, const float* tap2, int C2,
                            float* xsq, void* stream);
 int gx_kmeans_assign(const float* S, long rows, int K, long ld, const float* csq, const int* labels_prev, int* labels,
                      float* onehot, long ld_onehot, int* counts, int* nchanged, void* stream);
+int gx_kmeans_accumulate_supported(int K);
+size_t gx_kmeans_accumulate_workspace_bytes(long rows, int K, int C);
+int gx_kmeans_accumulate(const float* X, long rows, int C, long ldx, const int* labels, int K, float* sums,
+                         void* workspace, size_t workspace_bytes, void* stream);
 int gx_kmeans_update(const float* sums, const int* counts, int K, int C, const float* centers_old, float* centers_new,
                      float* csq, float* shift2, void* stream);
 int gx_kmeans_row_dist(const float* X, long rows, int C, long ldx, const float* centers, int K, const int* labels,

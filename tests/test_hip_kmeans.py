@@ -68,6 +68,44 @@ def test_assign_ties_nan_histogram(gpu):
         assert int(nch) == rows
 
 
+def test_accumulate_sums(gpu):
+    """per-cluster sums in one pass over X: LDS accumulators, fixed-order chunk reduction"""
+    from ganecdotes_amd import _lib
+    from ganecdotes_amd.ops import _p, _stream, lib, workspace
+    rng = np.random.RandomState(4)
+    L = lib()
+    assert L.gx_kmeans_accumulate_supported(256) and not L.gx_kmeans_accumulate_supported(257)
+    for rows, c, k in ((70000, 96, 64), (513, 300, 5), (4099, 1024, 130), (65, 8, 256)):
+        x = rng.randn(rows, c).astype(np.float32)
+        lab = rng.randint(0, k, rows).astype(np.int32)
+        lab[: rows // 3] = 1                                   # long runs of one label
+        dx, dl = T(x).cuda(), T(lab).cuda()
+        sums = torch.empty(k, c, device=gpu)
+        wsb = L.gx_kmeans_accumulate_workspace_bytes(rows, k, c)
+        ws = workspace("kmeans_acc", wsb, gpu)
+        for _ in range(2):
+            _lib.check(L.gx_kmeans_accumulate(_p(dx), rows, c, c, _p(dl), k, _p(sums), _p(ws), wsb, _stream()), "acc")
+            want = np.zeros((k, c), np.float64)
+            np.add.at(want, lab, x.astype(np.float64))
+            got = sums.cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(x).max() * max(1, rows // k))
+        first = got.copy()
+        _lib.check(L.gx_kmeans_accumulate(_p(dx), rows, c, c, _p(dl), k, _p(sums), _p(ws), wsb, _stream()), "acc")
+        np.testing.assert_array_equal(sums.cpu().numpy(), first)               # reproducible bit for bit
+
+
+def test_many_clusters_onehot_path(gpu, engine):
+    """more than 256 clusters: the sums come from onehot^T . X on the GEMM engine"""
+    from oracle import kmeans_ref as K
+    from ganecdotes_amd.kmeans import KMeans
+    x = blobs(31, n=6000, c=32, k=40, spread=1.5)
+    init = x[np.random.RandomState(0).choice(6000, 300, replace=False)]
+    ref = K.kmeans_fit(x, 300, n_init=1, init=init, max_iter=15)
+    km = KMeans(300, init=init, n_init=1, max_iter=15).fit(T(x).cuda())
+    assert (km.labels_ == ref["labels_"]).mean() > 0.995
+    assert abs(km.inertia_ - ref["inertia_"]) <= 1e-3 * ref["inertia_"]
+
+
 def test_update_rowdist_center_panel(gpu):
     from ganecdotes_amd import _lib
     from ganecdotes_amd.kmeans import KMeans
