@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void km_center_panel_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------
 // E step on the score matrix S = X.C^T: label = argmin_k (csq[k] - 2 S[n][k]), first minimum wins
-// (_update_chunk_dense of sklearn's _k_means_lloyd.pyx).  16 lanes per row, 16 rows per block.
+// (_update_chunk_dense of sklearn's _k_means_lloyd.pyx).  16 lanes per row, 16 rows per block and pass.
 // hist (LDS) collects the block's label histogram; one integer atomic per (block, cluster).
 constexpr int KM_HIST = 2048;
 __global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict__ S, long rows, int K, long ld,
@@ -56,8 +56,7 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict_
     if (threadIdx.x == 0) changed = 0;
     __syncthreads();
     const int tl = threadIdx.x & 15;
-    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (row < rows) {
+    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += (long)gridDim.x * 16) {
         const float* s = S + row * ld;
         float bv = __builtin_inff();
         int bi = 0x7fffffff;
@@ -119,12 +118,20 @@ __global__ void km_accumulate_kernel(const float* __restrict__ X, long rows, int
     if (live)
         for (int k = 0; k < K; ++k) part[((long)blockIdx.x * K + k) * C + col] = acc[k * W + t];
 }
-__global__ __launch_bounds__(256) void km_reduce_sums_kernel(const float* __restrict__ part, int nchunk, long kc,
-                                                             float* __restrict__ sums) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void km_reduce_sums_kernel(const float* __restrict__ part, int nchunk, long kc,
+                                                            float* __restrict__ sums) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= kc) return;
     float a = 0.f;
-    for (int c = 0; c < nchunk; ++c) a += part[(long)c * kc + i];
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {                    // eight loads in flight, summed in chunk order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(long)(c + j) * kc + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; c < nchunk; ++c) a += part[(long)c * kc + i];
     sums[i] = a;
 }
 
@@ -221,12 +228,14 @@ __global__ __launch_bounds__(256) void km_pp_pots_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) part[(long)t * gridDim.x + blockIdx.x] = red[0];
 }
-__global__ void km_pp_pots_finish_kernel(const double* __restrict__ part, int nblk, int T, double* __restrict__ pots) {
-    const int t = threadIdx.x;
-    if (t >= T) return;
+__global__ __launch_bounds__(64) void km_pp_pots_finish_kernel(const double* __restrict__ part, int nblk,
+                                                               double* __restrict__ pots) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += part[(long)t * nblk + b];
-    pots[t] = a;
+    for (int b = lane; b < nblk; b += 64) a += part[(long)t * nblk + b];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) pots[t] = a;
 }
 __global__ __launch_bounds__(256) void km_pp_commit_kernel(const float* __restrict__ G, long rows, long ld,
                                                            const float* __restrict__ xsq, const int* __restrict__ cand,
@@ -236,18 +245,31 @@ __global__ __launch_bounds__(256) void km_pp_commit_kernel(const float* __restri
     const float d = km_pp_dist(G, ld, xsq, cand, n, best);
     closest[n] = first ? d : fminf(closest[n], d);
 }
-// cand[t] = min(searchsorted(cumsum_f64(closest), target[t], side='left'), rows - 1).  One block: every
-// thread owns a contiguous chunk, chunk sums are scanned in LDS, the owning thread walks its chunk.
+// cand[t] = min(searchsorted(cumsum_f64(closest), target[t], side='left'), rows - 1).  The rows are cut into
+// 1024 contiguous chunks: km_pp_chunk_sums_kernel sums them (a wave per chunk, coalesced), then one block scans
+// the chunk sums in LDS and the thread owning the chunk a target falls into walks it.
 constexpr int KM_PP_MAXT = 16;
 struct KmTargets { double v[KM_PP_MAXT]; };
-__global__ __launch_bounds__(1024) void km_pp_sample_kernel(const float* __restrict__ closest, long rows, KmTargets tg,
-                                                            int T, int* __restrict__ cand) {
+__global__ __launch_bounds__(256) void km_pp_chunk_sums_kernel(const float* __restrict__ closest, long rows,
+                                                               double* __restrict__ csum) {
+    const long per = (rows + 1023) / 1024;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long c0 = (long)chunk * per;
+    const long c1 = c0 + per < rows ? c0 + per : rows;
+    double a = 0.0;
+    for (long i = c0 + lane; i < c1; i += 64) a += (double)closest[i];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) csum[chunk] = a;
+}
+__global__ __launch_bounds__(1024) void km_pp_sample_kernel(const float* __restrict__ closest, long rows,
+                                                            const double* __restrict__ csum, KmTargets tg, int T,
+                                                            int* __restrict__ cand) {
     __shared__ double incl[1024];
     const long per = (rows + 1023) / 1024;
     const long lo = (long)threadIdx.x * per, hi = lo + per < rows ? lo + per : rows;
-    double a = 0.0;
-    for (long i = lo; i < hi; ++i) a += (double)closest[i];
-    incl[threadIdx.x] = a;
+    incl[threadIdx.x] = csum[threadIdx.x];
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1024 chunk sums
         const double add = (int)threadIdx.x >= off ? incl[threadIdx.x - off] : 0.0;
@@ -319,7 +341,9 @@ int gx_kmeans_assign(const float* S, long rows, int K, long ld, const float* csq
     hipStream_t s = (hipStream_t)stream;
     if (counts && hipMemsetAsync(counts, 0, sizeof(int) * K, s) != hipSuccess) return GX_ERR_LAUNCH;
     if (nchanged && hipMemsetAsync(nchanged, 0, sizeof(int), s) != hipSuccess) return GX_ERR_LAUNCH;
-    hipLaunchKernelGGL(gx::km_assign_kernel, dim3(gx_cdiv(rows, 16)), dim3(256), 0, s, S, rows, K, ld, csq, labels_prev,
+    // at most 512 blocks: the label histogram costs one global atomic per (block, cluster)
+    const int nblk = (int)(rows < 512L * 16 ? gx_cdiv(rows, 16) : 512);
+    hipLaunchKernelGGL(gx::km_assign_kernel, dim3(nblk), dim3(256), 0, s, S, rows, K, ld, csq, labels_prev,
                        labels, onehot, ld_onehot, counts, nchanged);
     GX_CHECK_LAUNCH();
     return GX_OK;
@@ -356,7 +380,7 @@ int gx_kmeans_accumulate(const float* X, long rows, int C, long ldx, const int* 
                        ldx, labels, K, rpb, (float*)workspace);
     GX_CHECK_LAUNCH();
     const long kc = (long)K * C;
-    hipLaunchKernelGGL(gx::km_reduce_sums_kernel, dim3(gx_cdiv(kc, 256)), dim3(256), 0, s, (const float*)workspace, nchunk, kc,
+    hipLaunchKernelGGL(gx::km_reduce_sums_kernel, dim3(gx_cdiv(kc, 64)), dim3(64), 0, s, (const float*)workspace, nchunk, kc,
                        sums);
     GX_CHECK_LAUNCH();
     return GX_OK;
@@ -384,7 +408,10 @@ int gx_kmeans_row_dist(const float* X, long rows, int C, long ldx, const float* 
     return GX_OK;
 }
 
-size_t gx_kmeans_pp_workspace_bytes(int T) { return (size_t)T * gx::KM_PP_BLOCKS * sizeof(double); }
+size_t gx_kmeans_pp_workspace_bytes(int T) {
+    const size_t n = (size_t)T * gx::KM_PP_BLOCKS;          // pots partials; sample: 1024 chunk sums
+    return (n > 1024 ? n : 1024) * sizeof(double);
+}
 
 int gx_kmeans_pp_pots(const float* G, long rows, int T, long ld, const float* xsq, const int* cand, const float* closest,
                       double* pots, void* workspace, size_t workspace_bytes, void* stream) {
@@ -395,7 +422,7 @@ int gx_kmeans_pp_pots(const float* G, long rows, int T, long ld, const float* xs
     hipLaunchKernelGGL(gx::km_pp_pots_kernel, dim3(nblk, T), dim3(256), 0, s, G, rows, T, ld, xsq, cand, closest,
                        (double*)workspace);
     GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gx::km_pp_pots_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nblk, T, pots);
+    hipLaunchKernelGGL(gx::km_pp_pots_finish_kernel, dim3(T), dim3(64), 0, s, (const double*)workspace, nblk, pots);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -410,11 +437,15 @@ int gx_kmeans_pp_commit(const float* G, long rows, int T, long ld, const float* 
 }
 
 int gx_kmeans_pp_sample(const float* closest, long rows, const double* targets /*host, T values*/, int T, int* cand,
-                        void* stream) {
+                        void* workspace, size_t workspace_bytes, void* stream) {
     if (!closest || !targets || !cand || rows <= 0 || T <= 0 || T > gx::KM_PP_MAXT) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < 1024 * sizeof(double)) return GX_ERR_WORKSPACE;
     gx::KmTargets tg;
     for (int t = 0; t < gx::KM_PP_MAXT; ++t) tg.v[t] = t < T ? targets[t] : 0.0;
-    hipLaunchKernelGGL(gx::km_pp_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, closest, rows, tg, T, cand);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gx::km_pp_chunk_sums_kernel, dim3(256), dim3(256), 0, s, closest, rows, (double*)workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gx::km_pp_sample_kernel, dim3(1), dim3(1024), 0, s, closest, rows, (const double*)workspace, tg, T, cand);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -111,7 +111,7 @@ class KMeans:
         for _ in range(1, k):
             targets = (rs.uniform(size=T) * np.float32(pot)).astype(np.float64)
             _lib.check(L.gx_kmeans_pp_sample(_p(closest), rows, targets.ctypes.data_as(ctypes.c_void_p), T, _p(cand),
-                                             _stream()), "gx_kmeans_pp_sample")
+                                             _p(ws), wsb, _stream()), "gx_kmeans_pp_sample")
             ops.gemm(X, X.index_select(0, cand.long()), False, True, out=G)
             _lib.check(L.gx_kmeans_pp_pots(_p(G), rows, T, G.stride(0), _p(xsq), _p(cand), _p(closest), _p(pots), _p(ws),
                                            wsb, _stream()), "gx_kmeans_pp_pots")

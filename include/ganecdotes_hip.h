@@ -359,7 +359,7 @@ int gx_kmeans_pp_pots(const float* G, long rows, int T, long ld, const float* xs
 int gx_kmeans_pp_commit(const float* G, long rows, int T, long ld, const float* xsq, const int* cand, int best, int first,
                         float* closest, void* stream);
 int gx_kmeans_pp_sample(const float* closest, long rows, const double* targets /*host, T values*/, int T, int* cand,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 int gx_kmeans_label_maps(int nlayers, const int* const* labels /*host array of device ptrs*/, const int* res /*host*/,
                          const int* K /*host*/, int B, int out_size, float hi, float lo, float* out, void* stream);
 

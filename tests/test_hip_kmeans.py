@@ -150,8 +150,10 @@ def test_kmeanspp_sample_pots_commit(gpu):
         want = np.minimum(np.searchsorted(cum, targets), rows - 1)
         cand = torch.empty(len(targets), dtype=torch.int32, device=gpu)
         dc = T(closest).cuda()
+        wsb = lib().gx_kmeans_pp_workspace_bytes(len(targets))
+        ws = workspace("kmeans_pp", wsb, gpu)
         _lib.check(lib().gx_kmeans_pp_sample(_p(dc), rows, targets.ctypes.data_as(ctypes.c_void_p), len(targets), _p(cand),
-                                             _stream()), "sample")
+                                             _p(ws), wsb, _stream()), "sample")
         got = cand.cpu().numpy()
         # a knife-edge target (== a cumsum entry) may resolve one slot apart under a different summation order
         assert np.all(np.abs(got - want) <= 1), (rows, got, want)
