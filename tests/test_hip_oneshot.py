@@ -106,6 +106,41 @@ def test_head_full_size_vs_oracle(gpu, size, n_class):
     assert (head.predict(f).cpu() == ref_pred).float().mean() > 0.995
 
 
+@pytest.mark.parametrize("size,hw", [("S", 96), ("L", 64)])
+def test_head_kmeans_plans_vs_oracle(gpu, size, hw):
+    """the hfc_kmeans head: 124 label-map channels into the 5-layer 'S' plan (dilations 1, 2, 1, 2, 1;
+    configs/segmentors/hfc_kmeans_config.py:74-75) and the 9-layer 'L' plan (dilations up to 8) — forward,
+    3 Adam epochs and predictions against the oracle"""
+    from oracle import oneshot_ref as O
+    from ganecdotes_amd.oneshot import OneShotHead
+    torch.manual_seed(6)
+    n_class, in_ch = 6, 124
+    head = OneShotHead(in_ch, n_class, size)
+    sd = {k: v.cpu().clone() for k, v in head.state_dict().items()}
+    plan = O.segmentor_plan(size, in_ch, n_class)
+    params = []
+    for i in range(len(plan)):
+        params += [sd[f"layers.{2 * i}.weight"], sd[f"layers.{2 * i}.bias"]]
+    lab_maps = torch.randint(0, 8, (1, 1, hw, hw))
+    feats = (torch.arange(in_ch).reshape(1, -1, 1, 1) % 8 == lab_maps).float() * 2 - 1        # +-1 one-hot-like maps
+    labels = torch.randint(0, n_class, (1, hw, hw))
+    ref_losses, ref_final = O.finetune(feats, labels, params, plan, epochs=3, lr=1e-3, beta1=0.9, beta2=0.99)
+    f = feats.cuda().permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        assert rel(head.logits(f), O.segmentor_forward(feats, params, plan)) < 2e-5
+    losses = head.fit(f, labels.cuda(), num_epochs=3, lr=1e-3, beta1=0.9, beta2=0.99)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
+    got = head.state_dict()
+    for i in range(len(plan)):
+        for a, b in ((got[f"layers.{2 * i}.weight"], ref_final[2 * i]), (got[f"layers.{2 * i}.bias"], ref_final[2 * i + 1])):
+            diff = (a.cpu() - b).abs()
+            assert float((diff <= 1e-4).float().mean()) > 0.9
+            assert float(diff.max()) <= 2 * 3 * 1e-3 + 1e-6
+    with torch.no_grad():
+        ref_pred = O.segmentor_forward(feats, ref_final, plan).max(1)[1]
+    assert (head.predict(f).cpu() == ref_pred).float().mean() > 0.99
+
+
 def test_one_shot_pipeline_end_to_end_vs_oracle(gpu, tmp_path):
     """pretrained projection -> code map of the labelled latent -> fine-tuned head -> run_tests over
     test latents: predictions and the IoU results of the HIP pipeline against the oracle's
