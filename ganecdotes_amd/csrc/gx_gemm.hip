@@ -29,6 +29,11 @@ struct GemmArgs {
     // optional second A source, concatenated along K after the first K1 columns (A = [A | A2]);
     // K1 is a multiple of BK (K1 == K when unused).  Non-transposed A only.
     const float* A2; long lda2; int K1;
+    // optional epilogue term C[m][n] += up_src[coarse(m)][n]: C's rows are the pixels (b, y, x) of up_rf x up_rf
+    // images (up_rf = 1 << up_shift), up_src's the pixels (b, y / 2, x / 2) of the half-resolution table [.][N]
+    // (the upsample-add of the pyramid projection, fused).  Not with split-K.
+    const float* up_src; int up_shift;
+    int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
 
 // Accumulators of a wave's (32 MT) x (32 NT) sub-tile whose first row / column in C is (row0, col0).
@@ -52,15 +57,84 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                         if (g.row_scale) v *= g.row_scale[row];
                         if (g.col_bias) v += g.col_bias[col];
                         if (g.beta != 0.f) v += g.beta * out[(long)row * ldo + col];
+                        if (g.up_src) {
+                            const int s = g.up_shift, rc = 1 << (s - 1);
+                            const int b = row >> (2 * s), y = (row >> s) & ((1 << s) - 1), x = row & ((1 << s) - 1);
+                            v += g.up_src[(((long)b * rc + (y >> 1)) * rc + (x >> 1)) * g.N + col];
+                        }
                     }
                     out[(long)row * ldo + col] = v;
                 }
             }
         }
 }
+// The same epilogue through LDS: a wave parks 32 rows of its sub-tile in its own staging area (the operand
+// tiles are dead by now), reads them back row-contiguous and issues 16-B loads / stores — 256 contiguous bytes per
+// row segment instead of 64 dword stores (and as many dword loads for beta / up_src) per lane.
+constexpr int EP_STAGE_FLOATS = 32 * (64 + 4);           // per wave: 32 rows x (32 NT + 4) floats, NT <= 2
+// The epilogue-only fields of GemmArgs, re-read from the kernel-argument segment when the epilogue starts: read at
+// kernel entry they would sit in registers through the whole k loop (the compiler spilled them to scratch and
+// re-loaded them, with a full vmcnt(0) wait, once per store pass).  GemmArgs is the kernels' only parameter.
+__device__ __forceinline__ const GemmArgs* gemm_late_args() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const GemmArgs*)p;
+}
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane,
+                                                     float* stage) {
+    constexpr int SW = 32 * NT + 4, LPR = 8 * NT, RPP = 64 / LPR;
+    const GemmArgs& q = *gemm_late_args();
+    const float alpha = q.alpha, beta = q.beta;
+    const float* row_scale = q.row_scale;
+    const float* up_src = q.up_src;
+    const int up_s = q.up_shift;
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
+    const long ldo = to_slab ? g.N : g.ldc;
+    const int rl = lane / LPR, c4 = (lane % LPR) * 4;
+    const int col = col0 + c4;
+    f32x4 cb = zero4();
+    if (!to_slab && q.col_bias && col < g.N) cb = f32x4{q.col_bias[col], q.col_bias[col + 1], q.col_bias[col + 2], q.col_bias[col + 3]};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SW + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = row0 + mt * 32 + ps * RPP + rl;
+            if (row < g.M && col < g.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + (ps * RPP + rl) * SW + c4);
+                float* dst = out + (long)row * ldo + col;
+                if (!to_slab) {
+                    v *= alpha;
+                    if (row_scale) v *= row_scale[row];
+                    v += cb;
+                    if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(dst);
+                    if (up_src) {
+                        const int s = up_s, rc = 1 << (s - 1);
+                        const int b = row >> (2 * s), y = (row >> s) & ((1 << s) - 1), x = row & ((1 << s) - 1);
+                        v += *reinterpret_cast<const f32x4*>(up_src + (((long)b * rc + (y >> 1)) * rc + (x >> 1)) * g.N + col);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
-                                              int lane) {
-    gemm_epilogue_t<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane);
+                                              int lane, float* stage) {
+    if (g.ep_vec) gemm_epilogue_staged<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane, stage);
+    else gemm_epilogue_t<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
@@ -111,7 +185,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue(g, acc, m0, n0, wr, wc, lane);
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, lds + wid * EP_STAGE_FLOATS);
 }
 
 // The same contraction on the bf16 matrix cores (gx_mfma_x6.h): 128 x 128 x 16 tiles, every operand
@@ -161,7 +235,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    gemm_epilogue(g, acc, m0, n0, wr, wc, lane);
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS);
 }
 
 // Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
@@ -240,7 +314,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         x6_mfma_tile<A_KC, B_KC, 4, 2, WS_BM, WS_BN>(slot, slot + XImg<WS_BM>::BYTES, acc, wr * 128, wc * 64, lane);
         __syncthreads();                                             // barrier t+1
     }
-    gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    if (g.ep_vec)
+        gemm_epilogue_staged<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS);
+    else
+        gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
@@ -272,12 +349,23 @@ static int gemm_mode() {
     return g_gemm_mode;
 }
 
+static bool ep_scalar() {          // GX_GEMM_EPILOGUE=scalar: the dword epilogue (A/B measurements)
+    static const bool v = [] { const char* e = getenv("GX_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
+    return v;
+}
+
 static int launch_gemm(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
                        long ldb, float* C, long ldc, float alpha, float beta, const float* row_scale,
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
-                       hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1) {
+                       hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
+                       const float* up_src = nullptr, int up_rf = 0) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
+    g.up_src = up_src; g.up_shift = 0;
+    if (up_src) {
+        if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
+        while ((1 << g.up_shift) < up_rf) ++g.up_shift;
+    }
     g.A2 = A2; g.lda2 = lda2; g.K1 = (A2 ? K1 : K);
     if (A2 && (transA || K1 <= 0 || K1 >= K || (K1 % BK) != 0 || lda2 <= 0)) return GX_ERR_BAD_ARG;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -299,6 +387,12 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     if (split_k > 1) {
         if (!workspace || workspace_bytes < (size_t)split_k * M * N * sizeof(float)) return GX_ERR_WORKSPACE;
         g.slab = workspace;
+    }
+    {   // float4 epilogue: every row segment it touches must be 16-B aligned
+        const bool direct = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+        const bool slab_ok = (((uintptr_t)workspace & 15) == 0);
+        const bool up_ok = !up_src || (((uintptr_t)up_src & 15) == 0);
+        g.ep_vec = (N % 4 == 0) && (g.slab ? slab_ok : (direct && up_ok)) && !ep_scalar();
     }
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
 #define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
@@ -361,6 +455,16 @@ int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1
     if (!A2 || K2 <= 0) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(0, transB, M, N, K1 + K2, A1, lda1, B, ldb, C, ldc, alpha, beta, nullptr, col_bias, 1,
                            nullptr, 0, (hipStream_t)stream, A2, lda2, K1);
+}
+
+// C = [A1 | A2] opB + upsample2(coarse): C's M rows are the pixels of (fine_res x fine_res) images, coarse
+// [M / 4][N] the finished table of the level below (K2 = 0: a single A).  One level of the pyramid projection.
+int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                      const float* B, long ldb, float* C, long ldc, float beta, const float* coarse, int fine_res,
+                      void* stream) {
+    if (!coarse || K2 < 0 || (K2 > 0 && !A2)) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(0, transB, M, N, K1 + K2, A1, lda1, B, ldb, C, ldc, 1.f, beta, nullptr, nullptr, 1, nullptr, 0,
+                           (hipStream_t)stream, K2 > 0 ? A2 : nullptr, K2 > 0 ? lda2 : 0, K2 > 0 ? K1 : -1, coarse, fine_res);
 }
 
 }  // extern "C"

@@ -1864,8 +1864,9 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
 
 // Finest pyramid level of the low-rank path: fine += upsample2(coarse) AND the score / rnorm tables
 // of the finished rows in the same pass.  One wave per coarse pixel = 2x2 block of fine pixels:
-// one coarse row + four fine rows in flight per lane.
-template <int KP>
+// one coarse row + four fine rows in flight per lane.  ADD = false: the table is already finished (the
+// upsample-add rode on the projection GEMM's epilogue, gx_gemm_f32_upadd): tables only, nothing stored back.
+template <int KP, bool ADD>
 __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* __restrict__ coarse, float* __restrict__ fine,
                                                                    long ncoarse, int rc, int D,
                                                                    const float* __restrict__ Wc,
@@ -1891,7 +1892,7 @@ __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* 
         f32x4 c[2], z[4][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            c[i] = i < nv ? *reinterpret_cast<const f32x4*>(coarse + g * D + (i * 64 + lane) * 4) : zero4();
+            c[i] = (ADD && i < nv) ? *reinterpret_cast<const f32x4*>(coarse + g * D + (i * 64 + lane) * 4) : zero4();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1912,8 +1913,8 @@ __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* 
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[j] = z[j][i] + c[i];
-                    *reinterpret_cast<f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) = v[j];
+                    v[j] = ADD ? z[j][i] + c[i] : z[j][i];
+                    if (ADD) *reinterpret_cast<f32x4*>(fine + pq[j] * D + (i * 64 + lane) * 4) = v[j];
                     ss[j] += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
                 }
 #pragma unroll
@@ -2061,21 +2062,22 @@ int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, i
 
 // fine (B, 2rc, 2rc, D) += upsample2(coarse (B, rc, rc, D)); rn_table (B*4rc^2), sc_table (B*4rc^2, K)
 // = what gx_proto_fwd_lowrank(picks = NULL) gives on the finished table.  D in {256, 512}, K <= 16.
+// coarse == NULL: fine is already finished (gx_gemm_f32_upadd); only the tables are written.
 int gx_upsample2_add_scores(const float* coarse, float* fine, int B, int rc, int D, const float* Wc, const float* bias,
                             int K, float* rn_table, float* sc_table, void* stream) {
-    if (!coarse || !fine || !Wc || !rn_table || !sc_table || B <= 0 || rc <= 0) return GX_ERR_BAD_ARG;
+    if (!fine || !Wc || !rn_table || !sc_table || B <= 0 || rc <= 0) return GX_ERR_BAD_ARG;
     if (K < 1 || K > gx::LR_MAXK || (D & 255) || D > 512) return GX_ERR_BAD_ARG;
     const long ncoarse = (long)B * rc * rc;
     long nb = (ncoarse + 3) / 4;
     if (nb > 4096) nb = 4096;
     const int kp = K <= 8 ? 8 : 16;
     const size_t lds = (size_t)kp * D * sizeof(float);
-    if (kp == 8)
-        hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<8>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, coarse,
-                           fine, ncoarse, rc, D, Wc, bias, K, rn_table, sc_table);
-    else
-        hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<16>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, coarse,
-                           fine, ncoarse, rc, D, Wc, bias, K, rn_table, sc_table);
+#define GX_LAUNCH_UAS(KP_, ADD_)                                                                                   \
+    hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<KP_, ADD_>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, \
+                       coarse, fine, ncoarse, rc, D, Wc, bias, K, rn_table, sc_table)
+    if (kp == 8) { if (coarse) GX_LAUNCH_UAS(8, true); else GX_LAUNCH_UAS(8, false); }
+    else { if (coarse) GX_LAUNCH_UAS(16, true); else GX_LAUNCH_UAS(16, false); }
+#undef GX_LAUNCH_UAS
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -134,6 +134,22 @@ def gemm_cat(a1, a2, b, out, trans_b=True, alpha=1.0, beta=0.0):
     return out
 
 
+def gemm_upadd(a1, a2, b, out, coarse, fine_res, beta=0.0):
+    """out = [a1 | a2] @ b.T + beta*out + upsample2(coarse): one pyramid level in one launch.  out's rows are the
+    pixels of fine_res x fine_res images, coarse (rows/4, N) the finished level below; a2 may be None."""
+    _chk2d(a1, a2, b, out, coarse)
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = b.shape[0]
+    if tuple(out.shape) != (m, n) or b.shape[1] != k1 + k2 or tuple(coarse.shape) != (m // 4, n) or coarse.stride(0) != n:
+        raise RuntimeError("gemm_upadd: shape mismatch")
+    with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
+        _lib.check(lib().gx_gemm_f32_upadd(1, m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
+                                           _p(b), b.stride(0), _p(out), out.stride(0), beta, _p(coarse), fine_res,
+                                           _stream()), "gx_gemm_f32_upadd")
+    return out
+
+
 # ------------------------------------------------------------------------------------- pyramid projection
 def upsample2_add_(coarse, fine):
     """fine (B, 2r, 2r, D) += nearest-upsampled coarse (B, r, r, D)."""
@@ -303,9 +319,10 @@ def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False):
 
 def upsample2_add_scores_(coarse, fine, wc, bias):
     """fine (B,2r,2r,D) += upsample2(coarse (B,r,r,D)) and, in the same pass, the prototype score
-    table (B*4r^2, K) and 1/||row|| table (B*4r^2) of the finished rows."""
+    table (B*4r^2, K) and 1/||row|| table (B*4r^2) of the finished rows.  coarse=None: fine is
+    already finished (gemm_upadd); only the tables are computed."""
     _chk(coarse, fine, wc, bias)
-    b, r, _, d = coarse.shape
+    b, r, d = fine.shape[0], fine.shape[1] // 2, fine.shape[3]
     k = wc.shape[0]
     rn = torch.empty(b * 4 * r * r, dtype=torch.float32, device=fine.device)
     sc = torch.empty(b * 4 * r * r, k, dtype=torch.float32, device=fine.device)

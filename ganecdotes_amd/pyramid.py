@@ -10,9 +10,13 @@ the exact adjoint (scatter-add, 2x2 sum-pooling, one TN GEMM per tap).  Same rea
 as swav_clustering.py:108-130 + :160-171 (and autograd of them); only the fp32 summation order
 differs (13 partial dot products instead of one 5376-long chain).
 """
+import os
+
 import torch
 
 from . import ops
+
+FUSE_UP = os.environ.get("GX_PYRAMID_FUSE", "1") != "0"      # 0: separate upsample-add passes (A/B measurements)
 
 
 class Pyramid:
@@ -42,20 +46,28 @@ class Pyramid:
         for r, taps in zip(self.res, self.levels):
             p = torch.empty(self.B * r * r, d, dtype=torch.float32, device=wp.device)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
+            # the level below rides on the epilogue of this level's (first) GEMM: p = taps . Wp^T + upsample2(prev)
+            up = prev.reshape(-1, d) if (FUSE_UP and prev is not None and used and (r & (r - 1)) == 0) else None
             if not used:
                 p.zero_()
             elif (len(used) == 2 and used[0][2] == used[0][0].shape[1] and used[0][2] % 32 == 0 and
                   used[1][1] == used[0][1] + used[0][2]):
                 (ta, off, ca), (tb, _, cb) = used
-                ops.gemm_cat(ta, tb[:, :cb], wp[:, off:off + ca + cb], p)
+                if up is not None:
+                    ops.gemm_upadd(ta, tb[:, :cb], wp[:, off:off + ca + cb], p, up, r)
+                else:
+                    ops.gemm_cat(ta, tb[:, :cb], wp[:, off:off + ca + cb], p)
             else:
                 for i, (t, off, cu) in enumerate(used):
-                    ops.gemm(t[:, :cu], wp[:, off:off + cu], False, True, out=p, beta=0.0 if i == 0 else 1.0)
+                    if up is not None and i == 0:
+                        ops.gemm_upadd(t[:, :cu], None, wp[:, off:off + cu], p, up, r)
+                    else:
+                        ops.gemm(t[:, :cu], wp[:, off:off + cu], False, True, out=p, beta=0.0 if i == 0 else 1.0)
             p = p.reshape(self.B, r, r, d)
             if prev is not None:
                 if score_head is not None and r == self.res[-1]:
-                    tables = ops.upsample2_add_scores_(prev, p, *score_head)
-                else:
+                    tables = ops.upsample2_add_scores_(prev if up is None else None, p, *score_head)
+                elif up is None:
                     ops.upsample2_add_(prev, p)
             prev = p
         if score_head is not None:

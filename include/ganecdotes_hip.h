@@ -74,6 +74,13 @@ int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lon
 int gx_gemm_f32_cat(int transB, int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                     const float* B, long ldb, float* C, long ldc, float alpha, float beta, const float* col_bias,
                     void* stream);
+/* One level of the pyramid projection in one launch: C = [A1 | A2] opB + beta*C + upsample2(coarse), where C's M rows
+ * are the pixels (b, y, x) of fine_res x fine_res images (a power of two) and coarse [M/4][N] is the finished table
+ * of the level below, row (b, y/2, x/2).  K2 = 0: a single A.  (F.interpolate(nearest) + concat + F.linear of
+ * swav_clustering.py:108-130, :171, factorised; replaces a separate gx_upsample2_add pass over C.) */
+int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                      const float* B, long ldb, float* C, long ldc, float beta, const float* coarse, int fine_res,
+                      void* stream);
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110
@@ -212,7 +219,8 @@ int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, i
                             float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
                             void* stream);   /* Gpool != NULL: also the 2x2 sum-pooled G (B*rc*rc, D) */
 /* finest pyramid level + score table in one pass: fine += upsample2(coarse); rn_table, sc_table as
- * gx_proto_fwd_lowrank(picks = NULL) on the result */
+ * gx_proto_fwd_lowrank(picks = NULL) on the result.  coarse == NULL: fine is already finished
+ * (gx_gemm_f32_upadd) and only the tables are written */
 int gx_upsample2_add_scores(const float* coarse, float* fine, int B, int rc, int D, const float* Wc, const float* bias,
                             int K, float* rn_table, float* sc_table, void* stream);
 

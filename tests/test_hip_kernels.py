@@ -518,6 +518,31 @@ def test_gemm_cat_and_strided_views(ops, engine):
     assert float(gw[:, :200].abs().max()) == 0 and float(gw[:, 280:].abs().max()) == 0
 
 
+def test_gemm_upadd_fused_pyramid_level(ops, engine):
+    """one pyramid level in one launch: [a1 | a2] . W^T + upsample2(coarse) (and the single-A / beta forms)"""
+    torch.manual_seed(18)
+    for b, rf, k1, k2, n in ((2, 8, 64, 40, 72), (3, 16, 32, 0, 256), (1, 4, 96, 32, 130)):
+        m = b * rf * rf
+        a1, a2 = torch.randn(m, k1), (torch.randn(m, k2 + 4) if k2 else None)
+        w = torch.randn(n, k1 + k2 + 9)
+        coarse = torch.randn(b, rf // 2, rf // 2, n)
+        up = coarse.repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(m, n).double()
+        acat = a1 if a2 is None else torch.cat([a1, a2[:, :k2]], 1)
+        ref = acat.double() @ w[:, 5:5 + k1 + k2].double().t() + up
+        out = torch.empty(m, n, device="cuda")
+        ops.gemm_upadd(dev(a1), None if a2 is None else dev(a2)[:, :k2], dev(w)[:, 5:5 + k1 + k2], out,
+                       dev(coarse.reshape(-1, n)), rf)
+        assert rel_err(out, ref) < 3e-6
+        prior = torch.randn(m, n)
+        out2 = dev(prior.clone())
+        ops.gemm_upadd(dev(a1), None if a2 is None else dev(a2)[:, :k2], dev(w)[:, 5:5 + k1 + k2], out2,
+                       dev(coarse.reshape(-1, n)), rf, beta=1.0)
+        assert rel_err(out2, ref + prior.double()) < 3e-6
+    with pytest.raises(RuntimeError):                  # a non-power-of-two resolution has no shift form
+        ops.gemm_upadd(dev(torch.randn(72, 32)), None, dev(torch.randn(8, 32)), torch.empty(72, 8, device="cuda"),
+                       dev(torch.randn(18, 8)), 6)
+
+
 def test_pyramid_pieces(ops):
     torch.manual_seed(12)
     b, r, d = 2, 8, 24
