@@ -551,20 +551,28 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 // ToRGB for Cin % 4 == 0, Cin <= 4 * 4 * lp: the lane's slice of the 3 x Cin weight stays in registers and a
 // wave keeps the rows of TG_R pixel groups in flight (the one-group-at-a-time form below reaches 1.8 TB/s).
 constexpr int TG_R = 4;
+// One output of upfirdn2d(up=2, pad=(2,1)): the zero-inserted image has samples at even (zy, zx) only, so of the
+// 4x4 FIR window exactly the 2x2 taps fy = (y & 1) + {0, 2}, fx = (x & 1) + {0, 2} meet a sample.  Branch-free:
+// out-of-range taps read a clamped address with weight 0.
 __device__ __forceinline__ float torgb_skip(const float* __restrict__ prev, const float* __restrict__ kf, int b, int c,
                                             int y, int xx, int H, int Wd) {
     const int ph = H >> 1, pw = Wd >> 1;
     const float* pp = prev + ((long)b * 3 + c) * ph * pw;
+    const int fy0 = y & 1, fx0 = xx & 1;
+    const int py0 = ((y + fy0) >> 1) - 1, px0 = ((xx + fx0) >> 1) - 1;       // (zy >> 1) of the first tap
     float u = 0.f;
 #pragma unroll
-    for (int fy = 0; fy < 4; ++fy) {
-        const int zy = y + fy - 2;
-        if (zy < 0 || zy >= H || (zy & 1)) continue;
+    for (int a = 0; a < 2; ++a) {
+        const int py = py0 + a;
+        const bool yok = py >= 0 && py < ph;
+        const int pyc = py < 0 ? 0 : (py >= ph ? ph - 1 : py);
 #pragma unroll
-        for (int fx = 0; fx < 4; ++fx) {
-            const int zx = xx + fx - 2;
-            if (zx < 0 || zx >= Wd || (zx & 1)) continue;
-            u = fmaf(kf[fy * 4 + fx], pp[(zy >> 1) * pw + (zx >> 1)], u);
+        for (int e = 0; e < 2; ++e) {
+            const int px = px0 + e;
+            const bool ok = yok && px >= 0 && px < pw;
+            const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+            const float wgt = ok ? kf[(fy0 + 2 * a) * 4 + fx0 + 2 * e] : 0.f;
+            u = fmaf(wgt, pp[pyc * pw + pxc], u);
         }
     }
     return u;
@@ -610,9 +618,10 @@ __global__ __launch_bounds__(256) void torgb_stream_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < TG_R; ++r) {
             const bool live = pix[r] < npix;
-            ob[r] = live ? (int)(pix[r] / hw) : 0;
-            const int rem = live ? (int)(pix[r] - (long)ob[r] * hw) : 0;
-            oy[r] = rem / Wd; ox[r] = rem - oy[r] * Wd;
+            const unsigned p32 = live ? (unsigned)pix[r] : 0u;       // the host checks npix < 2^31: 32-bit divisions
+            ob[r] = (int)(p32 / (unsigned)hw);
+            const unsigned rem = p32 - (unsigned)ob[r] * (unsigned)hw;
+            oy[r] = (int)(rem / (unsigned)Wd); ox[r] = (int)(rem - (unsigned)oy[r] * (unsigned)Wd);
             skipv[r] = (prev && live && tl < 3) ? torgb_skip(prev, kf, ob[r], tl, oy[r], ox[r], H, Wd) : 0.f;
         }
 #pragma unroll
@@ -978,7 +987,8 @@ int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, 
     while (lp < 64 && lp * 4 < Cin) lp <<= 1;
     const long waves = ((long)B * H * W + (64 / lp) - 1) / (64 / lp);
     const int ni = (Cin + lp * 4 - 1) / (lp * 4);
-    if ((Cin & 3) == 0 && ni <= 4 && (((uintptr_t)x | (uintptr_t)s | (uintptr_t)w3) & 15) == 0) {
+    if ((Cin & 3) == 0 && ni <= 4 && (((uintptr_t)x | (uintptr_t)s | (uintptr_t)w3) & 15) == 0 &&
+        (long)B * H * W < (1L << 31)) {
         long nb = gx_cdiv(gx_cdiv(waves, TG_R), 4);
         if (nb > 8192) nb = 8192;
 #define GX_TORGB(NI_) hipLaunchKernelGGL((torgb_stream_kernel<NI_>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, \
