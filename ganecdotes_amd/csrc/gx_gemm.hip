@@ -349,6 +349,10 @@ static int gemm_mode() {
     return g_gemm_mode;
 }
 
+static int ws_min_k() {             // GX_WS_MINK: shortest k extent (per split) that takes the wave-specialised kernel
+    static const int v = [] { const char* e = getenv("GX_WS_MINK"); return e ? atoi(e) : 768; }();
+    return v;
+}
 static bool ep_scalar() {          // GX_GEMM_EPILOGUE=scalar: the dword epilogue (A/B measurements)
     static const bool v = [] { const char* e = getenv("GX_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
     return v;
@@ -376,7 +380,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
-    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= 768;
+    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= ws_min_k();
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
