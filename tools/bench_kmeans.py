@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--layers", default="0,1,2,3,4")
     args = ap.parse_args()
-    from ganecdotes_amd import ops
     from ganecdotes_amd.config_defaults import kmeans_segmentor
     from ganecdotes_amd.generator import Generator
     from ganecdotes_amd.kmeans import KMeans, _pair
@@ -56,8 +55,6 @@ def main():
         total_gpu += dt
         row = dict(layer=k, rows=t1.shape[0], channels=t1.shape[1] + t2.shape[1], clusters=K, hip_s=dt, n_init=args.n_init,
                    n_iter_best=km.n_iter_, inertia=km.inertia_)
-        # one Lloyd iteration, timed with events (scores GEMM + assign + sums GEMM + update)
-        ops.PROFILE = None
         if str(k) in args.cpu_layers.split(","):
             from sklearn.cluster import KMeans as SkKMeans
             x = torch.cat([t1, t2], 1).cpu().numpy()
