@@ -137,20 +137,30 @@ __global__ __launch_bounds__(64) void km_reduce_sums_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------
 // M step tail (_average_centers + _center_shift): new centre k = sums[k] * (1 / count[k]);
-// shift2[k] = |new - old|^2, csq[k] = |new|^2.  One block per centre.  A cluster with count 0 (only
-// possible when relocation was pointless) keeps its centre.
+// shift2[k] = |new - old|^2, csq[k] = |new|^2.  One block per centre.  A cluster with count 0 (only left when
+// relocation was pointless: fewer distinct samples than clusters) follows sklearn's in-place, index-ordered loop:
+// it copies the row of the biggest cluster am = argmax(counts) as it is at that moment — the raw sum when
+// am > k, the mean when am < k.
 __global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict__ sums, const int* __restrict__ counts,
-                                                        int C, const float* __restrict__ centers_old,
+                                                        int K, int C, const float* __restrict__ centers_old,
                                                         float* __restrict__ centers, float* __restrict__ csq,
                                                         float* __restrict__ shift2) {
     __shared__ float red[16];
     const int k = blockIdx.x;
-    const float cnt = (float)counts[k];
-    const float alpha = cnt > 0.f ? 1.0f / cnt : 0.f;
+    int src = k;
+    float alpha = 1.0f;
+    const int cnt = counts[k];
+    if (cnt > 0) alpha = 1.0f / (float)cnt;
+    else {
+        int am = 0;
+        for (int j = 1; j < K; ++j) if (counts[j] > counts[am]) am = j;
+        src = am;
+        alpha = am < k ? 1.0f / (float)counts[am] : 1.0f;
+    }
     float sh = 0.f, sq = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) {
         const float old = centers_old[(long)k * C + c];
-        const float nw = cnt > 0.f ? sums[(long)k * C + c] * alpha : old;
+        const float nw = sums[(long)src * C + c] * alpha;
         centers[(long)k * C + c] = nw;
         sh += (nw - old) * (nw - old);
         sq += nw * nw;
@@ -389,7 +399,7 @@ int gx_kmeans_accumulate(const float* X, long rows, int C, long ldx, const int* 
 int gx_kmeans_update(const float* sums, const int* counts, int K, int C, const float* centers_old, float* centers_new,
                      float* csq, float* shift2, void* stream) {
     if (!sums || !counts || !centers_old || !centers_new || !csq || !shift2 || K <= 0 || C <= 0) return GX_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gx::km_update_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, sums, counts, C, centers_old,
+    hipLaunchKernelGGL(gx::km_update_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, sums, counts, K, C, centers_old,
                        centers_new, csq, shift2);
     GX_CHECK_LAUNCH();
     return GX_OK;

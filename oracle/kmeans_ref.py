@@ -101,12 +101,12 @@ def lloyd_iter(X, centers):
     np.add.at(sums, labels, X)
     counts = np.bincount(labels, minlength=k).astype(X.dtype)
     _relocate_empty(X, centers, sums, counts, labels)
-    new = np.empty_like(centers)
-    big = int(np.argmax(counts))
-    for j in range(k):
-        new[j] = sums[j] * (X.dtype.type(1.0) / counts[j]) if counts[j] > 0 else 0
-    for j in range(k):
-        if counts[j] <= 0:
+    new = sums.copy()                                   # _average_centers, in place and in index order: an empty
+    big = int(np.argmax(counts))                        # cluster (only left when relocation was pointless) copies
+    for j in range(k):                                  # the biggest cluster's row AS IT IS at that moment — the
+        if counts[j] > 0:                               # raw sum when big > j, the mean when big < j
+            new[j] *= X.dtype.type(1.0) / counts[j]
+        else:
             new[j] = new[big]
     shift = np.sqrt(((new - centers) ** 2).sum(axis=1))
     return labels, new, shift

@@ -106,6 +106,50 @@ def test_many_clusters_onehot_path(gpu, engine):
     assert abs(km.inertia_ - ref["inertia_"]) <= 1e-3 * ref["inertia_"]
 
 
+def test_edge_cases_vs_oracle(gpu):
+    """one cluster, as many clusters as samples, odd channel counts, duplicated samples (fewer distinct points
+    than clusters: relocation is pointless and the degenerate centres stay put), too few samples"""
+    from oracle import kmeans_ref as K
+    from ganecdotes_amd.kmeans import KMeans
+    rng = np.random.RandomState(41)
+    x = rng.randn(50, 7).astype(np.float32) + 1.5
+    for k in (1, 3):
+        ref = K.kmeans_fit(x, k, n_init=1, random_state=2)
+        km = KMeans(k, n_init=1, random_state=2).fit(T(x).cuda())
+        np.testing.assert_array_equal(km.labels_, ref["labels_"])
+        np.testing.assert_allclose(km.cluster_centers_, ref["cluster_centers_"], atol=2e-5)
+        assert km.n_iter_ == ref["n_iter_"]
+    small = x[:6]
+    ref = K.kmeans_fit(small, 6, n_init=1, init=small[::-1].copy())
+    km = KMeans(6, init=small[::-1].copy(), n_init=1).fit(T(small).cuda())
+    np.testing.assert_array_equal(km.labels_, ref["labels_"])
+    assert km.inertia_ <= 1e-8 and ref["inertia_"] <= 1e-8
+    dup = np.repeat(x[:3], 5, axis=0)                      # 3 distinct points, 5 clusters
+    init = np.concatenate([x[:3], x[:2] + 0.25])
+    ref = K.kmeans_fit(dup, 5, n_init=1, init=init)
+    km = KMeans(5, init=init, n_init=1).fit(T(dup).cuda())
+    np.testing.assert_array_equal(km.labels_, ref["labels_"])
+    assert len(set(km.labels_.tolist())) == 3
+    g = load_golden("gv15_kmeans")                         # the same situation as sklearn itself resolves it
+    for i in (0, 1):
+        km = KMeans(5, init=g[f"A_dup{i}_init"], n_init=1).fit(T(g["A_dup_x"]).cuda())
+        np.testing.assert_array_equal(km.labels_, g[f"A_dup{i}_labels"])
+        assert km.n_iter_ == int(g[f"A_dup{i}_n_iter"])
+        used = sorted(set(km.labels_.tolist()))
+        np.testing.assert_allclose(km.cluster_centers_[used], g[f"A_dup{i}_centers"][used], rtol=0, atol=2e-5)
+        # the second iteration's means differ from the points by rounding residue, so sklearn relocates the two empty
+        # clusters onto whichever duplicates carry the largest residue — a choice made by summation order; here as
+        # there they land on data points
+        pts = g["A_dup_x"][::5]
+        for j in set(range(5)) - set(used):
+            assert np.abs(pts - km.cluster_centers_[j]).max(axis=1).min() < 2e-5
+            assert np.abs(pts - g[f"A_dup{i}_centers"][j]).max(axis=1).min() < 2e-5
+    with pytest.raises(ValueError):
+        KMeans(8, n_init=1).fit(T(x[:5]).cuda())
+    with pytest.raises(RuntimeError):                      # no CPU fallback
+        KMeans(2).fit(T(x))
+
+
 def test_update_rowdist_center_panel(gpu):
     from ganecdotes_amd import _lib
     from ganecdotes_amd.kmeans import KMeans
@@ -118,10 +162,15 @@ def test_update_rowdist_center_panel(gpu):
     csq, sh = torch.empty(k, device=gpu), torch.empty(k, device=gpu)
     dsums, dcounts, dold = T(sums).cuda(), T(counts).cuda(), T(old).cuda()
     _lib.check(lib().gx_kmeans_update(_p(dsums), _p(dcounts), k, c, _p(dold), _p(new), _p(csq), _p(sh), _stream()), "update")
-    want = np.where(counts[:, None] > 0, sums * (np.float32(1) / np.maximum(counts, 1).astype(np.float32))[:, None], old)
+    want = sums * (np.float32(1) / np.maximum(counts, 1).astype(np.float32))[:, None]
+    want[2] = sums[3]              # empty cluster below the biggest one (k = 3): sklearn's in-place loop copies the raw sum
     np.testing.assert_allclose(new.cpu().numpy(), want, rtol=1e-6)
     np.testing.assert_allclose(sh.cpu().numpy(), ((want - old) ** 2).sum(1), rtol=1e-5)
     np.testing.assert_allclose(csq.cpu().numpy(), (want ** 2).sum(1), rtol=1e-5)
+    counts2 = np.array([30, 1, 0, 20, 5, 9, 2], np.int32)      # ... above it (k = 0): the mean
+    dc2 = T(counts2).cuda()
+    _lib.check(lib().gx_kmeans_update(_p(dsums), _p(dc2), k, c, _p(dold), _p(new), _p(csq), _p(sh), _stream()), "update")
+    np.testing.assert_allclose(new.cpu().numpy()[2], sums[0] * (np.float32(1) / np.float32(30)), rtol=1e-6)
     x = rng.randn(rows, c).astype(np.float32)
     lab = rng.randint(0, k, rows).astype(np.int32)
     dist = torch.empty(rows, device=gpu)

@@ -303,6 +303,17 @@ def test_gv15_lloyd_matches_sklearn(tag, kw):
     assert abs(m["inertia_"] - float(g[f"A_{tag}_inertia"])) <= 1e-5 * float(g[f"A_{tag}_inertia"])
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_gv15_degenerate_duplicates_match_sklearn(i):
+    """3 distinct points, 5 clusters: no relocation, and sklearn's in-order _average_centers quirk for the empties"""
+    from oracle import kmeans_ref as K
+    g = _gv15()
+    m = K.kmeans_fit(g["A_dup_x"], 5, n_init=1, init=g[f"A_dup{i}_init"])
+    np.testing.assert_array_equal(m["labels_"], g[f"A_dup{i}_labels"])
+    np.testing.assert_allclose(m["cluster_centers_"], g[f"A_dup{i}_centers"], rtol=0, atol=2e-5)
+    assert m["n_iter_"] == int(g[f"A_dup{i}_n_iter"])
+
+
 def test_gv15_kmeans_plusplus_stream_matches_sklearn():
     """seeded greedy k-means++: the same RandomState reproduces sklearn's chosen indices and final clustering"""
     from oracle import kmeans_ref as K

@@ -65,6 +65,15 @@ def main():
     xc = x - x.mean(axis=0)
     _, idx = kmeans_plusplus(xc, 6, random_state=np.random.RandomState(5))
     arrs["A_pp_indices"] = idx.astype(np.int64)
+    # fewer distinct points than clusters: relocation is pointless, _average_centers parks the empty clusters
+    dup = np.repeat(x[:3], 5, axis=0)
+    arrs["A_dup_x"] = dup
+    for i, init_d in enumerate((np.concatenate([x[:3], x[:2] + 0.25]), np.concatenate([x[:2] + 0.25, x[:3]]))):
+        arrs[f"A_dup{i}_init"] = init_d.astype(np.float32)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            keep(f"dup{i}", KMeans(n_clusters=5, init=init_d, n_init=1).fit(dup))
     arrs["A_pred_labels"] = KMeans(n_clusters=5, init=init, n_init=1).fit(x).predict(blobs(16)).astype(np.int32)
 
     # ------------------------------------------------------------------ B: the reference's own classes
