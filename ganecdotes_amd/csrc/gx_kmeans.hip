@@ -106,13 +106,14 @@ __global__ void km_accumulate_kernel(const float* __restrict__ X, long rows, int
     const bool live = col < C;
     const float* x = X + (live ? col : 0);
     long r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        const int l0 = labels[r], l1 = labels[r + 1], l2 = labels[r + 2], l3 = labels[r + 3];
-        const float x0 = x[r * ldx], x1 = x[(r + 1) * ldx], x2 = x[(r + 2) * ldx], x3 = x[(r + 3) * ldx];
-        acc[l0 * W + t] += x0;
-        acc[l1 * W + t] += x1;
-        acc[l2 * W + t] += x2;
-        acc[l3 * W + t] += x3;
+    constexpr int U = 16;                                // rows in flight per thread: 16 x 4 B x 256 threads = 16 KB per block
+    for (; r + U <= r1; r += U) {
+        int l[U];
+        float v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) { l[i] = labels[r + i]; v[i] = x[(r + i) * ldx]; }
+#pragma unroll
+        for (int i = 0; i < U; ++i) acc[l[i] * W + t] += v[i];
     }
     for (; r < r1; ++r) acc[labels[r] * W + t] += x[r * ldx];
     if (live)
@@ -368,7 +369,7 @@ static void km_acc_geometry(long rows, int K, int C, int* W, int* nslab, int* rp
     if (want < 1) want = 1;
     long per = (rows + want - 1) / want;
     if (per < 64) per = 64;
-    per = (per + 3) & ~3L;
+    per = (per + 15) & ~15L;
     *rpb = (int)per;
     *nchunk = gx_cdiv(rows, per);
 }
