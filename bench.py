@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: pretrain images/sec of the per-pixel SwAV path (ffhq-256, hfc_with_swav).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N>1: either under `python -m torch.distributed.run --nproc-per-node N ...` (RANK / WORLD_SIZE from the
+        environment) or plain — then this script starts its N ranks itself (one process per GPU, RCCL).
 
 One "step" = one optimizer step of the hot path over one batch of synthetic latents on every
 rank: draws -> 2 views (generator taps) -> 5 patches x {gather, projection, prototypes,
@@ -57,13 +59,61 @@ def build_generator(size, device):
     return g.eval().to(device)
 
 
-def cpu_baseline(nproto, threads):
-    """The oracle (CPU restatement of the reference op sequence) timed on the host cores on a
-    bounded sample of the same workload: both views of ONE image at full size + ONE of the 5
-    patches forward/backward; images/s = 1 / (t_views + 5 * t_patch)."""
+def host_cpu_info():
+    """What the host offers this process: CPU model, logical CPUs (nproc), physical cores, the
+    scheduler affinity and the cgroup CPU quota — the thread count used is the smallest of the
+    last three (oversubscribing a cgroup share only slows the oracle down)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+    except OSError:
+        pass
+    nproc = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = nproc
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    physical = len(phys) or nproc
+    threads = max(1, min(physical, affinity, int(quota) if quota and quota >= 1 else physical))
+    return dict(cpu_model=model, nproc=nproc, physical_cores=physical, affinity=affinity,
+                cgroup_cpu_quota=quota, threads=threads)
+
+
+def cpu_baseline(nproto, threads=None):
+    """The oracle (CPU restatement of the reference op sequence: materialised upsample+concat, rotation
+    / flip of the whole stack, norm maps, full-permute pixel sampling, N x 5376 projection GEMM, unfused
+    Sinkhorn, autograd backward) timed on the host cores on ONE whole image of the same workload: both
+    views at 256 x 256 and all 5 patches forward + backward — nothing extrapolated.  K = the GPU line's."""
     from oracle import stylegan2_ref as G
     from oracle import swav_ref as S
     from ganecdotes_amd.generator import Generator
+    info = host_cpu_info()
+    threads = threads or info["threads"]
     torch.set_num_threads(threads)
     torch.manual_seed(42)
     g = Generator(256, 512, 8)
@@ -76,7 +126,7 @@ def cpu_baseline(nproto, threads):
         ml = G.mean_latent(sd, 256, 512)
     proj_w, _ = S.init_linear_like_torch(512, 5376, False)
     proto_w, proto_b = S.init_linear_like_torch(nproto, 512, True)
-    im = S.draw_image_reference_order(512, 13, 6, 256 * 256, 1, transforms=True)
+    im = S.draw_image_reference_order(512, 13, 6, 256 * 256, 5, transforms=True)
     t0 = time.time()
     with torch.no_grad():
         w = G.mapping(im.z, sd)
@@ -85,16 +135,48 @@ def cpu_baseline(nproto, threads):
     t_views = time.time() - t0
     t0 = time.time()
     leaves = [proj_w.requires_grad_(True), proto_w.requires_grad_(True), proto_b.requires_grad_(True)]
-    sc = [S.codes(S.sample_pixels(s, im.picks[0], 20000), *leaves) for s in stacks]
+    loss = 0.0
+    for pno in range(5):
+        sc = [S.codes(S.sample_pixels(s, im.picks[pno], 20000), *leaves) for s in stacks]
+        with torch.no_grad():
+            q = [S.sinkhorn_knopp(s, 0.005, 10) for s in sc]
+        loss = loss + S.swapped_prediction_loss(sc[0] / 0.01, sc[1] / 0.01, q[0], q[1])
+    (loss / 5).backward()
     with torch.no_grad():
-        q = [S.sinkhorn_knopp(s, 0.005, 10) for s in sc]
-    loss = S.swapped_prediction_loss(sc[0] / 0.01, sc[1] / 0.01, q[0], q[1])
-    loss.backward()
-    t_patch = time.time() - t0
-    return dict(value=1.0 / (t_views + 5.0 * t_patch), unit="images/s", cores=threads, kind="port",
-                sample=f"1 image: 2 views at 256x256 ({t_views:.1f} s) + 1 of 5 patches fwd+bwd at N=20000 "
-                       f"({t_patch:.1f} s), extrapolated to 5 patches; oracle (torch CPU fp32, "
-                       f"{threads} threads)")
+        S.larc_sgd_step(leaves, [p.grad for p in leaves], [None] * 3, 0.01, 0.9, 0.01, True)
+    t_patches = time.time() - t0
+    return dict(value=1.0 / (t_views + t_patches), unit="images/s", cores=threads, kind="port",
+                cpu_model=info["cpu_model"], nproc=info["nproc"], physical_cores=info["physical_cores"],
+                affinity=info["affinity"], cgroup_cpu_quota=info["cgroup_cpu_quota"],
+                sample=f"1 whole image, K={nproto}: 2 views at 256x256 incl. rotate/flip + norm maps "
+                       f"({t_views:.1f} s) + all 5 patches fwd+bwd at N=20000 and the LARC-SGD step "
+                       f"({t_patches:.1f} s); oracle (torch CPU fp32, {threads} threads)")
+
+
+def self_launch(n):
+    """Run this script as n ranks on one node (what `torch.distributed.run --nproc-per-node n` would do):
+    one child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  The parent touches
+    no GPU; children are ordinary subprocesses (never an exec of a process that has initialised HIP)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -110,11 +192,15 @@ def main():
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves — fresh child processes, created
+        # before this process has made any GPU call (it never does); rank 0's JSON line is relayed.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))   # the box's CPU share
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -156,6 +242,7 @@ def main():
         q = queue.Queue(maxsize=2)
 
         def run():
+            torch.cuda.set_device(dev)             # a new thread starts on device 0: stage on this rank's GPU
             for _ in range(n):
                 q.put(sw.prepare_batch(sw.draw_batch(args.batch)))
         threading.Thread(target=run, daemon=True).start()
@@ -244,7 +331,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.prototypes, max(1, min(os.cpu_count() or 1, 16)))
+            out["cpu_baseline"] = cpu_baseline(args.prototypes)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -88,6 +88,9 @@ SIGNATURES = {
     "gx_blur_act_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
     "gx_torgb_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "gx_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "gx_upfirdn2d_out_shape": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "gx_upfirdn2d": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "gx_fused_bias_act": (c_i, [c_p, c_l, c_p, c_i, c_l, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "gx_random_subset_picks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_rotflip_map": (c_i, [c_f, c_i, c_i, c_i, c_p, c_p]),
     "gx_gather_taps": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),

@@ -13,6 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libganecdotes_hip.so")
 STAMP = LIB + ".srchash"
 SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_simclr.hip", "gx_head.hip", "gx_kmeans.hip"]
@@ -28,11 +29,12 @@ def _hipcc():
 
 def _src_hash():
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(CSRC, name), "rb") as f:
-                h.update(name.encode())
-                h.update(f.read())
+    for d in (CSRC, INCLUDE):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode())
+                    h.update(f.read())
     return h.hexdigest()
 
 
@@ -46,16 +48,23 @@ def build(force=False, verbose=True):
     objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
+    cmds = []
     for s in SOURCES:
         o = os.path.join(bdir, s.replace(".hip", ".o"))
         # -fno-slp-vectorize: SLP packs the bf16-split remainders into v_pk_add_f32, which stalls the
         # vector issue port next to MFMAs (bf16x6 GEMM 173 -> 193 TFLOP/s without it)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize",
-               *os.environ.get("GX_EXTRA_FLAGS", "").split(), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
+        cmds.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize",
+                     *os.environ.get("GX_EXTRA_FLAGS", "").split(), "-I", CSRC, "-I", INCLUDE, "-c",
+                     os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(o)
+    with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as ex:    # one hipcc per source file
+        list(ex.map(run, cmds))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -3,12 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// the public C ABI: every translation unit sees the prototypes, so a definition that drifts from
+// include/ganecdotes_hip.h (argument type or order) is a compile error, not silent garbage through ctypes
+#include "ganecdotes_hip.h"
 
-#define GX_OK 0
-#define GX_ERR_BAD_ARG (-1)       // null pointer / non-positive dimension / unsupported mode
-#define GX_ERR_ALIGN (-2)         // pointer or leading dimension not aligned as documented
-#define GX_ERR_WORKSPACE (-3)     // workspace too small
-#define GX_ERR_LAUNCH (-4)        // hipGetLastError() after launch
+// GX_OK / GX_ERR_BAD_ARG (null pointer, non-positive dimension, unsupported mode) / GX_ERR_ALIGN /
+// GX_ERR_WORKSPACE / GX_ERR_LAUNCH (hipGetLastError() after launch) come from ganecdotes_hip.h
 
 #define GX_CHECK_LAUNCH()                                  \
     do {                                                   \

@@ -736,6 +736,62 @@ __global__ void lerp_rows_kernel(const float* __restrict__ w, const float* __res
     }
 }
 
+// General up-FIR-down (upfirdn2d_kernel.cu:53-215 semantics) over [major][in_h][in_w][minor]:
+//   out[m,oy,ox,c] = sum_{ky,kx} K[kh-1-ky][kw-1-kx] * U[m, oy*down_y + ky - pad_y0, ox*down_x + kx - pad_x0, c]
+// where U is the zero-inserted (up_y, up_x) image.  One thread per output element, the minor index fastest:
+// writes and (for minor > 1, or up_x = down_x = 1) reads are coalesced; the taps that meet a sample are
+// enumerated directly (first ky with (oy*down_y + ky - pad_y0) % up_y == 0, then steps of up_y).
+__global__ void upfirdn2d_kernel(const float* __restrict__ in, const float* __restrict__ K, int major, int in_h,
+                                 int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                 int pad_x0, int pad_y0, int out_h, int out_w, float* __restrict__ out) {
+    const long total = (long)major * out_h * out_w * minor;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % minor);
+        long r = i / minor;
+        const int ox = (int)(r % out_w); r /= out_w;
+        const int oy = (int)(r % out_h);
+        const long m = r / out_h;
+        const int by = oy * down_y - pad_y0, bx = ox * down_x - pad_x0;       // U coordinate of tap (0, 0)
+        int ky0 = ((-by) % up_y + up_y) % up_y, kx0 = ((-bx) % up_x + up_x) % up_x;
+        const float* src = in + m * in_h * (long)in_w * minor + c;
+        float v = 0.f;
+        for (int ky = ky0; ky < kh; ky += up_y) {
+            const int uy = by + ky;
+            if (uy < 0) continue;
+            const int iy = uy / up_y;
+            if (iy >= in_h) break;
+            for (int kx = kx0; kx < kw; kx += up_x) {
+                const int ux = bx + kx;
+                if (ux < 0) continue;
+                const int ix = ux / up_x;
+                if (ix >= in_w) break;
+                v = fmaf(src[((long)iy * in_w + ix) * minor], K[(kh - 1 - ky) * kw + (kw - 1 - kx)], v);
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// fused_bias_act_kernel.cu:18-85: y = act'(x + b[(i / step_b) % size_b]) * scale
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, long n, const float* __restrict__ b, int size_b,
+                                      long step_b, const float* __restrict__ ref, int act, int grad, float alpha,
+                                      float scale, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (b) v += b[(i / step_b) % size_b];
+        const float rf = ref ? ref[i] : 0.f;
+        float y;
+        switch (act * 10 + grad) {
+            default:
+            case 10: case 11: y = v; break;
+            case 12: case 32: y = 0.f; break;
+            case 30: y = v > 0.f ? v : v * alpha; break;
+            case 31: y = rf > 0.f ? v : v * alpha; break;
+        }
+        out[i] = y * scale;
+    }
+}
+
 // NCHW <-> NHWC (API boundary only: the reference hands taps around as NCHW)
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, int HW, float* __restrict__ out) {
     const long total = (long)B * C * HW;
@@ -1000,6 +1056,44 @@ int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, 
     }
     hipLaunchKernelGGL(torgb_kernel, dim3(gx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, s, w3, scale,
                        bias3, prev_img, kf, B, H, W, Cin, lp, img);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_upfirdn2d_out_shape(int in_h, int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, int* out_h, int* out_w) {
+    if (!out_h || !out_w || in_h <= 0 || in_w <= 0 || kernel_h <= 0 || kernel_w <= 0 || up_x <= 0 || up_y <= 0 ||
+        down_x <= 0 || down_y <= 0)
+        return GX_ERR_BAD_ARG;
+    *out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y;
+    *out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
+    return (*out_h > 0 && *out_w > 0) ? GX_OK : GX_ERR_BAD_ARG;
+}
+
+int gx_upfirdn2d(const float* input, int major, int in_h, int in_w, int minor, const float* kernel, int kernel_h,
+                 int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                 int pad_y1, float* out, void* stream) {
+    int oh = 0, ow = 0;
+    if (!input || !kernel || !out || major <= 0 || minor <= 0) return GX_ERR_BAD_ARG;
+    const int rc = gx_upfirdn2d_out_shape(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                          pad_y0, pad_y1, &oh, &ow);
+    if (rc) return rc;
+    const long total = (long)major * oh * ow * minor;
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       input, kernel, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0,
+                       pad_y0, oh, ow, out);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_fused_bias_act(const float* input, long n, const float* bias, int size_b, long step_b, const float* refer,
+                      int act, int grad, float alpha, float scale, float* out, void* stream) {
+    if (!input || !out || n <= 0 || (act != 1 && act != 3) || grad < 0 || grad > 2) return GX_ERR_BAD_ARG;
+    if (bias && (size_b <= 0 || step_b <= 0)) return GX_ERR_BAD_ARG;
+    long want = (n + 255) / 256;
+    hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)(want < 16384 ? want : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, input, n, bias, size_b, step_b, refer, act, grad, alpha, scale, out);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -25,14 +25,23 @@ class ImageDraws:
     z: torch.Tensor                                         # (1, S)
     views: List[ViewDraws] = field(default_factory=list)    # [s, t]
     picks: List[torch.Tensor] = field(default_factory=list)  # num_patches x randperm(H*W) (int64, CPU)
+    patch_offsets: Optional[List[int]] = None               # 'patch' sampling: the crop offset of every patch
+
+
+def patch_pixels(offset, patch_size, side):
+    """pixel indices of the reference's 'patch' sampling (swav_clustering.py:150-158): the square crop
+    [o:o+ps, o:o+ps] of a side x side image — the SAME offset on both axes — in row-major order"""
+    ax = offset + torch.arange(patch_size)
+    return (ax[:, None] * side + ax[None, :]).reshape(-1)
 
 
 def draw_image(style_dim, gen_num_layers, n_perturb_layers, hw, num_patches, transforms=True, degrees=10.0,
-               layer_no=None, cpu_reference_rng=False):
+               layer_no=None, cpu_reference_rng=False, sampling_method='random', patch_size=None):
     """One image's draws in reference order: z (swav_clustering.py:323); per view
     `np.random.choice` of the layer (:611) and the mapping noises of the two perturbed latents
     (lib/oneshot/image_augmentor.py:47); rotation angle then flip for s, then for t (:358-359);
-    one randperm per patch (:388).
+    one randperm per patch (:388) — or, with sampling_method='patch', one `np.random.choice(h - patch_size)`
+    per patch (:383-385, numpy's global RNG), kept in `patch_offsets` next to the crop's pixel list.
 
     On a GPU the reference draws the per-layer noise maps of its discarded first generator call
     (models/stylegan2/model.py:380) and all 2*n_perturb_layers mapping noises from the DEVICE
@@ -56,5 +65,11 @@ def draw_image(style_dim, gen_num_layers, n_perturb_layers, hw, num_patches, tra
         for v in views:
             v.angle = float(torch.empty(1).uniform_(-degrees, degrees).item())
             v.flip = bool(torch.rand(1) < 0.5)
+    if sampling_method == 'patch' and num_patches > 0:
+        side = int(round(hw ** 0.5))
+        offs = [int(np.random.choice(side - patch_size)) for _ in range(num_patches)]
+        im = ImageDraws(z, views, [patch_pixels(o, patch_size, side) for o in offs])
+        im.patch_offsets = offs
+        return im
     picks = [torch.randperm(hw) for _ in range(num_patches)] if num_patches > 0 else []
     return ImageDraws(z, views, picks)

@@ -218,8 +218,16 @@ class KMeans:
         xsq = torch.empty(rows, dtype=torch.float32, device=dev)
         _lib.check(lib().gx_kmeans_center_panel(_p(tap1), tap1.shape[1], _p(tap2), 0 if tap2 is None else tap2.shape[1],
                                                 rows, _p(mean), _p(X), _p(xsq), _stream()), "gx_kmeans_center_panel")
-        rs = self.random_state if isinstance(self.random_state, np.random.RandomState) \
-            else np.random.RandomState(self.random_state)
+        # sklearn.utils.check_random_state: None -> numpy's GLOBAL RandomState (which the reference seeds with 42 at
+        # import, lib/util/util.py:21-24, and consumes in order: its fits are reproducible), an int -> a fresh
+        # RandomState(seed), a RandomState -> itself.  (The pinned scikit-learn 1.0.2 draws the first k-means++
+        # centre with randint where 1.7.2, which GV15 pins, uses choice(p=...): same stream, different draw.)
+        if self.random_state is None:
+            rs = np.random.mtrand._rand
+        elif isinstance(self.random_state, np.random.RandomState):
+            rs = self.random_state
+        else:
+            rs = np.random.RandomState(self.random_state)
         explicit = hasattr(self.init, 'shape')
         if explicit:
             init = torch.as_tensor(np.asarray(self.init, np.float32)).to(dev) - mean

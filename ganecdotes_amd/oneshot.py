@@ -14,6 +14,8 @@ flat NHWC so that a dilated 3x3 tap is a row shift and conv forward / dW / dX ar
 row-offset views of the same buffers; the 134 MB code map of a 256^2 image is read in place.
 No CPU fallback: constructing the head without a HIP device raises.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -244,21 +246,81 @@ def iou_from_confusion(conf, classes):
     return mask_iou, w_iou, (fg_inter / fg_union if fg_union > 0 else 0)
 
 
+def bb_iou(gt_mask, pred_mask, label):
+    """lib/metrics/segmentation.py get_bb_iou (:32-68) on host label maps: IoU of the class's bounding boxes,
+    filled with the reference's exclusive upper bounds; 0 when either map lacks the class."""
+    gt = (np.asarray(gt_mask) == label).astype(np.float64)
+    pred = (np.asarray(pred_mask) == label).astype(np.float64)
+    for m in (gt, pred):
+        if m.max() == 0:
+            return 0
+        nz = m.nonzero()
+        m[nz[0].min():nz[0].max(), nz[1].min():nz[1].max()] = 1
+    union = np.count_nonzero(gt + pred)
+    return np.count_nonzero(gt * pred) / union if union > 0 else 0
+
+
+def pd_at_iou_threshold(iou_table, classes, thr=0.5):
+    """get_pd_at_iou_threshold (:126-133) on a (samples, classes) IoU table"""
+    t = np.asarray(iou_table, np.float64)
+    return {c: float((t[:, i] > thr).mean()) for i, c in enumerate(classes)}
+
+
+def iou_vs_pd_curve(iou_table, classes, inc=0.05):
+    """get_iou_vs_pd_curve (:136-162)"""
+    vals = np.linspace(0, 1, int(1 / inc))
+    out = {c: [pd_at_iou_threshold(iou_table, classes, t)[c] for t in vals] for c in classes}
+    out['Mean'] = np.mean([out[c] for c in classes], axis=0)
+    return out
+
+
+def table_csv(rows, classes):
+    """The text pandas.DataFrame(data, columns=classes).to_csv() writes (src/one_shot_pipeline.py:776-791):
+    an unnamed index column, then one column per class; floats in repr form."""
+    lines = ["," + ",".join(classes)]
+    for i, r in enumerate(rows):
+        lines.append(",".join([str(i)] + [repr(float(r[c])) for c in classes]))
+    return "\n".join(lines) + "\n"
+
+
+def write_result_files(test_dir, results, classes):
+    """tests/mask_iou_results.csv, tests/bb_iou_results.csv and tests/results.npz exactly as run_tests leaves
+    them (src/one_shot_pipeline.py:775-791, :884: np.savez_compressed(**results), the per-sample dict lists
+    as object arrays)."""
+    with open(os.path.join(test_dir, 'mask_iou_results.csv'), 'w') as f:
+        f.write(table_csv(results['mask_iou'], classes))
+    with open(os.path.join(test_dir, 'bb_iou_results.csv'), 'w') as f:
+        f.write(table_csv(results['bb_iou'], classes))
+    np.savez_compressed(os.path.join(test_dir, 'results.npz'), **results)
+
+
 def run_tests(preprocessor, head, test_latents, test_labels, classes, batch=4):
-    """The numeric core of OneShotPipeline.run_tests (:611-748): per batch of test latents
-    predict_swav_codes -> head -> argmax; then per sample the IoU block.  test_labels (n, H, W).
-    Returns (pred_labels (n, H, W) int64 on the host, results dict shaped like the reference's)."""
+    """The numeric core of OneShotPipeline.run_tests (:611-748, tester 'all'): per batch of test latents
+    predict_swav_codes -> head -> argmax; then per sample the IoU / Dice block, and the PD-vs-IoU summaries.
+    test_labels (n, H, W).  Returns (pred_labels (n, H, W) int64 on the host, results dict with the
+    reference's keys).  batch: latents per predict call (the reference: 1, MAX_TEST_BATCH :30 — per-pixel
+    preprocessors give the same codes at any batch; SimCLR's train-mode BatchNorm does not, so its caller
+    passes 1)."""
     preds = []
     for s in range(0, test_latents.shape[0], batch):
         codes, _ = preprocessor.predict_swav_codes(test_latents[s:s + batch])
         preds.append(head.predict(codes.permute(0, 2, 3, 1)))
     pred = torch.cat(preds)
     nconf = max(len(classes), head.out_ch)
-    results = dict(mask_iou=[], w_iou=[], bin_iou=None)
+    results = dict(mask_iou=[], bb_iou=[], w_iou=[], bin_iou=None, mask_dice=[], bb_dice=[])
+    pred_h = pred.cpu()
+    gt_h = test_labels.cpu().numpy() if isinstance(test_labels, torch.Tensor) else np.asarray(test_labels)
     for i in range(pred.shape[0]):
         conf = confusion(test_labels[i], pred[i], nconf)
         mi, wi, bi = iou_from_confusion(conf, list(classes) + [f"_{j}" for j in range(len(classes), nconf)])
         results['mask_iou'].append({c: mi[c] for c in classes})
         results['w_iou'].append(wi)
         results['bin_iou'] = bi                     # the reference keeps the last sample's value (:737)
-    return pred.cpu(), results
+        bb = {c: bb_iou(gt_h[i], pred_h[i].numpy(), k) for k, c in enumerate(classes)}
+        results['bb_iou'].append(bb)
+        results['mask_dice'].append({c: 2 * mi[c] / (mi[c] + 1) for c in classes})
+        results['bb_dice'].append({c: 2 * bb[c] / (bb[c] + 1) for c in classes})
+    table = [[m[c] for c in classes] for m in results['mask_iou']]
+    results['pd'] = pd_at_iou_threshold(table, classes, 0.5)
+    results['iou_pd_curve'] = iou_vs_pd_curve(table, classes)
+    return pred_h, results

@@ -475,6 +475,54 @@ def nchw_to_nhwc(x):
     return out
 
 
+def upfirdn2d_native(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """The reference's native op with its own argument list (lib/gan/optim/upfirdn2d.cpp:18-35):
+    x (major, in_h, in_w, minor), kernel (kh, kw) -> (major, out_h, out_w, minor).  Like the reference's
+    CHECK_CUDA / CHECK_CONTIGUOUS (:9-15) a host or strided tensor raises RuntimeError."""
+    _chk(x, kernel)
+    if x.dim() != 4 or kernel.dim() != 2:
+        raise RuntimeError("upfirdn2d: input must be (major, in_h, in_w, minor) and kernel (kh, kw)")
+    major, in_h, in_w, minor = x.shape
+    oh, ow = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib().gx_upfirdn2d_out_shape(in_h, in_w, kernel.shape[0], kernel.shape[1], up_x, up_y, down_x, down_y,
+                                            pad_x0, pad_x1, pad_y0, pad_y1, ctypes.byref(oh), ctypes.byref(ow)),
+               "gx_upfirdn2d_out_shape")
+    out = torch.empty(major, oh.value, ow.value, minor, dtype=torch.float32, device=x.device)
+    _lib.check(lib().gx_upfirdn2d(_p(x), major, in_h, in_w, minor, _p(kernel), kernel.shape[0], kernel.shape[1],
+                                  up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, _p(out), _stream()),
+               "gx_upfirdn2d")
+    return out
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """upfirdn2d(input (N, C, H, W), kernel, up, down, pad) of lib/gan/optim/upfirdn2d.py:146-173 (and of
+    models/stylegan2/model.py:46-58): channels folded into `major`, minor = 1."""
+    n, c, h, w = x.shape
+    out = upfirdn2d_native(x.reshape(n * c, h, w, 1).contiguous(), kernel.contiguous(), up, up, down, down, pad[0],
+                           pad[1], pad[0], pad[1])
+    return out.reshape(n, c, out.shape[1], out.shape[2])
+
+
+def fused_bias_act(x, bias=None, refer=None, act=3, grad=0, alpha=0.2, scale=1.0):
+    """The reference's native op with its own argument list (lib/gan/optim/fused_bias_act.cpp:18-31): the bias
+    is indexed by dim 1 of x (step_b = product of the later dims); an empty tensor / None = no bias / no refer."""
+    bias = None if (bias is None or bias.numel() == 0) else bias
+    refer = None if (refer is None or refer.numel() == 0) else refer
+    _chk(x, bias, refer)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= int(d)
+    out = torch.empty_like(x)
+    _lib.check(lib().gx_fused_bias_act(_p(x), x.numel(), _p(bias), 0 if bias is None else bias.numel(), step_b,
+                                       _p(refer), act, grad, alpha, scale, _p(out), _stream()), "gx_fused_bias_act")
+    return out
+
+
+def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """fused_leaky_relu(input, bias, negative_slope, scale) of lib/gan/optim/fused_act.py:232-254 (forward)."""
+    return fused_bias_act(x, bias, None, 3, 0, negative_slope, scale)
+
+
 # ------------------------------------------------------------------------------------- gather
 def rotflip_map(angle_deg, flip, h, w, device, out=None):
     if out is None:

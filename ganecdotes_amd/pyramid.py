@@ -76,9 +76,11 @@ class Pyramid:
             return prev, tables
         return prev
 
-    def backward(self, g, gwp, accumulate, g_pooled=None):
+    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None):
         """g (B, H, W, D) = d loss / d Z -> gwp (D, hlen) (+)= sum over taps of G_level^T tap.
-        g_pooled: sumpool2(g) if the caller already has it."""
+        g_pooled: sumpool2(g) if the caller already has it.  on_level([(off, width), ...]) is called once
+        the GEMMs of a level are queued (its columns of gwp are final: a sharded caller starts their
+        all-reduce there)."""
         first = not accumulate
         touched = set()
         for r, taps in zip(reversed(self.res), reversed(self.levels)):
@@ -92,6 +94,8 @@ class Pyramid:
                 ops.gemm(g2, t[:, :cu], True, False, out=gwp[:, off:off + cu], beta=0.0 if first else 1.0,
                          split_k=split)
                 touched.add((off, cu))
+            if on_level is not None and any(cu > 0 for _, _, cu in taps):
+                on_level([(off, cu) for _, off, cu in taps if cu > 0])
             if r != self.res[0]:
                 g = g_pooled if (g_pooled is not None and r == self.res[-1]) else ops.sumpool2(g)
         if first:      # columns of hlen not covered by any tap cannot exist (sum C >= hlen); nothing to zero

@@ -2,8 +2,10 @@
 
 Same constructor `(in_ch, n_class, size)` and layer plan as the reference's OneShotSegmentor
 (hfc_with_swav/swav_clustering.py:697-758): a stack of dilated 3x3 convs + LeakyReLU(0.2)
-('XXS'..'L') or a per-pixel linear layer ('Lin').  It is NOT on this round's HIP hot path
-(SURVEY.md par. 8f rank 1: next); it is a plain torch module so the registry stays complete.
+('XXS'..'L') or a per-pixel linear layer ('Lin').  This is the torch module the plugin surface exports
+and that `projection.pt`-style pickles / `OneShotHead.to_module()` hand back; the fine-tune and the test
+loop themselves run on HIP (ganecdotes_amd/oneshot.py `OneShotHead`, csrc/gx_head.hip — same plan, same
+`layers.{2i}.weight/bias` state_dict keys; 'Lin', used by no shipped config, has no HIP twin).
 """
 from torch import nn
 

@@ -8,7 +8,9 @@ stand-in), so the N>1 control flow is exercised by world_size-2 tests without a 
 Exchange steps (everything else is rank-local):
   Sinkhorn, per call :  all_reduce(MAX) of the K column maxima, then per iteration one
                         all_reduce(SUM) of the K column sums (20 KB at K=5000; latency-bound)
-  optimizer step     :  one all_reduce(SUM) of the flattened {dWp, dWc, db, loss}
+  optimizer step     :  all_reduce(SUM) of {dWc, db, loss} (issued before the pyramid backward) and of
+                        every pyramid level's column block of dWp as soon as it is produced, all
+                        asynchronous: only the coarsest levels' message is not hidden behind GEMMs
 """
 import torch
 
@@ -83,3 +85,37 @@ def allreduce_flat(tensors, group):
         t.copy_(flat[o:o + t.numel()].reshape(t.shape))
         o += t.numel()
     return tensors
+
+
+def allreduce_flat_async(tensors, group):
+    """allreduce_flat issued with async_op=True: the message travels on the backend's communication
+    stream while the caller keeps queueing kernels; the returned closure makes the current stream wait for
+    it and scatters the sums back."""
+    import torch.distributed as dist
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    work = dist.all_reduce(flat, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].reshape(t.shape))
+            o += t.numel()
+    return finish
+
+
+def allreduce_cols_async(mat, cols, group):
+    """Async sum-all-reduce of the column blocks `cols` = [(offset, width), ...] of a row-major matrix
+    (the slices of dWp one pyramid level has just produced): staged into one contiguous message."""
+    import torch.distributed as dist
+    cols = sorted(set(cols))
+    stage = torch.cat([mat[:, o:o + w] for o, w in cols], dim=1).contiguous()
+    work = dist.all_reduce(stage, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        c = 0
+        for o, w in cols:
+            mat[:, o:o + w].copy_(stage[:, c:c + w])
+            c += w
+    return finish

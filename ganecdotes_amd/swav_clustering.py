@@ -6,12 +6,18 @@ constructor keywords, `preprocess` / `pretrain` / `predict_swav_codes`, the `pro
 not the reference's op chain but hand-written gfx950 kernels reached through the C ABI
 (`ganecdotes_amd.ops`):
 
-  views      : batched NHWC generator forward (the reference's discarded first forward is
-               replaced by the 3-line latent computation it was run for)
-  S1/S1b/S2  : one gather kernel (taps -> sampled panel X), never the 1.3 GiB stack
-  S3         : fp32-MFMA GEMMs, L2-normalise in place
-  S4         : log-domain scaling-vector Sinkhorn (12 passes over the scores, Q never formed)
-  S5/S6      : fused codes + swapped-CE + d(scores); MFMA GEMMs for dWc, dz, dWp (split-K)
+  views      : both views of the batch as ONE 2B-image NHWC generator forward (the reference's discarded
+               first forward is replaced by the 3-line latent computation it was run for)
+  S1/S1b/S2/S3 (default, projection_mode='pyramid'): every tap is projected ONCE at its native resolution
+               and the levels are summed up the pyramid into the table Z (2B, H, W, D) (pyramid.py); the
+               1.3 GiB stack and the N x 5376 panel never exist — rotation / flip / sampling are an index
+               into Z.  K <= 16: the finest level also emits every pixel's prototype scores, a patch is a
+               gather of (K+1)-float rows and the backward a scatter of K+1 coefficients (low-rank path).
+               projection_mode='panel' keeps the reference-shaped gather + N x 5376 GEMM.
+  S4         : log-domain scaling-vector Sinkhorn, all views x patches of a step as ONE batched problem
+               (one read of the scores per iteration, Q never formed)
+  S5/S6      : fused codes + swapped-CE + d(scores); dense finish / MFMA GEMMs for dWc, dz; the pyramid's
+               adjoint (sum-pooling + one TN GEMM per tap) for dWp
   S7/S8      : row normalise, LARC-SGD
 
 Extensions over the reference (opt-in `swav_args` keys, defaults = reference behaviour):
@@ -74,6 +80,9 @@ class SwAVClustering(ViewMixin):
         self.dist_group = dist_group
         self.world = 1
         self.rank = 0
+        # a process group => the sharded protocol with its collectives, also when it has ONE rank (the
+        # exchange steps then run through RCCL as identities: tests/test_hip_multirank.py)
+        self.sharded = dist_group is not None
         if dist_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(dist_group)
@@ -100,9 +109,24 @@ class SwAVClustering(ViewMixin):
         self._bufs = None
         self._step_no = 0
 
+    def _patch_mode(self):
+        """'patch' sampling (swav_clustering.py:150-158, :383-385): a square crop of patch_size x patch_size
+        pixels at one random offset instead of patch_size random pixels; here it is only a different pick
+        list (draws.patch_pixels).  patch_size None / == image side means every pixel in both modes."""
+        sa = self.swav_args
+        method = sa.get('sampling_method', 'random')
+        if method not in ('random', 'patch'):
+            raise NotImplementedError(f"sampling_method={method!r}: the reference knows 'random' and 'patch'")
+        return method == 'patch' and sa['patch_size'] is not None and sa['patch_size'] < self.model.size
+
+    def _rows_per_image(self):
+        ps = self.swav_args['patch_size']
+        return ps * ps if (ps is not None and self._patch_mode()) else ps
+
     def _pick_spec(self):
         sa = self.swav_args
-        return sa['patch_size'], sa['num_patches'], sa.get('pick_source', 'host')
+        # a crop offset is one host draw per patch (numpy's stream, like the reference): never the device path
+        return self._rows_per_image(), sa['num_patches'], ('host' if self._patch_mode() else sa.get('pick_source', 'host'))
 
     # ------------------------------------------------------------------------------------- modules
     def build_heads(self):
@@ -157,7 +181,7 @@ class SwAVClustering(ViewMixin):
     def _marginals(self, img, k, nrows, shared=False):
         """'image' source pdf (swav_clustering.py:523-532): r from a K-bin, c from an nrows-bin
         histogram of the whole norm map."""
-        red = self._reduce if (self.world > 1 and shared) else None
+        red = self._reduce if (self.sharded and shared) else None
         r = ops.hist_marginal(img, k, red)
         c = ops.hist_marginal(img, nrows * (self.world if shared else 1), red)
         if red is not None:             # this rank's rows of the global per-sample marginal
@@ -173,7 +197,7 @@ class SwAVClustering(ViewMixin):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
         as a 1-element HIP tensor (global mean; no host sync)."""
         sa = self.swav_args
-        P, N, hlen = sa['num_patches'], sa['patch_size'], sa['hlen']
+        P, N, hlen = sa['num_patches'], self._rows_per_image(), sa['hlen']
         T = sa['temperature']
         scope = sa.get('sinkhorn_scope', 'image')
         use_larc = sa.get('use_larc', True)
@@ -289,7 +313,7 @@ class SwAVClustering(ViewMixin):
             with self._timed("sinkhorn"):
                 skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
                                         c=c_all, c_uniform=1.0 / nglob)
-                skb.run(self._reduce if (scope == 'global' and self.world > 1) else None)
+                skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
             if batched:
                 dS_all = torch.empty_like(Sc_all)
                 ops.swapped_ce_batch(Sc_all, ngroups, skb, T, gscale, loss, gscale, 1.0, dS_all)
@@ -335,6 +359,7 @@ class SwAVClustering(ViewMixin):
                 keep[gi] = None
                 del X, Zh, Rn, Sc, dS
             del keep, Sc_all, skb
+        pending = []
         if mode == 'pyramid':
             Gp = None
             if lowrank:
@@ -342,11 +367,20 @@ class SwAVClustering(ViewMixin):
                     pool = len(pyr.res) > 1
                     out = ops.proto_lowrank_finish(Ct_all, Z_all, Wc, gWc, 0.0, want_pool=pool)
                     G_all, Gp = out if pool else (out, None)
+            on_level = None
+            if self.sharded:
+                # the prototype gradients and the loss are final here: their all-reduce travels while the
+                # pyramid backward runs, and every pyramid level's slice of dWp follows as soon as its GEMMs
+                # are queued (finest levels first), so only the coarsest levels' message is exposed
+                pending.append(sharded.allreduce_flat_async([gWc, gb, loss], self.dist_group))
+                on_level = lambda cols: pending.append(sharded.allreduce_cols_async(gWp, cols, self.dist_group))
             with self._timed("pyramid_bwd"):
-                pyr.backward(G_all, gWp, accumulate=False, g_pooled=Gp)
+                pyr.backward(G_all, gWp, accumulate=False, g_pooled=Gp, on_level=on_level)
             del Zt, Z_all, G_all
-        if self.world > 1:
-            sharded.allreduce_flat(list(self._grads) + [loss], self.dist_group)
+        elif self.sharded:
+            pending.append(sharded.allreduce_flat_async(list(self._grads) + [loss], self.dist_group))
+        for fin in pending:
+            fin()
         # S8: LARC + momentum SGD
         lr = sa['train_args']['lr']
         mom = sa['train_args'].get('momentum', 0.0)
@@ -370,11 +404,14 @@ class SwAVClustering(ViewMixin):
     def draw_batch(self, batch):
         sa = self.swav_args
         hw = self.model.size * self.model.size
-        npick = 0 if sa.get('pick_source', 'host') == 'device' else sa['num_patches']
+        patch = self._patch_mode()
+        npick = 0 if (sa.get('pick_source', 'host') == 'device' and not patch) else sa['num_patches']
         return [draw_image(self.model.style_dim, self.model.num_layers, self.perturb_args['n_layers'], hw,
                            npick, transforms=sa.get('transforms', True),
                            layer_no=self.perturb_args['layer_no'],
-                           cpu_reference_rng=sa.get('cpu_reference_rng', False)) for _ in range(batch)]
+                           cpu_reference_rng=sa.get('cpu_reference_rng', False),
+                           sampling_method='patch' if patch else 'random', patch_size=sa['patch_size'])
+                for _ in range(batch)]
 
     def pretrain(self, input_latent, num_test_samples=5):
         """Self-supervised pretraining loop (swav_clustering.py:205-505): num_epochs x num_samples
@@ -390,6 +427,16 @@ class SwAVClustering(ViewMixin):
                 r = 2 ** ((i + 5) // 2)
                 torch.empty(1, 1, r, r).normal_()
         self.build_heads()
+        if self.world > 1:
+            # data parallel: every rank starts from rank 0's heads and then draws its OWN images — the host
+            # and device generators are re-seeded per rank (the reference seeds 42 at import,
+            # lib/util/util.py:21-24, which would otherwise hand every rank the same z, layers, angles, picks)
+            import torch.distributed as dist
+            for p in self._params():
+                dist.broadcast(p, 0, group=self.dist_group)
+            seed = int(sa.get('seed', 42)) + self.rank
+            torch.manual_seed(seed)
+            np.random.seed(seed)
         self.logger.info("Projection Network:")
         self.logger.info(self.projection.__str__())
         self.logger.info("Prototype Matrix:")

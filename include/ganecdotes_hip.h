@@ -141,6 +141,30 @@ int gx_torgb_fwd(const float* x, int B, int H, int W, int Cin, const float* w3, 
                  const float* bias3, const float* prev_img, const float* kf, float* img, void* stream);
 int gx_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, void* stream);
 
+/* ---- the reference's two native ops, with THEIR argument lists --------------------------------------
+ * gx_upfirdn2d       = upfirdn2d(input [major][in_h][in_w][minor], kernel [kh][kw], up_x, up_y, down_x, down_y,
+ *                      pad_x0, pad_x1, pad_y0, pad_y1) -> out [major][out_h][out_w][minor]
+ *                      (lib/gan/optim/upfirdn2d.cpp:18-35; arithmetic of upfirdn2d_kernel.cu:53-215 for any
+ *                      up / down / pad, negative pads = crop: zero-insert upsample, pad, correlate with the
+ *                      FLIPPED kernel, decimate).  out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y
+ *                      (same for w): gx_upfirdn2d_out_shape.  The caller allocates `out` (the reference
+ *                      allocates it, upfirdn2d_kernel.cu:252-253).
+ * gx_fused_bias_act  = fused_bias_act(input, bias, refer, act, grad, alpha, scale) -> out
+ *                      (lib/gan/optim/fused_bias_act.cpp:18-31, kernel :18-85): x += bias[(i / step_b) % size_b]
+ *                      when bias != NULL; act 1 linear / 3 leaky-ReLU(alpha); grad 0 forward, 1 gradient
+ *                      (gated by the sign of `refer`), 2 second gradient (= 0); out = y * scale.
+ *                      step_b = product of input dims after dim 1 (the reference derives it from the tensor).
+ * The hot path uses the FUSED forms above (gx_blur_act_fwd, gx_torgb_fwd, gx_modconv_*: no standalone
+ * pass over a feature map); these two exist so that the reference's own Python wrappers
+ * (lib/gan/optim/upfirdn2d.py:86-143, fused_act.py:110-168) can bind to this library unchanged. */
+int gx_upfirdn2d_out_shape(int in_h, int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, int* out_h, int* out_w /* host */);
+int gx_upfirdn2d(const float* input, int major, int in_h, int in_w, int minor, const float* kernel, int kernel_h,
+                 int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                 int pad_y1, float* out, void* stream);
+int gx_fused_bias_act(const float* input, long n, const float* bias, int size_b, long step_b, const float* refer,
+                      int act, int grad, float alpha, float scale, float* out, void* stream);
+
 /* ---- multi-scale upsample + concat + rotate/flip + pixel sampling ---------------------------
  * gx_rotflip_map   source-pixel map of RandomRotation(10)+RandomHorizontalFlip
  *                                                  swav_clustering.py:98-102, :358-359 (torchvision, restated)

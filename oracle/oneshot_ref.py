@@ -107,3 +107,37 @@ def run_tests_metrics(gt_masks, pred_masks, classes):
         res['w_iou'].append(weighted_iou(gt, mi, classes))
         res['bin_iou'] = bin_iou(gt, pred)            # the reference keeps the LAST sample's value (:737)
     return res
+
+
+def bb_iou(gt_mask, pred_mask, label):
+    """get_bb_iou (lib/metrics/segmentation.py:32-68), quirks kept: the class's bounding box is filled with
+    EXCLUSIVE upper bounds ([min:max], so the last row / column keeps only its own pixels), 0 when either
+    mask lacks the class."""
+    gt = (np.asarray(gt_mask) == label).astype(np.float64)
+    pred = (np.asarray(pred_mask) == label).astype(np.float64)
+    for m in (gt, pred):
+        if m.max() == 0:
+            return 0
+        nz = m.nonzero()
+        m[nz[0].min():nz[0].max(), nz[1].min():nz[1].max()] = 1
+    union = np.count_nonzero(gt + pred)
+    return np.count_nonzero(gt * pred) / union if union > 0 else 0
+
+
+def dice_of_iou(iou):
+    """get_mask_dice / get_bb_dice (:71-78)"""
+    return 2 * iou / (iou + 1)
+
+
+def pd_at_iou_threshold(iou_table, classes, thr=0.5):
+    """get_pd_at_iou_threshold (:126-133): iou_table (samples, classes) -> fraction of samples above thr"""
+    t = np.asarray(iou_table, np.float64)
+    return {c: float((t[:, i] > thr).mean()) for i, c in enumerate(classes)}
+
+
+def iou_vs_pd_curve(iou_table, classes, inc=0.05):
+    """get_iou_vs_pd_curve (:136-162): int(1/inc) thresholds on linspace(0, 1), plus the class mean"""
+    vals = np.linspace(0, 1, int(1 / inc))
+    out = {c: [pd_at_iou_threshold(iou_table, classes, t)[c] for t in vals] for c in classes}
+    out['Mean'] = np.mean([out[c] for c in classes], axis=0)
+    return out

@@ -83,6 +83,35 @@ def upfirdn2d(x, kernel, up=1, pad=(0, 0)):
     return y.reshape(b, c, y.shape[2], y.shape[3])
 
 
+def upfirdn2d_general(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """The native op's own signature (lib/gan/optim/upfirdn2d.cpp:18-35; arithmetic of
+    upfirdn2d_kernel.cu:53-112 == upfirdn2d_native, model.py:61-102) on x [major][in_h][in_w][minor]:
+    zero-insert upsample, pad (negative pad = crop), correlate with the flipped kernel, decimate."""
+    major, ih, iw, minor = x.shape
+    kh, kw = kernel.shape
+    u = x.new_zeros(major, ih * up_y, iw * up_x, minor)
+    u[:, ::up_y, ::up_x] = x
+    u = F.pad(u, [0, 0, max(pad_x0, 0), max(pad_x1, 0), max(pad_y0, 0), max(pad_y1, 0)])
+    u = u[:, max(-pad_y0, 0):u.shape[1] - max(-pad_y1, 0), max(-pad_x0, 0):u.shape[2] - max(-pad_x1, 0)]
+    img = u.permute(0, 3, 1, 2).reshape(major * minor, 1, u.shape[1], u.shape[2])
+    y = F.conv2d(img, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw))
+    y = y.reshape(major, minor, y.shape[2], y.shape[3])[:, :, ::down_y, ::down_x]
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def fused_bias_act(x, bias=None, refer=None, act=3, grad=0, alpha=0.2, scale=1.0):
+    """fused_bias_act_kernel.cu:18-85 with the op's own argument list (fused_bias_act.cpp:18-31): bias over
+    dim 1; act 1 linear / 3 leaky-ReLU; grad 0 forward, 1 first gradient (gated by sign of refer), 2 -> 0."""
+    if bias is not None:
+        x = x + bias.reshape([1, -1] + [1] * (x.ndim - 2))
+    if grad == 2:
+        return torch.zeros_like(x)
+    if act == 1:
+        return x * scale
+    gate = x if grad == 0 else refer
+    return torch.where(gate > 0, x, x * alpha) * scale
+
+
 def modulated_conv(x, style, weight, mod_w, mod_b, demodulate=True, upsample=False,
                    blur_kernel=None):
     """ModulatedConv2d.forward (model.py:327-368).

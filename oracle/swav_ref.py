@@ -79,7 +79,12 @@ def norm_map(stack):
 # ----------------------------------------------------------------------------- S2 + S3
 def sample_pixels(stack, picks, patch_size):
     """'random' sampling (swav_clustering.py:160-167): permute all columns by `picks`,
-    keep the first patch_size; returns (N, C)."""
+    keep the first patch_size; 'patch' sampling (:150-158): `picks` is ONE integer offset (np.random.choice(h -
+    patch_size), :383-385) and the pixels are the square crop [o:o+ps, o:o+ps] in row-major order.
+    Returns (N, C)."""
+    if isinstance(picks, (int, np.integer)):
+        stack = stack[:, :, picks:picks + patch_size, picks:picks + patch_size]
+        picks = None
     flat = torch.squeeze(stack).flatten(1)
     if picks is not None:
         flat = flat[:, picks][:, :patch_size]

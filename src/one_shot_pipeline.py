@@ -30,7 +30,13 @@ class OneShotPipeline(object):
         self.out_dir = out_dir
         os.makedirs(self.out_dir, exist_ok=True)
         self.start_time = time.strftime("%m%d%Y_%H%M%S", time.localtime())
-        self.logfile = os.path.join(self.out_dir, f'one_shot_learner_{self.start_time}.log')
+        self.rank = 0
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.rank = dist.get_rank(dist_group)
+        # one log per rank; every other file (heads, cluster map, predictions, IoU tables) is rank 0's
+        self.logfile = os.path.join(self.out_dir, f'one_shot_learner_{self.start_time}' +
+                                    (f'_rank{self.rank}' if self.rank else '') + '.log')
         self.logger = get_logger('OneShot', self.logfile)
         self.summary_writer = None            # tensorboard is not a dependency of this build
         self.model_str, self.seg_str, self.train_str, self.test_str = model, segmentor, trainer, tester
@@ -65,7 +71,7 @@ class OneShotPipeline(object):
                 if n.endswith("noise.weight"):
                     p.data.fill_(0.1)
         else:
-            sd = torch.load(self.model_config.model_path, map_location='cpu')
+            sd = torch.load(self.model_config.model_path, map_location='cpu', weights_only=False)
             self.model.load_state_dict(sd["g_ema"] if 'g_ema' in sd.keys() else sd, strict=False)
         self.logger.info(f"Model Name: {self.model_str}")
         for k, v in self.model_config.gen_args.items():
@@ -110,9 +116,10 @@ class OneShotPipeline(object):
             self.test_labels = lab.unsqueeze(0).repeat(n, 1, 1).float()
             self.one_shot_ind = 0
             return
-        lat = torch.load(self.model_config.sample_latents)
+        # weights_only=False: labels.pt may hold a pickled numpy array (the reference predates torch's safe default)
+        lat = torch.load(self.model_config.sample_latents, weights_only=False)
         self.test_latents = (lat[0] if isinstance(lat, (tuple, list)) else lat).to(self.device)
-        lab = torch.load(self.model_config.sample_labels)
+        lab = torch.load(self.model_config.sample_labels, weights_only=False)
         if not isinstance(lab, torch.Tensor):
             lab = torch.from_numpy(lab)
         if lab.max() < 1:
@@ -162,6 +169,8 @@ class OneShotPipeline(object):
                                                   **({'dist_group': self.dist_group} if self.dist_group else {}), **kw)
             if self.seg_config.train_hfc:
                 self.preprocessor.preprocess(self.one_shot_latent)
+            if self.rank != 0:           # the pretraining was the data-parallel part: rank 0 fits the head and tests
+                return
             self._predict = getattr(self.preprocessor, 'predict_swav_codes', None) or self.preprocessor.predict_simclr_codes
             self.one_shot_features, self.one_shot_clusters = self._predict(self.one_shot_latent.reshape(1, -1))
             self.one_shot_features = self.one_shot_features.detach().clone()
@@ -180,7 +189,9 @@ class OneShotPipeline(object):
     def run_tests(self):
         """(:595-886) predictions of the fine-tuned head on the test latents, label_predictions.pt and the
         IoU block (per-class mask IoU, area-weighted IoU, binary IoU)."""
-        from ganecdotes_amd.oneshot import run_tests
+        from ganecdotes_amd.oneshot import run_tests, write_result_files
+        if self.rank != 0:
+            return None
 
         class _Prep:                                    # run_tests only needs predict_swav_codes-shaped access
             predict_swav_codes = staticmethod(lambda lat: self._predict(lat))
@@ -189,9 +200,14 @@ class OneShotPipeline(object):
         os.makedirs(self.test_dir, exist_ok=True)
         size = self.one_shot_features.shape[-1]
         labels = self._resize_labels(self.test_labels[:n], size)
-        pred, self.results = run_tests(_Prep, self.head, self.test_latents[:n], labels, self.model_config.classes)
+        # SimCLR's BatchNorm takes its statistics over the rows of ONE predict call: one latent per call, like the
+        # reference (MAX_TEST_BATCH = 1, :30, :614-639); the per-pixel preprocessors are batch-independent
+        per_call = 1 if self.seg_str == 'hfc_with_simclr' else 4
+        pred, self.results = run_tests(_Prep, self.head, self.test_latents[:n], labels, self.model_config.classes,
+                                       batch=per_call)
         torch.save(pred, os.path.join(self.test_dir, 'label_predictions.pt'))
         classes = self.model_config.classes
+        write_result_files(self.test_dir, self.results, classes)     # mask / bb IoU tables, results.npz (:775-791, :884)
         mean_iou = {c: float(sum(m[c] for m in self.results['mask_iou']) / n) for c in classes}
         self.results['mean_mask_iou'] = mean_iou
         self.results['mIoU'] = float(sum(mean_iou.values()) / len(classes))

@@ -1,6 +1,9 @@
 """BASELINE.json's configurations at their FULL sizes (256^2 x 5376 channels x 20 000 pixels;
 512^2 for car) on a real MI355X:
 
+  * the cat-256 (K = 16, 'image' source pdf, eps 0.003), car-512 (train step at 512^2, K = 16 and
+    4000, eps 0.01) and SimCLR (ffhq width, 20 pixel pairs) configurations: one optimizer step each
+    against the CPU oracle on the same draws;
   * one whole optimizer step of the ffhq-256 / K=8 workload against the CPU oracle on the same
     draws (one image, one patch: what the oracle finishes in seconds on the box's host cores);
   * the car-512 generator + all-pixel projection + cluster map against the oracle;
@@ -140,6 +143,133 @@ def test_car512_generator_and_cluster_map_vs_oracle(gpu, engine):
     # idempotence: no atomics anywhere on the predict path
     preds2, labels2 = sw.predict_swav_codes(w.cuda())
     assert torch.equal(preds, preds2) and torch.equal(labels, labels2)
+
+
+def _oracle_images(images, size):
+    """the oracle's draws of the same images, fed the HIP rotate/flip source maps (the maps
+    themselves are compared with the oracle's restatement in test_hip_kernels.py)"""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    return [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                            ops.rotflip_map(v.angle, v.flip, size, size, "cuda").cpu().long())
+                                for v in im.views], im.picks) for im in images]
+
+
+def test_cat256_full_size_step_vs_oracle(gpu, engine):
+    """configs[2] (cat-256) parameters at full size: 16 prototypes, source_pdf='image' (marginals from
+    the histograms of the whole 256^2 norm map, swav_clustering.py:523-532), eps = 0.003
+    (configs/segmentors/hfc_with_swav_cat_config.py:52-65), one image / one patch of 20 000 pixels:
+    loss, the three gradients and the LARC update against the oracle on identical draws."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(256, seed=43)
+    g = g.to(gpu)
+    a = ffhq_args(1, 16, num_patches=1, pick_source="host")
+    a["sinkhorn_args"] = dict(source_pdf="image", niters=10, eps=0.003)
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", **a)
+    torch.manual_seed(6)
+    np.random.seed(6)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 128, 512)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(512, 13, 6, 256 * 256, 1, transforms=True)]
+    loss = sw.train_step(images)
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, _oracle_images(images, 256), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
+        use_larc=True, hlen=5376, patch_size=20000, num_patches=1, temperature=0.01, eps=0.003, niters=10,
+        source_pdf="image", sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < 2e-3
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("nproto", [16, 4000])
+def test_car512_full_size_train_step_vs_oracle(gpu, nproto):
+    """configs[3] (car-512) TRAIN step at full size: a true 512^2 generator (15 taps, sum C = 5504;
+    hlen = 5376 drops the two native-resolution taps, so every channel of the descriptor is
+    upsampled), 20 000 of 262 144 pixels, eps = 0.01 (configs/segmentors/hfc_with_swav_car_config.py:
+    52-65), 7 perturbable layers; BASELINE.json's 16 prototypes (low-rank path) and the reference's own
+    4000 (generic MFMA path) at batch 1, one patch."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(512, seed=9)
+    g = g.to(gpu)
+    a = ffhq_args(1, nproto, num_patches=1, pick_source="host")
+    a["perturb_args"] = dict(truncation=0.7, n_layers=7, n_samples=1, layer_no=None, perturb_std=[1.0] * 7)
+    a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.01)
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", **a)
+    torch.manual_seed(8)
+    np.random.seed(8)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 64, 512)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(512, 15, 7, 512 * 512, 1, transforms=True)]
+    loss = sw.train_step(images)
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, _oracle_images(images, 512), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
+        use_larc=True, hlen=5376, patch_size=20000, num_patches=1, temperature=0.01, eps=0.01, niters=10,
+        source_pdf="uniform", sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < 2e-3
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-4
+
+
+def test_simclr_ffhq256_iteration_vs_oracle(gpu):
+    """configs[4] (ffhq-256 hfc_with_simclr) at full width: one optimizer iteration — 20 picked pixel
+    pairs of two 256^2 x 5376 views, Linear -> BatchNorm1d(train) -> LeakyReLU -> Linear, the reference's
+    inline NT-Xent (T = 1.0) — against the oracle on identical draws: loss, the four gradients, the
+    LARC update and the BatchNorm running statistics."""
+    from oracle import simclr_ref as C
+    from oracle import swav_ref as S
+    from ganecdotes_amd.simclr_clustering import SimCLRClustering, draw_simclr_iteration
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(256, seed=44)
+    g = g.to(gpu)
+    args = dict(num_iters=1, batch_size=20, patch_size=20000, hf_interp="nearest", trust_coeff=0.01,
+                train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=512, hlen=5376,
+                epoch_print_freq=1, max_masks=4, use_larc=True, transforms=True)
+    sim = SimCLRClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", simclr_args=args,
+                           perturb_args=dict(truncation=0.7, n_layers=6, n_samples=1, layer_no=None,
+                                             perturb_std=[1.0] * 6))
+    torch.manual_seed(12)
+    np.random.seed(12)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 128, 512)
+    sim.mean_latent = ml.cuda()
+    sim.build_heads()
+    leaves = [p.detach().cpu().clone() for p in sim._params()]
+    im = draw_simclr_iteration(512, 13, 6, 256 * 256, transforms=True)
+    loss = sim.train_step(im)
+    oim = _oracle_images([im], 256)[0]
+    for p in leaves:
+        p.requires_grad_(True)
+    ref_loss, mean, var_u = C.simclr_step_loss(sd, ml, 0.7, oim, *leaves, hlen=5376, batch=20, temperature=1.0)
+    ref_loss.backward()
+    grads = [p.grad.detach().clone() for p in leaves]
+    np.testing.assert_allclose(loss.item(), float(ref_loss.detach()), rtol=1e-3)
+    for got, want in zip(sim._grads, grads):
+        assert rel(got, want) < 2e-3
+    for p in leaves:
+        p.requires_grad_(False)
+    with torch.no_grad():
+        S.larc_sgd_step(leaves, grads, [None] * 4, 0.01, 0.9, 0.01, True)
+    for got, want in zip(sim._params(), leaves):
+        assert rel(got, want) < 1e-4
+    bn = sim.projection[1]
+    assert rel(bn.running_mean, 0.1 * mean) < 2e-3
+    assert rel(bn.running_var, 0.9 + 0.1 * var_u) < 2e-3
 
 
 # --------------------------------------------------------------------------- properties at the bench batch

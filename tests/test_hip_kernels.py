@@ -797,3 +797,47 @@ def test_random_subset_picks(ops, rows, hw, n, quant):
         for r in range(rows):
             freq[picks[r]] += 1
         assert abs(float(freq.mean()) / rows - n / hw) < 1e-6
+
+
+# ------------------------------------------------------------------------------------- the reference's native-op signatures
+def test_upfirdn2d_reference_signature_gv1_gv16(ops):
+    """gx_upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    (lib/gan/optim/upfirdn2d.cpp:18-35): GV1's own outputs for the generator's modes 1 and 3, and GV16's
+    general parameter sets (down 2, mixed up/down, non-square kernel, negative pads, minor > 1)."""
+    d = load_golden("gv1_upfirdn2d")
+    k = dev(T(d["kernel"]) * 4)
+    y1 = ops.upfirdn2d(dev(T(d["x_mode1"])), k, up=1, down=1, pad=(1, 1))
+    y3 = ops.upfirdn2d(dev(T(d["x_mode3"])), k, up=2, down=1, pad=(2, 1))
+    assert tuple(y1.shape) == d["y_mode1"].shape and tuple(y3.shape) == d["y_mode3"].shape
+    assert rel_err(y1, T(d["y_mode1"])) < 1e-6 and rel_err(y3, T(d["y_mode3"])) < 1e-6
+    g = load_golden("gv16_native_ops")
+    for i, case in enumerate(g["upfirdn_cases"]):
+        rest = [int(v) for v in case[6:]]
+        y = ops.upfirdn2d_native(dev(T(g[f"up{i}_x"])), dev(T(g[f"up{i}_k"])), *rest)
+        assert tuple(y.shape) == g[f"up{i}_y"].shape, i
+        assert rel_err(y, T(g[f"up{i}_y"])) < 2e-6, i
+    with pytest.raises(RuntimeError):                      # CHECK_CUDA of the reference boundary (upfirdn2d.cpp:9-15)
+        ops.upfirdn2d_native(T(g["up0_x"]), T(g["up0_k"]), 1, 1, 1, 1, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError):                      # CHECK_CONTIGUOUS
+        ops.upfirdn2d_native(dev(T(g["up3_x"])).transpose(1, 2), dev(T(g["up3_k"])), 1, 1, 1, 1, 0, 0, 0, 0)
+
+
+def test_fused_bias_act_reference_signature_gv3_gv16(ops):
+    """gx_fused_bias_act(input, bias, refer, act, grad, alpha, scale) (fused_bias_act.cpp:18-31): forward and the
+    grad = 1 / 2 modes against GV16 (fused_leaky_relu + its autograd), the EqualLinear(activation) output
+    of GV3 through it, and the linear activation."""
+    g = load_golden("gv16_native_ops")
+    x, b = dev(T(g["fl_x"])), dev(T(g["fl_b"]))
+    y = ops.fused_leaky_relu(x, b)
+    assert rel_err(y, T(g["fl_y"])) < 1e-6
+    gx = ops.fused_bias_act(dev(T(g["fl_gy"])), None, y, 3, 1, 0.2, 2 ** 0.5)
+    assert rel_err(gx, T(g["fl_gx"])) < 1e-6
+    assert float(ops.fused_bias_act(x, None, y, 3, 2, 0.2, 1.0).abs().max()) == 0.0
+    assert rel_err(ops.fused_bias_act(dev(T(g["fl2_x"])), dev(T(g["fl2_b"])), None, 3, 0, 0.2, 1.5), T(g["fl2_y"])) < 1e-6
+    lin = ops.fused_bias_act(x, b, None, 1, 0, 0.2, 3.0)
+    assert rel_err(lin, (T(g["fl_x"]) + T(g["fl_b"]).reshape(1, -1, 1, 1)) * 3.0) < 1e-6
+    # GV3: EqualLinear(activation='fused_lrelu') = fused_leaky_relu(F.linear(x, W * scale), bias * lr_mul)
+    d = load_golden("gv3_layers")
+    w, xin = T(d["el_weight"]), T(d["el_x"])
+    lin = ops.gemm(dev(xin), dev(w), False, True, alpha=1.0 / math.sqrt(w.shape[1]))
+    assert rel_err(ops.fused_leaky_relu(lin, dev(T(d["el_bias"]))), T(d["el_y"])) < 2e-6

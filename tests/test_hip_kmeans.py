@@ -106,6 +106,26 @@ def test_many_clusters_onehot_path(gpu, engine):
     assert abs(km.inertia_ - ref["inertia_"]) <= 1e-3 * ref["inertia_"]
 
 
+def test_random_state_none_uses_the_seeded_global_stream(gpu):
+    """random_state=None (the shipped kmeans_args) = sklearn's check_random_state(None): numpy's GLOBAL
+    RandomState, which the reference seeds with 42 at import (lib/util/util.py:21-24) — the fit is
+    reproducible under that seed, equals the fit driven by an explicit RandomState(42), and advances
+    the global stream."""
+    from ganecdotes_amd.kmeans import KMeans
+    rng = np.random.RandomState(5)
+    x = (rng.randn(400, 12) + 3 * rng.randint(0, 4, (400, 1))).astype(np.float32)
+    np.random.seed(42)
+    a = KMeans(5, n_init=2).fit(T(x).cuda())
+    after = np.random.rand()
+    np.random.seed(42)
+    b = KMeans(5, n_init=2).fit(T(x).cuda())
+    c = KMeans(5, n_init=2, random_state=np.random.RandomState(42)).fit(T(x).cuda())
+    np.testing.assert_array_equal(a.labels_, b.labels_)
+    np.testing.assert_array_equal(a.labels_, c.labels_)
+    np.random.seed(42)
+    assert after != np.random.rand()                      # the global stream was consumed by the fit
+
+
 def test_edge_cases_vs_oracle(gpu):
     """one cluster, as many clusters as samples, odd channel counts, duplicated samples (fewer distinct points
     than clusters: relocation is pointless and the degenerate centres stay put), too few samples"""

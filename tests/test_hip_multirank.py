@@ -90,3 +90,115 @@ def test_two_ranks_equal_one_rank(scope, pdf):
             np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-6 * np.abs(b).max())
     for a, b in zip(out[0][1], out[1][1]):          # replicas stay identical
         np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------- RCCL itself
+def _nccl_worker(rank, port, sd, scope, pdf, out):
+    """ONE rank on the `nccl` backend (= RCCL): every exchange step of the sharded protocol runs through
+    RCCL as an identity, asynchronous gradient messages included."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    dist.all_reduce = counted
+    sw = _build(sd, dist.group.WORLD, scope, pdf)
+    imgs = _images(4)
+    loss = None
+    for _ in range(2):
+        loss = sw.train_step(imgs)
+    torch.cuda.synchronize()
+    out[0] = (float(loss.item()), [p.cpu().numpy() for p in sw._params()], calls["n"], dist.get_backend())
+    dist.all_reduce = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scope,pdf", [("global", "uniform"), ("global", "image")])
+def test_nccl_backend_single_rank_equals_plain_step(scope, pdf):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    sd = golden_sd(load_golden("gv10_pretrain"))
+    sw = _build(sd, None, scope, pdf)
+    imgs = _images(4)
+    for _ in range(2):
+        loss1 = sw.train_step(imgs)
+    ref = (float(loss1.item()), [p.cpu().numpy() for p in sw._params()])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(port, sd, scope, pdf, out), nprocs=1, join=True)
+    loss, params, ncalls, backend = out[0]
+    assert backend == "nccl"
+    # per step: Sinkhorn 1 max + 10 sums (all patches and both views travel together), the {dWc, db, loss}
+    # message and one message per pyramid level (32^2 generator: 4 levels) — plus the marginal histograms
+    assert ncalls >= 2 * (11 + 1 + 4), ncalls
+    np.testing.assert_allclose(loss, ref[0], rtol=2e-4)
+    for a, b in zip(params, ref[1]):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-6 * np.abs(b).max())
+
+
+# ------------------------------------------------------------------------------------- pretrain() under N ranks
+def _pretrain_worker(rank, world, port, sd, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(42)                      # what lib/util/util.py does at import on EVERY rank
+    np.random.seed(42)
+    sw = _build(sd, dist.group.WORLD, "global", "uniform")
+    sw.swav_args.update(num_epochs=3, batch_size=2)
+    drawn = []
+    real = sw.draw_batch
+
+    def spy(batch):
+        imgs = real(batch)
+        drawn.append(np.concatenate([im.z.numpy().ravel() for im in imgs]))
+        return imgs
+    sw.draw_batch = spy
+    heads0 = None
+
+    def spy_heads():
+        nonlocal heads0
+        type(sw).build_heads(sw)
+        # give the ranks DIFFERENT initial heads, as un-broadcast per-rank inits would be
+        for p in sw._params():
+            p.add_(0.01 * rank)
+    sw.build_heads = spy_heads
+    sw.pretrain(None, num_test_samples=1)
+    out[rank] = (np.stack(drawn), [p.cpu().numpy() for p in sw._params()],
+                 [float(l.item()) for l in sw.loss_history])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pretrain_two_ranks_draw_different_images_and_stay_replicated():
+    """pretrain() itself under 2 ranks (gloo, sharing the GPU): rank 0's heads are broadcast, each rank
+    draws its own latents (a per-rank reseed — the import-time seed 42 is the same everywhere), and the
+    replicas hold bit-identical parameters and losses after every step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    sd = golden_sd(load_golden("gv10_pretrain"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_pretrain_worker, args=(2, port, sd, out), nprocs=2, join=True)
+    z0, p0, l0 = out[0]
+    z1, p1, l1 = out[1]
+    assert z0.shape == z1.shape == (3, 2 * 16)
+    assert not np.allclose(z0, z1)                       # different images per rank
+    for a, b in zip(p0, p1):
+        np.testing.assert_array_equal(a, b)               # replicas identical
+    assert l0 == l1 and all(np.isfinite(l0))

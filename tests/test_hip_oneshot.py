@@ -203,3 +203,96 @@ def test_one_shot_pipeline_end_to_end_vs_oracle(gpu, tmp_path):
             assert abs(a[c] - b[c]) < 0.005          # BASELINE.json: mIoU within +-0.5 pt of the reference
     np.testing.assert_allclose(res["w_iou"], ref["w_iou"], atol=0.005)
     assert abs(res["bin_iou"] - ref["bin_iou"]) < 0.005
+
+
+def test_pipeline_on_reference_format_files(gpu, tmp_path):
+    """OneShotPipeline on FILES in the reference's formats instead of the synthetic mode:
+    a rosinality checkpoint {'g_ema': state_dict, ...} with an extra key (strict=False,
+    src/one_shot_pipeline.py:140-147), `latents.pt` as the (latents, noises) tuple, numpy labels stored in
+    [0, 1) (x255 rule, :356-374), one_shot_ind != 0; run_pipeline() then leaves projection.pt / prototypes.pt /
+    cluster_map.pt / tests/label_predictions.pt / tests/mask_iou_results.csv / bb_iou_results.csv / results.npz."""
+    from oracle import swav_ref as S
+    from src.one_shot_pipeline import OneShotPipeline
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    torch.save({"g_ema": {**sd, "not.a.generator.key": torch.zeros(3)}, "g": {}, "latent_avg": torch.zeros(16)},
+               tmp_path / "ckpt.pt")
+    torch.manual_seed(21)
+    with torch.no_grad():
+        w = S.G.mapping(torch.randn(5, 16), sd)
+    torch.save((w, [torch.zeros(1, 1, 4, 4)]), tmp_path / "latents.pt")
+    yy, xx = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
+    ids = ((xx > 12).astype(np.int64) + (yy > 18).astype(np.int64))
+    torch.save(np.repeat((ids / 255.0).astype(np.float32)[None], 5, 0), tmp_path / "labels.pt")
+    (tmp_path / "model_cfg.py").write_text(
+        f"model_path = {str(tmp_path / 'ckpt.pt')!r}\nnum_latents_for_mean = 64\ntruncation = 0.7\nimage_size = 32\n"
+        "latent_dim = 16\ngen_args = dict(size=32, style_dim=16, n_mlp=2, channels={4: 16, 8: 16, 16: 8, 32: 8, 64: 8})\n"
+        f"is_baggan = False\nsample_latents = {str(tmp_path / 'latents.pt')!r}\n"
+        f"sample_labels = {str(tmp_path / 'labels.pt')!r}\none_shot_ind = 1\nclasses = ['background', 'a', 'b']\n")
+    (tmp_path / "seg_cfg.py").write_text(
+        "from ganecdotes_amd.config_defaults import swav_segmentor\n"
+        "globals().update(swav_segmentor(12, 0.05, 'XS', train_hfc=True, num_epochs=2, layer_hf_dim=[16, 32, 8], hlen=56,\n"
+        "                                nclasses=8, n_hfc_layers=3))\n"
+        "hfc_prep_args['swav_args'].update(patch_size=300, num_patches=2, temperature=0.1, epoch_print_freq=1)\n")
+    out = tmp_path / "run"
+    pipe = OneShotPipeline(out_dir=str(out), exp_name="file formats", model="ffhq-256", segmentor="hfc_with_swav_ffhq",
+                           custom=dict(model=str(tmp_path / "model_cfg.py"), seg=str(tmp_path / "seg_cfg.py")),
+                           num_test_samples=4, device="cuda:0")
+    got = pipe.model.state_dict()
+    for k, v in sd.items():                                    # the g_ema entry was the one loaded
+        assert torch.equal(got[k].cpu(), v), k
+    pipe.trainer_config.num_epochs = 30
+    pipe.run_pipeline()
+    assert pipe.one_shot_ind == 1 and torch.equal(pipe.one_shot_latent.cpu(), w[1])
+    assert float(pipe.test_labels.max()) == 2.0               # x255 brought the stored [0, 1) labels back to ids
+    for f in ("projection.pt", "prototypes.pt", "cluster_map.pt", "tests/label_predictions.pt",
+              "tests/mask_iou_results.csv", "tests/bb_iou_results.csv", "tests/results.npz"):
+        assert (out / f).exists(), f
+    pred = torch.load(out / "tests" / "label_predictions.pt")
+    assert pred.shape == (4, 32, 32) and pred.dtype == torch.int64
+    rows = (out / "tests" / "mask_iou_results.csv").read_text().splitlines()
+    assert rows[0] == ",background,a,b" and len(rows) == 5
+    res = np.load(out / "tests" / "results.npz", allow_pickle=True)
+    assert {"mask_iou", "bb_iou", "w_iou", "bin_iou", "mask_dice", "bb_dice", "pd", "iou_pd_curve"} <= set(res.files)
+    # the CSV is the table of results['mask_iou']
+    np.testing.assert_allclose([float(v) for v in rows[1].split(",")[1:]],
+                               [res["mask_iou"][0][c] for c in ("background", "a", "b")])
+    # evaluate.py's route: a second pipeline with train_hfc off loads the saved heads back
+    proj = torch.load(out / "projection.pt", weights_only=False)
+    assert proj[0].weight.shape == (8, 56)
+
+
+def test_simclr_predict_one_latent_per_call(gpu, tmp_path):
+    """hfc_with_simclr's run_tests route: the train-mode BatchNorm of predict_simclr_codes pools
+    its statistics over the rows of a call, so the test loop feeds ONE latent per call like the reference
+    (MAX_TEST_BATCH = 1, src/one_shot_pipeline.py:30): run_tests(batch=1) == per-latent predictions, and a
+    4-latent call would differ."""
+    from ganecdotes_amd.generator import Generator
+    from ganecdotes_amd.oneshot import OneShotHead, run_tests
+    from ganecdotes_amd.simclr_clustering import SimCLRClustering
+    d = load_golden("gv12_simclr")
+    g = Generator(32, 16, 2, channels={4: 16, 8: 16, 16: 8, 32: 8, 64: 8})
+    g.load_state_dict(golden_sd(d), strict=False)
+    g = g.eval().to(gpu)
+
+    class Cfg:
+        num_latents_for_mean, truncation, latent_dim = 64, 0.7, 16
+    args = dict(num_iters=1, batch_size=3, patch_size=30, hf_interp="nearest", trust_coeff=0.01,
+                train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=8, hlen=56, epoch_print_freq=1,
+                max_masks=4)
+    sim = SimCLRClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", simclr_args=args,
+                           perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None, perturb_std=[1.0] * 3))
+    torch.manual_seed(3)
+    sim.build_heads()
+    lat = g.style(torch.randn(4, 16, device="cuda"))
+    one = torch.cat([sim.predict_simclr_codes(lat[i:i + 1])[0] for i in range(4)])
+    four = sim.predict_simclr_codes(lat)[0]
+    assert float((one - four).abs().max()) > 1e-4              # pooled statistics are a different function
+    head = OneShotHead(8, 3, "XS")
+
+    class Prep:
+        predict_swav_codes = staticmethod(lambda l: sim.predict_simclr_codes(l))
+    labels = torch.zeros(4, 32, 32)
+    pred1, _ = run_tests(Prep, head, lat, labels, ["background", "a", "b"], batch=1)
+    want = torch.cat([head.predict(one[i:i + 1].permute(0, 2, 3, 1)) for i in range(4)]).cpu()
+    assert torch.equal(pred1, want)

@@ -220,6 +220,42 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["pyramid", "panel"])
+def test_patch_sampling_vs_oracle(gpu, tmp_path, mode):
+    """sampling_method='patch' (swav_clustering.py:150-158, :383-385): one np.random.choice(h - patch_size)
+    offset per patch, the pixels of the square crop [o:o+ps, o:o+ps]; loss, gradients and update against
+    the oracle's crop on identical draws (both rotated / flipped views, batch 2)."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    sw = make_swav(g, gpu, tmp_path, sampling_method="patch", patch_size=12, batch_size=2, sinkhorn_scope="image",
+                   projection_mode=mode)
+    torch.manual_seed(321)
+    np.random.seed(321)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = sw.draw_batch(2)
+    assert all(len(im.patch_offsets) == 2 and all(0 <= o < 32 - 12 for o in im.patch_offsets) for im in images)
+    assert all(p.numel() == 144 for im in images for p in im.picks)
+    loss = sw.train_step(images)
+    oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                             ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
+                                 for v in im.views], list(im.patch_offsets)) for im in images]
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
+        patch_size=12, num_patches=2, temperature=0.1, eps=0.05, niters=10, source_pdf="uniform",
+        sinkhorn_scope="image")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < 2e-3
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-4
+
+
 @pytest.mark.parametrize("hlen", [512 * 8 + 300, 512 * 7])
 def test_pyramid_equals_panel_at_ffhq_width(gpu, tmp_path, hlen):
     """Full-width 64x64 generator (512-channel taps): the pyramid projection and the

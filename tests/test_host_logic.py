@@ -55,6 +55,92 @@ def test_library_exports_every_declared_symbol():
     assert L.gx_gemm_f32_workspace_bytes(512, 5376, 8) == 8 * 512 * 5376 * 4
 
 
+def test_ctypes_table_matches_the_header_prototypes():
+    """Every prototype of include/ganecdotes_hip.h, parsed, against the hand-written ctypes table: same
+    return type, same argument count, same argument classes (pointer / int / long / size_t / float) in the
+    same order.  (The .hip definitions are checked against the same header by the compiler: gx_common.h
+    includes it.)"""
+    from ganecdotes_amd import _lib
+    import ctypes as C
+    header = open(os.path.join(ROOT, "include", "ganecdotes_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|const char\*|void\*|float\*)\s+(gx_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+
+    def ctype_of(decl):
+        decl = decl.strip()
+        if decl in ("void", ""):
+            return None
+        if "*" in decl:
+            return C.c_void_p
+        base = re.sub(r"\b(const|unsigned|signed)\b", " ", decl)
+        base = " ".join(base.split()[:-1]) if len(base.split()) > 1 else base.strip()      # drop the name
+        return {"int": C.c_int, "long": C.c_long, "long long": C.c_longlong, "size_t": C.c_size_t,
+                "float": C.c_float, "double": C.c_double}[base]
+    ret_of = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p, "void*": C.c_void_p,
+              "float*": C.c_void_p}
+    for ret, name, args in protos:
+        res, argtypes = _lib.SIGNATURES[name]
+        assert res is ret_of[ret], (name, ret, res)
+        want = [t for t in (ctype_of(a) for a in args.split(",")) if t is not None]
+        assert list(argtypes) == want, (name, argtypes, want)
+
+
+def test_result_tables_and_files_match_the_reference_format(tmp_path):
+    """bb IoU / Dice / PD summaries and the text of tests/mask_iou_results.csv against GV16 (captured from
+    lib/metrics/segmentation.py and pandas.DataFrame.to_csv, src/one_shot_pipeline.py:775-791, :884)."""
+    from conftest import load_golden
+    from ganecdotes_amd import oneshot as H
+    d = load_golden("gv16_native_ops")
+    classes = ["background", "a", "b", "c"]
+    gts, preds = d["met_gt"], d["met_pred"]
+    bb = np.array([[H.bb_iou(g, p, i) for i in range(4)] for g, p in zip(gts, preds)])
+    np.testing.assert_allclose(bb, d["met_bb_iou"], rtol=0, atol=1e-15)
+    mi = d["met_mask_iou"]
+    pdv = H.pd_at_iou_threshold(mi, classes)
+    np.testing.assert_allclose([pdv[c] for c in classes], d["met_pd"])
+    curve = H.iou_vs_pd_curve(mi, classes)
+    np.testing.assert_allclose(np.array([curve[c] for c in classes + ["Mean"]]), d["met_curve"], atol=1e-15)
+    rows = [{c: mi[i, j] for j, c in enumerate(classes)} for i in range(mi.shape[0])]
+    assert H.table_csv(rows, classes) == bytes(d["met_csv"]).decode()
+    res = dict(mask_iou=rows, bb_iou=[{c: bb[i, j] for j, c in enumerate(classes)} for i in range(bb.shape[0])],
+               w_iou=[0.5] * 6, bin_iou=0.25, pd=pdv, iou_pd_curve=curve)
+    H.write_result_files(str(tmp_path), res, classes)
+    assert (tmp_path / "mask_iou_results.csv").read_text() == bytes(d["met_csv"]).decode()
+    assert (tmp_path / "bb_iou_results.csv").read_text().splitlines()[0] == ",background,a,b,c"
+    back = np.load(tmp_path / "results.npz", allow_pickle=True)
+    assert set(back.files) == set(res) and float(back["bin_iou"]) == 0.25
+    assert back["mask_iou"][2]["b"] == rows[2]["b"]
+
+
+def test_sample_loader_rules(tmp_path):
+    """OneShotPipeline's latents / labels loading rules (src/one_shot_pipeline.py:356-384): the
+    (latents, noises) tuple form, numpy labels, the x255 rule for labels stored in [0, 1) and the LSUN-car
+    canvas (384 rows centred in 512)."""
+    from src.one_shot_pipeline import OneShotPipeline
+    lat = torch.randn(3, 14, 8)
+    lab01 = (np.random.RandomState(0).randint(0, 5, (3, 16, 16)) / 255.0).astype(np.float32)
+    torch.save((lat, [torch.zeros(1)]), tmp_path / "latents.pt")
+    torch.save(lab01, tmp_path / "labels.pt")
+
+    class MC:
+        sample_latents, sample_labels, one_shot_ind = str(tmp_path / "latents.pt"), str(tmp_path / "labels.pt"), 2
+    p = object.__new__(OneShotPipeline)
+    p.synthetic, p.device, p.model_config, p.model_str = False, "cpu", MC, "ffhq-256"
+    p._load_samples()
+    assert torch.equal(p.test_latents, lat) and p.one_shot_ind == 2
+    np.testing.assert_allclose(p.test_labels.numpy(), lab01 * 255, rtol=1e-6)
+    assert p.test_labels.max() >= 1
+    # plain tensors, class ids already; LSUN-car canvas
+    torch.save(lat, tmp_path / "latents.pt")
+    torch.save(torch.ones(3, 384, 512) * 2, tmp_path / "labels.pt")
+    p.model_str = "exp-car-512"
+    p._load_samples()
+    assert p.test_labels.shape == (3, 512, 512)
+    assert float(p.test_labels[:, :64].abs().max()) == 0 and float(p.test_labels[:, 64:448].min()) == 2
+    assert float(p.test_labels[:, 448:].abs().max()) == 0
+
+
 def test_product_path_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ganecdotes_amd")):

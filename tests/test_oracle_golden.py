@@ -367,3 +367,34 @@ def test_gv15_reference_hfc_preprocessor():
     np.testing.assert_array_equal(maps * 2 - 1, g["B_pred_maps"])
     assert sorted(g["B_saved_files"].tolist()) == ["clusterer_layer_0.sav", "clusterer_layer_1.sav", "clusterer_layer_2.sav",
                                                    "model_stats.npz"]
+
+
+# ------------------------------------------------------------------------------------- GV16: native-op signatures, metrics
+def test_gv16_upfirdn2d_general_and_fused_bias_act():
+    d = load_golden("gv16_native_ops")
+    for i, case in enumerate(d["upfirdn_cases"]):
+        major, ih, iw, minor, kh, kw, *rest = [int(v) for v in case]
+        y = G.upfirdn2d_general(T(d[f"up{i}_x"]), T(d[f"up{i}_k"]), *rest)
+        assert tuple(y.shape) == d[f"up{i}_y"].shape, i
+        close(y, d[f"up{i}_y"], rtol=1e-5, atol=1e-5)
+    close(G.fused_bias_act(T(d["fl_x"]), T(d["fl_b"]), None, 3, 0, 0.2, 2 ** 0.5), d["fl_y"])
+    close(G.fused_bias_act(T(d["fl_gy"]), None, T(d["fl_y"]), 3, 1, 0.2, 2 ** 0.5), d["fl_gx"])
+    close(G.fused_bias_act(T(d["fl2_x"]), T(d["fl2_b"]), None, 3, 0, 0.2, 1.5), d["fl2_y"])
+    assert float(G.fused_bias_act(T(d["fl_x"]), None, T(d["fl_y"]), 3, 2, 0.2, 1.0).abs().max()) == 0.0
+
+
+def test_gv16_remaining_test_metrics():
+    from oracle import oneshot_ref as O
+    d = load_golden("gv16_native_ops")
+    classes = ["background", "a", "b", "c"]
+    gts, preds = d["met_gt"], d["met_pred"]
+    mi = np.array([[O.mask_iou(g, p, i) for i in range(4)] for g, p in zip(gts, preds)])
+    bb = np.array([[O.bb_iou(g, p, i) for i in range(4)] for g, p in zip(gts, preds)])
+    np.testing.assert_allclose(mi, d["met_mask_iou"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(bb, d["met_bb_iou"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.dice_of_iou(mi), d["met_mask_dice"], atol=1e-15)
+    np.testing.assert_allclose(O.dice_of_iou(bb), d["met_bb_dice"], atol=1e-15)
+    pdv = O.pd_at_iou_threshold(mi, classes)
+    np.testing.assert_allclose([pdv[c] for c in classes], d["met_pd"])
+    curve = O.iou_vs_pd_curve(mi, classes)
+    np.testing.assert_allclose(np.array([curve[c] for c in classes + ["Mean"]]), d["met_curve"], atol=1e-15)
