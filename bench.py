@@ -174,8 +174,9 @@ def self_launch(n):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    for line in out.decode().splitlines():          # ONE JSON line (backends may chat on stdout: "[Gloo] Rank 0 is ...")
+        if line.startswith("{"):
+            print(line, flush=True)
     return rc
 
 

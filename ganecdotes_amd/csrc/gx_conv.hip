@@ -46,6 +46,8 @@ struct ConvArgs {
     int tiles_n, ntile;
     unsigned in_bytes, wt_bytes, style_bytes;  // extents for the buffer descriptors (VEC path)
     int splits; float* slab;                   // split-K over k-tiles: raw partial sums [split][B*outH*outW*Cout]
+    const unsigned short* xp;                  // optional pre-split MODULATED input (gx_modsplit): see modconv_xp_kernel
+    unsigned xp_plane_bytes;                   // bytes of one (chunk, plane) image = B*(IH+2)*(IW+2)*32
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
@@ -355,6 +357,145 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 #undef GX_CONV_LOOP
 
     conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// ---- the modulated input, split once ("x planes") -------------------------------------------------------
+// modconv_kernel<.., X6> re-splits every activation element (x * s into three bf16) once per tap and per Cout
+// tile: 9-36 x redundant VALU + LDS-write work next to the MFMAs.  Here the split happens ONCE, in the kernel that
+// produces the activation (or in modsplit_kernel), into
+//     xp [ncc = ceil(Cin/16)][3 planes h, m, l][B][IH+2][IW+2][16] bf16        (zero border, zero channel padding)
+// i.e. chunk-major, pixel-contiguous: the 128-pixel x 16-channel A tile of tap (dy, dx) is, per plane, the
+// 32-B records of 128 padded pixel indices that differ from the un-shifted ones by the CONSTANT dy*(IW+2)+dx — no
+// masks (the border is real zeros), and for tiles inside one image row one contiguous 4 KB run.  Both operands
+// then go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no VALU, no ds_write; the
+// half-swap swizzle of the KC image (x_kc_off) is applied on the per-lane SOURCE address, the LDS side is linear.
+// Main loop = 6 DMA + 12 ds_read_b128 + 24 MFMA per wave and k-tile.
+constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + B planes of one k-tile: 24 KB
+
+template <int NT>
+__device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, f32x16 (&acc)[2][2],
+                                                 unsigned pixbyte, int n0, int tid, int wr, int wc, int lane) {
+    const int ncc = g.wtp_ncc;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(reinterpret_cast<const float*>(g.wtp), g.wtp_bytes);
+    const int wp_ntn = (g.Cout + 127) >> 7;
+    const int IWp = g.IW + 2;
+    int tapoff[NT];                                                  // byte offset of the tap's padded pixel
+    unsigned wblk[NT];                                               // weight block of (tap, Cout tile, chunk 0)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        tapoff[t] = (sb.dy[t] * IWp + sb.dx[t]) * 32;
+        wblk[t] = (unsigned)(((sb.tw[t] * wp_ntn + (n0 >> 7)) * ncc) * 3) * 4096u;
+    }
+    const unsigned wlane = (unsigned)tid * 16u;
+    const char* xp = reinterpret_cast<const char*>(g.xp);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    auto issue = [&](int cc, int tap, int to, unsigned wb, char* dst) {
+        const unsigned va = pixbyte + (unsigned)to;                  // signed add: the padded pixel is never negative
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const char* base = xp + (long)(cc * 3 + p) * (long)g.xp_plane_bytes;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)g.xp_plane_bytes, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)va, 0, 0, 0);
+        }
+        const unsigned blk = wb + (unsigned)cc * 3u * 4096u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + 12288 + p * 4096 + wid * 1024), 16,
+                                                     (int)wlane, (int)(blk + p * 4096u), 0, 0);
+        (void)tap;
+    };
+
+    if (ncc > 0) issue(0, 0, tapoff[0], wblk[0], lds);
+    int buf = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+        const bool last_cc = (cc + 1 == ncc);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            // tile k has landed (this wave's DMAs: vmcnt; the other waves': the barrier), and every wave is done
+            // reading the other stage (its MFMAs of tile k-1 were issued before it arrived here)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            char* As = lds + buf * XP_STAGE_BYTES;
+            const bool wrap = (tap + 1 == NT);
+            if (!(wrap && last_cc))
+                issue(wrap ? cc + 1 : cc, wrap ? 0 : tap + 1, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
+                      lds + (buf ^ 1) * XP_STAGE_BYTES);
+            x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
+            buf ^= 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds_raw[2 * XP_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.nsub && (int)blockIdx.x >= g.sub[i].tile_base) si = i;
+    const ConvSub& sb = g.sub[si];
+    const int local = xcd_remap(blockIdx.x - sb.tile_base, sb.tiles_m * g.tiles_n);
+    const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const unsigned ohw = (unsigned)sb.OH * (unsigned)sb.OW;
+    const unsigned Mtot = (unsigned)g.B * ohw;
+    // this thread DMAs bytes [16 tid, 16 tid + 16) of every plane of the A image: row R = tid >> 1, 16-B slot tid & 1,
+    // which under the half-swap swizzle holds channel half (tid & 1) ^ ((R >> 3) & 1) of the row's 16 channels
+    const int R = tid >> 1;
+    unsigned m = (unsigned)m0 + (unsigned)R;
+    if (m >= Mtot) m = Mtot - 1;                                     // tail rows: any valid pixel (outputs are dropped)
+    const unsigned b = m / ohw, rem = m - b * ohw;
+    const unsigned oy = rem / (unsigned)sb.OW, ox = rem - oy * (unsigned)sb.OW;
+    const unsigned pixpad = (b * (unsigned)(g.IH + 2) + oy + 1u) * (unsigned)(g.IW + 2) + ox + 1u;
+    const unsigned pixbyte = pixpad * 32u + (unsigned)(((tid & 1) ^ ((R >> 3) & 1)) << 4);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    switch (sb.ntaps) {
+        case 9: conv_mainloop_xp<9>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+        case 4: conv_mainloop_xp<4>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+        case 2: conv_mainloop_xp<2>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+        default: conv_mainloop_xp<1>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+    }
+    conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// x [B][H][W][Cin] fp32 NHWC times s [B][Cin] (or s = NULL) -> xp (layout above).  A thread owns 4 channels of a
+// pixel (float4 load, 8 B per plane); the channel padding up to ncc*16 is written as zeros, the spatial border is not
+// touched (the host zeroes the buffer once).
+__global__ void modsplit_kernel(const float* __restrict__ x, const float* __restrict__ s, int B, int H, int W, int Cin,
+                                int ncc, unsigned short* __restrict__ xp) {
+    const int q4 = ncc * 4;
+    const long total = (long)B * H * W * q4;
+    const long plane = (long)B * (H + 2) * (W + 2) * 16;            // bf16 elements of one (chunk, plane) image
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % q4) * 4;
+        long pix = i / q4;
+        const int xx = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        f32x4 v = zero4();
+        if (c < Cin) {
+            const long src = (((long)b * H + y) * W + xx) * Cin + c;
+            if (c + 4 <= Cin && (Cin & 3) == 0) {
+                v = *reinterpret_cast<const f32x4*>(x + src);
+                if (s) v *= *reinterpret_cast<const f32x4*>(s + (long)b * Cin + c);
+            } else {
+                for (int e = 0; e < 4 && c + e < Cin; ++e) v[e] = x[src + e] * (s ? s[(long)b * Cin + c + e] : 1.f);
+            }
+        }
+        unsigned h[2], m[2], l[2];
+        split3(v[0], v[1], h[0], m[0], l[0]);
+        split3(v[2], v[3], h[1], m[1], l[1]);
+        const long ppix = ((long)b * (H + 2) + y + 1) * (W + 2) + xx + 1;
+        unsigned short* d = xp + ((long)(c >> 4) * 3) * plane + ppix * 16 + (c & 15);
+        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+        *reinterpret_cast<u32x2*>(d + plane) = (u32x2){m[0], m[1]};
+        *reinterpret_cast<u32x2*>(d + 2 * plane) = (u32x2){l[0], l[1]};
+    }
 }
 
 // Split-K tail: out = epilogue(sum_s slab[s]) over the whole NHWC output (fixed order).
@@ -840,13 +981,22 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         if ((long)g.B * g.sub[i].OH * g.sub[i].OW >= (1L << 31)) return GX_ERR_BAD_ARG;
     }
     g.ntile = base;
-    g.splits = conv_pick_splits(0, g.Cout, base, min_kt);
+    g.splits = g.xp ? 1 : conv_pick_splits(0, g.Cout, base, min_kt);
     g.slab = nullptr;
     if (g.splits > 1) {
         if (!slab || slab_bytes < conv_slab_bytes(g.B, g.outH, g.outW, g.Cout, g.splits)) g.splits = 1;   // no scratch: unsplit
         else g.slab = slab;
     }
     dim3 grid(g.ntile, g.splits);
+    if (g.xp) {       // pre-split modulated input: bf16x6 engine, pre-split weights, no split-K
+        if (!x6 || !g.wtp || g.splits != 1 || ((uintptr_t)g.xp & 15)) return GX_ERR_BAD_ARG;
+        const size_t pb = (size_t)g.B * (g.IH + 2) * (g.IW + 2) * 32;
+        if (pb >= 0x7FFFFFF0ull) return GX_ERR_BAD_ARG;
+        g.xp_plane_bytes = (unsigned)pb;
+        hipLaunchKernelGGL(modconv_xp_kernel, grid, dim3(GEMM_THREADS), 0, stream, g);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     if (x6 && g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
     else if (x6) hipLaunchKernelGGL((modconv_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
     else if (g.vec_ok) hipLaunchKernelGGL((modconv_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, stream, g);
@@ -967,6 +1117,71 @@ int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt
                    const float* bias, int act, float* out, float* slab, size_t slab_bytes, void* stream) {
     return gx_modconv_fwd_p(x, B, H, W, Cin, wt, nullptr, ksize, Cout, s, demod, noise, noise_bstride, noise_w, bias, act,
                             out, slab, slab_bytes, stream);
+}
+
+// The modulated input x * s split once into bf16 planes (layout: modconv_xp_kernel).  `planes` holds
+// gx_xplanes_bytes(B, H, W, Cin) bytes whose spatial border the CALLER has zeroed once (kernels never write it).
+size_t gx_xplanes_bytes(int B, int H, int W, int Cin) {
+    return (size_t)gx_cdiv(Cin, 16) * 3 * B * (H + 2) * (W + 2) * 32;
+}
+int gx_modsplit(const float* x, int B, int H, int W, int Cin, const float* s, unsigned short* planes, void* stream) {
+    if (!x || !planes || B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return GX_ERR_BAD_ARG;
+    if ((((uintptr_t)x | (uintptr_t)s | (uintptr_t)planes) & 15) != 0) return GX_ERR_ALIGN;
+    const int ncc = gx_cdiv(Cin, 16);
+    const long total = (long)B * H * W * ncc * 4;
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(modsplit_kernel, dim3((int)(want < 32768 ? want : 32768)), dim3(256), 0, (hipStream_t)stream, x, s, B,
+                       H, W, Cin, ncc, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// gx_modconv_fwd_p / gx_modconv_up_convt_p with the input given as x planes (x and s are then unused by the
+// contraction; bf16x6 engine and wt_planes required, layers with >= 256 output tiles only).
+int gx_modconv_fwd_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
+                      const unsigned short* wt_planes, int ksize, int Cout, const float* demod, const float* noise,
+                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out, void* stream) {
+    if (!x_planes || !wt || !wt_planes || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 ||
+        (ksize != 1 && ksize != 3))
+        return GX_ERR_BAD_ARG;
+    ConvArgs g{};
+    g.xp = x_planes; g.wtp = wt_planes;
+    g.in = wt; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = nullptr;
+    g.nsub = 1;
+    ConvSub& sb = g.sub[0];
+    sb.ntaps = ksize * ksize;
+    for (int ky = 0; ky < ksize; ++ky)
+        for (int kx = 0; kx < ksize; ++kx) {
+            const int t = ky * ksize + kx;
+            sb.dy[t] = ky - ksize / 2; sb.dx[t] = kx - ksize / 2; sb.tw[t] = t;
+        }
+    sb.OH = H; sb.OW = W; sb.yadd = 0; sb.xadd = 0;
+    g.out = out; g.outH = H; g.outW = W; g.Cout = Cout;
+    g.ymul = 1; g.xmul = 1;
+    g.demod = demod; g.noise = noise; g.noise_bstride = noise_bstride; g.noise_w = noise_w; g.bias = bias; g.act = act;
+    return launch_conv(g, nullptr, 0, (hipStream_t)stream);
+}
+int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
+                           const unsigned short* wt_planes, int Cout, float* T, void* stream) {
+    if (!x_planes || !wt || !wt_planes || !T || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return GX_ERR_BAD_ARG;
+    ConvArgs g{};
+    g.xp = x_planes; g.wtp = wt_planes;
+    g.in = wt; g.B = B; g.IH = H; g.IW = W; g.Cin = Cin; g.wt = wt; g.style = nullptr;
+    g.nsub = 4;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvSub& sb = g.sub[py * 2 + px];
+            int n = 0;
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2) {
+                    sb.dy[n] = -(ky >> 1); sb.dx[n] = -(kx >> 1); sb.tw[n] = ky * 3 + kx; ++n;
+                }
+            sb.ntaps = n;
+            sb.OH = py ? H : H + 1; sb.OW = px ? W : W + 1;
+            sb.yadd = py; sb.xadd = px;
+        }
+    g.out = T; g.outH = 2 * H + 1; g.outW = 2 * W + 1; g.Cout = Cout;
+    g.ymul = 2; g.xmul = 2;
+    return launch_conv(g, nullptr, 0, (hipStream_t)stream);
 }
 
 // Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur

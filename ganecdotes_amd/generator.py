@@ -13,6 +13,7 @@ device raises RuntimeError.
 the gather kernel consumes.
 """
 import math
+import os
 import random
 
 import torch
@@ -65,6 +66,9 @@ def _to_rgb_params(cin, style_dim, upsample, blur_kernel):
     m.conv.modulation = _equal_linear_params(style_dim, cin, bias_init=1.0)
     m.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
     return m
+
+
+CONV_XP = os.environ.get("GX_CONV_XP", "0") == "1"     # x-planes conv path (pre-split modulated activations + LDS-DMA)
 
 
 class MappingNetwork(nn.Module):
@@ -253,9 +257,16 @@ class Generator(nn.Module):
         dm = self._slab(dmp, bsz, d[key + ".doff"])
         nw = m.noise.weight.detach()
         b = m.activate.bias.detach()
+        wtp = d[key + ".wtp"]
+        _, h, w, cin = x.shape
+        cout = d[key + ".wt"].shape[1]
+        xp = None
+        if CONV_XP and cin % 4 == 0 and ops.conv_xp_ok(bsz, (h + 1) if m.upsample else h, (w + 1) if m.upsample else w,
+                                                       cout, cin, wtp):
+            xp = ops.modsplit(x, s)
         if m.upsample:
-            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=d[key + ".wtp"])
-        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True, wt_planes=d[key + ".wtp"])
+            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=wtp, x_planes=xp)
+        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True, wt_planes=wtp, x_planes=xp)
 
     def _rgb(self, m, key, x, sp, skip, d):
         s = self._slab(sp, x.shape[0], d[key + ".soff"])

@@ -421,14 +421,52 @@ def split_conv_weights(wt):
     return planes
 
 
-def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=None):
-    """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin); wt_planes = split_conv_weights(wt) (optional)."""
+_XPLANES = {}
+
+
+def xplanes_buffer(b, h, w, cin, device, slot=0):
+    """A persistent x-planes buffer for (b, h, w, cin) (gx_xplanes_bytes; int16 view).  Its zero border is written
+    here, once; kernels only ever write the interior, so the buffer is reused step after step."""
+    key = (b, h, w, cin, str(device), slot)
+    buf = _XPLANES.get(key)
+    if buf is None:
+        buf = torch.zeros(lib().gx_xplanes_bytes(b, h, w, cin) // 2, dtype=torch.int16, device=device)
+        _XPLANES[key] = buf
+    return buf
+
+
+def conv_xp_ok(b, oh, ow, cout, cin, wt_planes):
+    """the x-planes conv path applies: bf16x6 engine, pre-split weights, enough output tiles to fill the chip
+    without split-K"""
+    return (wt_planes is not None and get_gemm_mode() == 1 and
+            ((b * oh * ow + 127) // 128) * ((cout + 127) // 128) >= 256)
+
+
+def modsplit(x, s, out=None):
+    """x (B,H,W,Cin) NHWC * s (B,Cin) -> the three bf16 planes the _xp convs read (csrc/gx_conv.hip)."""
+    _chk(x, s)
+    b, h, w, cin = x.shape
+    if out is None:
+        out = xplanes_buffer(b, h, w, cin, x.device)
+    with record("modsplit_kernel", 0.0, 10.0 * b * h * w * cin):
+        _lib.check(lib().gx_modsplit(_p(x), b, h, w, cin, _p(s), _p(out), _stream()), "gx_modsplit")
+    return out
+
+
+def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None):
+    """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin); wt_planes = split_conv_weights(wt) (optional);
+    x_planes = modsplit(x, s) (optional: the pre-split modulated input, then x and s are not read)."""
     _chk(x, wt, s, dmod, noise_w, bias)
     b, h, w, cin = x.shape
     cout = wt.shape[1]
     nz, nbs = _noise_args(noise, b, h, w)
     out = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
     L = lib()
+    if x_planes is not None:
+        with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
+            _lib.check(L.gx_modconv_fwd_xp(_p(x_planes), b, h, w, cin, _p(wt), _p(wt_planes), ksize, cout, _p(dmod), _p(nz),
+                                           nbs, _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_modconv_fwd_xp")
+        return out
     slab, sbytes = _conv_slab(L, b, h, w, cout, x.device)
     with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
         _lib.check(L.gx_modconv_fwd_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
@@ -437,8 +475,8 @@ def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=Non
     return out
 
 
-def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=None):
-    """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC."""
+def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None):
+    """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC.  x_planes: as in modconv."""
     _chk(x, wt, s, dmod, kf, noise_w, bias)
     b, h, w, cin = x.shape
     cout = wt.shape[1]
@@ -448,8 +486,12 @@ def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=Non
     out = torch.empty(b, 2 * h, 2 * w, cout, dtype=torch.float32, device=x.device)
     slab, sbytes = _conv_slab(L, b, 2 * h + 1, 2 * w + 1, cout, x.device)
     with record("modconv_kernel", 2.0 * b * h * w * cin * cout * 9):
-        _lib.check(L.gx_modconv_up_convt_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), cout, _p(s), _p(scratch), _p(slab),
-                                           sbytes, _stream()), "gx_modconv_up_convt_p")
+        if x_planes is not None:
+            _lib.check(L.gx_modconv_up_convt_xp(_p(x_planes), b, h, w, cin, _p(wt), _p(wt_planes), cout, _p(scratch),
+                                                _stream()), "gx_modconv_up_convt_xp")
+        else:
+            _lib.check(L.gx_modconv_up_convt_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), cout, _p(s), _p(scratch),
+                                               _p(slab), sbytes, _stream()), "gx_modconv_up_convt_p")
     tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
     with record("blur_act_kernel", 0.0, tbytes):
         _lib.check(L.gx_blur_act_fwd(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,

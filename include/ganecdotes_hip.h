@@ -134,6 +134,17 @@ int gx_modconv_fwd_p(const float* x, int B, int H, int W, int Cin, const float* 
                      void* stream);
 int gx_modconv_up_convt_p(const float* x, int B, int H, int W, int Cin, const float* wt, const unsigned short* wt_planes,
                           int Cout, const float* s, float* T, float* slab, size_t slab_bytes, void* stream);   /* stage 1: transposed conv -> T */
+/* bf16x6 engine, the ACTIVATION side: the modulated input x * s split ONCE into three bf16 planes
+ * (chunk-major [ceil(Cin/16)][3][B][H+2][W+2][16], zero border: the caller zeroes the gx_xplanes_bytes() buffer once,
+ * kernels write the interior only) instead of once per tap and Cout tile inside the conv; the _xp convs stream both
+ * operands HBM -> LDS by LDS-DMA.  Needs wt_planes and >= 256 output tiles (no split-K).  Same arithmetic as the _p forms. */
+size_t gx_xplanes_bytes(int B, int H, int W, int Cin);
+int gx_modsplit(const float* x, int B, int H, int W, int Cin, const float* s, unsigned short* planes, void* stream);
+int gx_modconv_fwd_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
+                      const unsigned short* wt_planes, int ksize, int Cout, const float* demod, const float* noise,
+                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out, void* stream);
+int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
+                           const unsigned short* wt_planes, int Cout, float* T, void* stream);
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                     const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                     float* out, void* stream);                         /* stage 2: blur + epilogue */

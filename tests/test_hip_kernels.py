@@ -836,8 +836,87 @@ def test_fused_bias_act_reference_signature_gv3_gv16(ops):
     assert rel_err(ops.fused_bias_act(dev(T(g["fl2_x"])), dev(T(g["fl2_b"])), None, 3, 0, 0.2, 1.5), T(g["fl2_y"])) < 1e-6
     lin = ops.fused_bias_act(x, b, None, 1, 0, 0.2, 3.0)
     assert rel_err(lin, (T(g["fl_x"]) + T(g["fl_b"]).reshape(1, -1, 1, 1)) * 3.0) < 1e-6
-    # GV3: EqualLinear(activation='fused_lrelu') = fused_leaky_relu(F.linear(x, W * scale), bias * lr_mul)
+    # GV3: EqualLinear(lr_mul = 0.01, activation='fused_lrelu') = fused_leaky_relu(F.linear(x, W * scale), bias * lr_mul)
+    # with scale = lr_mul / sqrt(in)   (model.py:242-252)
     d = load_golden("gv3_layers")
     w, xin = T(d["el_weight"]), T(d["el_x"])
-    lin = ops.gemm(dev(xin), dev(w), False, True, alpha=1.0 / math.sqrt(w.shape[1]))
-    assert rel_err(ops.fused_leaky_relu(lin, dev(T(d["el_bias"]))), T(d["el_y"])) < 2e-6
+    lin = ops.gemm(dev(xin), dev(w), False, True, alpha=0.01 / math.sqrt(w.shape[1]))
+    assert rel_err(ops.fused_leaky_relu(lin, dev(T(d["el_bias"]) * 0.01)), T(d["el_y"])) < 2e-6
+
+
+# ------------------------------------------------------------------------------------- x-planes conv path
+def test_modconv_xp_golden_gv2_gv3(ops):
+    """The pre-split-activation conv (gx_modsplit + gx_modconv_fwd_xp / gx_modconv_up_convt_xp: both operands by
+    LDS-DMA) on the reference's own ModulatedConv2d / StyledConv outputs (GV2, GV3): Cin = 8 (zero channel
+    padding to 16), Cout = 12 / 6 (tile tails), one 128-row tile spanning both images."""
+    prev = ops.set_gemm_mode(1)
+    try:
+        d = load_golden("gv2_modconv")
+        kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
+        for tag in ("plain", "up", "rgb"):
+            w = T(d[f"{tag}_weight"])
+            wt, wsq = _prep_conv(w)
+            cin, k = w.shape[2], w.shape[3]
+            scale = 1.0 / math.sqrt(cin * k * k)
+            s = _style(ops, T(d[f"{tag}_style"]), T(d[f"{tag}_mod_weight"]), T(d[f"{tag}_mod_bias"]))
+            x = dev(T(d[f"{tag}_x"]).permute(0, 2, 3, 1))
+            wtd = dev(wt)
+            wtp, xp = ops.split_conv_weights(wtd), ops.modsplit(x, s)
+            if tag == "plain":
+                y = ops.modconv(x, wtd, 3, s, ops.demod(s, dev(wsq), scale), None, None, None, act=False, wt_planes=wtp,
+                                x_planes=xp)
+            elif tag == "up":
+                y = ops.modconv_up(x, wtd, s, ops.demod(s, dev(wsq), scale), kf, None, None, None, act=False,
+                                   wt_planes=wtp, x_planes=xp)
+            else:
+                y = ops.modconv(x, wtd, 1, s, None, None, None, None, act=False, wt_planes=wtp, x_planes=xp) * scale
+            assert rel_err(y.permute(0, 3, 1, 2), T(d[f"{tag}_y"])) < 5e-6, tag
+        d = load_golden("gv3_layers")
+        kf = dev(torch.flip(T(d["up_sd_conv.blur.kernel"]), [0, 1]))
+        for tag in ("plain", "up"):
+            sd = {k[len(tag) + 4:]: T(v) for k, v in d.items() if k.startswith(f"{tag}_sd_")}
+            wt, wsq = _prep_conv(sd["conv.weight"])
+            scale = 1.0 / math.sqrt(sd["conv.weight"].shape[2] * 9)
+            s = _style(ops, T(d[f"{tag}_style"]), sd["conv.modulation.weight"], sd["conv.modulation.bias"])
+            dm = ops.demod(s, dev(wsq), scale)
+            x = dev(T(d[f"{tag}_x"]).permute(0, 2, 3, 1))
+            wtd = dev(wt)
+            kw = dict(wt_planes=ops.split_conv_weights(wtd), x_planes=ops.modsplit(x, s))
+            args = (dev(T(d[f"{tag}_noise"])), dev(sd["noise.weight"]), dev(sd["activate.bias"]))
+            y = (ops.modconv(x, wtd, 3, s, dm, *args, **kw) if tag == "plain"
+                 else ops.modconv_up(x, wtd, s, dm, kf, *args, **kw))
+            assert rel_err(y.permute(0, 3, 1, 2), T(d[f"{tag}_y"])) < 5e-6, tag
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("b,h,cin,cout,up", [(3, 16, 64, 160, False), (2, 24, 40, 128, True), (5, 8, 512, 512, False),
+                                             (1, 64, 128, 96, True), (2, 33, 20, 72, False)])
+def test_modconv_xp_equals_in_kernel_split(ops, b, h, cin, cout, up):
+    """random shapes (odd sizes, several images per tile, Cin not a multiple of 16, Cout tails, all four parity
+    classes of the transposed conv): the x-planes path computes exactly the bf16x6 sums of the in-kernel-split path
+    — same products, same k order — so the two agree to fp32 rounding of identical operations."""
+    prev = ops.set_gemm_mode(1)
+    try:
+        torch.manual_seed(b * 100 + h)
+        x = dev(torch.randn(b, h, h + 1, cin))
+        wt = dev(torch.randn(9, cout, cin) / math.sqrt(9 * cin))
+        s = dev(torch.rand(b, cin) + 0.5)
+        dm = dev(torch.rand(b, cout) + 0.5)
+        wtp = ops.split_conv_weights(wt)
+        kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
+        oh, ow = (2 * h, 2 * (h + 1)) if up else (h, h + 1)
+        noise, nw, bias = dev(torch.randn(1, 1, oh, ow)), dev(torch.tensor([0.3])), dev(torch.randn(cout))
+        xp = ops.modsplit(x, s)
+        if up:
+            ref = ops.modconv_up(x, wt, s, dm, kf, noise, nw, bias, True, wt_planes=wtp)
+            got = ops.modconv_up(x, wt, s, dm, kf, noise, nw, bias, True, wt_planes=wtp, x_planes=xp)
+        else:
+            ref = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True, wt_planes=wtp)
+            got = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True, wt_planes=wtp, x_planes=xp)
+        assert rel_err(got, ref) < 1e-6
+        # the border of the planes buffer is still zero after the kernels ran
+        planes = xp.view(-1, 3, b, h + 2, h + 3, 16)
+        assert int(planes[:, :, :, 0].abs().max()) == 0 and int(planes[:, :, :, :, -1].abs().max()) == 0
+    finally:
+        ops.set_gemm_mode(prev)
