@@ -87,7 +87,9 @@ SIGNATURES = {
     "gx_modconv_up_convt": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gx_xplanes_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gx_modsplit": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
-    "gx_modconv_fwd_xp": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
+    "gx_modconv_fwd_xp": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_p,
+                                c_p]),
+    "gx_blur_act_fwd_xp": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_modconv_up_convt_xp": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "gx_blur_act_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_p]),
     "gx_torgb_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -17,8 +17,7 @@
 #include "gx_mfma_x6.h"
 #include <cstdlib>
 
-extern "C" int gx_get_gemm_mode(void);      // gx_gemm.hip: 0 = exact-fp32 MFMA, 1 = bf16x6
-extern "C" size_t gx_conv_weight_planes_bytes(int taps, int Cout, int Cin);
+// (prototypes of the C ABI: ganecdotes_hip.h via gx_common.h)
 
 namespace gx {
 
@@ -48,6 +47,8 @@ struct ConvArgs {
     int splits; float* slab;                   // split-K over k-tiles: raw partial sums [split][B*outH*outW*Cout]
     const unsigned short* xp;                  // optional pre-split MODULATED input (gx_modsplit): see modconv_xp_kernel
     unsigned xp_plane_bytes;                   // bytes of one (chunk, plane) image = B*(IH+2)*(IW+2)*32
+    const float* s_next;                       // [B][Cout] modulation of the NEXT conv, or nullptr
+    unsigned short* xp_out;                    // x planes of the output for the next conv (out * s_next), or nullptr
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
@@ -372,6 +373,72 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 // Main loop = 6 DMA + 12 ds_read_b128 + 24 MFMA per wave and k-tile.
 constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + B planes of one k-tile: 24 KB
 
+// Epilogue of modconv_xp_kernel for a plain conv, through LDS: the wave parks one 32 x 64 accumulator block at a time
+// in its own 8 KB of (now idle) stage memory and reads it back row-contiguous, 4 channels per lane — 16-B fp32 stores
+// (a 256-B run per pixel) instead of 64 dword stores per lane, the demod / noise / bias / activation on float4, and,
+// when the next conv reads x planes, that conv's modulated input split RIGHT HERE (out * s_next -> three bf16
+// planes, 8 B per lane and plane): the activation is split once, by its producer, not per tap and Cout tile.
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvSub& sb, f32x16 (&acc)[2][2], char* lds,
+                                                  unsigned row0, int col0, int wid, int lane) {
+    float* S = reinterpret_cast<float*>(lds) + wid * 2048;           // [32][64] fp32
+    const int OH = sb.OH, OW = sb.OW;
+    const unsigned ohw = (unsigned)OH * (unsigned)OW, Mtot = (unsigned)g.B * ohw;
+    const int c4 = col0 + (lane & 15) * 4;                           // this lane's 4 output channels
+    const bool cok = c4 < g.Cout;                                    // host: Cout % 4 == 0
+    const float nw = (g.noise && g.noise_w) ? *g.noise_w : 0.f;
+    f32x4 bias4 = zero4();
+    if (g.bias && cok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + c4);
+    const long oplane = (long)g.B * (g.outH + 2) * (g.outW + 2) * 16;   // bf16 elements of one output (chunk, plane)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+        // (same wave wrote and reads: program order + the LDS counter, no barrier)
+        unsigned mrow = row0 + mt * 32 + (lane >> 4);
+        unsigned b = mrow / ohw, rem = mrow - b * ohw;
+        int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+        int bcur = -1;
+        f32x4 dm4 = {1.f, 1.f, 1.f, 1.f}, s4 = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(S + (p * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+            if (mrow < Mtot && cok) {
+                if ((int)b != bcur) {
+                    bcur = (int)b;
+                    if (g.demod) dm4 = *reinterpret_cast<const f32x4*>(g.demod + (long)b * g.Cout + c4);
+                    if (g.s_next) s4 = *reinterpret_cast<const f32x4*>(g.s_next + (long)b * g.Cout + c4);
+                }
+                const long pix = ((long)b * g.outH + oy) * g.outW + ox;
+                const float nz = g.noise ? nw * g.noise[(long)b * g.noise_bstride + (long)oy * g.outW + ox] : 0.f;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = fmaf(a[q], dm4[q], nz + bias4[q]);
+                    v[q] = g.act ? lrelu_sqrt2(t) : t;
+                }
+                *reinterpret_cast<f32x4*>(g.out + pix * g.Cout + c4) = v;
+                if (g.xp_out) {
+                    v *= s4;
+                    unsigned h[2], m[2], l[2];
+                    split3(v[0], v[1], h[0], m[0], l[0]);
+                    split3(v[2], v[3], h[1], m[1], l[1]);
+                    const long ppix = ((long)b * (g.outH + 2) + oy + 1) * (g.outW + 2) + ox + 1;
+                    unsigned short* d = g.xp_out + ((long)(c4 >> 4) * 3) * oplane + ppix * 16 + (c4 & 15);
+                    *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+                    *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
+                    *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
+                }
+            }
+            mrow += 4; ox += 4;
+            while (ox >= OW) { ox -= OW; ++oy; }
+            while (oy >= OH) { oy -= OH; ++b; }
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, f32x16 (&acc)[2][2],
                                                  unsigned pixbyte, int n0, int tid, int wr, int wc, int lane) {
@@ -460,7 +527,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
         case 2: conv_mainloop_xp<2>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
         default: conv_mainloop_xp<1>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
     }
-    conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+    if (g.nsub == 1 && g.ymul == 1 && (g.Cout & 3) == 0) {          // plain conv: epilogue through LDS (+ next layer's planes)
+        __syncthreads();                                             // every wave has read its last fragments
+        conv_epilogue_lds(g, sb, acc, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
+    } else {
+        conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+    }
 }
 
 // x [B][H][W][Cin] fp32 NHWC times s [B][Cin] (or s = NULL) -> xp (layout above).  A thread owns 4 channels of a
@@ -622,7 +694,10 @@ constexpr int BLUR_ROWS = 16;
 __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int TW, int C, const float* __restrict__ kf,
                                 const float* __restrict__ demod, const float* __restrict__ noise, long noise_bstride,
                                 const float* __restrict__ noise_w, const float* __restrict__ bias, int act,
-                                float* __restrict__ out, int OH, int OW) {
+                                float* __restrict__ out, int OH, int OW, const float* __restrict__ s_next,
+                                unsigned short* __restrict__ xp_out) {
+    // s_next / xp_out (optional): also write the NEXT conv's modulated input out * s_next as x planes (modconv_xp_kernel)
+    const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
     const int c4n = C >> 2;
     const int nseg = (OH + BLUR_ROWS - 1) / BLUR_ROWS;
     const long total = (long)B * nseg * OW * c4n;
@@ -640,6 +715,8 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f};
         if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
         if (demod) dm4 = *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
+        f32x4 sn4 = {1.f, 1.f, 1.f, 1.f};
+        if (xp_out && s_next) sn4 = *reinterpret_cast<const f32x4*>(s_next + (long)b * C + c);
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -677,6 +754,17 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
                         ov[q] = act ? lrelu_sqrt2(t) : t;
                     }
                     *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;
+                    if (xp_out) {
+                        ov *= sn4;
+                        unsigned h[2], m[2], l[2];
+                        split3(ov[0], ov[1], h[0], m[0], l[0]);
+                        split3(ov[2], ov[3], h[1], m[1], l[1]);
+                        const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + x + 1;
+                        unsigned short* d = xp_out + ((long)(c >> 4) * 3) * oplane + ppix * 16 + (c & 15);
+                        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+                        *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
+                        *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
+                    }
                 }
                 acc[(j + 1) & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -1139,7 +1227,9 @@ int gx_modsplit(const float* x, int B, int H, int W, int Cin, const float* s, un
 // contraction; bf16x6 engine and wt_planes required, layers with >= 256 output tiles only).
 int gx_modconv_fwd_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
                       const unsigned short* wt_planes, int ksize, int Cout, const float* demod, const float* noise,
-                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out, void* stream) {
+                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out,
+                      const float* s_next, unsigned short* planes_out, void* stream) {
+    if (planes_out && (Cout & 3)) return GX_ERR_BAD_ARG;
     if (!x_planes || !wt || !wt_planes || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 ||
         (ksize != 1 && ksize != 3))
         return GX_ERR_BAD_ARG;
@@ -1158,6 +1248,7 @@ int gx_modconv_fwd_xp(const unsigned short* x_planes, int B, int H, int W, int C
     g.out = out; g.outH = H; g.outW = W; g.Cout = Cout;
     g.ymul = 1; g.xmul = 1;
     g.demod = demod; g.noise = noise; g.noise_bstride = noise_bstride; g.noise_w = noise_w; g.bias = bias; g.act = act;
+    g.s_next = s_next; g.xp_out = planes_out;
     return launch_conv(g, nullptr, 0, (hipStream_t)stream);
 }
 int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
@@ -1195,13 +1286,20 @@ size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout) {
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                     const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                     float* out, void* stream) {
+    return gx_blur_act_fwd_xp(T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, nullptr, nullptr,
+                              stream);
+}
+// ... and, optionally, the x planes of out * s_next for the next conv (planes_out: gx_xplanes_bytes(B, TH-1, TW-1, C))
+int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
+                       const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
+                       float* out, const float* s_next, unsigned short* planes_out, void* stream) {
     if (!T || !kf || !out || B <= 0 || TH < 2 || TW < 2 || C <= 0 || (C & 3)) return GX_ERR_BAD_ARG;
     const int OH = TH - 1, OW = TW - 1;
     const long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
     long want = (total + 255) / 256;
     const int nb = (int)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod,
-                       noise, noise_bstride, noise_w, bias, act, out, OH, OW);
+                       noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -68,7 +68,9 @@ def _to_rgb_params(cin, style_dim, upsample, blur_kernel):
     return m
 
 
-CONV_XP = os.environ.get("GX_CONV_XP", "0") == "1"     # x-planes conv path (pre-split modulated activations + LDS-DMA)
+# x-planes conv path (activations split once by their producer, both conv operands by LDS-DMA: csrc/gx_conv.hip
+# modconv_xp_kernel) for every layer big enough to fill the chip; GX_CONV_XP=0 keeps the in-kernel split everywhere
+CONV_XP = os.environ.get("GX_CONV_XP", "1") != "0"
 
 
 class MappingNetwork(nn.Module):
@@ -251,22 +253,36 @@ class Generator(nn.Module):
         off, n = span
         return packed[bsz * off:bsz * (off + n)].view(bsz, n)
 
-    def _styled(self, m, key, x, sp, dmp, noise, d):
-        bsz = x.shape[0]
+    def _uses_xp(self, m, key, bsz, h, w, d):
+        """does the styled conv `key`, fed a (bsz, h, w, cin) input, take the x-planes path?"""
+        cout, cin = d[key + ".wt"].shape[1], d[key + ".wt"].shape[2]
+        return CONV_XP and ops.conv_xp_ok(bsz, h, w, cout, cin, d[key + ".wtp"], up=m.upsample)
+
+    def _styled(self, m, key, x, sp, dmp, noise, d, xp=None, nxt=None):
+        """One StyledConv.  xp: this layer's pre-split modulated input if its producer already made it;
+        nxt = (module, key) of the next styled conv: if that one reads x planes, this layer's output pass also
+        writes them (out * next style).  Returns (out, planes for the next conv or None)."""
+        bsz, h, w, cin = x.shape
         s = self._slab(sp, bsz, d[key + ".soff"])
         dm = self._slab(dmp, bsz, d[key + ".doff"])
         nw = m.noise.weight.detach()
         b = m.activate.bias.detach()
         wtp = d[key + ".wtp"]
-        _, h, w, cin = x.shape
         cout = d[key + ".wt"].shape[1]
-        xp = None
-        if CONV_XP and cin % 4 == 0 and ops.conv_xp_ok(bsz, (h + 1) if m.upsample else h, (w + 1) if m.upsample else w,
-                                                       cout, cin, wtp):
-            xp = ops.modsplit(x, s)
+        if xp is None and self._uses_xp(m, key, bsz, h, w, d):
+            xp = ops.modsplit(x, s, out=ops.xplanes_buffer(bsz, h, w, cin, x.device, key))
+        oh, ow = (2 * h, 2 * w) if m.upsample else (h, w)
+        ns = npl = None
+        if nxt is not None and self._uses_xp(nxt[0], nxt[1], bsz, oh, ow, d):
+            ns = self._slab(sp, bsz, d[nxt[1] + ".soff"])
+            npl = ops.xplanes_buffer(bsz, oh, ow, cout, x.device, nxt[1])
         if m.upsample:
-            return ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=wtp, x_planes=xp)
-        return ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True, wt_planes=wtp, x_planes=xp)
+            out = ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=wtp, x_planes=xp,
+                                 next_style=ns, next_planes=npl)
+        else:
+            out = ops.modconv(x, d[key + ".wt"], 3, s, dm, noise, nw, b, True, wt_planes=wtp, x_planes=xp,
+                              next_style=ns, next_planes=npl)
+        return out, npl
 
     def _rgb(self, m, key, x, sp, skip, d):
         s = self._slab(sp, x.shape[0], d[key + ".soff"])
@@ -283,15 +299,18 @@ class Generator(nn.Module):
                 return torch.randn(bsz, 1, res, res, device=latent.device)
             return noise[i].contiguous()
 
+        chain = [(self.conv1, "conv1")] + [(m, f"convs.{i}") for i, m in enumerate(self.convs)]
         x = d["const"].expand(bsz, -1, -1, -1).contiguous()
-        x = self._styled(self.conv1, "conv1", x, sp, dmp, nz(0, 4), d)
+        x, xp = self._styled(self.conv1, "conv1", x, sp, dmp, nz(0, 4), d, None, chain[1] if len(chain) > 1 else None)
         taps = [x]
         skip = self._rgb(self.to_rgb1, "to_rgb1", x, sp, None, d) if self.want_image else None
         for blk in range(len(self.to_rgbs)):
             res = 2 ** (blk + 3)
-            x = self._styled(self.convs[2 * blk], f"convs.{2 * blk}", x, sp, dmp, nz(2 * blk + 1, res), d)
+            i = 2 * blk + 1                                            # index of this block's up-conv in `chain`
+            x, xp = self._styled(*chain[i], x, sp, dmp, nz(2 * blk + 1, res), d, xp, chain[i + 1])
             taps.append(x)
-            x = self._styled(self.convs[2 * blk + 1], f"convs.{2 * blk + 1}", x, sp, dmp, nz(2 * blk + 2, res), d)
+            x, xp = self._styled(*chain[i + 1], x, sp, dmp, nz(2 * blk + 2, res), d, xp,
+                                 chain[i + 2] if i + 2 < len(chain) else None)
             taps.append(x)
             if self.want_image:
                 skip = self._rgb(self.to_rgbs[blk], f"to_rgbs.{blk}", x, sp, skip, d)

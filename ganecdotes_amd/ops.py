@@ -424,7 +424,7 @@ def split_conv_weights(wt):
 _XPLANES = {}
 
 
-def xplanes_buffer(b, h, w, cin, device, slot=0):
+def xplanes_buffer(b, h, w, cin, device, slot=""):
     """A persistent x-planes buffer for (b, h, w, cin) (gx_xplanes_bytes; int16 view).  Its zero border is written
     here, once; kernels only ever write the interior, so the buffer is reused step after step."""
     key = (b, h, w, cin, str(device), slot)
@@ -435,11 +435,19 @@ def xplanes_buffer(b, h, w, cin, device, slot=0):
     return buf
 
 
-def conv_xp_ok(b, oh, ow, cout, cin, wt_planes):
+def conv_tiles(b, h, w, cout, up):
+    """128 x 128 output tiles of a styled conv on a (b, h, w, .) input: a plain 3x3 conv, or the four parity
+    classes of the stride-2 transposed conv (one launch)"""
+    ntn = (cout + 127) // 128
+    if not up:
+        return ((b * h * w + 127) // 128) * ntn
+    return sum((b * oh * ow + 127) // 128 for oh in (h + 1, h) for ow in (w + 1, w)) * ntn
+
+
+def conv_xp_ok(b, h, w, cout, cin, wt_planes, up=False):
     """the x-planes conv path applies: bf16x6 engine, pre-split weights, enough output tiles to fill the chip
     without split-K"""
-    return (wt_planes is not None and get_gemm_mode() == 1 and
-            ((b * oh * ow + 127) // 128) * ((cout + 127) // 128) >= 256)
+    return wt_planes is not None and get_gemm_mode() == 1 and cin % 4 == 0 and conv_tiles(b, h, w, cout, up) >= 256
 
 
 def modsplit(x, s, out=None):
@@ -453,10 +461,13 @@ def modsplit(x, s, out=None):
     return out
 
 
-def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None):
+def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None, next_style=None,
+            next_planes=None):
     """x (B,H,W,Cin) NHWC -> (B,H,W,Cout) NHWC.  wt (k*k, Cout, Cin); wt_planes = split_conv_weights(wt) (optional);
-    x_planes = modsplit(x, s) (optional: the pre-split modulated input, then x and s are not read)."""
-    _chk(x, wt, s, dmod, noise_w, bias)
+    x_planes = modsplit(x, s) (optional: the pre-split modulated input, then x and s are not read).
+    next_style (B,Cout) + next_planes (xplanes_buffer of the output shape): also leave out * next_style there as
+    x planes for the next conv (from the conv's own epilogue on the x-planes path, else by one modsplit pass)."""
+    _chk(x, wt, s, dmod, noise_w, bias, next_style)
     b, h, w, cin = x.shape
     cout = wt.shape[1]
     nz, nbs = _noise_args(noise, b, h, w)
@@ -464,20 +475,28 @@ def modconv(x, wt, ksize, s, dmod, noise, noise_w, bias, act=True, wt_planes=Non
     L = lib()
     if x_planes is not None:
         with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
+            fuse = next_planes is not None and cout % 4 == 0
             _lib.check(L.gx_modconv_fwd_xp(_p(x_planes), b, h, w, cin, _p(wt), _p(wt_planes), ksize, cout, _p(dmod), _p(nz),
-                                           nbs, _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_modconv_fwd_xp")
+                                           nbs, _p(noise_w), _p(bias), int(act), _p(out), _p(next_style) if fuse else None,
+                                           _p(next_planes) if fuse else None, _stream()), "gx_modconv_fwd_xp")
+        if next_planes is not None and not fuse:
+            modsplit(out, next_style, out=next_planes)
         return out
     slab, sbytes = _conv_slab(L, b, h, w, cout, x.device)
     with record("modconv_kernel", 2.0 * b * h * w * cin * cout * ksize * ksize):
         _lib.check(L.gx_modconv_fwd_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), ksize, cout, _p(s), _p(dmod), _p(nz), nbs,
                                       _p(noise_w), _p(bias), int(act), _p(out), _p(slab), sbytes, _stream()),
                    "gx_modconv_fwd_p")
+    if next_planes is not None:
+        modsplit(out, next_style, out=next_planes)
     return out
 
 
-def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None):
-    """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC.  x_planes: as in modconv."""
-    _chk(x, wt, s, dmod, kf, noise_w, bias)
+def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=None, x_planes=None, next_style=None,
+               next_planes=None):
+    """Upsampling StyledConv: (B,H,W,Cin) -> (B,2H,2W,Cout) NHWC.  x_planes / next_style / next_planes: as in
+    modconv (the planes of the output come from the blur + activation pass that writes it)."""
+    _chk(x, wt, s, dmod, kf, noise_w, bias, next_style)
     b, h, w, cin = x.shape
     cout = wt.shape[1]
     nz, nbs = _noise_args(noise, b, 2 * h, 2 * w)
@@ -494,8 +513,9 @@ def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=Non
                                                _p(slab), sbytes, _stream()), "gx_modconv_up_convt_p")
     tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
     with record("blur_act_kernel", 0.0, tbytes):
-        _lib.check(L.gx_blur_act_fwd(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,
-                                     _p(noise_w), _p(bias), int(act), _p(out), _stream()), "gx_blur_act_fwd")
+        _lib.check(L.gx_blur_act_fwd_xp(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,
+                                        _p(noise_w), _p(bias), int(act), _p(out), _p(next_style), _p(next_planes),
+                                        _stream()), "gx_blur_act_fwd_xp")
     return out
 
 

@@ -142,7 +142,14 @@ size_t gx_xplanes_bytes(int B, int H, int W, int Cin);
 int gx_modsplit(const float* x, int B, int H, int W, int Cin, const float* s, unsigned short* planes, void* stream);
 int gx_modconv_fwd_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
                       const unsigned short* wt_planes, int ksize, int Cout, const float* demod, const float* noise,
-                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out, void* stream);
+                      long noise_bstride, const float* noise_w, const float* bias, int act, float* out,
+                      const float* s_next /* [B][Cout] or NULL */, unsigned short* planes_out /* or NULL */, void* stream);
+/* s_next / planes_out: the producer also writes the x planes of out * s_next, the NEXT conv's modulated input
+ * (gx_xplanes_bytes(B, out H, out W, Cout) bytes, border zeroed once by the caller): the activation is split once,
+ * where it is made.  gx_blur_act_fwd_xp = gx_blur_act_fwd with the same two arguments. */
+int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
+                       const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
+                       float* out, const float* s_next, unsigned short* planes_out, void* stream);
 int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
                            const unsigned short* wt_planes, int Cout, float* T, void* stream);
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,

@@ -914,7 +914,8 @@ def test_modconv_xp_equals_in_kernel_split(ops, b, h, cin, cout, up):
         else:
             ref = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True, wt_planes=wtp)
             got = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True, wt_planes=wtp, x_planes=xp)
-        assert rel_err(got, ref) < 1e-6
+        assert rel_err(got, ref) < (1e-6 if ops.conv_tiles(b, h, h + 1, cout, up) >= 256 else 5e-6)   # small layers: the
+        # in-kernel-split path runs split-K there (another summation order)
         # the border of the planes buffer is still zero after the kernels ran
         planes = xp.view(-1, 3, b, h + 2, h + 3, 16)
         assert int(planes[:, :, :, 0].abs().max()) == 0 and int(planes[:, :, :, :, -1].abs().max()) == 0

@@ -109,6 +109,39 @@ def test_generator_full_width_vs_oracle(gpu):
         assert rel(a, b) < 5e-5
 
 
+def test_generator_xp_path_equals_in_kernel_split(gpu):
+    """ffhq-width generator at 64 x 64, 16 images: with the x-planes conv path (activations split once by the
+    producing epilogue / blur pass, LDS-DMA main loop) the layers that qualify (>= 256 tiles) give the same taps
+    and image as the in-kernel-split path — same products, same k order."""
+    from ganecdotes_amd import generator as GM
+    from ganecdotes_amd import ops
+    torch.manual_seed(17)
+    g = GM.Generator(64, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)
+    g = g.eval().to(gpu)
+    w = g.style(torch.randn(16, 512, device="cuda"))
+    ml = g.mean_latent(64)
+    kw = dict(truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+    prev, prev_mode = GM.CONV_XP, ops.set_gemm_mode(1)
+    try:
+        GM.CONV_XP = False
+        img0, taps0 = g([w], **kw)
+        taps0 = [t.clone() for t in taps0]
+        GM.CONV_XP = True
+        ops._XPLANES.clear()
+        img1, taps1 = g([w], **kw)
+        users = {k[-1] for k in ops._XPLANES}               # consumer layers that read x planes
+        assert {"convs.4", "convs.5", "convs.6", "convs.7"} <= users, users
+        assert rel(img1, img0) < 2e-6
+        for a, b in zip(taps1, taps0):
+            assert rel(a, b) < 2e-6
+    finally:
+        GM.CONV_XP = prev
+        ops.set_gemm_mode(prev_mode)
+
+
 def test_baggan_generator_golden_gv14(gpu):
     """pidray-* models: the reference BagGAN StyleGANGenerator's mapping, image and
     7 feature taps, loaded from its own state_dict through the key translation"""
