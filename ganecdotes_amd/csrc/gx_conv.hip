@@ -380,39 +380,41 @@ constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + 
 // planes, 8 B per lane and plane): the activation is split once, by its producer, not per tap and Cout tile.
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvSub& sb, f32x16 (&acc)[2][2], char* lds,
                                                   unsigned row0, int col0, int wid, int lane) {
-    float* S = reinterpret_cast<float*>(lds) + wid * 2048;           // [32][64] fp32
+    constexpr int LDW = 68;                                          // floats per LDS row (64 + 4: the 16-row column reads
+    float* S = reinterpret_cast<float*>(lds) + wid * 32 * LDW;       //  below then fall in distinct banks)
     const int OH = sb.OH, OW = sb.OW;
     const unsigned ohw = (unsigned)OH * (unsigned)OW, Mtot = (unsigned)g.B * ohw;
-    const int c4 = col0 + (lane & 15) * 4;                           // this lane's 4 output channels
-    const bool cok = c4 < g.Cout;                                    // host: Cout % 4 == 0
     const float nw = (g.noise && g.noise_w) ? *g.noise_w : 0.f;
-    f32x4 bias4 = zero4();
-    if (g.bias && cok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + c4);
     const long oplane = (long)g.B * (g.outH + 2) * (g.outW + 2) * 16;   // bf16 elements of one output (chunk, plane)
+    // a pass = 16 pixel rows x ONE 16-channel chunk: lane -> row (lane >> 2), channel quad (lane & 3); its store into a
+    // (chunk, plane) image is one contiguous 512-B run when the 16 pixels are neighbours in an image row
+    const int q4 = (lane & 3) * 4, lrow = lane >> 2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDW + nt * 32 + (lane & 31)] = acc[mt][nt][r];
         // (same wave wrote and reads: program order + the LDS counter, no barrier)
-        unsigned mrow = row0 + mt * 32 + (lane >> 4);
-        unsigned b = mrow / ohw, rem = mrow - b * ohw;
-        int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
-        int bcur = -1;
-        f32x4 dm4 = {1.f, 1.f, 1.f, 1.f}, s4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(S + (p * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
-            if (mrow < Mtot && cok) {
-                if ((int)b != bcur) {
-                    bcur = (int)b;
-                    if (g.demod) dm4 = *reinterpret_cast<const f32x4*>(g.demod + (long)b * g.Cout + c4);
-                    if (g.s_next) s4 = *reinterpret_cast<const f32x4*>(g.s_next + (long)b * g.Cout + c4);
-                }
-                const long pix = ((long)b * g.outH + oy) * g.outW + ox;
-                const float nz = g.noise ? nw * g.noise[(long)b * g.noise_bstride + (long)oy * g.outW + ox] : 0.f;
+        for (int rg = 0; rg < 2; ++rg) {
+            const unsigned mrow = row0 + mt * 32 + rg * 16 + lrow;
+            const bool rok = mrow < Mtot;
+            const unsigned mm = rok ? mrow : 0u;
+            const unsigned b = mm / ohw, rem = mm - b * ohw;
+            const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+            const int y = oy * g.ymul + sb.yadd, x = ox * g.xmul + sb.xadd;
+            const long pix = ((long)b * g.outH + y) * g.outW + x;
+            const float nz = (g.noise && rok) ? nw * g.noise[(long)b * g.noise_bstride + (long)y * g.outW + x] : 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int c4 = col0 + ch * 16 + q4;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(S + (rg * 16 + lrow) * LDW + ch * 16 + q4);
+                if (!rok || c4 >= g.Cout) continue;                  // host: Cout % 4 == 0
+                f32x4 dm4 = {1.f, 1.f, 1.f, 1.f}, bias4 = zero4();
+                if (g.demod) dm4 = *reinterpret_cast<const f32x4*>(g.demod + (long)b * g.Cout + c4);
+                if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + c4);
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -421,20 +423,17 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
                 }
                 *reinterpret_cast<f32x4*>(g.out + pix * g.Cout + c4) = v;
                 if (g.xp_out) {
-                    v *= s4;
+                    if (g.s_next) v *= *reinterpret_cast<const f32x4*>(g.s_next + (long)b * g.Cout + c4);
                     unsigned h[2], m[2], l[2];
                     split3(v[0], v[1], h[0], m[0], l[0]);
                     split3(v[2], v[3], h[1], m[1], l[1]);
-                    const long ppix = ((long)b * (g.outH + 2) + oy + 1) * (g.outW + 2) + ox + 1;
+                    const long ppix = ((long)b * (g.outH + 2) + y + 1) * (g.outW + 2) + x + 1;
                     unsigned short* d = g.xp_out + ((long)(c4 >> 4) * 3) * oplane + ppix * 16 + (c4 & 15);
                     *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
                     *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
                     *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
                 }
             }
-            mrow += 4; ox += 4;
-            while (ox >= OW) { ox -= OW; ++oy; }
-            while (oy >= OH) { oy -= OH; ++b; }
         }
     }
 }
@@ -527,7 +526,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
         case 2: conv_mainloop_xp<2>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
         default: conv_mainloop_xp<1>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
     }
-    if (g.nsub == 1 && g.ymul == 1 && (g.Cout & 3) == 0) {          // plain conv: epilogue through LDS (+ next layer's planes)
+    if ((g.Cout & 3) == 0) {                                         // epilogue through LDS (+ the next layer's planes)
         __syncthreads();                                             // every wave has read its last fragments
         conv_epilogue_lds(g, sb, acc, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
     } else {
@@ -705,12 +704,32 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) k[i] = kf[i];
     const float nw = (noise && noise_w) ? *noise_w : 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        long rest = i / c4n;
-        const int x = (int)(rest % OW); rest /= OW;
-        const int seg = (int)(rest % nseg);
-        const int b = (int)(rest / nseg);
+    // Thread -> (pixel column x, 4 channels).  Default: channels fastest (a wave reads / writes whole pixels).  When the x
+    // planes are written too (C % 16 == 0), a wave instead owns 16 consecutive pixels x ONE 16-channel chunk, so that its
+    // store into a (chunk, plane) image is 16 x 32 B = one contiguous 512-B run instead of 16 scattered 32-B pieces;
+    // consecutive waves take the other chunks of the same pixels (the fp32 side then moves in 64-B pieces).
+    const bool pmap = xp_out && (C & 15) == 0;
+    const int ncc = C >> 4, nxb = (OW + 15) >> 4;
+    const long total_p = (long)B * nseg * nxb * ncc * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (pmap ? total_p : total);
+         i += (long)gridDim.x * blockDim.x) {
+        int c, x, seg, b;
+        if (pmap) {
+            long rest = i >> 6;
+            const int cc = (int)(rest % ncc); rest /= ncc;
+            const int xb = (int)(rest % nxb); rest /= nxb;
+            seg = (int)(rest % nseg);
+            b = (int)(rest / nseg);
+            c = cc * 16 + ((int)i & 3) * 4;
+            x = xb * 16 + (((int)i >> 2) & 15);
+            if (x >= OW) continue;
+        } else {
+            c = (int)(i % c4n) * 4;
+            long rest = i / c4n;
+            x = (int)(rest % OW); rest /= OW;
+            seg = (int)(rest % nseg);
+            b = (int)(rest / nseg);
+        }
         const int y0 = seg * BLUR_ROWS;
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f};
         if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
@@ -1295,7 +1314,8 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
                        float* out, const float* s_next, unsigned short* planes_out, void* stream) {
     if (!T || !kf || !out || B <= 0 || TH < 2 || TW < 2 || C <= 0 || (C & 3)) return GX_ERR_BAD_ARG;
     const int OH = TH - 1, OW = TW - 1;
-    const long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
+    long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
+    if (planes_out && (C & 15) == 0) total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * ((OW + 15) / 16) * (C >> 4) * 64;
     long want = (total + 255) / 256;
     const int nb = (int)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod,
