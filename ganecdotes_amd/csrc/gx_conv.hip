@@ -457,7 +457,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
     const char* xp = reinterpret_cast<const char*>(g.xp);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-    auto issue = [&](int cc, int tap, int to, unsigned wb, char* dst) {
+    auto issue = [&](int cc, int to, unsigned wb, char* dst) {       // 6 LDS-DMA instructions per thread
         const unsigned va = pixbyte + (unsigned)to;                  // signed add: the padded pixel is never negative
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -471,10 +471,12 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
         for (int p = 0; p < 3; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + 12288 + p * 4096 + wid * 1024), 16,
                                                      (int)wlane, (int)(blk + p * 4096u), 0, 0);
-        (void)tap;
     };
 
-    if (ncc > 0) issue(0, 0, tapoff[0], wblk[0], lds);
+    // Two stages: the DMAs of tile k+1 are issued right after the barrier that retires tile k and have the 24 MFMAs
+    // of tile k to land; three workgroups per CU (48 KB of LDS, 118 VGPRs) cover what that does not.  (A three-stage
+    // ring with a counted vmcnt(6) and a raw s_barrier measured 3.5 % SLOWER: 72 KB of LDS = two workgroups per CU.)
+    if (ncc > 0) issue(0, tapoff[0], wblk[0], lds);
     int buf = 0;
     for (int cc = 0; cc < ncc; ++cc) {
         const bool last_cc = (cc + 1 == ncc);
@@ -487,7 +489,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             char* As = lds + buf * XP_STAGE_BYTES;
             const bool wrap = (tap + 1 == NT);
             if (!(wrap && last_cc))
-                issue(wrap ? cc + 1 : cc, wrap ? 0 : tap + 1, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
+                issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
                       lds + (buf ^ 1) * XP_STAGE_BYTES);
             x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
             buf ^= 1;

@@ -70,6 +70,26 @@ def main():
         print(f"H={h:3d} {cin:3d}->{cout:3d} {'up ' if up else '   '} {gf:7.1f} GF | old {med['old']:.3f} ms "
               f"{gf / med['old']:.0f} TF/s | xp {med['xp']:.3f} ms {gf / med['xp']:.0f} TF/s | split {med['split']:.3f} ms",
               flush=True)
+    # per-tile overhead probe: 1x1 convs (one tap: ncc k-tiles per output tile) next to the 3x3 rows above
+    for h, cin, cout in ((128, 256, 128), (128, 256, 256), (64, 512, 256), (256, 128, 128)):
+        x = torch.randn(B, h, h, cin, device=dev)
+        wt = torch.randn(1, cout, cin, device=dev) / math.sqrt(cin)
+        s = torch.rand(B, cin, device=dev) + 0.5
+        wtp = ops.split_conv_weights(wt)
+        xp = ops.modsplit(x, s)
+        ts = []
+        for _ in range(rounds + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                ops.modconv(x, wt, 1, s, None, None, None, None, False, wt_planes=wtp, x_planes=xp)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / 3)
+        t1 = sorted(ts[1:])[len(ts[1:]) // 2]
+        gf = 2.0 * B * h * h * cin * cout / 1e9
+        tiles = ((B * h * h + 127) // 128) * ((cout + 127) // 128)
+        print(f"1x1 H={h:3d} {cin:3d}->{cout:3d}: {t1:.3f} ms  {gf / t1:.0f} TF/s  {tiles} tiles of {cin // 16} k-tiles")
     print(f"total old {tot['old']:.2f} ms, xp {tot['xp']:.2f} ms (+ split {tot['split']:.2f} ms)")
 
 
