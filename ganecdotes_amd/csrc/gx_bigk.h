@@ -21,6 +21,19 @@ __device__ __forceinline__ float bk_ord2f(unsigned o) {
 
 enum { BK_COLMAX = 0, BK_COLSUM = 1, BK_FIRST = 2, BK_SWEEP = 3 };
 
+// exp(x) for x <= ~0 (every call site subtracts a maximum first) as v_exp_f32(x * log2 e) with the product carried
+// in two floats: y = fl(x L) and its error fma(x, L, -y) + x (log2 e - L), folded back as exp2(y) (1 + r ln 2).
+// Five VALU instructions instead of the ~12 of expf (range reduction + ldexp + overflow selects), same accuracy
+// class (<= 2 ulp); arguments below -126 / ln 2 return 0 like expf's underflow.
+__device__ __forceinline__ float bk_exp(float x) {
+    constexpr float L = 1.44269502162933349609375f, L_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    x = fmaxf(x, -200.f);                                            // exp(-inf) = exp(-200) = 0 (no inf - inf below)
+    const float y = x * L;
+    const float r = fmaf(x, L, -y) + x * L_LO;
+    const float e = __builtin_amdgcn_exp2f(y);
+    return fmaf(e * LN2, r, e);
+}
+
 // A score row through a buffer descriptor: columns past K read as 0 with no branch (hipcc turns
 // `k < K ? p[k] : x` into one branch + s_waitcnt vmcnt(0) PER LOAD, i.e. 80 serial round trips per
 // row).  `row` is wave-uniform by construction; readfirstlane makes that provable so the
@@ -43,174 +56,221 @@ __device__ __forceinline__ void bk_store4(__amdgpu_buffer_rsrc_t r, int first_co
 // covers 1 KiB of the row).  Needs K % 4 == 0, ld % 4 == 0, 16-B aligned base.
 #define BK_COL(lane, c) (4 * ((lane) + 64 * (c)))
 
+// Column pass over a score matrix, BLOCK per group of BK_R rows: thread t owns columns 4 (t + 256 c) + q, c < NJ/16,
+// for every row the block visits, so its column accumulators are NJ/4 registers (with a wave per row they were NJ:
+// 275 VGPRs with the row itself, one wave per SIMD, 4.2 TB/s) and the block's partial row is written straight from
+// registers, no LDS atomics.  The row reductions of the sweep (max, then sum of exp, over all K columns) cross the four
+// waves through LDS; BK_R rows travel together (BK_R x NJ/16 float4 loads in flight per thread, two barriers per group).
 // MODE BK_COLMAX : cmax[k] = max_n S_nk                     (ordered-uint atomicMax into `cmax_out`)
 //      BK_COLSUM : part[b][k] = sum_{rows of block} S_nk
 //      BK_FIRST  : part[b][k] = sum exp((S_nk - cmax_k)/eps)
 //      BK_SWEEP  : lb_n = log c_n - logsumexp_k(S_nk/eps + la_k); part[b][k] = sum exp(S_nk/eps + la_k + lb_n)
+constexpr int BK_R = 4;
 template <int NJ, int MODE>
-__global__ __launch_bounds__(256) void bigk_pass_kernel(const float* __restrict__ S, long rows, int K, long ld,
-                                                        float inv_eps, const unsigned* __restrict__ cmax,
-                                                        const float* __restrict__ la, const float* __restrict__ c,
-                                                        float c_uniform, float* __restrict__ lb_out,
-                                                        float* __restrict__ part, unsigned* __restrict__ cmax_out) {
-    constexpr int NC = NJ / 4;
-    extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | acc[K]
+__global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restrict__ S, long rows, int K, long ld,
+                                                           float inv_eps, const unsigned* __restrict__ cmax,
+                                                           const float* __restrict__ la, const float* __restrict__ c,
+                                                           float c_uniform, float* __restrict__ lb_out,
+                                                           float* __restrict__ part, unsigned* __restrict__ cmax_out) {
+    constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | red[2][BK_R][4]
     float* vec = sm;
-    float* acc = sm + K;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        if (MODE == BK_FIRST) vec[k] = -bk_ord2f(cmax[k]) * inv_eps;
-        if (MODE == BK_SWEEP) vec[k] = la[k];
-        if (MODE == BK_COLMAX) reinterpret_cast<unsigned*>(acc)[k] = 0u; else acc[k] = 0.f;
+    float* red = sm + K;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (MODE == BK_FIRST) {
+        const float neg = -inv_eps;       // (a float negation of the decoded value was folded into the decode's
+        for (int k = tid; k < K; k += 256) vec[k] = bk_ord2f(cmax[k]) * neg;      //  integer selects and lost: hipcc 7.2)
+        __syncthreads();
+    } else if (MODE == BK_SWEEP) {
+        for (int k = tid; k < K; k += 256) vec[k] = la[k];
+        __syncthreads();
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
     f32x4 u[NC];
 #pragma unroll
     for (int cidx = 0; cidx < NC; ++cidx) {
         const float init = (MODE == BK_COLMAX) ? -INFINITY : 0.f;
         u[cidx] = f32x4{init, init, init, init};
     }
-    for (long row = wave0; row < rows; row += nwave) {
-        const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, row, ld, K);
-        f32x4 w[NC];
+    const long ngroups = (rows + BK_R - 1) / BK_R;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long r0 = grp * BK_R;
+        f32x4 w[BK_R][NC];
 #pragma unroll
-        for (int cidx = 0; cidx < NC; ++cidx) w[cidx] = bk_load4(rs, BK_COL(lane, cidx));
+        for (int r = 0; r < BK_R; ++r) {
+            // rows past the end read as zeros through an EMPTY descriptor (their contributions are masked below)
+            const bool live = r0 + r < rows;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, live ? r0 + r : 0, ld, live ? K : 0);
+#pragma unroll
+            for (int cidx = 0; cidx < NC; ++cidx) w[r][cidx] = bk_load4(rs, 4 * (tid + 256 * cidx));
+        }
         if (MODE == BK_COLMAX) {
 #pragma unroll
-            for (int cidx = 0; cidx < NC; ++cidx)
-                if (BK_COL(lane, cidx) < K)
+            for (int r = 0; r < BK_R; ++r)
+                if (r0 + r < rows)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) u[cidx][q] = fmaxf(u[cidx][q], w[cidx][q]);
+                    for (int cidx = 0; cidx < NC; ++cidx)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[cidx][q] = fmaxf(u[cidx][q], w[r][cidx][q]);
         } else if (MODE == BK_COLSUM) {
 #pragma unroll
-            for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[cidx];                 // columns past K read 0
+            for (int r = 0; r < BK_R; ++r)
+#pragma unroll
+                for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[r][cidx];          // dead rows / columns read 0
         } else if (MODE == BK_FIRST) {
+#pragma unroll
+            for (int cidx = 0; cidx < NC; ++cidx) {
+                const int k = 4 * (tid + 256 * cidx);
+                if (k < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + k);
+#pragma unroll
+                    for (int r = 0; r < BK_R; ++r)
+                        if (r0 + r < rows)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) u[cidx][q] += bk_exp(fmaf(w[r][cidx][q], inv_eps, v[q]));
+                }
+            }
+        } else {
+            float mx[BK_R];
+#pragma unroll
+            for (int r = 0; r < BK_R; ++r) mx[r] = -INFINITY;
+#pragma unroll
+            for (int cidx = 0; cidx < NC; ++cidx) {
+                const int k = 4 * (tid + 256 * cidx);
+                const bool ok = k < K;
+                const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(vec + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < BK_R; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w[r][cidx][q] = ok ? fmaf(w[r][cidx][q], inv_eps, v[q]) : -INFINITY;
+                        mx[r] = fmaxf(mx[r], w[r][cidx][q]);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < BK_R; ++r) {
+                mx[r] = gx_wave_max(mx[r]);
+                if (lane == 0) red[r * 4 + wid] = mx[r];
+            }
+            __syncthreads();
+            float sum[BK_R];
+#pragma unroll
+            for (int r = 0; r < BK_R; ++r) {
+                mx[r] = fmaxf(fmaxf(red[r * 4], red[r * 4 + 1]), fmaxf(red[r * 4 + 2], red[r * 4 + 3]));
+                sum[r] = 0.f;
+#pragma unroll
+                for (int cidx = 0; cidx < NC; ++cidx)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { w[r][cidx][q] = bk_exp(w[r][cidx][q] - mx[r]); sum[r] += w[r][cidx][q]; }
+                sum[r] = gx_wave_sum(sum[r]);
+                if (lane == 0) red[BK_R * 4 + r * 4 + wid] = sum[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < BK_R; ++r) {
+                const float* rs = red + BK_R * 4 + r * 4;
+                const float tot = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+                const bool live = r0 + r < rows;
+                const float cn = c ? (live ? c[r0 + r] : 0.f) : c_uniform;
+                const float f = live ? cn / tot : 0.f;                  // exp(lb + mx)
+#pragma unroll
+                for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[r][cidx] * f;
+                if (lb_out && live && tid == 0) lb_out[r0 + r] = logf(cn) - mx[r] - logf(tot);
+            }
+            // (the next group's first barrier orders this group's reads of `red` before its writes: every wave
+            //  passes through it only after finishing here)
+        }
+    }
+    // the block's partial row straight from registers (or one global atomicMax per column)
+#pragma unroll
+    for (int cidx = 0; cidx < NC; ++cidx) {
+        const int k = 4 * (tid + 256 * cidx);
+        if (k < K) {
+            if (MODE == BK_COLMAX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicMax(cmax_out + k + q, bk_f2ord(u[cidx][q]));
+            } else {
+                *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * K + k) = u[cidx];
+            }
+        }
+    }
+}
+
+// Swapped-prediction CE forward + d(scores) for many prototypes, as two streaming kernels (the one-kernel form
+// kept a row of codes in registers next to three re-reads of the other view's row: 468 VGPRs, one wave per SIMD,
+// 2.4 TB/s):
+//   ce_rowstats : per row and view X in {s, t}: wm_X = max_k(X_k/eps + la_X,k), v_X = sum_k exp(. - wm_X)   (codes)
+//                                               m_X = max_k X_k,               z_X = sum_k exp((X_k - m_X)/T) (prediction)
+//                 one row in registers at a time (NJ VGPRs), both views one after the other;
+//   ce_apply    : elementwise over (row, k): q_X = exp(X/eps + la_X - wm_X)/v_X, p_X = exp((X - m_X)/T)/z_X,
+//                 dS_t = f (q_s - p_t), dS_s = f (q_t - p_s), loss partial sum_k q_s (x_t - log z_t) + q_t (x_s - log z_s);
+//                 a handful of registers per lane, row statistics wave-uniform.
+// stats [rows][8] = {wm_s, 1/v_s, m_s, z_s, wm_t, 1/v_t, m_t, z_t}.
+template <int NJ>
+__global__ __launch_bounds__(256, 4) void ce_rowstats_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+                                                                  long rows, int K, long ld, float inv_eps, float inv_T,
+                                                                  const float* __restrict__ la_s,
+                                                                  const float* __restrict__ la_t,
+                                                                  float* __restrict__ stats) {
+    constexpr int NC = NJ / 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // las[K] | lat[K]
+    float* las = sm;
+    float* lat = sm + K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { las[k] = la_s[k]; lat[k] = la_t[k]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    for (long row = wave0; row < rows; row += nwave) {
+#pragma unroll
+        for (int view = 0; view < 2; ++view) {
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(view ? St : Ss, row, ld, K);
+            const float* la = view ? lat : las;
+            f32x4 w[NC];
+#pragma unroll
+            for (int cidx = 0; cidx < NC; ++cidx) w[cidx] = bk_load4(rs, BK_COL(lane, cidx));
+            float wm = -INFINITY, m = -INFINITY;
 #pragma unroll
             for (int cidx = 0; cidx < NC; ++cidx) {
                 const int k = BK_COL(lane, cidx);
                 if (k < K) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + k);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(la + k);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) u[cidx][q] += expf(fmaf(w[cidx][q], inv_eps, v[q]));
+                    for (int q = 0; q < 4; ++q) {
+                        m = fmaxf(m, w[cidx][q]);
+                        wm = fmaxf(wm, fmaf(w[cidx][q], inv_eps, v[q]));
+                    }
                 }
             }
-        } else {
-            float mx = -INFINITY;
+            wm = gx_wave_max(wm); m = gx_wave_max(m);
+            float vs = 0.f, z = 0.f;
 #pragma unroll
             for (int cidx = 0; cidx < NC; ++cidx) {
                 const int k = BK_COL(lane, cidx);
-                const bool ok = k < K;
-                const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(vec + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(la + k);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w[cidx][q] = ok ? fmaf(w[cidx][q], inv_eps, v[q]) : -INFINITY;
-                    mx = fmaxf(mx, w[cidx][q]);
+                    for (int q = 0; q < 4; ++q) {
+                        vs += bk_exp(fmaf(w[cidx][q], inv_eps, v[q]) - wm);
+                        z += bk_exp((w[cidx][q] - m) * inv_T);
+                    }
                 }
             }
-            mx = gx_wave_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int cidx = 0; cidx < NC; ++cidx)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { w[cidx][q] = expf(w[cidx][q] - mx); sum += w[cidx][q]; }   // exp(-inf) = 0
-            sum = gx_wave_sum(sum);
-            const float cn = c ? c[row] : c_uniform;
-            const float f = cn / sum;                       // exp(lb + mx)
-#pragma unroll
-            for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[cidx] * f;
-            if (lb_out && lane == 0) lb_out[row] = logf(cn) - mx - logf(sum);
-        }
-    }
-    // combine the block's waves in LDS, then one partial row (or one global atomicMax) per block
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx) {
-        const int k = BK_COL(lane, cidx);
-        if (k < K)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (MODE == BK_COLMAX) atomicMax(reinterpret_cast<unsigned*>(acc) + k + q, bk_f2ord(u[cidx][q]));
-                else atomicAdd(acc + k + q, u[cidx][q]);
+            vs = gx_wave_sum(vs); z = gx_wave_sum(z);
+            if (lane == 0) {
+                float* o = stats + row * 8 + view * 4;
+                o[0] = wm; o[1] = 1.f / vs; o[2] = m; o[3] = z;
             }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        if (MODE == BK_COLMAX) atomicMax(cmax_out + k, reinterpret_cast<unsigned*>(acc)[k]);
-        else part[(long)blockIdx.x * K + k] = acc[k];
+        }
     }
 }
 
-// One direction of the swapped CE for one row: codes q = softmax_k(Sq/eps + laq) (kept in
-// registers), prediction p = softmax_k(Sp/T):  returns sum_k q_k log p_k  and writes
-// dSp = f (q - p sum_k q_k).
-template <int NJ>
-__device__ __forceinline__ float ce_direction(__amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rp, int K,
-                                              const float* __restrict__ laq, float inv_eps, float inv_T, float f,
-                                              bool write, __amdgpu_buffer_rsrc_t rd, int lane) {
-    constexpr int NC = NJ / 4;
-    f32x4 e[NC];
-    float wm = -INFINITY, m = -INFINITY;
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx) {
-        const int k = BK_COL(lane, cidx);
-        const bool ok = k < K;
-        const f32x4 sq = bk_load4(rq, k), sp = bk_load4(rp, k);
-        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(laq + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            e[cidx][q] = ok ? fmaf(sq[q], inv_eps, v[q]) : -INFINITY;
-            wm = fmaxf(wm, e[cidx][q]);
-            m = fmaxf(m, ok ? sp[q] : -INFINITY);
-        }
-    }
-    wm = gx_wave_max(wm); m = gx_wave_max(m);
-    float v = 0.f, z = 0.f;
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx) {
-        const int k = BK_COL(lane, cidx);
-        const f32x4 sp = bk_load4(rp, k);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            e[cidx][q] = expf(e[cidx][q] - wm);            // exp(-inf) = 0 past K
-            v += e[cidx][q];
-            z += (k < K) ? expf((sp[q] - m) * inv_T) : 0.f;
-        }
-    }
-    v = gx_wave_sum(v); z = gx_wave_sum(z);
-    const float iv = 1.f / v, iz = 1.f / z, lz = logf(z);
-    float qsum = 0.f;
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e[cidx][q] *= iv; qsum += e[cidx][q]; }
-    qsum = gx_wave_sum(qsum);
-    float l = 0.f;
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx) {
-        const int k = BK_COL(lane, cidx);
-        const f32x4 sp = bk_load4(rp, k);
-        f32x4 d;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x = (sp[q] - m) * inv_T;
-            l += (k < K) ? e[cidx][q] * (x - lz) : 0.f;
-            d[q] = f * (e[cidx][q] - expf(x) * iz * qsum);
-        }
-        if (write) bk_store4(rd, k, d);                    // columns past K are dropped by the range check
-    }
-    return l;
-}
-
-// Swapped-prediction CE forward + d(scores) for many prototypes (same maths as swapped_ce_kernel);
-// the two directions run one after the other so only one row of codes lives in registers.
-template <int NJ>
-__global__ __launch_bounds__(256) void swapped_ce_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
-                                                              long rows, int K, long ld, float inv_eps, float inv_T,
-                                                              const float* __restrict__ la_s,
-                                                              const float* __restrict__ la_t, float gscale,
-                                                              float* __restrict__ dSs, float* __restrict__ dSt,
-                                                              long ldd, float* __restrict__ loss_part) {
+__global__ __launch_bounds__(256, 4) void ce_apply_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+                                                               long rows, int K, long ld, float inv_eps, float inv_T,
+                                                               const float* __restrict__ la_s,
+                                                               const float* __restrict__ la_t,
+                                                               const float* __restrict__ stats, float gscale,
+                                                               float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
+                                                               float* __restrict__ loss_part) {
     extern __shared__ __attribute__((aligned(16))) float sm[];           // las[K] | lat[K]
     float* las = sm;
     float* lat = sm + K;
@@ -226,8 +286,26 @@ __global__ __launch_bounds__(256) void swapped_ce_bigk_kernel(const float* __res
         const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(Ss, row, ld, K), rt = bk_row_rsrc(St, row, ld, K);
         const __amdgpu_buffer_rsrc_t ds = bk_row_rsrc(write ? dSs : Ss, row, write ? ldd : ld, K);
         const __amdgpu_buffer_rsrc_t dt = bk_row_rsrc(write ? dSt : St, row, write ? ldd : ld, K);
-        lacc += ce_direction<NJ>(rs, rt, K, las, inv_eps, inv_T, f, write, dt, lane);
-        lacc += ce_direction<NJ>(rt, rs, K, lat, inv_eps, inv_T, f, write, ds, lane);
+        const float* st = stats + row * 8;                               // wave-uniform
+        const float wm_s = st[0], iv_s = st[1], m_s = st[2], z_s = st[3];
+        const float wm_t = st[4], iv_t = st[5], m_t = st[6], z_t = st[7];
+        const float iz_s = 1.f / z_s, iz_t = 1.f / z_t, lz_s = logf(z_s), lz_t = logf(z_t);
+#pragma unroll 4
+        for (int k = 4 * lane; k < K; k += 256) {
+            const f32x4 a = bk_load4(rs, k), b = bk_load4(rt, k);
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(las + k), lt = *reinterpret_cast<const f32x4*>(lat + k);
+            f32x4 d_s, d_t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float qs = bk_exp(fmaf(a[q], inv_eps, ls[q]) - wm_s) * iv_s;
+                const float qt = bk_exp(fmaf(b[q], inv_eps, lt[q]) - wm_t) * iv_t;
+                const float xs = (a[q] - m_s) * inv_T, xt = (b[q] - m_t) * inv_T;
+                lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
+                d_t[q] = f * (qs - bk_exp(xt) * iz_t);
+                d_s[q] = f * (qt - bk_exp(xs) * iz_s);
+            }
+            if (write) { bk_store4(dt, k, d_t); bk_store4(ds, k, d_s); }
+        }
     }
     __shared__ float red[16];
     const float tot = gx_block_sum(lacc, red);
@@ -258,5 +336,6 @@ static inline int bigk_blocks(long rows, int cap) {
     long nb = (rows + 3) / 4;
     return (int)(nb < cap ? nb : cap);
 }
+static inline size_t bigk_pass_lds(int K) { return ((size_t)K + 2 * BK_R * 4) * sizeof(float); }
 
 }  // namespace gx

@@ -296,10 +296,33 @@ __global__ void partial_reduce_kernel(const float* __restrict__ part, int nblk, 
     }
     if (ty == 0 && k < K) out[k] = alpha * red[tx] + (beta != 0.f ? beta * out[k] : 0.f);
 }
+// out2[g][k] = sum of the g-th slice of partial rows (fixed order); blockIdx.y = slice
+__global__ void partial_reduce_slices_kernel(const float* __restrict__ part, int nblk, int K, int per,
+                                             float* __restrict__ out2) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + tx;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float s = 0.f;
+    if (k < K) for (int b = b0 + ty; b < b1; b += 4) s += part[(long)b * K + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && k < K) out2[(long)blockIdx.y * K + k] = (red[tx] + red[tx + 64]) + (red[tx + 128] + red[tx + 192]);
+}
+// `spare` (optional): >= 8*K floats of scratch; with it, many partial rows of many columns are reduced in two stages
+// (8 row slices x K/64 column blocks fill the chip: one stage ran 79 blocks over 40 MB at 0.25 TB/s for K = 5000)
 static inline void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out,
-                                         hipStream_t stream) {
+                                         hipStream_t stream, float* spare = nullptr) {
     int kx = 1;
     while (kx < 64 && kx < K) kx <<= 1;
+    if (spare && K >= 1024 && nblk >= 64) {
+        const int per = (nblk + 7) / 8;
+        hipLaunchKernelGGL(partial_reduce_slices_kernel, dim3((K + 63) / 64, 8), dim3(256), 0, stream, part, nblk, K, per,
+                           spare);
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx), dim3(256), 0, stream, spare, 8, K, alpha, beta,
+                           out, kx);
+        return;
+    }
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx), dim3(256), 0, stream, part, nblk, K, alpha,
                        beta, out, kx);
 }
@@ -689,7 +712,7 @@ int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta
     if (!workspace || workspace_bytes < gx_colsum_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     if (bigk_ok(K) && bigk_aligned(x, ld)) {   // many columns: wave-per-row streaming kernel
         const int nbk = bigk_blocks(rows, GX_COLSUM_BLOCKS);
-        const size_t lds = (size_t)2 * K * sizeof(float);
+        const size_t lds = bigk_pass_lds(K);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLSUM>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, x, rows, K, ld, 0.f, nullptr, nullptr,
                                                         nullptr, 0.f, nullptr, workspace, nullptr));
@@ -729,7 +752,7 @@ int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspa
     if (hipMemsetAsync(workspace, 0, (size_t)K * 4, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
     if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);
-        const size_t lds = (size_t)2 * K * sizeof(float);
+        const size_t lds = bigk_pass_lds(K);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, S, rows, K, ld, 0.f, nullptr, nullptr,
                                                         nullptr, 0.f, nullptr, nullptr, (unsigned*)workspace));
@@ -774,6 +797,7 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     if (lds > 160 * 1024) return GX_ERR_BAD_ARG;
     if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);           // partial area holds 2048*K floats
+        const size_t lds = bigk_pass_lds(K);
         if (first) {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
                                                             (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
@@ -786,7 +810,7 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
                                                             nullptr));
         }
         GX_CHECK_LAUNCH();
-        launch_partial_reduce(part, nbk, K, 1.f, 0.f, u, (hipStream_t)stream);
+        launch_partial_reduce(part, nbk, K, 1.f, 0.f, u, (hipStream_t)stream, part + (size_t)2040 * K);   // rows 2040..2047 are spare
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
@@ -837,21 +861,27 @@ int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, cons
 
 // ---- swapped-prediction CE forward + d(scores) ---------------------------------------------
 // loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0]
-size_t gx_swapped_ce_workspace_bytes(void) { return (size_t)2048 * sizeof(float); }
+// 2048 loss partials, then (many-prototype path) 8 row statistics per row
+size_t gx_swapped_ce_workspace_bytes(long rows, int K) {
+    return ((size_t)2048 + (bigk_ok(K) ? (size_t)rows * 8 : 0)) * sizeof(float);
+}
 int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
                   const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
                   float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
                   void* stream) {
     if (!Ss || !St || !la_s || !la_t || !loss_out || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if ((dSs == nullptr) != (dSt == nullptr) || (dSs && ldd < K)) return GX_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < gx_swapped_ce_workspace_bytes()) return GX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < gx_swapped_ce_workspace_bytes(rows, K)) return GX_ERR_WORKSPACE;
     if (bigk_ok(K) && bigk_aligned(Ss, ld) && bigk_aligned(St, ld) && (!dSs || (bigk_aligned(dSs, ldd) && bigk_aligned(dSt, ldd)))) {
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = (size_t)2 * K * sizeof(float);
-        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((swapped_ce_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
+        float* stats = workspace + 2048;
+        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((ce_rowstats_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, Ss, St, rows, K, ld, 1.f / eps,
-                                                        1.f / temperature, la_s, la_t, grad_scale, dSs, dSt, ldd,
-                                                        workspace));
+                                                        1.f / temperature, la_s, la_t, stats));
+        GX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ce_apply_bigk_kernel, dim3(nbk), dim3(256), lds, (hipStream_t)stream, Ss, St, rows, K, ld,
+                           1.f / eps, 1.f / temperature, la_s, la_t, stats, grad_scale, dSs, dSt, ldd, workspace);
         GX_CHECK_LAUNCH();
         launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
         GX_CHECK_LAUNCH();

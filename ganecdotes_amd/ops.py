@@ -882,7 +882,7 @@ def swapped_ce(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_b
     S, T = sk_s.S, sk_t.S
     _chk(loss_out, d_s, d_t)
     L = lib()
-    wsb = L.gx_swapped_ce_workspace_bytes()
+    wsb = L.gx_swapped_ce_workspace_bytes(sk_s.rows, sk_s.K)
     ws = workspace("ce", wsb, S.device)
     _lib.check(L.gx_swapped_ce(_p(S), _p(T), sk_s.rows, sk_s.K, S.stride(0), sk_s.eps, temperature, _p(sk_s.la),
                                _p(sk_t.la), grad_scale, _p(d_s), _p(d_t),

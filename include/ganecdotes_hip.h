@@ -333,7 +333,7 @@ int gx_hist_finish(float* hist, int bins, void* stream);
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).
  * loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0];
  * dS_t = -grad_scale/(2T) (q_s - softmax(S_t/T) sum_k q_s), dS_s likewise (NULL,NULL = forward only). */
-size_t gx_swapped_ce_workspace_bytes(void);
+size_t gx_swapped_ce_workspace_bytes(long rows, int K);
 int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
                   const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
                   float loss_scale, float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes,
