@@ -114,7 +114,7 @@ class SimCLRClustering(ViewMixin):
         w1, gamma, beta, w2 = self._params()
         bn = self.projection[1]
         pb = self.prepare_batch([image])
-        views = self.make_views(pb)                                            # acquires pb on this stream
+        views = self.make_views(pb, want_image=False)                          # acquires pb on this stream
         pb_picks = pb.picks[0]                                                 # (1, bsz) int32
         xs = []
         for ts, maps, _ in views:

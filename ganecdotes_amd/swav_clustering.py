@@ -212,7 +212,7 @@ class SwAVClustering(ViewMixin):
         ops.row_l2_normalize_(Wc, want_rnorm=False)
 
         with self._timed("views"):
-            views, ts_all = self.make_views(pb, want_all=True)
+            views, ts_all = self.make_views(pb, want_all=True, want_image=False)
         hw = views[0][0].size
         if N is None or N >= hw * hw:
             N = hw * hw

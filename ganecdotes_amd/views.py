@@ -125,10 +125,12 @@ class ViewMixin(object):
         return ops.view_latents(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation),
                                 nw.reshape(w.shape[0], 2, -1).contiguous(), mix.contiguous())
 
-    def make_views(self, images, want_all=False):
+    def make_views(self, images, want_all=False, want_image=True):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->
         per view (TapSet, maps or None, image); want_all: also the TapSet of the whole 2B-image batch
-        (view s = images [0, B), view t = [B, 2B))."""
+        (view s = images [0, B), view t = [B, 2B)).  want_image=False skips the ToRGB branch: the RGB image of a
+        view enters no loss term — the reference keeps it for plots only (swav_clustering.py:347-356, :474-499) — so
+        the training step does not compute it (image = None)."""
         pb = self.prepare_batch(images)
         pb.acquire()
         n = pb.n
@@ -140,8 +142,13 @@ class ViewMixin(object):
         # low-resolution layers get enough tiles to fill the chip)
         lat = torch.cat([self._view_latents(w, None, pb.mix[v], nw=allw[n + 2 * n * v:n + 2 * n * (v + 1)])
                          for v in range(2)])
-        img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
-                                input_is_latent=True, randomize_noise=False)
+        prev = getattr(self.model, "want_image", True)
+        self.model.want_image = bool(want_image)
+        try:
+            img, feats = self.model([lat], truncation=self.truncation, truncation_latent=self.mean_latent,
+                                    input_is_latent=True, randomize_noise=False)
+        finally:
+            self.model.want_image = prev
         out = []
         for v in range(2):
             ts = ops.TapSet([f[v * n:(v + 1) * n].permute(0, 2, 3, 1) for f in feats])
