@@ -291,8 +291,9 @@ def main():
         x6 = ops.get_gemm_mode() == 1
         eng = ("bf16 MFMA, bf16x6: each fp32 operand split exactly into three bf16, six MFMA products per fp32 "
                "product, fp32 accumulate" if x6 else "fp32 MFMA")
-        what = {"modconv_kernel": f"gx::modconv_kernel (3x3 modulated conv, implicit GEMM on {eng}; "
-                                  "algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
+        what = {"modconv_kernel": f"gx::modconv_xp_kernel / gx::modconv_kernel (3x3 modulated conv, implicit GEMM on {eng}; "
+                                  "the modulated activations are split once by their producer and both operands reach LDS by "
+                                  "LDS-DMA; algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
                 "gemm_f32_kernel": f"gx::gemm kernels (pyramid projection / prototype / gradient GEMMs on {eng}; "
                                    "algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
         # peak for ALGORITHMIC fp32 FLOPs: the fp32 MFMA peak, or (bf16x6) the dense bf16 MFMA peak / 6
@@ -300,9 +301,10 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tfile):
-            cands = [t for k, t in json.load(open(tfile)).items() if name.replace("gemm_f32", "gemm") in k]
+            stem = {"modconv_kernel": "modconv", "gemm_f32_kernel": "gemm"}.get(name, name)
+            cands = [t for k, t in json.load(open(tfile)).items() if stem in k]
             if cands:
                 traffic = max(cands, key=lambda t: t["launches"])["hbm_bytes_per_launch"]
         roof = dict(bound="mfma", achieved=ach / 1e12, peak=peak / 1e12, unit="TFLOP/s",
