@@ -36,11 +36,24 @@ struct GemmArgs {
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
 
+// (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
+// order (x fastest), so `blockIdx.x -> tile, blockIdx.y -> split` put the tiles of ONE split — which read the same
+// K-slice of A and of B — on different XCDs: every XCD's L2 then fetched every slice itself (the pyramid-backward TN
+// GEMMs, 512 x C_l outputs = 4-8 tiles x ~100 splits, moved 2.3 x their operands).  Here the dispatch index is
+// remapped as a whole, split-major / tile-minor: an XCD owns a contiguous run of (split, tile) pairs, so the tiles
+// of a split run side by side on one L2.
+__device__ __forceinline__ void gemm_tile_of_block(int ntile, int& logical, int& split) {
+    const int L = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), ntile * (int)gridDim.y);
+    split = L / ntile;
+    logical = L - split * ntile;
+}
+
 // Accumulators of a wave's (32 MT) x (32 NT) sub-tile whose first row / column in C is (row0, col0).
 template <int MT, int NT>
-__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane) {
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane,
+                                                int split) {
     const bool to_slab = g.slab != nullptr;
-    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
+    float* out = to_slab ? g.slab + (long)split * g.M * g.N : g.C;
     const long ldo = to_slab ? g.N : g.ldc;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -82,7 +95,7 @@ __device__ __forceinline__ const GemmArgs* gemm_late_args() {
 }
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane,
-                                                     float* stage) {
+                                                     float* stage, int split) {
     constexpr int SW = 32 * NT + 4, LPR = 8 * NT, RPP = 64 / LPR;
     const GemmArgs& q = *gemm_late_args();
     const float alpha = q.alpha, beta = q.beta;
@@ -90,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x16 (
     const float* up_src = q.up_src;
     const int up_s = q.up_shift;
     const bool to_slab = g.slab != nullptr;
-    float* out = to_slab ? g.slab + (long)blockIdx.y * g.M * g.N : g.C;
+    float* out = to_slab ? g.slab + (long)split * g.M * g.N : g.C;
     const long ldo = to_slab ? g.N : g.ldc;
     const int rl = lane / LPR, c4 = (lane % LPR) * 4;
     const int col = col0 + c4;
@@ -132,9 +145,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x16 (
     }
 }
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
-                                              int lane, float* stage) {
-    if (g.ep_vec) gemm_epilogue_staged<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane, stage);
-    else gemm_epilogue_t<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane);
+                                              int lane, float* stage, int split) {
+    if (g.ep_vec) gemm_epilogue_staged<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane, stage, split);
+    else gemm_epilogue_t<2, 2>(g, acc, m0 + wr * 64, n0 + wc * 64, lane, split);
 }
 
 // TA: A given as [K][M] (m contiguous).  TB: B given as [N][K] (k contiguous).
@@ -145,10 +158,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A0 B0 A1 B1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int ntile = g.tiles_m * g.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, ntile);
+    int logical, split;
+    gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     f32x16 acc[2][2];
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, lds + wid * EP_STAGE_FLOATS);
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, lds + wid * EP_STAGE_FLOATS, split);
 }
 
 // The same contraction on the bf16 matrix cores (gx_mfma_x6.h): 128 x 128 x 16 tiles, every operand
@@ -196,10 +210,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char lds[4 * X_TILE_BYTES];   // A0 B0 A1 B1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int ntile = g.tiles_m * g.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, ntile);
+    int logical, split;
+    gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     f32x16 acc[2][2];
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS);
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
 }
 
 // Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
@@ -259,10 +274,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = g.tiles_m * g.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, ntile);
+    int logical, split;
+    gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * WS_BM, n0 = tn * WS_BN;
-    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nkt = (kend - kbeg + XK - 1) / XK;
     char* slot0 = lds;
@@ -315,9 +331,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         __syncthreads();                                             // barrier t+1
     }
     if (g.ep_vec)
-        gemm_epilogue_staged<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS);
+        gemm_epilogue_staged<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
     else
-        gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, split);
 }
 
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
