@@ -378,9 +378,34 @@ constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + 
 // (a 256-B run per pixel) instead of 64 dword stores per lane, the demod / noise / bias / activation on float4, and,
 // when the next conv reads x planes, that conv's modulated input split RIGHT HERE (out * s_next -> three bf16
 // planes, 8 B per lane and plane): the activation is split once, by its producer, not per tap and Cout tile.
-__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvSub& sb, f32x16 (&acc)[2][2], char* lds,
+constexpr int EPI_LDW = 68;
+// staging writers: one 32-row half (mt) of a wave's 64 x 64 accumulators -> S [32][EPI_LDW]
+struct StageAcc32 {          // 2 x 2 tiles of v_mfma_f32_32x32x16_bf16: lane = column, 16 registers = rows
+    const f32x16 (&acc)[2][2];
+    __device__ __forceinline__ void operator()(int mt, float* S, int lane) const {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LDW + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+    }
+};
+struct StageAcc16 {          // 4 x 4 tiles of v_mfma_f32_16x16x32_bf16: column = lane & 15, row = 4 (lane >> 4) + register
+    const f32x4 (&acc)[4][4];
+    __device__ __forceinline__ void operator()(int mt, float* S, int lane) const {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    S[(rb * 16 + 4 * (lane >> 4) + j) * EPI_LDW + cb * 16 + (lane & 15)] = acc[2 * mt + rb][cb][j];
+    }
+};
+template <class STAGE>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvSub& sb, const STAGE& stage_write, char* lds,
                                                   unsigned row0, int col0, int wid, int lane) {
-    constexpr int LDW = 68;                                          // floats per LDS row (64 + 4: the 16-row column reads
+    constexpr int LDW = EPI_LDW;                                          // floats per LDS row (64 + 4: the 16-row column reads
     float* S = reinterpret_cast<float*>(lds) + wid * 32 * LDW;       //  below then fall in distinct banks)
     const int OH = sb.OH, OW = sb.OW;
     const unsigned ohw = (unsigned)OH * (unsigned)OW, Mtot = (unsigned)g.B * ohw;
@@ -391,11 +416,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
     const int q4 = (lane & 3) * 4, lrow = lane >> 2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDW + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+        stage_write(mt, S, lane);
         // (same wave wrote and reads: program order + the LDS counter, no barrier)
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
@@ -438,8 +459,44 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, f32x16 (&acc)[2][2],
+// 16x16x32 form of the six products: two planes side by side fill the K = 32 of one v_mfma_f32_16x16x32_bf16, so
+//   [a_h | a_l] x [b_l | b_h] = a_h b_l + a_l b_h,   [a_h | a_m] x [b_m | b_h] = a_h b_m + a_m b_h,
+//   [a_h | a_m] x [b_h | b_m] = a_h b_h + a_m b_m
+// are three MFMAs (16 cycles each: the same pipe time as six 32x32x16 products per 32 x 32 outputs).  Lane l holds row /
+// column l & 15 and the 8 k of group l >> 4: groups 0, 1 come from the first plane, 2, 3 from the second.  The LDS image
+// is half-major here ([2 halves][128 rows][16 B] per plane): any 16 rows of a fragment read fall in 16 distinct slots.
+__device__ __forceinline__ bf16x8 xp16_frag(const char* S, int px, int py, int row, int lane) {
+    const int kq = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(S + (kq < 2 ? px : py) * 4096 + (kq & 1) * 2048 + row * 16);
+}
+__device__ __forceinline__ void xp16_mfma_ktile(const char* As, const char* Bs, f32x4 (&acc)[4][4], int wr, int wc, int lane) {
+    const int ar = wr * 64 + (lane & 15), br = wc * 64 + (lane & 15);
+    bf16x8 ahl[4], ahm[4], blh[4], bmh[4], bhm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ahl[i] = xp16_frag(As, 0, 2, ar + 16 * i, lane); blh[i] = xp16_frag(Bs, 2, 0, br + 16 * i, lane); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ahm[i] = xp16_frag(As, 0, 1, ar + 16 * i, lane); bmh[i] = xp16_frag(Bs, 1, 0, br + 16 * i, lane); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bhm[i] = xp16_frag(Bs, 0, 1, br + 16 * i, lane);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[rb], blh[cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[rb], bmh[cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[rb], bhm[cb], acc[rb][cb], 0, 0, 0);
+}
+
+template <int NT, bool M16, class ACC>
+__device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, ACC& acc,
                                                  unsigned pixbyte, int n0, int tid, int wr, int wc, int lane) {
     const int ncc = g.wtp_ncc;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -453,7 +510,9 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
         tapoff[t] = (sb.dy[t] * IWp + sb.dx[t]) * 32;
         wblk[t] = (unsigned)(((sb.tw[t] * wp_ntn + (n0 >> 7)) * ncc) * 3) * 4096u;
     }
-    const unsigned wlane = (unsigned)tid * 16u;
+    // this thread's 16 bytes of a pre-split weight plane (stored in the half-swap layout): linear for the 32x32 image,
+    // (row tid & 127, half tid >> 7) for the half-major image
+    const unsigned wlane = M16 ? (unsigned)x_kc_off(tid & 127, tid >> 7) : (unsigned)tid * 16u;
     const char* xp = reinterpret_cast<const char*>(g.xp);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -491,12 +550,14 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             if (!(wrap && last_cc))
                 issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
                       lds + (buf ^ 1) * XP_STAGE_BYTES);
-            x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
+            if constexpr (M16) xp16_mfma_ktile(As, As + 12288, acc, wr, wc, lane);
+            else x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
             buf ^= 1;
         }
     }
 }
 
+template <bool M16>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g) {
     __shared__ __attribute__((aligned(16))) char lds_raw[2 * XP_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
@@ -512,27 +573,44 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
     const unsigned Mtot = (unsigned)g.B * ohw;
     // this thread DMAs bytes [16 tid, 16 tid + 16) of every plane of the A image: row R = tid >> 1, 16-B slot tid & 1,
     // which under the half-swap swizzle holds channel half (tid & 1) ^ ((R >> 3) & 1) of the row's 16 channels
-    const int R = tid >> 1;
+    // (half-major image of the 16x16x32 form: row tid & 127, channel half tid >> 7, no swizzle)
+    const int R = M16 ? (tid & 127) : (tid >> 1);
     unsigned m = (unsigned)m0 + (unsigned)R;
     if (m >= Mtot) m = Mtot - 1;                                     // tail rows: any valid pixel (outputs are dropped)
     const unsigned b = m / ohw, rem = m - b * ohw;
     const unsigned oy = rem / (unsigned)sb.OW, ox = rem - oy * (unsigned)sb.OW;
     const unsigned pixpad = (b * (unsigned)(g.IH + 2) + oy + 1u) * (unsigned)(g.IW + 2) + ox + 1u;
-    const unsigned pixbyte = pixpad * 32u + (unsigned)(((tid & 1) ^ ((R >> 3) & 1)) << 4);
+    const unsigned pixbyte = pixpad * 32u + (unsigned)((M16 ? (tid >> 7) : ((tid & 1) ^ ((R >> 3) & 1))) << 4);
 
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    switch (sb.ntaps) {
-        case 9: conv_mainloop_xp<9>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-        case 4: conv_mainloop_xp<4>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-        case 2: conv_mainloop_xp<2>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-        default: conv_mainloop_xp<1>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-    }
-    if ((g.Cout & 3) == 0) {                                         // epilogue through LDS (+ the next layer's planes)
+    if constexpr (M16) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+        switch (sb.ntaps) {
+            case 9: conv_mainloop_xp<9, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+        }
         __syncthreads();                                             // every wave has read its last fragments
-        conv_epilogue_lds(g, sb, acc, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
+        conv_epilogue_lds(g, sb, StageAcc16{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
     } else {
-        conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        switch (sb.ntaps) {
+            case 9: conv_mainloop_xp<9, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+        }
+        if ((g.Cout & 3) == 0) {                                     // epilogue through LDS (+ the next layer's planes)
+            __syncthreads();                                         // every wave has read its last fragments
+            conv_epilogue_lds(g, sb, StageAcc32{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
+        } else {
+            conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+        }
     }
 }
 
@@ -1102,7 +1180,12 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         const size_t pb = (size_t)g.B * (g.IH + 2) * (g.IW + 2) * 32;
         if (pb >= 0x7FFFFFF0ull) return GX_ERR_BAD_ARG;
         g.xp_plane_bytes = (unsigned)pb;
-        hipLaunchKernelGGL(modconv_xp_kernel, grid, dim3(GEMM_THREADS), 0, stream, g);
+        // MFMA shape of the six products: 16x16x32 (plane pairs along K, default) or 32x32x16 (GX_CONV_MFMA16=0).  Equal pipe
+        // cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
+        // 243-246 -> 256-260 TFLOP/s, same-process A/B (tools/bench_conv_xp.py)
+        static const bool m16 = [] { const char* e = getenv("GX_CONV_MFMA16"); return !(e && e[0] == '0'); }();
+        if (m16 && (g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
+        else hipLaunchKernelGGL(modconv_xp_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
         GX_CHECK_LAUNCH();
         return GX_OK;
     }

@@ -894,8 +894,9 @@ def test_modconv_xp_golden_gv2_gv3(ops):
                                              (1, 64, 128, 96, True), (2, 33, 20, 72, False)])
 def test_modconv_xp_equals_in_kernel_split(ops, b, h, cin, cout, up):
     """random shapes (odd sizes, several images per tile, Cin not a multiple of 16, Cout tails, all four parity
-    classes of the transposed conv): the x-planes path computes exactly the bf16x6 sums of the in-kernel-split path
-    — same products, same k order — so the two agree to fp32 rounding of identical operations."""
+    classes of the transposed conv): the x-planes path computes the bf16x6 sums of the in-kernel-split path — the same
+    six products per fp32 product in the same k order (pairs of them inside one 16x16x32 MFMA) — so the two agree to
+    fp32 summation-order rounding."""
     prev = ops.set_gemm_mode(1)
     try:
         torch.manual_seed(b * 100 + h)

@@ -112,7 +112,8 @@ def test_generator_full_width_vs_oracle(gpu):
 def test_generator_xp_path_equals_in_kernel_split(gpu):
     """ffhq-width generator at 64 x 64, 16 images: with the x-planes conv path (activations split once by the
     producing epilogue / blur pass, LDS-DMA main loop) the layers that qualify (>= 256 tiles) give the same taps
-    and image as the in-kernel-split path — same products, same k order."""
+    and image as the in-kernel-split path — the same six bf16 products per fp32 product; the 16x16x32 MFMA form adds
+    them pairwise inside one instruction, so the fp32 summation order (only) differs: 1e-5 after 9 layers."""
     from ganecdotes_amd import generator as GM
     from ganecdotes_amd import ops
     torch.manual_seed(17)
@@ -134,9 +135,9 @@ def test_generator_xp_path_equals_in_kernel_split(gpu):
         img1, taps1 = g([w], **kw)
         users = {k[-1] for k in ops._XPLANES}               # consumer layers that read x planes
         assert {"convs.4", "convs.5", "convs.6", "convs.7"} <= users, users
-        assert rel(img1, img0) < 2e-6
+        assert rel(img1, img0) < 1e-5
         for a, b in zip(taps1, taps0):
-            assert rel(a, b) < 2e-6
+            assert rel(a, b) < 1e-5
     finally:
         GM.CONV_XP = prev
         ops.set_gemm_mode(prev_mode)
