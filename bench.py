@@ -327,7 +327,8 @@ def main():
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
-                               f"the device generator (= the set randperm[:N] selects)",
+                               f"the device generator (= the set randperm[:N] selects); views = the 13 feature taps of both "
+                               f"perturbed latents (the RGB image, which enters no loss term, is not rendered)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": float(loss.item())},
         "roofline": roof,
