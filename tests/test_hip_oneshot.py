@@ -242,6 +242,7 @@ def test_pipeline_on_reference_format_files(gpu, tmp_path):
     for k, v in sd.items():                                    # the g_ema entry was the one loaded
         assert torch.equal(got[k].cpu(), v), k
     pipe.trainer_config.num_epochs = 30
+    torch.manual_seed(77)                  # the preprocessor's mean_latent is its first device draw
     pipe.run_pipeline()
     assert pipe.one_shot_ind == 1 and torch.equal(pipe.one_shot_latent.cpu(), w[1])
     assert float(pipe.test_labels.max()) == 2.0               # x255 brought the stored [0, 1) labels back to ids
@@ -257,9 +258,22 @@ def test_pipeline_on_reference_format_files(gpu, tmp_path):
     # the CSV is the table of results['mask_iou']
     np.testing.assert_allclose([float(v) for v in rows[1].split(",")[1:]],
                                [res["mask_iou"][0][c] for c in ("background", "a", "b")])
-    # evaluate.py's route: a second pipeline with train_hfc off loads the saved heads back
     proj = torch.load(out / "projection.pt", weights_only=False)
     assert proj[0].weight.shape == (8, 56)
+    # evaluate.py's route (evaluate.py:93-95): train_hfc / train off -> the constructor loads projection.pt /
+    # prototypes.pt back (swav_clustering.py:82-86) and the same code map, head fit and predictions come out
+    code0 = pipe.one_shot_features.clone()
+    pipe2 = OneShotPipeline(out_dir=str(out), exp_name="evaluate", model="ffhq-256", segmentor="hfc_with_swav_ffhq",
+                            custom=dict(model=str(tmp_path / "model_cfg.py"), seg=str(tmp_path / "seg_cfg.py")),
+                            num_test_samples=4, device="cuda:0")
+    pipe2.seg_config.train_hfc = False
+    pipe2.seg_config.hfc_prep_args['train'] = False
+    pipe2.trainer_config.num_epochs = 30
+    pipe2.run_pipeline(blocks_to_run=('setup',))
+    torch.manual_seed(77)                  # same mean_latent draw as the training run
+    pipe2.run_trainer()
+    assert torch.equal(pipe2.preprocessor.projection[0].weight.data.cpu(), proj[0].weight.data.cpu())
+    assert float((pipe2.one_shot_features - code0).abs().max()) == 0.0      # same heads, same generator: same codes
 
 
 def test_simclr_predict_one_latent_per_call(gpu, tmp_path):
