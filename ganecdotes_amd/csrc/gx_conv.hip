@@ -369,13 +369,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 // 32-B records of 128 padded pixel indices that differ from the un-shifted ones by the CONSTANT dy*(IW+2)+dx — no
 // masks (the border is real zeros), and for tiles inside one image row one contiguous 4 KB run.  Both operands
 // then go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no VALU, no ds_write; the
-// half-swap swizzle of the KC image (x_kc_off) is applied on the per-lane SOURCE address, the LDS side is linear.
-// Main loop = 6 DMA + 12 ds_read_b128 + 24 MFMA per wave and k-tile.
+// layout of the LDS image (half-major for the default 16x16x32 product form, the half-swap swizzle x_kc_off for the
+// 32x32x16 form) is applied on the per-lane SOURCE address, the LDS side of a DMA is linear.
+// Main loop per wave and k-tile: 6 DMA + 20 ds_read_b128 + 48 MFMA 16x16x32 (or 12 reads + 24 MFMA 32x32x16).
 constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + B planes of one k-tile: 24 KB
 
-// Epilogue of modconv_xp_kernel for a plain conv, through LDS: the wave parks one 32 x 64 accumulator block at a time
-// in its own 8 KB of (now idle) stage memory and reads it back row-contiguous, 4 channels per lane — 16-B fp32 stores
-// (a 256-B run per pixel) instead of 64 dword stores per lane, the demod / noise / bias / activation on float4, and,
+// Epilogue of modconv_xp_kernel, through LDS: the wave parks one 32 x 64 accumulator block at a time in its own
+// 8.5 KB of (now idle) stage memory and reads it back as 16 pixels x one 16-channel chunk, 4 channels per lane — 16-B
+// fp32 stores instead of 64 dword stores per lane, the demod / noise / bias / activation on float4, and,
 // when the next conv reads x planes, that conv's modulated input split RIGHT HERE (out * s_next -> three bf16
 // planes, 8 B per lane and plane): the activation is split once, by its producer, not per tap and Cout tile.
 constexpr int EPI_LDW = 68;
