@@ -687,8 +687,8 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
 // (tap, 128-row Cout tile, 16-channel chunk) one 12 KB block = the three bf16 planes (h, m, l with
 // w = h + m + l exactly) of that weight tile, each plane already in the LDS image layout (32-B rows with
 // the half-swap swizzle).  A workgroup copies a block linearly: thread t moves bytes [16 t, 16 t + 16) of each plane.
-__global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps, int Cout, int Cin, int ntn, int ncc,
-                                          unsigned short* __restrict__ planes) {
+__global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps, int Cout, int Cin, long ld, int ntn,
+                                          int ncc, unsigned short* __restrict__ planes) {
     const long total = (long)taps * ntn * ncc * 128 * 16;          // padded element count
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
@@ -696,7 +696,7 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
         const int cc = (int)(blk % ncc); blk /= ncc;
         const int tn = (int)(blk % ntn); const int tap = (int)(blk / ntn);
         const int co = tn * 128 + row, ci = cc * 16 + k;
-        const float x = (co < Cout && ci < Cin) ? wt[((long)tap * Cout + co) * Cin + ci] : 0.f;
+        const float x = (co < Cout && ci < Cin) ? wt[((long)tap * Cout + co) * ld + ci] : 0.f;
         unsigned h, m, l;
         split3(x, 0.f, h, m, l);
         unsigned short* base = planes + ((((long)tap * ntn + tn) * ncc + cc) * 3) * 2048;      // 2048 bf16 per plane
@@ -1231,7 +1231,19 @@ int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned
     const long total = (long)taps * ntn * ncc * 2048;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       wt, taps, Cout, Cin, ntn, ncc, planes);
+                       wt, taps, Cout, Cin, (long)Cin, ntn, ncc, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// The same planes for the weight operand B [N][K] (row stride ldb) of gx_gemm_f32_nt_planes: one "tap";
+// gx_gemm_weight_planes_bytes(N, K) bytes.
+int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream) {
+    if (!B || !planes || N <= 0 || K <= 0 || ldb < K) return GX_ERR_BAD_ARG;
+    const int ntn = gx_cdiv(N, 128), ncc = gx_cdiv(K, 16);
+    const long total = (long)ntn * ncc * 2048;
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       B, 1, N, K, ldb, ntn, ncc, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -33,6 +33,7 @@ struct GemmArgs {
     // images (up_rf = 1 << up_shift), up_src's the pixels (b, y / 2, x / 2) of the half-resolution table [.][N]
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
     const float* up_src; int up_shift;
+    const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
 
@@ -52,6 +53,7 @@ __device__ __forceinline__ void gemm_tile_of_block(int ntile, int& logical, int&
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane,
                                                 int split) {
+#pragma clang fp contract(off)      // one rounding per written operation: every epilogue form gives the same bits
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (long)split * g.M * g.N : g.C;
     const long ldo = to_slab ? g.N : g.ldc;
@@ -96,6 +98,7 @@ __device__ __forceinline__ const GemmArgs* gemm_late_args() {
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x16 (&acc)[MT][NT], int row0, int col0, int lane,
                                                      float* stage, int split) {
+#pragma clang fp contract(off)      // one rounding per written operation: every epilogue form gives the same bits
     constexpr int SW = 32 * NT + 4, LPR = 8 * NT, RPP = 64 / LPR;
     const GemmArgs& q = *gemm_late_args();
     const float alpha = q.alpha, beta = q.beta;
@@ -253,6 +256,190 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
     gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
 }
 
+// Epilogue of gemm_xw_kernel for beta == 0: a wave's 32 rows x 64 columns through its LDS staging area, as
+// gemm_epilogue_staged<1, 2>, but with every global LOAD the 8 store passes need — the coarse rows of the fused
+// upsample-add, the row scales — issued up front: issued pass by pass behind the wave barriers each one cost a full
+// memory latency before its store (16 dependent round trips per tile).
+__device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][2], int row0, int col0, int lane, float* stage) {
+#pragma clang fp contract(off)      // one rounding per written operation: every epilogue form gives the same bits
+    constexpr int SW = 68;
+    const GemmArgs& q = *gemm_late_args();
+    const float alpha = q.alpha;
+    const float* row_scale = q.row_scale;
+    const float* up_src = q.up_src;
+    const int rl = lane >> 4, c4 = (lane & 15) * 4;
+    const int col = col0 + c4;
+    const bool colok = col < g.N;
+    const int colc = colok ? col : 0;
+    f32x4 cb = zero4();
+    if (q.col_bias && colok) cb = *reinterpret_cast<const f32x4*>(q.col_bias + col);
+    f32x4 up[8];
+    float rs[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) { up[ps] = zero4(); rs[ps] = 1.f; }
+    if (up_src) {
+        const int s = q.up_shift, rc = 1 << (s - 1);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = min(row0 + ps * 4 + rl, g.M - 1);
+            const int b = row >> (2 * s), y = (row >> s) & ((1 << s) - 1), x = row & ((1 << s) - 1);
+            up[ps] = *reinterpret_cast<const f32x4*>(up_src + (((long)b * rc + (y >> 1)) * rc + (x >> 1)) * g.N + colc);
+        }
+    }
+    if (row_scale) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) rs[ps] = row_scale[min(row0 + ps * 4 + rl, g.M - 1)];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SW + nt * 32 + (lane & 31)] = acc[0][nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int row = row0 + ps * 4 + rl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + (ps * 4 + rl) * SW + c4);
+        v *= alpha;
+        v *= rs[ps];
+        v += cb;
+        v += up[ps];
+        if (row < g.M && colok) *reinterpret_cast<f32x4*>(g.C + (long)row * g.ldc + col) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// NT contraction with the weight operand PRE-SPLIT (gx_split_gemm_weights: the projection / prototype weights change
+// once per step, their planes are made once per step) — "xw".  What the kernel above strings in series per 16-deep
+// k-tile (global loads -> registers -> split -> six LDS plane stores -> barrier) becomes, as in modconv_xp_kernel,
+// LDS-DMA for both operands: the B planes land in their LDS image as they are stored, and A lands as RAW fp32
+// (128 rows x 16 floats = 8 KB, 16-B units swizzled so the fragment reads are conflict-free).  The activation split
+// moves to the fragment read: the four waves are stacked along M (each 32 rows x all 128 columns), so a lane's 8 k
+// values of its row are read (2 ds_read_b128) and split by exactly one lane — half the split arithmetic per k-tile of
+// the kernel above (its threads split 8 A + 8 B elements), no plane stores, no staging registers, NS-deep prefetch.
+// Products and their order equal x6_mfma_tile's, so results are bitwise those of gemm_x6_kernel.
+//   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
+constexpr int XW_A = 8192, XW_B = 3 * 4096;                          // one A tile (raw fp32), one B tile (planes)
+template <int NS>
+__global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // A ring of NS tiles, B ring of 2
+    char* const ldsB = lds + NS * XW_A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap((int)blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;                      // K, K1 are multiples of 16
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // A: units p = tid and 256 + tid; tail rows re-read the last valid row (their outputs are dropped)
+    unsigned aoff1[2], aoff2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 256 + tid;
+        int row = p >> 2;
+        const int q = (p & 3) ^ ((p >> 4) & 3);
+        row = min(row, g.M - 1 - m0);
+        aoff1[i] = ((unsigned)row * (unsigned)g.lda + (unsigned)q * 4u) * 4u;
+        aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A + (long)m0 * g.lda, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
+    const unsigned boff = (unsigned)tid * 16u;
+    const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * 3u * 4096u;
+
+    auto issue_b = [&](int kt, char* dst) {
+        const unsigned blk = bblk0 + (unsigned)kt * 3u * 4096u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)boff,
+                                                     (int)(blk + p * 4096u), 0, 0);
+    };
+    auto issue_a = [&](int kt, char* dst) {
+        const bool second = kt >= nkt1;                              // wave-uniform
+        const int ks = (second ? kt - nkt1 : kt) * 64;               // byte offset of the k-tile inside a row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff1[i], ks, 0, 0);
+        }
+    };
+
+    f32x16 acc0[1][2], acc1[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; }
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int arow = wid * 32 + r32;
+    const int af = (arow >> 2) & 3;
+    const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
+    auto compute = [&](const char* st, const char* Bs) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
+        bf16x8 b[4][3];
+        constexpr int PB[3] = {0, 2, 1};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t][PB[q]] = x6_frag<true, 128>(Bs, PB[q], t * 32 + r32, hh);
+        unsigned h[4], m[4], l[4];
+        split3(x0[0], x0[1], h[0], m[0], l[0]);
+        split3(x0[2], x0[3], h[1], m[1], l[1]);
+        split3(x1[0], x1[1], h[2], m[2], l[2]);
+        split3(x1[2], x1[3], h[3], m[3], l[3]);
+        const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]}),
+                             __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
+                             __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})};
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            acc0[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[0][TB[t]], acc0[0][0], 0, 0, 0);
+            acc0[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[1][TB[t]], acc0[0][1], 0, 0, 0);
+            acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[2][TB[t]], acc1[0][0], 0, 0, 0);
+            acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[3][TB[t]], acc1[0][1], 0, 0, 0);
+        }
+    };
+
+    // Rings: A (streamed from HBM once, 64 B per row and k-tile) NS tiles deep, B (L2-resident weights) 2 deep.  Behind
+    // the barrier that retires tile t - 1 a wave issues B(t + 1), then A(t + NS - 1), into the slots tile t - 1 used;
+    // before tile t it waits for everything up to B(t) — all but the 2 DMAs of the newest A tile.
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        if (t == NS - 2 && nkt > 0) issue_b(0, ldsB);
+        if (t < nkt) issue_a(t, lds + t * XW_A);
+    }
+    int rd = 0, wr = NS - 1;
+    for (int t = 0; t < nkt; ++t) {
+        if (NS > 2 && t + NS - 2 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nkt) issue_b(t + 1, ldsB + ((t + 1) & 1) * XW_B);
+        if (t + NS - 1 < nkt) issue_a(t + NS - 1, lds + wr * XW_A);
+        compute(lds + rd * XW_A, ldsB + (t & 1) * XW_B);
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    }
+    __syncthreads();                                                 // every wave has read its last fragments
+    float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
+    if (g.beta != 0.f) {
+        gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
+        gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
+    } else {
+        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage);
+        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage);
+    }
+}
+
 // Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
 // split arithmetic, the LDS round trip and a barrier that the 4-wave kernel above strings in series
 // with it (its MFMA pipe is busy 55 % of the time).  Here a workgroup of 512 threads owns a 256 x 128
@@ -341,6 +528,7 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int sp
                                           int M, int N, long ldc, float alpha, float beta,
                                           const float* __restrict__ row_scale,
                                           const float* __restrict__ col_bias) {
+#pragma clang fp contract(off)
     const long total = (long)M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -381,6 +569,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* up_src = nullptr, int up_rf = 0) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
+    g.Bp = nullptr; g.Bp_bytes = 0;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -441,6 +630,44 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     return GX_OK;
 }
 
+// C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C (+ upsample2(coarse)) with B given as pre-split planes
+// (gx_split_gemm_weights of the [N][K1 + K2] weight).  bf16x6 engine only; K1, K2 multiples of 16, rows 16-B aligned.
+static int xw_stages() {            // GX_GEMM_XW_STAGES=2|3 (LDS ring depth: 3 workgroups/CU at 2, 2 at 3)
+    static const int v = [] { const char* e = getenv("GX_GEMM_XW_STAGES"); return (e && e[0] == '3') ? 3 : (e && e[0] == '4') ? 4 : 2; }();
+    return v;
+}
+static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                          const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
+                          const float* col_bias, const float* up_src, int up_rf, hipStream_t stream) {
+    if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
+    if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
+    const int K = K1 + K2;
+    if ((K1 & 15) || (K2 & 15) || (lda1 & 3) || (K2 > 0 && (lda2 & 3)) || lda1 < K1 || (K2 > 0 && lda2 < K2) ||
+        lda1 >= (1 << 22) || lda2 >= (1 << 22) || (N & 3) || (ldc & 3) ||
+        (((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)Bp | (uintptr_t)C | (uintptr_t)up_src) & 15))
+        return GX_ERR_BAD_ARG;
+    GemmArgs g;
+    g.up_src = up_src; g.up_shift = 0;
+    if (up_src) {
+        if (up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
+        while ((1 << g.up_shift) < up_rf) ++g.up_shift;
+    }
+    g.A = A1; g.lda = lda1; g.A2 = K2 > 0 ? A2 : nullptr; g.lda2 = K2 > 0 ? lda2 : lda1; g.K1 = K1;
+    g.B = nullptr; g.ldb = 0; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+    g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
+    g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
+    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
+    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
+    if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
+    g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
+    const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
+    if (xw_stages() == 3) hipLaunchKernelGGL(gemm_xw_kernel<3>, grid, block, 0, stream, g);
+    else if (xw_stages() == 4) hipLaunchKernelGGL(gemm_xw_kernel<4>, grid, block, 0, stream, g);
+    else hipLaunchKernelGGL(gemm_xw_kernel<2>, grid, block, 0, stream, g);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
 }  // namespace gx
 
 extern "C" {
@@ -485,6 +712,18 @@ int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long ld
     if (!coarse || K2 < 0 || (K2 > 0 && !A2)) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(0, transB, M, N, K1 + K2, A1, lda1, B, ldb, C, ldc, 1.f, beta, nullptr, nullptr, 1, nullptr, 0,
                            (hipStream_t)stream, K2 > 0 ? A2 : nullptr, K2 > 0 ? lda2 : 0, K2 > 0 ? K1 : -1, coarse, fine_res);
+}
+
+// The NT contraction with pre-split weight planes (gemm_xw_kernel): C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias
+// + beta * C + upsample2(coarse).  b_planes = gx_split_gemm_weights(B [N][K1 + K2]); K2 = 0 / coarse = NULL / row_scale
+// = NULL / col_bias = NULL switch the optional parts off.  Results are bitwise those of gx_gemm_f32 / _cat / _upadd on
+// the bf16x6 engine.
+size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 3 * 4096; }
+int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                          const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
+                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream) {
+    return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
+                              fine_res, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -150,6 +150,49 @@ def gemm_upadd(a1, a2, b, out, coarse, fine_res, beta=0.0):
     return out
 
 
+def split_gemm_weights(b):
+    """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
+    Made once per optimizer step: the projection / prototype weights only change there."""
+    _chk2d(b)
+    n, k = b.shape
+    L = lib()
+    planes = torch.empty(L.gx_gemm_weight_planes_bytes(n, k) // 2, dtype=torch.int16, device=b.device)
+    _lib.check(L.gx_split_gemm_weights(_p(b), n, k, b.stride(0), _p(planes), _stream()), "gx_split_gemm_weights")
+    return planes
+
+
+def gemm_planes_ok(a1, a2, n, out):
+    """shapes gemm_nt_planes takes (bf16x6 engine, 16-channel chunks, 16-B aligned rows)"""
+    if lib().gx_get_gemm_mode() != 1 or n % 4 or out.stride(0) % 4 or out.data_ptr() % 16:
+        return False
+    for a in (a1, a2):
+        if a is not None and (a.shape[1] % 16 or a.stride(0) % 4 or a.data_ptr() % 16 or a.stride(0) >= (1 << 22)):
+            return False
+    return True
+
+
+def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0):
+    """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
+    split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd."""
+    _chk2d(a1, a2, out, coarse)
+    _chk(row_scale, col_bias)
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = out.shape[1]
+    if out.shape[0] != m or (a2 is not None and a2.shape[0] != m):
+        raise RuntimeError("gemm_nt_planes: shape mismatch")
+    if coarse is not None and (tuple(coarse.shape) != (m // 4, n) or coarse.stride(0) != n):
+        raise RuntimeError("gemm_nt_planes: bad coarse table")
+    L = lib()
+    if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(n, k1 + k2):
+        raise RuntimeError("gemm_nt_planes: planes do not match (N, K)")
+    with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
+        _lib.check(L.gx_gemm_f32_nt_planes(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
+                                           _p(b_planes), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
+                                           _p(coarse), fine_res, _stream()), "gx_gemm_f32_nt_planes")
+    return out
+
+
 # ------------------------------------------------------------------------------------- pyramid projection
 def upsample2_add_(coarse, fine):
     """fine (B, 2r, 2r, D) += nearest-upsampled coarse (B, r, r, D)."""

@@ -17,6 +17,7 @@ import torch
 from . import ops
 
 FUSE_UP = os.environ.get("GX_PYRAMID_FUSE", "1") != "0"      # 0: separate upsample-add passes (A/B measurements)
+WP_PLANES = os.environ.get("GX_PYRAMID_PLANES", "1") != "0"  # 0: in-kernel weight split (gemm_x6_kernel; A/B measurements)
 
 
 class Pyramid:
@@ -50,6 +51,15 @@ class Pyramid:
             up = prev.reshape(-1, d) if (FUSE_UP and prev is not None and used and (r & (r - 1)) == 0) else None
             if not used:
                 p.zero_()
+            elif (WP_PLANES and len(used) <= 2 and used[0][2] == used[0][0].shape[1] and
+                  (len(used) == 1 or used[1][1] == used[0][1] + used[0][2]) and
+                  ops.gemm_planes_ok(used[0][0], used[1][0][:, :used[1][2]] if len(used) == 2 else None, d, p)):
+                # the level's weight columns as bf16x6 planes, split once per call (Wp changes once per step):
+                # both operands of the projection then reach LDS by DMA (gemm_xw_kernel)
+                ta, off, ca = used[0]
+                tb = used[1][0][:, :used[1][2]] if len(used) == 2 else None
+                kk = ca + (used[1][2] if len(used) == 2 else 0)
+                ops.gemm_nt_planes(ta, tb, ops.split_gemm_weights(wp[:, off:off + kk]), p, coarse=up, fine_res=r if up is not None else 0)
             elif (len(used) == 2 and used[0][2] == used[0][0].shape[1] and used[0][2] % 32 == 0 and
                   used[1][1] == used[0][1] + used[0][2]):
                 (ta, off, ca), (tb, _, cb) = used

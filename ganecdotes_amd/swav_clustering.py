@@ -273,6 +273,8 @@ class SwAVClustering(ViewMixin):
         # batched Sinkhorn (as many as fit 16 GB of scores); the panel path keeps a (rows, hlen)
         # descriptor panel per view alive until its backward, so it goes patch by patch.
         pgroup = max(1, min(P, int(16e9 // (8.0 * rows * K)))) if mode == 'pyramid' else 1
+        # generic-K scores: the prototype weights as bf16x6 planes, once per step (gemm_xw_kernel)
+        wc_planes = ops.split_gemm_weights(Wc) if (not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0) else None
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
@@ -302,7 +304,10 @@ class SwAVClustering(ViewMixin):
                             z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
                         X.append(x)
-                    ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)              # (B*N, K)
+                    if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
+                        ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)        # (B*N, K), Wc split once per step
+                    else:
+                        ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)
                     Zh.append(z); Rn.append(rn)
                 keep.append((X, Zh, Rn))
             # S4: every (patch, view[, image]) problem of the group in one batched Sinkhorn

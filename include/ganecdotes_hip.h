@@ -82,6 +82,18 @@ int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long ld
                       const float* B, long ldb, float* C, long ldc, float beta, const float* coarse, int fine_res,
                       void* stream);
 
+/* The NT contraction with the weight operand pre-split into bf16x6 planes once per step (the projection / prototype
+ * weights change once per optimizer step): C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C
+ * + upsample2(coarse).  b_planes = gx_split_gemm_weights(B [N][K1 + K2], ldb) (gx_gemm_weight_planes_bytes(N, K1 + K2)
+ * bytes); K2 = 0, coarse / row_scale / col_bias = NULL switch the optional parts off.  bf16x6 engine only (GX_ERR_BAD_ARG
+ * otherwise); K1, K2 multiples of 16, 16-B aligned rows.  Bitwise the result of gx_gemm_f32 / _cat / _upadd on that
+ * engine.  Same reference ops as gx_gemm_f32 (swav_clustering.py:171-175). */
+size_t gx_gemm_weight_planes_bytes(int N, int K);
+int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream);
+int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                          const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
+                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream);
+
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110
  * gx_bias_act        EqualLinear epilogue / fused_leaky_relu     model.py:32-43, :242-252;

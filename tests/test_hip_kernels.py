@@ -543,6 +543,54 @@ def test_gemm_upadd_fused_pyramid_level(ops, engine):
                        dev(torch.randn(18, 8)), 6)
 
 
+def test_gemm_nt_planes_bitwise_and_fp64(ops):
+    """gx_gemm_f32_nt_planes (weights pre-split once per step, both operands by LDS-DMA): against fp64 and BITWISE
+    against gx_gemm_f32 / _cat / _upadd on the bf16x6 engine, incl. ragged M / N tails, strided views, every epilogue
+    term; the exact-fp32 engine and unaligned shapes are refused loudly."""
+    torch.manual_seed(28)
+    prev = ops.set_gemm_mode(1)
+    try:
+        for (m, n, k1, k2, up) in ((300, 132, 32, 0, 0), (1024, 512, 64, 16, 8), (4160, 260, 128, 128, 0), (4096, 512, 256, 0, 16),
+                                   (77, 8, 16, 0, 0)):
+            a1 = torch.randn(m, k1 + 8)
+            a2 = torch.randn(m, k2 + 4) if k2 else None
+            w = torch.randn(n, k1 + k2 + 12)
+            rs, cb = torch.rand(m) + 0.5, torch.randn(n)
+            co = torch.randn(m // 4, n) if up else None
+            a1d, a2d, wd = dev(a1)[:, :k1], (dev(a2)[:, :k2] if k2 else None), dev(w)[:, 4:4 + k1 + k2]
+            bp = ops.split_gemm_weights(wd)
+            acat = (a1[:, :k1] if not k2 else torch.cat([a1[:, :k1], a2[:, :k2]], 1)).double()
+            base = acat @ w[:, 4:4 + k1 + k2].double().t()
+            prior = torch.randn(m, n)
+            ref, out = dev(prior.clone()), dev(prior.clone())
+            if up:
+                upd = co.reshape(-1, up // 2, up // 2, n).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(m, n).double()
+                ops.gemm_upadd(a1d, a2d, wd, ref, dev(co), up)
+                ops.gemm_nt_planes(a1d, a2d, bp, out, coarse=dev(co), fine_res=up)
+                want = base + upd
+            elif k2:
+                ops.gemm_cat(a1d, a2d, wd, ref, alpha=0.7, beta=0.25)
+                ops.gemm_nt_planes(a1d, a2d, bp, out, alpha=0.7, beta=0.25)
+                want = 0.7 * base + 0.25 * prior.double()
+            else:
+                ops.gemm(a1d, wd, False, True, out=ref, alpha=1.3, row_scale=dev(rs), col_bias=dev(cb))
+                ops.gemm_nt_planes(a1d, None, bp, out, alpha=1.3, row_scale=dev(rs), col_bias=dev(cb))
+                want = 1.3 * rs.double()[:, None] * base + cb.double()[None, :]
+            assert rel_err(out, want) < 3e-6
+            assert torch.equal(out, ref), (m, n, k1, k2, up)
+        a, w = dev(torch.randn(64, 24)), dev(torch.randn(16, 24))            # K % 16 != 0
+        assert not ops.gemm_planes_ok(a, None, 16, torch.empty(64, 16, device="cuda"))
+        with pytest.raises(RuntimeError):
+            ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), torch.empty(64, 16, device="cuda"))
+        ops.set_gemm_mode(0)                                                  # planes belong to the bf16x6 engine
+        a, w = dev(torch.randn(64, 32)), dev(torch.randn(16, 32))
+        assert not ops.gemm_planes_ok(a, None, 16, torch.empty(64, 16, device="cuda"))
+        with pytest.raises(RuntimeError):
+            ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), torch.empty(64, 16, device="cuda"))
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 def test_pyramid_pieces(ops):
     torch.manual_seed(12)
     b, r, d = 2, 8, 24
