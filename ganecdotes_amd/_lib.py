@@ -46,6 +46,7 @@ SIGNATURES = {
     "gx_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p,
                           c_sz, c_p]),
     "gx_gemm_f32_cat": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p]),
+    "gx_gemm_f32_tn_cat": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_i, c_p, c_sz, c_p]),
     "gx_gemm_weight_planes_bytes": (c_sz, [c_i, c_i]),
     "gx_split_gemm_weights": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p]),

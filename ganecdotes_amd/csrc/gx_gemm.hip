@@ -29,6 +29,9 @@ struct GemmArgs {
     // optional second A source, concatenated along K after the first K1 columns (A = [A | A2]);
     // K1 is a multiple of BK (K1 == K when unused).  Non-transposed A only.
     const float* A2; long lda2; int K1;
+    // optional second B source, concatenated along N after the first N1 columns (B = [B1 | B2], both [K][.], n
+    // contiguous); N1 is a multiple of BN, so a tile's columns come from one source (N1 == N when unused)
+    const float* B2; long ldb2; int N1;
     // optional epilogue term C[m][n] += up_src[coarse(m)][n]: C's rows are the pixels (b, y, x) of up_rf x up_rf
     // images (up_rf = 1 << up_shift), up_src's the pixels (b, y / 2, x / 2) of the half-resolution table [.][N]
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
@@ -165,6 +168,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const bool bsec = n0 >= g.N1;                                    // [B1 | B2]: this tile's columns are B2's
+    const float* Bsrc = bsec ? g.B2 : g.B;
+    const long ldbs = bsec ? g.ldb2 : g.ldb;
+    const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (nkt > 0) {
         load_a(kbeg);
-        load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
+        load_tile<B_KC, VEC>(Bsrc, ldbs, nb0, nbN, kbeg, kend, rb, tid);
         store_tile<A_KC>(lds, ra, tid);
         store_tile<B_KC>(lds + TILE_FLOATS, rb, tid);
     }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         const bool more = (t + 1 < nkt);
         if (more) {   // issue next tile's global loads before the MFMA phase (latency hides under it)
             load_a(kbeg + (t + 1) * BK);
-            load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, rb, tid);
+            load_tile<B_KC, VEC>(Bsrc, ldbs, nb0, nbN, kbeg + (t + 1) * BK, kend, rb, tid);
         }
         mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
         if (more) {
@@ -217,6 +224,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
     gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const bool bsec = n0 >= g.N1;                                    // [B1 | B2]: this tile's columns are B2's
+    const float* Bsrc = bsec ? g.B2 : g.B;
+    const long ldbs = bsec ? g.ldb2 : g.ldb;
+    const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
     const int nkt = (kend - kbeg + XK - 1) / XK;
     if (nkt > 0) {
         load_a(kbeg);
-        x6_load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
+        x6_load_tile<B_KC, VEC>(Bsrc, ldbs, nb0, nbN, kbeg, kend, rb, tid);
         x6_store_tile<A_KC>(lds, ra, tid);
         x6_store_tile<B_KC>(lds + X_TILE_BYTES, rb, tid);
     }
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
         const bool more = (t + 1 < nkt);
         if (more) {   // next tile's global loads fly under this tile's MFMAs (a deeper, two-tile prefetch was slower)
             load_a(kbeg + (t + 1) * XK);
-            x6_load_tile<B_KC, VEC>(g.B, g.ldb, n0, g.N, kbeg + (t + 1) * XK, kend, rb, tid);
+            x6_load_tile<B_KC, VEC>(Bsrc, ldbs, nb0, nbN, kbeg + (t + 1) * XK, kend, rb, tid);
         }
         x6_mfma_ktile<A_KC, B_KC>(As, Bs, acc, wr, wc, lane);
         if (more) {
@@ -465,6 +476,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     gemm_tile_of_block(ntile, logical, split);
     const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
     const int m0 = tm * WS_BM, n0 = tn * WS_BN;
+    const bool bsec = n0 >= g.N1;                                    // [B1 | B2]: this tile's columns are B2's
+    const float* Bsrc = bsec ? g.B2 : g.B;
+    const long ldbs = bsec ? g.ldb2 : g.ldb;
+    const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nkt = (kend - kbeg + XK - 1) / XK;
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
             x6_load_tile<A_KC, VEC, WS_BM>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M,
                                            second ? k0 - g.K1 : k0,
                                            second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, p);
-            x6_load_tile<B_KC, VEC, WS_BN>(g.B, g.ldb, n0, g.N, k0, kend, rb, p);
+            x6_load_tile<B_KC, VEC, WS_BN>(Bsrc, ldbs, nb0, nbN, k0, kend, rb, p);
         };
         auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
             x6_store_tile<A_KC, WS_BM>(slot, ra, p);
@@ -566,7 +581,8 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        long ldb, float* C, long ldc, float alpha, float beta, const float* row_scale,
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
-                       const float* up_src = nullptr, int up_rf = 0) {
+                       const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
+                       int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.Bp = nullptr; g.Bp_bytes = 0;
@@ -576,11 +592,13 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         while ((1 << g.up_shift) < up_rf) ++g.up_shift;
     }
     g.A2 = A2; g.lda2 = lda2; g.K1 = (A2 ? K1 : K);
+    g.B2 = B2; g.ldb2 = B2 ? ldb2 : ldb; g.N1 = (B2 ? N1 : N);
+    if (B2 && (transB || N1 <= 0 || N1 >= N || (N1 % BN) != 0 || ldb2 < N - N1)) return GX_ERR_BAD_ARG;
     if (A2 && (transA || K1 <= 0 || K1 >= K || (K1 % BK) != 0 || lda2 <= 0)) return GX_ERR_BAD_ARG;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
-    g.vec_ok = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
-               (lda2 % 4 == 0) && lda < (1 << 22) && ldb < (1 << 22) && lda2 < (1 << 22) && (K % 4 == 0) && (g.K1 % 4 == 0) && (!transA || M % 4 == 0) &&
+    g.vec_ok = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
+               (lda2 % 4 == 0) && (g.ldb2 % 4 == 0) && g.ldb2 < (1 << 22) && lda < (1 << 22) && ldb < (1 << 22) && lda2 < (1 << 22) && (K % 4 == 0) && (g.K1 % 4 == 0) && (!transA || M % 4 == 0) &&
                (transB || N % 4 == 0);
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
@@ -653,7 +671,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
         while ((1 << g.up_shift) < up_rf) ++g.up_shift;
     }
     g.A = A1; g.lda = lda1; g.A2 = K2 > 0 ? A2 : nullptr; g.lda2 = K2 > 0 ? lda2 : lda1; g.K1 = K1;
-    g.B = nullptr; g.ldb = 0; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+    g.B = nullptr; g.ldb = 0; g.B2 = nullptr; g.ldb2 = 0; g.N1 = N; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
@@ -724,6 +742,16 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream) {
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
                               fine_res, (hipStream_t)stream);
+}
+
+// C = alpha * A^T [B1 | B2] + beta * C: A is [K][M], B1 [K][N1], B2 [K][N2] (N1 a multiple of 128).  The weight gradient
+// of one pyramid level against both of its taps in ONE pass over the (large) A = dZ table instead of two.
+int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
+                       long ldb2, float* C, long ldc, float alpha, float beta, int split_k, float* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!B2 || N2 <= 0) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(1, 0, M, N1 + N2, K, A, lda, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
+                           workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1);
 }
 
 }  // extern "C"

@@ -150,6 +150,24 @@ def gemm_upadd(a1, a2, b, out, coarse, fine_res, beta=0.0):
     return out
 
 
+def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
+    """out (M, N1+N2) = alpha * a.T @ [b1 | b2] + beta*out for a stored (K, M), b1 (K, N1), b2 (K, N2); N1 % 128 == 0."""
+    _chk2d(a, b1, b2, out)
+    k, m = a.shape
+    n1, n2 = b1.shape[1], b2.shape[1]
+    if b1.shape[0] != k or b2.shape[0] != k or tuple(out.shape) != (m, n1 + n2):
+        raise RuntimeError("gemm_tn_cat: shape mismatch")
+    L = lib()
+    ws, wsb = None, 0
+    if split_k > 1:
+        wsb = L.gx_gemm_f32_workspace_bytes(m, n1 + n2, split_k)
+        ws = workspace("gemm", wsb, a.device)
+    with record("gemm_f32_kernel", 2.0 * m * (n1 + n2) * k):
+        _lib.check(L.gx_gemm_f32_tn_cat(m, n1, n2, k, _p(a), a.stride(0), _p(b1), b1.stride(0), _p(b2), b2.stride(0), _p(out),
+                                        out.stride(0), alpha, beta, split_k, _p(ws), wsb, _stream()), "gx_gemm_f32_tn_cat")
+    return out
+
+
 def split_gemm_weights(b):
     """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
     Made once per optimizer step: the projection / prototype weights only change there."""

@@ -17,6 +17,7 @@ import torch
 from . import ops
 
 FUSE_UP = os.environ.get("GX_PYRAMID_FUSE", "1") != "0"      # 0: separate upsample-add passes (A/B measurements)
+TN_CAT = os.environ.get("GX_PYRAMID_TNCAT", "1") != "0"      # 0: one weight-gradient GEMM per tap (A/B measurements)
 WP_PLANES = os.environ.get("GX_PYRAMID_PLANES", "1") != "0"  # 0: in-kernel weight split (gemm_x6_kernel; A/B measurements)
 
 
@@ -96,9 +97,16 @@ class Pyramid:
         for r, taps in zip(reversed(self.res), reversed(self.levels)):
             rows = self.B * r * r
             g2 = g.reshape(rows, -1)
-            for t, off, cu in taps:
-                if cu <= 0:
-                    continue
+            used = [(t, off, cu) for t, off, cu in taps if cu > 0]
+            if (TN_CAT and len(used) == 2 and used[0][2] % 128 == 0 and used[1][1] == used[0][1] + used[0][2]):
+                # both taps of the level against ONE pass over the level's dZ
+                (ta, off, ca), (tb, _, cb) = used
+                tiles = ((g2.shape[1] + 127) // 128) * ((ca + cb + 127) // 128)
+                split = int(max(1, min(512 // tiles, rows // 256)))
+                ops.gemm_tn_cat(g2, ta[:, :ca], tb[:, :cb], gwp[:, off:off + ca + cb], beta=0.0 if first else 1.0, split_k=split)
+                touched.update(((off, ca), (off + ca, cb)))
+                used = []
+            for t, off, cu in used:
                 tiles = ((g2.shape[1] + 127) // 128) * ((cu + 127) // 128)
                 split = int(max(1, min(512 // tiles, rows // 256)))
                 ops.gemm(g2, t[:, :cu], True, False, out=gwp[:, off:off + cu], beta=0.0 if first else 1.0,

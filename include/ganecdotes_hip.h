@@ -82,6 +82,12 @@ int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long ld
                       const float* B, long ldb, float* C, long ldc, float beta, const float* coarse, int fine_res,
                       void* stream);
 
+/* C = alpha * A^T [B1 | B2] + beta * C with A [K][M], B1 [K][N1], B2 [K][N2] (N1 a multiple of 128): the projection-weight
+ * gradient of one pyramid level against both of its taps in one pass over dZ (autograd of swav_clustering.py:171). */
+int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
+                       long ldb2, float* C, long ldc, float alpha, float beta, int split_k, float* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* The NT contraction with the weight operand pre-split into bf16x6 planes once per step (the projection / prototype
  * weights change once per optimizer step): C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C
  * + upsample2(coarse).  b_planes = gx_split_gemm_weights(B [N][K1 + K2], ldb) (gx_gemm_weight_planes_bytes(N, K1 + K2)

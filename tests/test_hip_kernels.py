@@ -591,6 +591,26 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
         ops.set_gemm_mode(prev)
 
 
+def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
+    """gx_gemm_f32_tn_cat: A^T [B1 | B2] in one launch == the two per-tap TN GEMMs (bitwise at equal split) == fp64"""
+    torch.manual_seed(29)
+    for k, m, n1, n2, split in ((700, 48, 128, 40, 3), (4096, 512, 256, 256, 8), (1030, 130, 128, 128, 1)):
+        a, b1, b2 = torch.randn(k, m), torch.randn(k, n1 + 4), torch.randn(k, n2 + 8)
+        ad, b1d, b2d = dev(a), dev(b1)[:, :n1], dev(b2)[:, :n2]
+        prior = torch.randn(m, n1 + n2 + 6)
+        out, ref = dev(prior.clone()), dev(prior.clone())
+        ops.gemm_tn_cat(ad, b1d, b2d, out[:, 3:3 + n1 + n2], alpha=0.5, beta=1.0, split_k=split)
+        ops.gemm(ad, b1d, True, False, out=ref[:, 3:3 + n1], alpha=0.5, beta=1.0, split_k=split)
+        ops.gemm(ad, b2d, True, False, out=ref[:, 3 + n1:3 + n1 + n2], alpha=0.5, beta=1.0, split_k=split)
+        want = prior.double()
+        want[:, 3:3 + n1 + n2] += 0.5 * (a.double().t() @ torch.cat([b1[:, :n1], b2[:, :n2]], 1).double())
+        assert rel_err(out, want) < 3e-6
+        assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError):                      # N1 must be a whole number of 128-column tiles
+        ops.gemm_tn_cat(dev(torch.randn(64, 32)), dev(torch.randn(64, 40)), dev(torch.randn(64, 8)),
+                        torch.empty(32, 48, device="cuda"))
+
+
 def test_pyramid_pieces(ops):
     torch.manual_seed(12)
     b, r, d = 2, 8, 24
