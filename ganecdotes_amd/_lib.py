@@ -132,6 +132,9 @@ SIGNATURES = {
     "gx_hist_counts": (c_i, [c_p, c_l, c_p, c_i, c_p, c_p, c_p]),
     "gx_hist_finish": (c_i, [c_p, c_i, c_p]),
     "gx_swapped_ce_workspace_bytes": (c_sz, [c_l, c_i]),
+    "gx_swapped_ce_fused_workspace_bytes": (c_sz, [c_i]),
+    "gx_swapped_ce_fused": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_f,
+                                  c_p, c_sz, c_p]),
     "gx_swapped_ce": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p,
                             c_sz, c_p]),
     "gx_col_stats_workspace_bytes": (c_sz, [c_i]),

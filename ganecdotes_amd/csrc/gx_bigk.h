@@ -312,6 +312,162 @@ __global__ __launch_bounds__(256, 4) void ce_apply_bigk_kernel(const float* __re
     if (threadIdx.x == 0) loss_part[blockIdx.x] = -0.5f * tot;
 }
 
+// The swapped CE as ONE pass (block per pair of rows, columns spread over the 256 threads as in bigk_pass_kernel):
+// both views' rows stay in registers (2 rows x 2 views x NJ/4 floats per thread) between the row statistics — two
+// block reductions through LDS — and the element-wise part, so the score matrices are read once instead of twice,
+// and the column sums of dS (the prototype-bias gradient, until now a pass of its own over dS) leave as the block's
+// partial row.  4 passes over a (rows, K) matrix per view pair (read 2, write 2) instead of 7.
+//   part_s / part_t [gridDim.x][K]: column sums of dSs / dSt over the block's rows
+constexpr int CE_R = 2;
+template <int NJ>
+__global__ __launch_bounds__(256, 3) void ce_fused_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+                                                               long rows, int K, long ld, float inv_eps, float inv_T,
+                                                               const float* __restrict__ la_s, const float* __restrict__ la_t,
+                                                               float gscale, float* __restrict__ dSs, float* __restrict__ dSt,
+                                                               long ldd, float* __restrict__ loss_part,
+                                                               float* __restrict__ part_s, float* __restrict__ part_t) {
+    constexpr int NC = (NJ + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // las[K] | lat[K] | red[2][CE_R][4 stats][4 waves]
+    float* las = sm;
+    float* lat = sm + K;
+    float* red = sm + 2 * K;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int k = tid; k < K; k += 256) { las[k] = la_s[k]; lat[k] = la_t[k]; }
+    __syncthreads();
+    const float f = -0.5f * gscale * inv_T;
+    f32x4 cs[NC], ct[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { cs[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ct[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float lacc = 0.f;
+    const long ngroups = (rows + CE_R - 1) / CE_R;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long r0 = grp * CE_R;
+        f32x4 a[CE_R][NC], b[CE_R][NC];
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r) {
+            const bool live = r0 + r < rows;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(Ss, live ? r0 + r : 0, ld, live ? K : 0);
+            const __amdgpu_buffer_rsrc_t rt = bk_row_rsrc(St, live ? r0 + r : 0, ld, live ? K : 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { a[r][c] = bk_load4(rs, 4 * (tid + 256 * c)); b[r][c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+        }
+        // maxima: wm_X = max_k (X_k / eps + la_X,k), m_X = max_k X_k
+        float mx[CE_R][4];
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx[r][j] = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = 4 * (tid + 256 * c);
+            if (k < K) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(las + k), lt = *reinterpret_cast<const f32x4*>(lat + k);
+#pragma unroll
+                for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        mx[r][0] = fmaxf(mx[r][0], fmaf(a[r][c][q], inv_eps, ls[q]));
+                        mx[r][1] = fmaxf(mx[r][1], a[r][c][q]);
+                        mx[r][2] = fmaxf(mx[r][2], fmaf(b[r][c][q], inv_eps, lt[q]));
+                        mx[r][3] = fmaxf(mx[r][3], b[r][c][q]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = gx_wave_max(mx[r][j]);
+                if (lane == 0) red[(r * 4 + j) * 4 + wid] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* p = red + (r * 4 + j) * 4;
+                mx[r][j] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+            }
+        // sums: v_X = sum_k exp(X_k / eps + la_X,k - wm_X), z_X = sum_k exp((X_k - m_X) / T)
+        float sv[CE_R][4];
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv[r][j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = 4 * (tid + 256 * c);
+            if (k < K) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(las + k), lt = *reinterpret_cast<const f32x4*>(lat + k);
+#pragma unroll
+                for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sv[r][0] += bk_exp(fmaf(a[r][c][q], inv_eps, ls[q]) - mx[r][0]);
+                        sv[r][1] += bk_exp((a[r][c][q] - mx[r][1]) * inv_T);
+                        sv[r][2] += bk_exp(fmaf(b[r][c][q], inv_eps, lt[q]) - mx[r][2]);
+                        sv[r][3] += bk_exp((b[r][c][q] - mx[r][3]) * inv_T);
+                    }
+            }
+        }
+        float* red2 = red + CE_R * 16;
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = gx_wave_sum(sv[r][j]);
+                if (lane == 0) red2[(r * 4 + j) * 4 + wid] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CE_R; ++r) {
+            if (r0 + r >= rows) continue;                                // block-uniform
+            float t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* p = red2 + (r * 4 + j) * 4;
+                t4[j] = (p[0] + p[1]) + (p[2] + p[3]);
+            }
+            const float wm_s = mx[r][0], m_s = mx[r][1], wm_t = mx[r][2], m_t = mx[r][3];
+            const float iv_s = 1.f / t4[0], z_s = t4[1], iv_t = 1.f / t4[2], z_t = t4[3];
+            const float iz_s = 1.f / z_s, iz_t = 1.f / z_t, lz_s = logf(z_s), lz_t = logf(z_t);
+            const __amdgpu_buffer_rsrc_t ds = bk_row_rsrc(dSs, r0 + r, ldd, K), dt = bk_row_rsrc(dSt, r0 + r, ldd, K);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = 4 * (tid + 256 * c);
+                if (k < K) {
+                    const f32x4 ls = *reinterpret_cast<const f32x4*>(las + k), lt = *reinterpret_cast<const f32x4*>(lat + k);
+                    f32x4 d_s, d_t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float qs = bk_exp(fmaf(a[r][c][q], inv_eps, ls[q]) - wm_s) * iv_s;
+                        const float qt = bk_exp(fmaf(b[r][c][q], inv_eps, lt[q]) - wm_t) * iv_t;
+                        const float xs = (a[r][c][q] - m_s) * inv_T, xt = (b[r][c][q] - m_t) * inv_T;
+                        lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
+                        d_t[q] = f * (qs - bk_exp(xt) * iz_t);
+                        d_s[q] = f * (qt - bk_exp(xs) * iz_s);
+                    }
+                    bk_store4(dt, k, d_t); bk_store4(ds, k, d_s);
+                    cs[c] += d_s; ct[c] += d_t;
+                }
+            }
+        }
+        // (the next group's first barrier orders this group's reads of `red2` before its writes, and its second
+        //  barrier those of `red`)
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = 4 * (tid + 256 * c);
+        if (k < K) {
+            *reinterpret_cast<f32x4*>(part_s + (long)blockIdx.x * K + k) = cs[c];
+            *reinterpret_cast<f32x4*>(part_t + (long)blockIdx.x * K + k) = ct[c];
+        }
+    }
+    __syncthreads();
+    const float tot = gx_block_sum(lacc, red);
+    if (tid == 0) loss_part[blockIdx.x] = -0.5f * tot;
+}
+
 static inline int bigk_nj(int K) {          // registers per lane for a row of K scores; 0 = not supported
     const int need = (K + 63) / 64;
     const int opts[] = {16, 32, 48, 64, 80, 96};

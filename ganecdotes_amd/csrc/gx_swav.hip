@@ -897,6 +897,37 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
+// The same loss and d(scores) as gx_swapped_ce for many prototypes (64 < K <= 6144, 16-B aligned rows) in ONE pass
+// over the two score matrices (ce_fused_bigk_kernel), plus gb = gb_beta * gb + column sums of (dSs + dSt) — the
+// prototype-bias gradient, otherwise a gx_colsum pass over each dS.  GX_ERR_BAD_ARG for shapes the fused kernel
+// does not take (the caller then uses gx_swapped_ce + gx_colsum).
+size_t gx_swapped_ce_fused_workspace_bytes(int K) { return ((size_t)2048 + (size_t)2 * 2048 * K) * sizeof(float); }
+int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
+                        const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
+                        float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta, float* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!Ss || !St || !la_s || !la_t || !loss_out || !dSs || !dSt || !gb || rows <= 0 || K <= 0 || ld < K || ldd < K)
+        return GX_ERR_BAD_ARG;
+    if (!bigk_ok(K) || !bigk_aligned(Ss, ld) || !bigk_aligned(St, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd))
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_swapped_ce_fused_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    long nb = (rows + CE_R - 1) / CE_R;
+    const int nbk = (int)(nb < 2040 ? nb : 2040);
+    const size_t lds = ((size_t)2 * K + 2 * CE_R * 16) * sizeof(float);
+    float* part_s = workspace + 2048;
+    float* part_t = part_s + (size_t)2048 * K;
+    GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((ce_fused_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds, (hipStream_t)stream,
+                                                    Ss, St, rows, K, ld, 1.f / eps, 1.f / temperature, la_s, la_t, grad_scale,
+                                                    dSs, dSt, ldd, workspace, part_s, part_t));
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(part_s, nbk, K, 1.f, gb_beta, gb, (hipStream_t)stream, part_s + (size_t)2040 * K);
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(part_t, nbk, K, 1.f, 1.f, gb, (hipStream_t)stream, part_t + (size_t)2040 * K);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 // Every (patch, row group) pair of a step in one launch (K <= 64, contiguous rows: ld == K).  Scores S_all
 // [npatch][2 views][rows_per_patch][K] with row groups of `rows` rows (ngroups per patch: 1 for the global
 // Sinkhorn scope, B for the per-image one); la_all [(patch*2 + view)*ngroups + group][K] (SinkhornBatch order);

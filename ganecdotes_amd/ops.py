@@ -952,6 +952,26 @@ def swapped_ce(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_b
     return loss_out
 
 
+def swapped_ce_fused_ok(sk_s, d_s):
+    """many prototypes, aligned rows: the one-pass CE that also returns the bias gradient (gx_swapped_ce_fused)"""
+    k, S = sk_s.K, sk_s.S
+    return (64 < k <= 6144 and k % 4 == 0 and d_s is not None and S.stride(0) % 4 == 0 and d_s.stride(0) % 4 == 0 and
+            S.data_ptr() % 16 == 0 and d_s.data_ptr() % 16 == 0)
+
+
+def swapped_ce_fused(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, gb, gb_beta):
+    """swapped_ce + gb = gb_beta * gb + colsum(d_s) + colsum(d_t), one pass over the two score matrices"""
+    S, T = sk_s.S, sk_t.S
+    _chk(loss_out, d_s, d_t, gb)
+    L = lib()
+    wsb = L.gx_swapped_ce_fused_workspace_bytes(sk_s.K)
+    ws = workspace("ce_fused", wsb, S.device)
+    _lib.check(L.gx_swapped_ce_fused(_p(S), _p(T), sk_s.rows, sk_s.K, S.stride(0), sk_s.eps, temperature, _p(sk_s.la),
+                                     _p(sk_t.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), loss_scale, loss_beta,
+                                     _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()), "gx_swapped_ce_fused")
+    return loss_out
+
+
 # ------------------------------------------------------------------------------------- SimCLR head
 def col_stats(x):
     """(mean, biased var) over the rows of x (rows, D)"""

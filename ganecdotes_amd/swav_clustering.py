@@ -335,10 +335,16 @@ class SwAVClustering(ViewMixin):
                 X, Zh, Rn = keep[gi]
                 Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
                 dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
+                # many prototypes: loss, dS and the bias gradient in one pass over the score matrices
+                gb_in_ce = not (mode == 'pyramid' and small) and ops.swapped_ce_fused_ok(skb[0], dS[0])
                 for g in range(ngroups):
                     r0, r1 = g * grows, (g + 1) * grows
                     sk = [skb[(gi * 2 + v) * ngroups + g] for v in range(2)]
-                    ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
+                    if gb_in_ce:
+                        ops.swapped_ce_fused(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1], gb,
+                                             0.0 if (first_acc and g == 0) else 1.0)
+                    else:
+                        ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
                     if return_aux and pno == 0 and g == 0:
                         aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
                                    q_s=sk[0].codes(), q_t=sk[1].codes())
@@ -351,7 +357,8 @@ class SwAVClustering(ViewMixin):
                         first_acc = False
                         continue
                     ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
-                    ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
+                    if not gb_in_ce:
+                        ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
                     dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)
                     if mode == 'pyramid':
                         with self._timed("scatter_rows"):

@@ -358,6 +358,14 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
                   void* stream);
 /* every (patch, row group) pair of a step in one launch; S_all / dS_all [npatch][2][rows_per_patch][K],
  * la_all in SinkhornBatch order; workspace >= npatch * ngroups * 512 floats */
+/* many prototypes (64 < K <= 6144, 16-B aligned rows), ONE pass over the two score matrices: the same loss and dS,
+ * plus gb = gb_beta * gb + column sums of (dSs + dSt) (the prototype-bias gradient, autograd of swav_clustering.py:175);
+ * GX_ERR_BAD_ARG for shapes it does not take (use gx_swapped_ce + gx_colsum then) */
+size_t gx_swapped_ce_fused_workspace_bytes(int K);
+int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long ld, float eps, float temperature,
+                        const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
+                        float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta, float* workspace,
+                        size_t workspace_bytes, void* stream);
 int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
                         float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
                         float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream);

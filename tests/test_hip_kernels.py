@@ -465,6 +465,49 @@ def test_swapped_ce_vs_oracle(ops, n, k):
     assert rel_err(ds, s1.grad) < 1e-3 and rel_err(dt, t1.grad) < 1e-3
 
 
+@pytest.mark.parametrize("n,k", [(301, 700), (1030, 5000), (64, 68)])
+def test_swapped_ce_fused_many_prototypes(ops, n, k):
+    """gx_swapped_ce_fused (one pass over both score matrices, bias gradient from the same pass): against the oracle's
+    loss / autograd, and against the two-kernel gx_swapped_ce + gx_colsum on the same inputs; odd row counts, K not
+    a multiple of the 1024-column register tile, accumulation into gb"""
+    from oracle import swav_ref as S
+    torch.manual_seed(n + k)
+    s = 0.3 * torch.randn(n, k)
+    t = s + 0.1 * torch.randn(n, k)
+    eps, tt = 0.01, 0.05
+    qs = S.sinkhorn_knopp(s, eps, 10, fp64=True)
+    qt = S.sinkhorn_knopp(t, eps, 10, fp64=True)
+    s1, t1 = s.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    ref = S.swapped_prediction_loss(s1 / tt, t1 / tt, qs, qt)
+    ref.backward()
+    sk_s = ops.Sinkhorn(dev(s), eps, 10).run()
+    sk_t = ops.Sinkhorn(dev(t), eps, 10, tag="sk2").run()
+    ds, dt = torch.empty(n, k, device="cuda"), torch.empty(n, k, device="cuda")
+    assert ops.swapped_ce_fused_ok(sk_s, ds)
+    loss = torch.zeros(1, device="cuda")
+    gb0 = torch.randn(k)
+    gb = dev(gb0.clone())
+    ops.swapped_ce_fused(sk_s, sk_t, tt, 1.0 / n, loss, 1.0 / n, 0.0, ds, dt, gb, 1.0)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-3)
+    assert rel_err(ds, s1.grad) < 1e-3 and rel_err(dt, t1.grad) < 1e-3
+    want_gb = gb0.double() + s1.grad.double().sum(0) + t1.grad.double().sum(0)
+    assert float((gb.cpu().double() - want_gb).abs().max()) < 1e-3 * float(s1.grad.abs().sum(0).max()) + 1e-6
+    # the two-kernel form on the same Sinkhorn states
+    ds2, dt2 = torch.empty_like(ds), torch.empty_like(dt)
+    loss2 = torch.zeros(1, device="cuda")
+    ops.swapped_ce(sk_s, sk_t, tt, 1.0 / n, loss2, 1.0 / n, 0.0, ds2, dt2)
+    assert rel_err(ds, ds2) < 1e-5 and rel_err(dt, dt2) < 1e-5 and abs(loss.item() - loss2.item()) < 1e-5 * abs(loss2.item())
+    gb2 = torch.empty(k, device="cuda")
+    ops.colsum(ds2, gb2, beta=0.0)
+    ops.colsum(dt2, gb2, beta=1.0)
+    ops.swapped_ce_fused(sk_s, sk_t, tt, 1.0 / n, loss, 1.0 / n, 0.0, ds, dt, gb, 0.0)         # beta = 0 overwrites
+    assert float((gb - gb2).abs().max()) < 1e-5 * float(gb2.abs().max()) + 1e-9
+    with pytest.raises(RuntimeError):                                                          # K <= 64: not this kernel
+        sk8 = ops.Sinkhorn(dev(0.3 * torch.randn(100, 8)), eps, 3).run()
+        ops.swapped_ce_fused(sk8, sk8, tt, 1.0, loss, 1.0, 0.0, torch.empty(100, 8, device="cuda"),
+                             torch.empty(100, 8, device="cuda"), torch.zeros(8, device="cuda"), 0.0)
+
+
 # ------------------------------------------------------------------------------------- gather
 def test_gather_golden_gv5(ops):
     d = load_golden("gv5_pixel_features")
