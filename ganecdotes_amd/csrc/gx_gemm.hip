@@ -37,6 +37,7 @@ struct GemmArgs {
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
     const float* up_src; int up_shift;
     const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
+    float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
 
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
 // gemm_epilogue_staged<1, 2>, but with every global LOAD the 8 store passes need — the coarse rows of the fused
 // upsample-add, the row scales — issued up front: issued pass by pass behind the wave barriers each one cost a full
 // memory latency before its store (16 dependent round trips per tile).
-__device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][2], int row0, int col0, int lane, float* stage) {
+__device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][2], int row0, int col0, int lane, float* stage,
+                                            long part_row) {
 #pragma clang fp contract(off)      // one rounding per written operation: every epilogue form gives the same bits
     constexpr int SW = 68;
     const GemmArgs& q = *gemm_late_args();
@@ -309,6 +311,7 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 cm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int row = row0 + ps * 4 + rl;
@@ -317,7 +320,19 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
         v *= rs[ps];
         v += cb;
         v += up[ps];
-        if (row < g.M && colok) *reinterpret_cast<f32x4*>(g.C + (long)row * g.ldc + col) = v;
+        if (row < g.M && colok) {
+            *reinterpret_cast<f32x4*>(g.C + (long)row * g.ldc + col) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], v[e]);
+        }
+    }
+    if (q.colmax_part) {      // column maxima of what this wave wrote (the Sinkhorn stabiliser: no pass of its own over C)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cm[e] = fmaxf(cm[e], __shfl_xor(cm[e], 16));
+            cm[e] = fmaxf(cm[e], __shfl_xor(cm[e], 32));
+        }
+        if (lane < 16 && colok) *reinterpret_cast<f32x4*>(q.colmax_part + part_row * g.N + col) = cm;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(
         gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
         gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
     } else {
-        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage);
-        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage);
+        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
+        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
     }
 }
 
@@ -585,7 +600,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
-    g.Bp = nullptr; g.Bp_bytes = 0;
+    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -656,7 +671,7 @@ static int xw_stages() {            // GX_GEMM_XW_STAGES=2|3 (LDS ring depth: 3 
 }
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
-                          const float* col_bias, const float* up_src, int up_rf, hipStream_t stream) {
+                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -678,6 +693,8 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
+    if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;
+    g.colmax_part = colmax_part;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
     if (xw_stages() == 3) hipLaunchKernelGGL(gemm_xw_kernel<3>, grid, block, 0, stream, g);
     else if (xw_stages() == 4) hipLaunchKernelGGL(gemm_xw_kernel<4>, grid, block, 0, stream, g);
@@ -734,15 +751,19 @@ int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long ld
 
 // The NT contraction with pre-split weight planes (gemm_xw_kernel): C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias
 // + beta * C + upsample2(coarse).  b_planes = gx_split_gemm_weights(B [N][K1 + K2]); K2 = 0 / coarse = NULL / row_scale
-// = NULL / col_bias = NULL switch the optional parts off.  Results are bitwise those of gx_gemm_f32 / _cat / _upadd on
+// = NULL / col_bias = NULL switch the optional parts off.  colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N]
+// partial column maxima of C (rows past M: -inf) — max over its rows = the Sinkhorn column maxima, without a pass over C.  Results are bitwise those of gx_gemm_f32 / _cat / _upadd on
 // the bf16x6 engine.
 size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 3 * 4096; }
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream) {
+                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
+                          float* colmax_part, void* stream) {
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, (hipStream_t)stream);
+                              fine_res, colmax_part, (hipStream_t)stream);
 }
+// bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
+size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }
 
 // C = alpha * A^T [B1 | B2] + beta * C: A is [K][M], B1 [K][N1], B2 [K][N2] (N1 a multiple of 128).  The weight gradient
 // of one pyramid level against both of its taps in ONE pass over the (large) A = dZ table instead of two.

@@ -189,9 +189,11 @@ def gemm_planes_ok(a1, a2, n, out):
     return True
 
 
-def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0):
+def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0,
+                   want_colmax=False):
     """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
-    split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd."""
+    split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd.
+    want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out)."""
     _chk2d(a1, a2, out, coarse)
     _chk(row_scale, col_bias)
     m, k1 = a1.shape
@@ -204,10 +206,16 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
     L = lib()
     if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(n, k1 + k2):
         raise RuntimeError("gemm_nt_planes: planes do not match (N, K)")
+    part = None
+    if want_colmax:
+        pb = L.gx_gemm_colmax_part_bytes(m, n)
+        part = workspace("gemm_colmax", pb, a1.device)[:pb // 4]
     with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
         _lib.check(L.gx_gemm_f32_nt_planes(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
                                            _p(b_planes), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
-                                           _p(coarse), fine_res, _stream()), "gx_gemm_f32_nt_planes")
+                                           _p(coarse), fine_res, _p(part), _stream()), "gx_gemm_f32_nt_planes")
+    if want_colmax:
+        return out, part.view(-1, n).amax(0)
     return out
 
 
@@ -787,6 +795,7 @@ class Sinkhorn:
         self.wsb = lib().gx_sinkhorn_workspace_bytes(self.K)
         self._ws = None
         self.la = torch.empty(self.K, dtype=torch.float32, device=scores.device) if la is None else la
+        self.cmax_preset = None       # (K,) column maxima of `scores` when the producer already has them (gemm_nt_planes)
 
     @property
     def ws(self):
@@ -796,7 +805,7 @@ class Sinkhorn:
 
     def run(self, reduce=None):
         L, S, K = lib(), self.S, self.K
-        if reduce is None and self.c_uniform == 1.0 / self.rows:
+        if reduce is None and self.c_uniform == 1.0 / self.rows and self.cmax_preset is None:
             if K <= 64 and self.rows >= 4096:
                 _lib.check(L.gx_sinkhorn_small(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r),
                                                _p(self.c), _p(self.la), _p(self.ws), self.wsb, _stream()),
@@ -811,6 +820,8 @@ class Sinkhorn:
     # --- kernel object interface of sharded.run_sinkhorn ---
     def colmax(self):
         S = self.S
+        if self.cmax_preset is not None:          # the pass over S is already paid for
+            return self.cmax_set(self.cmax_preset)
         _lib.check(lib().gx_sinkhorn_colmax(_p(S), self.rows, self.K, S.stride(0), _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_colmax")
 

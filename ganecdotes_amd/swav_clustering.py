@@ -280,6 +280,7 @@ class SwAVClustering(ViewMixin):
             G = len(pnos)
             Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)
             keep = []
+            cmax_pre = {}
             batched = lowrank                    # K <= 16: gather / loss / scatter of all patches in single launches
             if batched:      # every patch and both views in single launches (tables over the 2B-image batch)
                 gpicks = pb.picks[pnos[0]:pnos[-1] + 1].contiguous()
@@ -305,7 +306,11 @@ class SwAVClustering(ViewMixin):
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
                         X.append(x)
                     if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
-                        ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)        # (B*N, K), Wc split once per step
+                        # (B*N, K), Wc split once per step; the Sinkhorn column maxima come out of the epilogue
+                        if ngroups == 1 and K > 64:
+                            _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc, want_colmax=True)
+                        else:
+                            ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)
                     else:
                         ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)
                     Zh.append(z); Rn.append(rn)
@@ -318,6 +323,8 @@ class SwAVClustering(ViewMixin):
             with self._timed("sinkhorn"):
                 skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
                                         c=c_all, c_uniform=1.0 / nglob)
+                for (gi, v), cm in cmax_pre.items():
+                    skb[gi * 2 + v].cmax_preset = cm
                 skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
             if batched:
                 dS_all = torch.empty_like(Sc_all)

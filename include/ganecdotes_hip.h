@@ -98,7 +98,12 @@ size_t gx_gemm_weight_planes_bytes(int N, int K);
 int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream);
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream);
+                          const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
+                          float* colmax_part, void* stream);
+/* colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N] partial column maxima of C, one row per 32 rows
+ * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
+ * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
+size_t gx_gemm_colmax_part_bytes(int M, int N);
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110

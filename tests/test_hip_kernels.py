@@ -621,6 +621,17 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
                 want = 1.3 * rs.double()[:, None] * base + cb.double()[None, :]
             assert rel_err(out, want) < 3e-6
             assert torch.equal(out, ref), (m, n, k1, k2, up)
+        # column maxima of the written matrix from the epilogue (the Sinkhorn stabiliser), ragged M and N
+        for (m, n, k) in ((300, 132, 32), (4097, 5000, 64), (31, 68, 16)):
+            a, w, cb = dev(torch.randn(m, k)), dev(torch.randn(n, k)), dev(torch.randn(n))
+            out = torch.empty(m, n, device="cuda")
+            _, cm = ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), out, col_bias=cb, want_colmax=True)
+            assert torch.equal(cm, out.amax(0))
+            sk1 = ops.Sinkhorn(out, 0.05, 5).run()
+            sk2 = ops.Sinkhorn(out, 0.05, 5, tag="skp")
+            sk2.cmax_preset = cm
+            sk2.run()
+            np.testing.assert_allclose(sk2.la.cpu().numpy(), sk1.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
         a, w = dev(torch.randn(64, 24)), dev(torch.randn(16, 24))            # K % 16 != 0
         assert not ops.gemm_planes_ok(a, None, 16, torch.empty(64, 16, device="cuda"))
         with pytest.raises(RuntimeError):
