@@ -20,23 +20,23 @@ class Cfg:
     latent_dim = 16
 
 
-def _args(scope, pdf):
+def _args(scope, pdf, nproto=12):
     swav = dict(num_epochs=1, num_samples=1, num_patches=2, sampling_method="random", patch_size=300,
                 hf_interp="nearest", warmup_epochs=1, start_warmup=0.01, use_scheduler=False, base_lr=0.01,
                 final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9), projn_nw="linear",
-                temperature=0.1, nprototypes=12, nclasses=8, hlen=56, add_local_loss=False, plot_test_images=False,
+                temperature=0.1, nprototypes=nproto, nclasses=8, hlen=56, add_local_loss=False, plot_test_images=False,
                 epoch_print_freq=1, max_masks=4, sinkhorn_scope=scope)
     return dict(perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None, perturb_std=[1.0] * 3),
                 swav_args=swav, sinkhorn_args=dict(source_pdf=pdf, niters=10, eps=0.05))
 
 
-def _build(sd, group, scope, pdf):
+def _build(sd, group, scope, pdf, nproto=12):
     from ganecdotes_amd.generator import Generator
     from ganecdotes_amd.swav_clustering import SwAVClustering
     g = Generator(32, 16, 2, channels=MINI)
     g.load_state_dict(sd, strict=False)
     g = g.eval().cuda()
-    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", dist_group=group, **_args(scope, pdf))
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", dist_group=group, **_args(scope, pdf, nproto))
     torch.manual_seed(77)
     sw.mean_latent = g.style(torch.randn(64, 16).cuda()).mean(0, keepdim=True)
     torch.manual_seed(78)
@@ -51,12 +51,12 @@ def _images(n):
     return [draw_image(16, 7, 3, 32 * 32, 2) for _ in range(n)]
 
 
-def _worker(rank, world, port, sd, scope, pdf, out):
+def _worker(rank, world, port, sd, scope, pdf, out, nproto=12):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sw = _build(sd, dist.group.WORLD, scope, pdf)
+    sw = _build(sd, dist.group.WORLD, scope, pdf, nproto)
     imgs = _images(4)
     loss = None
     for _ in range(2):
@@ -66,13 +66,16 @@ def _worker(rank, world, port, sd, scope, pdf, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scope,pdf", [("global", "uniform"), ("image", "uniform"), ("global", "image")])
-def test_two_ranks_equal_one_rank(scope, pdf):
+@pytest.mark.parametrize("scope,pdf,nproto", [("global", "uniform", 12), ("image", "uniform", 12), ("global", "image", 12),
+                                              ("global", "uniform", 200), ("image", "uniform", 200)])
+def test_two_ranks_equal_one_rank(scope, pdf, nproto):
+    """nproto = 200: the many-prototype path (score GEMM on weight planes with the Sinkhorn column maxima from its
+    epilogue, one-pass CE with the bias gradient) under the sharded protocol"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     sd = golden_sd(load_golden("gv10_pretrain"))
-    sw = _build(sd, None, scope, pdf)
+    sw = _build(sd, None, scope, pdf, nproto)
     imgs = _images(4)
     for _ in range(2):
         loss1 = sw.train_step(imgs)
@@ -83,7 +86,7 @@ def test_two_ranks_equal_one_rank(scope, pdf):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, sd, scope, pdf, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, sd, scope, pdf, out, nproto), nprocs=2, join=True)
     for r in range(2):
         np.testing.assert_allclose(out[r][0], ref[0], rtol=2e-4)
         for a, b in zip(out[r][1], ref[1]):
