@@ -872,6 +872,106 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
     }
 }
 
+// blur_act_kernel for layers that also write the next conv's x planes (C % 64 == 0, OW % 16 == 0): a WORKGROUP owns
+// 16 consecutive pixels x 64 channels of a BLUR_ROWS-row strip, thread t = (pixel t >> 4, channel quad t & 15).  The T
+// reads and the fp32 stores are then 256-B runs per pixel (the per-wave "16 pixels x one chunk" map of blur_act_kernel
+// moves them in 64-B pieces), and the three bf16 planes of an output row go through LDS ([4 chunks][3 planes][16 px][32 B],
+// double-buffered, one barrier per row) so that every (chunk, plane) image still receives one contiguous 512-B run.
+__global__ __launch_bounds__(256) void blur_act_xp_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
+                                                          const float* __restrict__ kf, const float* __restrict__ demod,
+                                                          const float* __restrict__ noise, long noise_bstride,
+                                                          const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                          int act, float* __restrict__ out, int OH, int OW,
+                                                          const float* __restrict__ s_next, unsigned short* __restrict__ xp_out) {
+    __shared__ __attribute__((aligned(16))) char stage[2][12 * 512];
+    const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
+    const int nseg = (OH + BLUR_ROWS - 1) / BLUR_ROWS, nxb = OW >> 4, ncg = C >> 6;
+    const int tid = threadIdx.x, px = tid >> 4, c4 = tid & 15;
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = kf[i];
+    const float nw = (noise && noise_w) ? *noise_w : 0.f;
+    const long nblk = (long)B * nseg * nxb * ncg;
+    int par = 0;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        long rest = blk;
+        const int cg = (int)(rest % ncg); rest /= ncg;
+        const int xb = (int)(rest % nxb); rest /= nxb;
+        const int seg = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int c = cg * 64 + c4 * 4, x = xb * 16 + px, y0 = seg * BLUR_ROWS;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f}, sn4 = {1.f, 1.f, 1.f, 1.f};
+        if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
+        if (demod) dm4 = *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
+        if (s_next) sn4 = *reinterpret_cast<const f32x4*>(s_next + (long)b * C + c);
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Tb = T + (long)b * TH * TW * C + c;
+        auto load_row = [&](int r, f32x4 (&v)[4]) {          // input row y0 - 1 + r, columns x - 1 .. x + 2 (zero outside T)
+            const int ty = y0 - 1 + r;
+#pragma unroll
+            for (int fx = 0; fx < 4; ++fx) {
+                const int tx = x + fx - 1;
+                v[fx] = (ty >= 0 && ty < TH && tx >= 0 && tx < TW)
+                            ? *reinterpret_cast<const f32x4*>(Tb + ((long)ty * TW + tx) * C)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+#pragma unroll 1
+        for (int g4 = 0; g4 < BLUR_ROWS / 4 + 1; ++g4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g4 + j;                 // input row y0 - 1 + r
+                if (r > BLUR_ROWS + 2) break;
+                f32x4 v[4];
+                load_row(r, v);       // (loading row r + 1 ahead of this row's barrier measured 10 % slower: 16 more registers)
+#pragma unroll
+                for (int fy = 0; fy < 4; ++fy) {
+                    const f32x4 h = v[0] * k[fy * 4 + 0] + v[1] * k[fy * 4 + 1] + v[2] * k[fy * 4 + 2] + v[3] * k[fy * 4 + 3];
+                    acc[(j - fy) & 3] += h;
+                }
+                const int o = r - 3;                      // this output row is now complete
+                const int y = y0 + o;
+                if (o >= 0 && o < BLUR_ROWS && y < OH) {  // block-uniform
+                    const f32x4 a = acc[(j + 1) & 3];
+                    const float nz = noise ? nw * noise[(long)b * noise_bstride + (long)y * OW + x] : 0.f;
+                    f32x4 ov;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = a[q] * dm4[q] + nz + bias4[q];
+                        ov[q] = act ? lrelu_sqrt2(t) : t;
+                    }
+                    *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;
+                    ov *= sn4;
+                    unsigned h[2], m[2], l[2];
+                    split3(ov[0], ov[1], h[0], m[0], l[0]);
+                    split3(ov[2], ov[3], h[1], m[1], l[1]);
+                    char* st = stage[par] + ((c4 >> 2) * 3 * 16 + px) * 32 + (c4 & 3) * 8;
+                    *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
+                    *reinterpret_cast<u32x2*>(st + 512) = (u32x2){m[0], m[1]};
+                    *reinterpret_cast<u32x2*>(st + 1024) = (u32x2){l[0], l[1]};
+                    __syncthreads();
+                    // 12 runs (chunk, plane) of 512 B = 384 16-B units
+                    const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + xb * 16 + 1;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int u = it * 256 + tid;
+                        if (u < 384) {
+                            const int run = u >> 5, chunk = run / 3, plane = run - chunk * 3;
+                            const u32x4 d = *reinterpret_cast<const u32x4*>(stage[par] + u * 16);
+                            unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * 3 + plane) * oplane + ppix * 16 + (u & 31) * 8;
+                            *reinterpret_cast<u32x4*>(dst) = d;
+                        }
+                    }
+                    par ^= 1;        // the next row writes the other buffer; its barrier orders these reads before the row after
+                }
+                acc[(j + 1) & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
 // ToRGB (model.py:445-454): 1x1 modulated conv without demod + bias + FIR-upsampled skip.
 //   img[b][c][y][x] = scale * sum_ci x[b,y,x,ci] s[b,ci] W[c][ci] + bias[c] + up2(prev)[b][c][y][x]
 // up2 = upfirdn2d(up=2, pad=(2,1)) with the flipped 4x4 FIR kf (already x4).  Image is planar
@@ -1415,6 +1515,15 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
     long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
     if (planes_out && (C & 15) == 0) total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * ((OW + 15) / 16) * (C >> 4) * 64;
     long want = (total + 255) / 256;
+    static const bool lds_planes = [] { const char* e = getenv("GX_BLUR_LDS"); return !(e && e[0] == '0'); }();
+    if (planes_out && lds_planes && (C & 63) == 0 && (OW & 15) == 0 &&
+        ((((uintptr_t)T | (uintptr_t)out | (uintptr_t)planes_out) & 15) == 0)) {
+        const long nblk = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * (OW >> 4) * (C >> 6);
+        hipLaunchKernelGGL(blur_act_xp_kernel, dim3((int)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, (hipStream_t)stream, T, B,
+                           TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     const int nb = (int)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod,
                        noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
