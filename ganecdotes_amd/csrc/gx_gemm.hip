@@ -677,6 +677,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     const int K = K1 + K2;
     if ((K1 & 15) || (K2 & 15) || (lda1 & 3) || (K2 > 0 && (lda2 & 3)) || lda1 < K1 || (K2 > 0 && lda2 < K2) ||
         lda1 >= (1 << 22) || lda2 >= (1 << 22) || (N & 3) || (ldc & 3) ||
+        127L * lda1 * 4 + 4L * K1 >= 0x7FFFFFF0L || 127L * lda2 * 4 + 4L * K2 >= 0x7FFFFFF0L ||      // 32-bit buffer offsets of a tile
         (((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)Bp | (uintptr_t)C | (uintptr_t)up_src) & 15))
         return GX_ERR_BAD_ARG;
     GemmArgs g;
