@@ -707,6 +707,26 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
     }
 }
 
+// EXPERIMENTAL fp16x3 engine: B [N][K] as two fp16 pieces per element (w = p0 + 2^-11 p1 up to 2^-22),
+// tiled like the bf16 planes: per (128-row tile, 16-column chunk) two 4 KB pieces in the LDS image layout.
+__global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N, int K, long ld, int ntn, int ncc,
+                                             unsigned short* __restrict__ planes) {
+    const long total = (long)ntn * ncc * 128 * 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
+        long blk = i >> 11;
+        const int cc = (int)(blk % ncc); const int tn = (int)(blk / ncc);
+        const int co = tn * 128 + row, ci = cc * 16 + k;
+        const float x = (co < N && ci < K) ? B[(long)co * ld + ci] : 0.f;
+        const _Float16 p0 = (_Float16)x;
+        const _Float16 p1 = (_Float16)((x - (float)p0) * 2048.f);
+        unsigned short* base = planes + (((long)tn * ncc + cc) * 2) * 2048;
+        const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
+        base[off] = __builtin_bit_cast(unsigned short, p0);
+        base[2048 + off] = __builtin_bit_cast(unsigned short, p1);
+    }
+}
+
 // Latents of one view of a batch (swav_clustering.py:599-640 + image_augmentor.py:42-53 + the truncation of
 // model.py:594-602): lat[b][l][:] = keep * (m + psi (w_b - m)) + mix[b][l][0] nw[b][0][:] + mix[b][l][1] nw[b][1][:]
 // with keep = 1 - mix[b][l][0] - mix[b][l][1]  (mix is sigma at the two perturbed latents of image b, else 0).
@@ -1490,6 +1510,17 @@ int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, 
     g.out = T; g.outH = 2 * H + 1; g.outW = 2 * W + 1; g.Cout = Cout;
     g.ymul = 2; g.xmul = 2;
     return launch_conv(g, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t gx_gemm_weight_planes_h3_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 2 * 4096; }
+int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream) {
+    if (!B || !planes || N <= 0 || K <= 0 || ldb < K) return GX_ERR_BAD_ARG;
+    const int ntn = gx_cdiv(N, 128), ncc = gx_cdiv(K, 16);
+    long want = ((long)ntn * ncc * 2048 + 255) / 256;
+    hipLaunchKernelGGL(split_gemm_weights_h3_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       B, N, K, ldb, ntn, ncc, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
 }
 
 // Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur

@@ -466,6 +466,130 @@ __global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(
     }
 }
 
+// ---- EXPERIMENTAL engine "fp16x3" (opt-in, never the default): the NT contraction of gemm_xw_kernel
+// with every operand as TWO fp16 pieces a = a0 + 2^-11 a1 (11 + 11 bits) and a b ~ a0 b0 + 2^-11 (a0 b1 + a1 b0): three
+// MFMA products per fp32 product instead of six, per-product error 2^-22 instead of 2^-24 (tools/split_accuracy.py).
+// Same structure as gemm_xw_kernel (A raw fp32 by LDS-DMA, split at the fragment read; B planes by LDS-DMA); the two
+// orders of magnitude accumulate separately (acc0: a0 b0, acc1: the cross terms) and meet in the epilogue.
+// Operands must lie in fp16's range (|x| < 65504; below 6e-5 the relative precision of a piece degrades).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& p0, unsigned& p1) {
+    const f16x2 h = __builtin_convertvector((f32x2){x0, x1}, f16x2);
+    p0 = __builtin_bit_cast(unsigned, h);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){(x0 - back[0]) * 2048.f, (x1 - back[1]) * 2048.f}, f16x2));
+}
+constexpr int XH_B = 2 * 4096;                                       // one B tile: two fp16 pieces
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xh_kernel(GemmArgs g) {
+    constexpr int NS = 2;
+    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // (sized as gemm_xw_kernel: the epilogue stage)
+    char* const ldsB = lds + NS * XW_A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int logical = xcd_remap((int)blockIdx.x, ntile);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned aoff1[2], aoff2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 256 + tid;
+        int row = p >> 2;
+        const int q = (p & 3) ^ ((p >> 4) & 3);
+        row = min(row, g.M - 1 - m0);
+        aoff1[i] = ((unsigned)row * (unsigned)g.lda + (unsigned)q * 4u) * 4u;
+        aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A + (long)m0 * g.lda, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
+    const unsigned boff = (unsigned)tid * 16u;
+    const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * 2u * 4096u;
+    auto issue_b = [&](int kt, char* dst) {
+        const unsigned blk = bblk0 + (unsigned)kt * 2u * 4096u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)boff,
+                                                     (int)(blk + p * 4096u), 0, 0);
+    };
+    auto issue_a = [&](int kt, char* dst) {
+        const bool second = kt >= nkt1;
+        const int ks = (second ? kt - nkt1 : kt) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff1[i], ks, 0, 0);
+        }
+    };
+    f32x16 acc0[1][2], acc1[1][2], crs0[2], crs1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; crs0[j][r] = 0.f; crs1[j][r] = 0.f; }
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int arow = wid * 32 + r32;
+    const int af = (arow >> 2) & 3;
+    const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
+    auto compute = [&](const char* st, const char* Bs) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
+        f16x8 b[4][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                b[t][q] = *reinterpret_cast<const f16x8*>(Bs + q * 4096 + x_kc_off(t * 32 + r32, hh));
+        unsigned p0[4], p1[4];
+        split2h(x0[0], x0[1], p0[0], p1[0]);
+        split2h(x0[2], x0[3], p0[1], p1[1]);
+        split2h(x1[0], x1[1], p0[2], p1[2]);
+        split2h(x1[2], x1[3], p0[3], p1[3]);
+        const f16x8 a0 = __builtin_bit_cast(f16x8, (u32x4){p0[0], p0[1], p0[2], p0[3]});
+        const f16x8 a1 = __builtin_bit_cast(f16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
+        // cross terms first (the smaller magnitudes), then a0 b0
+        crs0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0][0], crs0[0], 0, 0, 0);
+        crs0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[1][0], crs0[1], 0, 0, 0);
+        crs1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2][0], crs1[0], 0, 0, 0);
+        crs1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[3][0], crs1[1], 0, 0, 0);
+        crs0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0][1], crs0[0], 0, 0, 0);
+        crs0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1][1], crs0[1], 0, 0, 0);
+        crs1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2][1], crs1[0], 0, 0, 0);
+        crs1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3][1], crs1[1], 0, 0, 0);
+        acc0[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0][0], acc0[0][0], 0, 0, 0);
+        acc0[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1][0], acc0[0][1], 0, 0, 0);
+        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2][0], acc1[0][0], 0, 0, 0);
+        acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3][0], acc1[0][1], 0, 0, 0);
+    };
+    if (nkt > 0) { issue_b(0, ldsB); issue_a(0, lds); }
+    for (int t = 0; t < nkt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nkt) { issue_b(t + 1, ldsB + ((t + 1) & 1) * XW_B); issue_a(t + 1, lds + ((t + 1) & 1) * XW_A); }
+        compute(lds + (t & 1) * XW_A, ldsB + (t & 1) * XW_B);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[0][j][r] = fmaf(crs0[j][r], 1.f / 2048.f, acc0[0][j][r]);
+            acc1[0][j][r] = fmaf(crs1[j][r], 1.f / 2048.f, acc1[0][j][r]);
+        }
+    float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
+    if (g.beta != 0.f) {
+        gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
+        gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
+    } else {
+        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
+        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
+    }
+}
+
 // Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
 // split arithmetic, the LDS round trip and a barrier that the 4-wave kernel above strings in series
 // with it (its MFMA pipe is busy 55 % of the time).  Here a workgroup of 512 threads owns a 256 x 128
@@ -671,7 +795,8 @@ static int xw_stages() {            // GX_GEMM_XW_STAGES=2|3 (LDS ring depth: 3 
 }
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
-                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream) {
+                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
+                          bool h3 = false) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -691,13 +816,14 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
-    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
+    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h3 ? 2 : 3) * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
     if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;
     g.colmax_part = colmax_part;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
-    if (xw_stages() == 3) hipLaunchKernelGGL(gemm_xw_kernel<3>, grid, block, 0, stream, g);
+    if (h3) hipLaunchKernelGGL(gemm_xh_kernel, grid, block, 0, stream, g);
+    else if (xw_stages() == 3) hipLaunchKernelGGL(gemm_xw_kernel<3>, grid, block, 0, stream, g);
     else if (xw_stages() == 4) hipLaunchKernelGGL(gemm_xw_kernel<4>, grid, block, 0, stream, g);
     else hipLaunchKernelGGL(gemm_xw_kernel<2>, grid, block, 0, stream, g);
     GX_CHECK_LAUNCH();
@@ -774,6 +900,15 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
     if (!B2 || N2 <= 0) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(1, 0, M, N1 + N2, K, A, lda, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
                            workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1);
+}
+
+// EXPERIMENTAL (nothing in the product path calls it): gx_gemm_f32_nt_planes on the "fp16x3"
+// engine — two fp16 pieces per operand, three MFMA products per fp32 product.  b_planes = gx_split_gemm_weights_h3.
+int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
+                             const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
+                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream) {
+    return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
+                              fine_res, nullptr, (hipStream_t)stream, true);
 }
 
 }  // extern "C"

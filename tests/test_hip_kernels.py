@@ -665,6 +665,40 @@ def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
                         torch.empty(32, 48, device="cuda"))
 
 
+def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
+    """gx_gemm_f32_nt_planes_h3 (EXPERIMENTAL, not on the product path): two fp16 pieces per operand,
+    three MFMA products per fp32 product.  On operands inside fp16's range its error against fp64 is no larger than
+    the exact-fp32 MFMA engine's; the upsample-add / dual-A epilogue is the shared one."""
+    from ganecdotes_amd import _lib
+    from ganecdotes_amd.ops import _p, _stream, lib
+    L = lib()
+    torch.manual_seed(31)
+    prev = ops.set_gemm_mode(1)
+    try:
+        for (m, n, k1, k2, up) in ((2048, 512, 256, 0, 0), (1024, 260, 64, 48, 8), (300, 132, 4608, 0, 0)):
+            a1, a2 = dev(torch.randn(m, k1)), (dev(torch.randn(m, k2)) if k2 else None)
+            w = dev(torch.randn(n, k1 + k2) / (k1 + k2) ** 0.5)
+            co = dev(torch.randn(m // 4, n)) if up else None
+            pl = torch.empty(L.gx_gemm_weight_planes_h3_bytes(n, k1 + k2) // 2, dtype=torch.int16, device="cuda")
+            _lib.check(L.gx_split_gemm_weights_h3(_p(w), n, k1 + k2, w.stride(0), _p(pl), _stream()), "split_h3")
+            out = torch.empty(m, n, device="cuda")
+            _lib.check(L.gx_gemm_f32_nt_planes_h3(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
+                                                  _p(pl), _p(out), n, 1.0, 0.0, None, None, _p(co), up, _stream()), "h3")
+            acat = a1 if a2 is None else torch.cat([a1, a2], 1)
+            ref = acat.double() @ w.double().t()
+            if up:
+                ref = ref + co.reshape(-1, up // 2, up // 2, n).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(m, n).double()
+            ops.set_gemm_mode(0)
+            exact = ops.gemm(acat.contiguous(), w, False, True)
+            if up:
+                exact = exact + (ref - acat.double() @ w.double().t()).float()
+            ops.set_gemm_mode(1)
+            e3, e32 = rel_err(out, ref), rel_err(exact, ref)
+            assert e3 < 3e-6 and e3 <= 1.5 * e32 + 1e-7, (e3, e32)
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 def test_pyramid_pieces(ops):
     torch.manual_seed(12)
     b, r, d = 2, 8, 24
