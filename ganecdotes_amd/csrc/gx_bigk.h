@@ -71,8 +71,20 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                                                            float inv_eps, const unsigned* __restrict__ cmax,
                                                            const float* __restrict__ la, const float* __restrict__ c,
                                                            float c_uniform, float* __restrict__ lb_out,
-                                                           float* __restrict__ part, unsigned* __restrict__ cmax_out) {
+                                                           float* __restrict__ part, unsigned* __restrict__ cmax_out,
+                                                           long s_stride = 0, long c_stride = 0) {
     constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
+    {   // blockIdx.y = problem of a batch of equally shaped ones: score matrices s_stride apart, K-vectors (cmax, la,
+        // cmax_out) K apart, row marginals c_stride apart, partials [problem][block][K]  (gridDim.y == 1: one problem)
+        const long prob = blockIdx.y;
+        S += prob * s_stride;
+        if (cmax) cmax += prob * K;
+        if (la) la += prob * K;
+        if (c) c += prob * c_stride;
+        if (part) part += prob * gridDim.x * K;
+        if (cmax_out) cmax_out += prob * K;
+        if (lb_out) lb_out += prob * rows;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | red[2][BK_R][4]
     float* vec = sm;
     float* red = sm + K;

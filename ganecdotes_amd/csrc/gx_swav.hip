@@ -420,9 +420,16 @@ __global__ void sk_pass_kernel(const float* __restrict__ S, long rows, int K, lo
 
 // la_k = (first ? -cmax_k/eps : la_k) + log r_k - log u_k     (r uniform = 1/K when r == nullptr)
 __global__ void sk_update_la_kernel(const float* __restrict__ u, const float* __restrict__ r, int K, int first,
-                                    const unsigned* __restrict__ cmax, float inv_eps, float* __restrict__ la) {
+                                    const unsigned* __restrict__ cmax, float inv_eps, float* __restrict__ la,
+                                    long r_stride = 0) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    {   // blockIdx.y = problem of a batch: K-vectors K apart, prototype marginals r_stride apart
+        const long prob = blockIdx.y;
+        u += prob * K; la += prob * K;
+        if (cmax) cmax += prob * K;
+        if (r) r += prob * r_stride;
+    }
     const float base = first ? -ord2f(cmax[k]) * inv_eps : la[k];
     la[k] = base + logf(r ? r[k] : 1.f / (float)K) - logf(u[k]);
 }
@@ -846,6 +853,68 @@ int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters
         if (rc) return rc;
         rc = gx_sinkhorn_update(workspace + K, r, K, it == 0, workspace, eps, la, stream);
         if (rc) return rc;
+    }
+    return GX_OK;
+}
+// Many equally shaped many-prototype problems at once (the per-image Sinkhorn scope at K = 5000: 2 views x 5 patches x 16
+// images = 160 problems of 20 000 x 5000 per step — one by one they are 1 760 passes + as many reductions of a few
+// tens of microseconds each, i.e. launch-bound): every pass of the iteration runs over all problems in one launch
+// (blockIdx.y = problem), like gx_sinkhorn_small_batch for K <= 64.
+//   S_all: problem i at S_all + i * prob_stride, [rows][K] with row stride ld; r_all / c_all optional (NULL = uniform);
+//   la_all [nprob][K]; cmax_all (optional) [nprob][K]: the problems' column maxima when their producer has them (no
+//   column-max pass then).  workspace: cmax [nprob][K] | u [nprob][K] | partials [nprob][NB][K].
+static int bigk_batch_blocks(int nprob, long rows) {
+    long nb = (4096 + nprob - 1) / nprob;
+    if (nb < 8) nb = 8;
+    if (nb > 512) nb = 512;
+    const long groups = (rows + BK_R - 1) / BK_R;
+    return (int)(nb < groups ? nb : groups);
+}
+size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K) {
+    return ((size_t)2 * nprob * K + (size_t)nprob * bigk_batch_blocks(nprob, rows) * K) * sizeof(float);
+}
+int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
+                           const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
+                           float* la_all, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S_all || !la_all || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || ld < K || eps <= 0.f || niters < 1)
+        return GX_ERR_BAD_ARG;
+    if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || (prob_stride & 3)) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_bigk_batch_workspace_bytes(nprob, rows, K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = bigk_batch_blocks(nprob, rows);
+    unsigned* cmax = (unsigned*)workspace;
+    float* u = workspace + (size_t)nprob * K;
+    float* part = u + (size_t)nprob * K;
+    const size_t lds = bigk_pass_lds(K);
+    const dim3 grid(nb, nprob);
+    if (cmax_all) {       // the producer of the scores already has the column maxima [nprob][K] (gx_gemm_f32_nt_planes)
+        if ((long)nprob * K >= (1L << 31)) return GX_ERR_BAD_ARG;
+        hipLaunchKernelGGL(sk_ord_encode_kernel, dim3(gx_cdiv((long)nprob * K, 256)), dim3(256), 0, st, cmax_all, nprob * K, cmax);
+    } else {
+        if (hipMemsetAsync(cmax, 0, (size_t)nprob * K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
+        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), grid, dim3(256), lds, st, S_all, rows, K,
+                                                        ld, 0.f, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, cmax,
+                                                        prob_stride, 0L));
+    }
+    GX_CHECK_LAUNCH();
+    int kx = 1;
+    while (kx < 64 && kx < K) kx <<= 1;
+    for (int it = 0; it < niters; ++it) {
+        if (it == 0) {
+            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), grid, dim3(256), lds, st, S_all, rows, K,
+                                                            ld, 1.f / eps, cmax, la_all, c_all, 1.f / (float)rows, nullptr, part,
+                                                            nullptr, prob_stride, c_stride));
+        } else {
+            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), grid, dim3(256), lds, st, S_all, rows, K,
+                                                            ld, 1.f / eps, cmax, la_all, c_all, 1.f / (float)rows, nullptr, part,
+                                                            nullptr, prob_stride, c_stride));
+        }
+        GX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx, nprob), dim3(256), 0, st, part, nb, K, 1.f, 0.f, u, kx);
+        GX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sk_update_la_kernel, dim3(gx_cdiv(K, 256), nprob), dim3(256), 0, st, u, r_all, K, it == 0 ? 1 : 0, cmax,
+                           1.f / eps, la_all, r_stride);
+        GX_CHECK_LAUNCH();
     }
     return GX_OK;
 }

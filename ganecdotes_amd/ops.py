@@ -193,7 +193,8 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
                    want_colmax=False):
     """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
     split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd.
-    want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out)."""
+    want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out); an int g > 1:
+    the maxima of g equal row groups, (g, N) (rows per group a multiple of 32)."""
     _chk2d(a1, a2, out, coarse)
     _chk(row_scale, col_bias)
     m, k1 = a1.shape
@@ -215,6 +216,11 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
                                            _p(b_planes), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
                                            _p(coarse), fine_res, _p(part), _stream()), "gx_gemm_f32_nt_planes")
     if want_colmax:
+        g = 1 if want_colmax is True else int(want_colmax)
+        if g > 1:
+            if m % (32 * g):
+                raise RuntimeError("gemm_nt_planes: row groups must be whole 32-row slices")
+            return out, part.view(-1, n)[:m // 32].view(g, m // (32 * g), n).amax(1)
         return out, part.view(-1, n).amax(0)
     return out
 
@@ -893,6 +899,20 @@ class SinkhornBatch:
                 "gx_sinkhorn_small_batch")
             return self
         if reduce is None:
+            S = self.S
+            npre = sum(p.cmax_preset is not None for p in self.probs)
+            if (self.nprob >= 16 and 64 < self.K <= 6144 and self.K % 4 == 0 and self.c_uniform == 1.0 / self.rows and
+                    npre in (0, self.nprob) and S.stride(1) % 4 == 0 and S.stride(0) % 4 == 0 and S.data_ptr() % 16 == 0):
+                # many many-prototype problems (the per-image scope at K = 5000): one launch per pass for all of them
+                L = lib()
+                wsb = L.gx_sinkhorn_bigk_batch_workspace_bytes(self.nprob, self.rows, self.K)
+                ws = workspace(self.tag + ".bigk", wsb, S.device)
+                cm = torch.stack([p.cmax_preset for p in self.probs]).contiguous() if npre else None
+                _lib.check(L.gx_sinkhorn_bigk_batch(
+                    _p(S), self.nprob, S.stride(0), self.rows, self.K, S.stride(1), self.eps, self.niters, _p(self.r),
+                    0 if self.r is None else self.r.stride(0), _p(self.c), 0 if self.c is None else self.c.stride(0),
+                    _p(cm), _p(self.la), _p(ws), wsb, _stream()), "gx_sinkhorn_bigk_batch")
+                return self
             for p in self.probs:
                 p.run()
             return self

@@ -307,8 +307,9 @@ class SwAVClustering(ViewMixin):
                         X.append(x)
                     if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
                         # (B*N, K), Wc split once per step; the Sinkhorn column maxima come out of the epilogue
-                        if ngroups == 1 and K > 64:
-                            _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc, want_colmax=True)
+                        if K > 64 and (ngroups == 1 or grows % 32 == 0):
+                            _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
+                                                                       want_colmax=True if ngroups == 1 else ngroups)
                         else:
                             ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)
                     else:
@@ -324,7 +325,8 @@ class SwAVClustering(ViewMixin):
                 skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
                                         c=c_all, c_uniform=1.0 / nglob)
                 for (gi, v), cm in cmax_pre.items():
-                    skb[gi * 2 + v].cmax_preset = cm
+                    for g in range(ngroups):
+                        skb[(gi * 2 + v) * ngroups + g].cmax_preset = cm if ngroups == 1 else cm[g]
                 skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
             if batched:
                 dS_all = torch.empty_like(Sc_all)

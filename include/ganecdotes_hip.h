@@ -360,6 +360,15 @@ int gx_hist_range(const float* x, long n, unsigned* scratch, float* lohi, void* 
 int gx_hist_counts(const float* x, long n, const float* lohi, int bins, float* hist, unsigned* scratch, void* stream);
 int gx_hist_finish(float* hist, int bins, void* stream);
 
+/* nprob equally shaped many-prototype problems (64 < K <= 6144) in one launch per pass (blockIdx.y = problem): the
+ * per-image Sinkhorn scope at the reference's own K = 5000 (swav_clustering.py:509-544 once per image, view and patch).
+ * S_all + i * prob_stride = problem i, [rows][K]; r_all / c_all NULL = uniform marginals; cmax_all NULL or the column
+ * maxima [nprob][K] (from gx_gemm_f32_nt_planes' colmax_part: no pass for them); la_all [nprob][K]. */
+size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K);
+int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
+                           const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
+                           float* la_all, float* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).
  * loss_out[0] = loss_scale * sum_n loss_n + loss_beta * loss_out[0];

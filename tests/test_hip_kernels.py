@@ -294,10 +294,12 @@ def test_sinkhorn_small_fused_path(ops, n, k, eps, pdf):
 
 
 @pytest.mark.parametrize("nprob,n,k,pdf", [(10, 20000, 8, "uniform"), (3, 4100, 16, "image"), (4, 5000, 40, "uniform"),
-                                           (2, 300, 12, "uniform"), (2, 4200, 80, "uniform")])
+                                           (2, 300, 12, "uniform"), (2, 4200, 80, "uniform"),
+                                           (20, 703, 300, "uniform"), (17, 1030, 5000, "uniform"), (16, 400, 132, "image")])
 def test_sinkhorn_batch_equals_per_problem(ops, nprob, n, k, pdf):
-    """SinkhornBatch (one launch per iteration over all problems when K <= 64, rows >= 4096;
-    per-problem kernels otherwise) == each problem solved alone; and with a (faked 2-rank)
+    """SinkhornBatch (one launch per iteration over all problems when K <= 64, rows >= 4096, and — many prototypes,
+    >= 16 problems, the per-image scope at K = 5000 — gx_sinkhorn_bigk_batch; per-problem kernels otherwise) == each
+    problem solved alone; and with a (faked 2-rank)
     reduce the grouped exchange gives the 1-rank codes of the concatenation."""
     torch.manual_seed(nprob * n + k)
     eps = 0.005
@@ -632,6 +634,18 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
             sk2.cmax_preset = cm
             sk2.run()
             np.testing.assert_allclose(sk2.la.cpu().numpy(), sk1.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        # per row group (the per-image Sinkhorn scope): groups of whole 32-row slices, and the batched solver fed with them
+        g, rows, n, k = 16, 96, 132, 32
+        a, w = dev(torch.randn(g * rows, k)), dev(0.3 * torch.randn(n, k))
+        out = torch.empty(g * rows, n, device="cuda")
+        _, cm = ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), out, want_colmax=g)
+        assert torch.equal(cm, out.view(g, rows, n).amax(1))
+        plain = ops.SinkhornBatch(out.view(g, rows, n), 0.05, 5).run()
+        fed = ops.SinkhornBatch(out.view(g, rows, n), 0.05, 5, tag="skfed")
+        for i in range(g):
+            fed[i].cmax_preset = cm[i]
+        fed.run()
+        np.testing.assert_allclose(fed.la.cpu().numpy(), plain.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
         a, w = dev(torch.randn(64, 24)), dev(torch.randn(16, 24))            # K % 16 != 0
         assert not ops.gemm_planes_ok(a, None, 16, torch.empty(64, 16, device="cuda"))
         with pytest.raises(RuntimeError):
