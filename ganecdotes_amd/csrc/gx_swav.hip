@@ -1335,6 +1335,70 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, lo
     if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
 }
 
+// The same pass with a ROW PER LANE for K = 4 KQ <= 16 (16-B aligned rows): a lane reads its row as KQ float4, so the
+// row maximum, the sum of exponentials and the K column contributions are plain register arithmetic — no team shuffles
+// (the team form above issues ~50 VALU instructions per score at K = 8, this one ~13), `exp` is bk_exp.  Column sums
+// leave through K per-lane accumulators, a wave reduction and LDS atomics once per block.
+template <int KQ>
+__global__ __launch_bounds__(256) void sk_pass_small_rowlane_kernel(
+    const float* __restrict__ S, long sprob, long rows, long ld, int kx, float inv_eps, int it, const unsigned* __restrict__ cmax,
+    const float* __restrict__ r, long rstride, const float* __restrict__ c, long cstride, float c_uniform,
+    const float* __restrict__ upart_prev, int nblk_prev, const float* __restrict__ la_prev, float* __restrict__ la_cur,
+    float* __restrict__ upart) {
+    constexpr int K = 4 * KQ;
+    __shared__ float las[64], uacc[64], red[256];
+    const long y = blockIdx.y;
+    S += y * sprob;
+    cmax += y * K;
+    if (r) r += y * rstride;
+    if (c) c += y * cstride;
+    upart_prev += y * nblk_prev * K;
+    upart += y * gridDim.x * K;
+    la_prev += y * K;
+    la_cur += y * K;
+    if (threadIdx.x < 64) uacc[threadIdx.x] = 0.f;
+    if (it == 0) {
+        if (threadIdx.x < K) las[threadIdx.x] = -ord2f(cmax[threadIdx.x]) * inv_eps;
+        __syncthreads();
+    } else {
+        sk_fold_update(upart_prev, nblk_prev, K, kx, la_prev, cmax, it == 1, inv_eps, r, las, red);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < K) la_cur[threadIdx.x] = las[threadIdx.x];
+    float lv[K], ul[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { lv[k] = las[k]; ul[k] = 0.f; }
+    for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long)gridDim.x * 256) {
+        float w[K];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(S + row * ld + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[4 * q + e] = fmaf(v[e], inv_eps, lv[4 * q + e]);
+        }
+        if (it > 0) {
+            float mx = w[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, w[k]);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { w[k] = bk_exp(w[k] - mx); sum += w[k]; }
+            const float f = (c ? c[row] : c_uniform) / sum;           // exp(lb + mx)
+#pragma unroll
+            for (int k = 0; k < K; ++k) ul[k] = fmaf(w[k], f, ul[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) ul[k] += bk_exp(w[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float t = gx_wave_sum(ul[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&uacc[k], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
+}
+
 // grid = nprob blocks
 __global__ void sk_finish_small_kernel(const float* __restrict__ upart_prev, int nblk_prev, int K, int kx,
                                        const float* __restrict__ la_prev, const unsigned* __restrict__ cmax,
@@ -1378,12 +1442,25 @@ int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, in
     hipLaunchKernelGGL(gx::sk_colmax_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, cmax);
     GX_CHECK_LAUNCH();
     const float c_uniform = 1.f / (float)rows;
+    // a row per lane for K in {4, 8, 12, 16} with 16-B aligned rows (GX_SK_ROWLANE=0: the team form, for A/B runs)
+    static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
+    const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
     for (int it = 0; it < niters; ++it) {
         float* up_prev = part + (size_t)((it + 1) & 1) * nb * PK;
         float* up_cur = part + (size_t)(it & 1) * nb * PK;
-        hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
-                           1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev, nb,
-                           labuf + (size_t)((it + 1) & 1) * PK, labuf + (size_t)(it & 1) * PK, up_cur);
+        float* la_p = labuf + (size_t)((it + 1) & 1) * PK;
+        float* la_c = labuf + (size_t)(it & 1) * PK;
+#define GX_SK_ROWLANE(KQ_)                                                                                                    \
+    hipLaunchKernelGGL(gx::sk_pass_small_rowlane_kernel<KQ_>, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, ld, kx,      \
+                       1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev, nb, la_p, la_c, up_cur)
+        if (rowlane && K == 4) GX_SK_ROWLANE(1);
+        else if (rowlane && K == 8) GX_SK_ROWLANE(2);
+        else if (rowlane && K == 12) GX_SK_ROWLANE(3);
+        else if (rowlane && K == 16) GX_SK_ROWLANE(4);
+        else
+            hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
+                               1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up_prev, nb, la_p, la_c, up_cur);
+#undef GX_SK_ROWLANE
         GX_CHECK_LAUNCH();
     }
     const int last = niters - 1;
