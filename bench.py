@@ -187,9 +187,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--prototypes", type=int, default=8)
-    ap.add_argument("--scope", default="image", choices=["global", "image"],
-                    help="Sinkhorn scope: 'image' = one problem per image, view and patch (the reference's own semantics, no "
-                         "Sinkhorn collective at N > 1; default), 'global' = one problem per view and patch over the rank's batch")
+    ap.add_argument("--scope", default="global", choices=["global", "image"],
+                    help="Sinkhorn scope: 'global' = one problem per view and patch over the whole (sharded) batch, normalised "
+                         "across ranks by all-reduce as BASELINE.json's north_star asks (default); 'image' = one problem per "
+                         "image, view and patch (the reference's batch-1 semantics, no Sinkhorn collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")

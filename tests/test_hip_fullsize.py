@@ -375,3 +375,39 @@ def test_bench_step_properties(gpu, bench_state, nproto):
     np.testing.assert_allclose(loss2.item(), loss.item(), rtol=1e-5)
     for a_, b_ in zip(sw2._grads, g0):
         assert rel(a_, b_) < 1e-4
+
+
+def test_bench_cli_contract_one_json_line(gpu):
+    """`python bench.py --gpus N --steps K --warmup W` as the driver runs it: exactly one JSON line on stdout with the
+    contract's keys (metric / unit of BASELINE.json, whole-job value, roofline of the dominant kernel with
+    frac = achieved / peak, the oracle timed as cpu_baseline at N = 1), and `--gpus 2` starting its own two ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+
+    def run(*args):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], cwd=root, capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    d = run("--steps", "3", "--warmup", "1")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == base.get("unit", d["unit"]) and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
+    d2 = run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert d2["n_gpus"] == 2 and d2["cpu_baseline"] is None
+    assert abs(d2["value"] - 2 * 16 * 1e3 / d2["ms_per_step"]) < 1e-3 * d2["value"]
