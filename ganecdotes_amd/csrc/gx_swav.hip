@@ -1530,9 +1530,24 @@ int gx_sinkhorn_small_batch_pass(const float* S, int nprob, long sprob, long row
         hipLaunchKernelGGL(gx::sk_ord_encode_kernel, dim3(gx_cdiv((long)PK, 256)), dim3(256), 0, st, cmax_in, (int)PK, cmax);
         GX_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
-                       1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, u_prev ? u_prev : part, 1,
-                       labuf + (size_t)((it + 1) & 1) * PK, labuf + (size_t)(it & 1) * PK, part);
+    {   // the sharded form of the pass takes the same row-per-lane kernel (gx_sinkhorn_small_batch)
+        static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
+        const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
+        const float* up = u_prev ? u_prev : part;
+        float* la_p = labuf + (size_t)((it + 1) & 1) * PK;
+        float* la_c = labuf + (size_t)(it & 1) * PK;
+#define GX_SK_ROWLANE(KQ_)                                                                                                    \
+    hipLaunchKernelGGL(gx::sk_pass_small_rowlane_kernel<KQ_>, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, ld, kx,      \
+                       1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up, 1, la_p, la_c, part)
+        if (rowlane && K == 4) GX_SK_ROWLANE(1);
+        else if (rowlane && K == 8) GX_SK_ROWLANE(2);
+        else if (rowlane && K == 12) GX_SK_ROWLANE(3);
+        else if (rowlane && K == 16) GX_SK_ROWLANE(4);
+        else
+            hipLaunchKernelGGL(gx::sk_pass_small_kernel, dim3(nb, nprob), dim3(256), 0, st, S, sprob, rows, K, ld, team, kx,
+                               1.f / eps, it, cmax, r, rstride, c, cstride, c_uniform, up, 1, la_p, la_c, part);
+#undef GX_SK_ROWLANE
+    }
     GX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gx::partial_reduce_kernel, dim3((K + kx - 1) / kx, nprob), dim3(256), 0, st, part, nb, K, 1.f, 0.f,
                        u_out, kx);
