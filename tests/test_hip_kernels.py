@@ -269,7 +269,8 @@ def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
 
 
 @pytest.mark.parametrize("n,k,eps,pdf", [(5000, 8, 0.005, "uniform"), (9000, 40, 0.01, "uniform"),
-                                         (4100, 16, 0.003, "image"), (320000, 8, 0.005, "uniform")])
+                                         (4100, 16, 0.003, "image"), (320000, 8, 0.005, "uniform"),
+                                         (5001, 12, 0.005, "uniform"), (4500, 4, 0.01, "image"), (4097, 6, 0.01, "uniform")])
 def test_sinkhorn_small_fused_path(ops, n, k, eps, pdf):
     """rows >= 4096 and K <= 64 take gx_sinkhorn_small (one launch per iteration): same codes as
     the generic 3-kernel sequence and as the oracle"""
