@@ -527,6 +527,80 @@ __global__ void swapped_ce_kernel(const float* __restrict__ Ss, const float* __r
     if (threadIdx.x == 0) loss_part[blockIdx.x] = -0.5f * tot;
 }
 
+// swapped_ce_kernel with a ROW PER LANE for K = 4 KQ <= 16 (16-B aligned rows): both views' rows and their exponentials
+// stay in registers — 4 K exponentials per row pair instead of 12 K, no team shuffles.  Same arguments and partials.
+template <int KQ>
+__global__ __launch_bounds__(256) void swapped_ce_rowlane_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+                                                                 long rows, long ld, float inv_eps, float inv_T,
+                                                                 const float* __restrict__ las, const float* __restrict__ lat,
+                                                                 float gscale, float* __restrict__ dSs, float* __restrict__ dSt,
+                                                                 long ldd, float* __restrict__ loss_part, CePairs pr) {
+    constexpr int K = 4 * KQ;
+    {
+        const long pa = blockIdx.y / pr.ngroups, gr = blockIdx.y % pr.ngroups;
+        const long so = pa * pr.patch_stride + gr * pr.group_stride, lo = pa * pr.la_patch_stride + gr * pr.la_group_stride;
+        Ss += so; St += so; las += lo; lat += lo;
+        if (dSs) { dSs += so; dSt += so; }
+        loss_part += (long)blockIdx.y * gridDim.x;
+    }
+    float ls[K], lt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ls[k] = las[k]; lt[k] = lat[k]; }
+    const float f = -0.5f * gscale * inv_T;
+    float lacc = 0.f;
+    for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long)gridDim.x * 256) {
+        float a[K], b[K];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Ss + row * ld + 4 * q);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(St + row * ld + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[4 * q + e] = va[e]; b[4 * q + e] = vb[e]; }
+        }
+        float wms = -INFINITY, wmt = -INFINITY, m_s = -INFINITY, m_t = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wms = fmaxf(wms, fmaf(a[k], inv_eps, ls[k])); wmt = fmaxf(wmt, fmaf(b[k], inv_eps, lt[k]));
+            m_s = fmaxf(m_s, a[k]); m_t = fmaxf(m_t, b[k]);
+        }
+        float qs[K], qt[K], es[K], et[K];
+        float vs = 0.f, vt = 0.f, zs = 0.f, zt = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            qs[k] = bk_exp(fmaf(a[k], inv_eps, ls[k]) - wms); vs += qs[k];
+            qt[k] = bk_exp(fmaf(b[k], inv_eps, lt[k]) - wmt); vt += qt[k];
+            es[k] = bk_exp((a[k] - m_s) * inv_T); zs += es[k];
+            et[k] = bk_exp((b[k] - m_t) * inv_T); zt += et[k];
+        }
+        const float ivs = 1.f / vs, ivt = 1.f / vt, izs = 1.f / zs, izt = 1.f / zt, lzs = logf(zs), lzt = logf(zt);
+        float qsum_s = 0.f, qsum_t = 0.f, l = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            qs[k] *= ivs; qt[k] *= ivt;
+            qsum_s += qs[k]; qsum_t += qt[k];
+            l += qs[k] * ((b[k] - m_t) * inv_T - lzt) + qt[k] * ((a[k] - m_s) * inv_T - lzs);
+        }
+        lacc += l;
+        if (dSs) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                f32x4 d_t, d_s;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
+                    d_t[e] = f * (qs[k] - et[k] * izt * qsum_s);
+                    d_s[e] = f * (qt[k] - es[k] * izs * qsum_t);
+                }
+                *reinterpret_cast<f32x4*>(dSt + row * ldd + 4 * q) = d_t;
+                *reinterpret_cast<f32x4*>(dSs + row * ldd + 4 * q) = d_s;
+            }
+        }
+    }
+    __shared__ float red[16];
+    const float tot = gx_block_sum(lacc, red);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = -0.5f * tot;
+}
+
 // ===================================================================== S7 / S8
 // LARC(clip=False) around momentum SGD (swav_clustering.py:286-292; apex LARC.step restated):
 //   g' = g * trust*|p| / (|g| + 1e-8)  if |p| != 0 and |g| != 0 ;  buf = first ? g' : mom*buf + g'
@@ -1014,9 +1088,22 @@ int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_p
     if (!workspace || workspace_bytes < (size_t)npair * nb * sizeof(float)) return GX_ERR_WORKSPACE;
     const long vs = rows_per_patch * K;                       // view stride
     CePairs pr{ngroups, 2 * vs, rows * K, (long)2 * ngroups * K, (long)K};
-    hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb, (unsigned)npair), dim3(256), 0, (hipStream_t)stream, S_all, S_all + vs,
-                       rows, K, (long)K, team, 1.f / eps, 1.f / temperature, la_all, la_all + (long)ngroups * K, grad_scale,
-                       dS_all, dS_all ? dS_all + vs : nullptr, (long)K, workspace, pr);
+    static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
+    const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (rows_per_patch * K) % 4 == 0 &&
+                         ((((uintptr_t)S_all | (uintptr_t)dS_all) & 15) == 0);
+#define GX_CE_ROWLANE(KQ_)                                                                                                     \
+    hipLaunchKernelGGL(swapped_ce_rowlane_kernel<KQ_>, dim3(nb, (unsigned)npair), dim3(256), 0, (hipStream_t)stream, S_all,     \
+                       S_all + vs, rows, (long)K, 1.f / eps, 1.f / temperature, la_all, la_all + (long)ngroups * K, grad_scale, \
+                       dS_all, dS_all ? dS_all + vs : nullptr, (long)K, workspace, pr)
+    if (rowlane && K == 4) GX_CE_ROWLANE(1);
+    else if (rowlane && K == 8) GX_CE_ROWLANE(2);
+    else if (rowlane && K == 12) GX_CE_ROWLANE(3);
+    else if (rowlane && K == 16) GX_CE_ROWLANE(4);
+    else
+        hipLaunchKernelGGL(swapped_ce_kernel, dim3(nb, (unsigned)npair), dim3(256), 0, (hipStream_t)stream, S_all, S_all + vs,
+                           rows, K, (long)K, team, 1.f / eps, 1.f / temperature, la_all, la_all + (long)ngroups * K, grad_scale,
+                           dS_all, dS_all ? dS_all + vs : nullptr, (long)K, workspace, pr);
+#undef GX_CE_ROWLANE
     GX_CHECK_LAUNCH();
     launch_partial_reduce(workspace, (int)(npair * nb), 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
