@@ -34,6 +34,9 @@ def _equal_linear_params(in_dim, out_dim, bias_init=0.0, lr_mul=1.0):
     return m
 
 
+MAP_SPLIT_K = int(os.environ.get("GX_MAP_SPLITK", "8"))       # mapping-MLP GEMMs (1: unsplit, for A/B runs)
+
+
 def _fir(taps):
     k = torch.tensor(taps, dtype=torch.float32)
     k = torch.outer(k, k)
@@ -92,7 +95,8 @@ class MappingNetwork(nn.Module):
         for i in range(self.n_mlp):
             lin = getattr(self, str(i + 1))
             w = lin.weight.detach()
-            y = ops.gemm(h, w, False, True)
+            # few rows x 512 x 512: four output tiles of a 32-k-tile loop are latency-bound; split the k loop over 8 x 4 tiles
+            y = ops.gemm(h, w, False, True, split_k=MAP_SPLIT_K if h.shape[0] <= 256 else 1)
             h = ops.bias_act_(y, alpha=(1.0 / math.sqrt(w.shape[1])) * self.lr_mlp, bias=lin.bias.detach(),
                               bscale=self.lr_mlp, act=True)
         return h.reshape(shape)
