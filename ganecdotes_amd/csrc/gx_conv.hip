@@ -707,7 +707,7 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
     }
 }
 
-// EXPERIMENTAL fp16x3 engine (DESIGN 10, item 2a): B [N][K] as two fp16 pieces per element (w = p0 + 2^-11 p1 up to 2^-22),
+// EXPERIMENTAL fp16x3 engine (DESIGN 10, item 0): B [N][K] as two fp16 pieces per element (w = p0 + 2^-11 p1 up to 2^-22),
 // tiled like the bf16 planes: per (128-row tile, 16-column chunk) two 4 KB pieces in the LDS image layout.
 __global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N, int K, long ld, int ntn, int ncc,
                                              unsigned short* __restrict__ planes) {

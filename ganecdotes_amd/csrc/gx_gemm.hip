@@ -466,7 +466,7 @@ __global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(
     }
 }
 
-// ---- EXPERIMENTAL engine "fp16x3" (DESIGN 10, item 2a; opt-in, never the default): the NT contraction of gemm_xw_kernel
+// ---- EXPERIMENTAL engine "fp16x3" (DESIGN 10, item 0; opt-in, never the default): the NT contraction of gemm_xw_kernel
 // with every operand as TWO fp16 pieces a = a0 + 2^-11 a1 (11 + 11 bits) and a b ~ a0 b0 + 2^-11 (a0 b1 + a1 b0): three
 // MFMA products per fp32 product instead of six, per-product error 2^-22 instead of 2^-24 (tools/split_accuracy.py).
 // Same structure as gemm_xw_kernel (A raw fp32 by LDS-DMA, split at the fragment read; B planes by LDS-DMA); the two
@@ -902,7 +902,7 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
                            workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1);
 }
 
-// EXPERIMENTAL (DESIGN 10, item 2a; nothing in the product path calls it): gx_gemm_f32_nt_planes on the "fp16x3"
+// EXPERIMENTAL (DESIGN 10, item 0; nothing in the product path calls it): gx_gemm_f32_nt_planes on the "fp16x3"
 // engine — two fp16 pieces per operand, three MFMA products per fp32 product.  b_planes = gx_split_gemm_weights_h3.
 int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                              const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,

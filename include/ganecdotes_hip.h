@@ -104,7 +104,7 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
-/* EXPERIMENTAL, not used by the product path (DESIGN.md par. 10, item 2a): the same NT contraction with every operand as
+/* EXPERIMENTAL, not used by the product path (DESIGN.md par. 10, item 0): the same NT contraction with every operand as
  * two fp16 pieces (11 + 11 bits) and three MFMA products per fp32 product — per-product error 2^-22 instead of 2^-24,
  * operands within fp16's range.  Exists so that the precision question can be answered with measurements. */
 size_t gx_gemm_weight_planes_h3_bytes(int N, int K);

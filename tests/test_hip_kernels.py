@@ -681,7 +681,7 @@ def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
 
 
 def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
-    """gx_gemm_f32_nt_planes_h3 (EXPERIMENTAL, not on the product path; DESIGN 10 item 2a): two fp16 pieces per operand,
+    """gx_gemm_f32_nt_planes_h3 (EXPERIMENTAL, not on the product path; DESIGN 10 item 0): two fp16 pieces per operand,
     three MFMA products per fp32 product.  On operands inside fp16's range its error against fp64 is no larger than
     the exact-fp32 MFMA engine's; the upsample-add / dual-A epilogue is the shared one."""
     from ganecdotes_amd import _lib

@@ -3,7 +3,7 @@
 in fp64, fp32 accumulation order ignored): relative error of C = A B^T against fp64 for
   fp32      every product and the sum rounded as an fp32 dot product (numpy float32 matmul),
   bf16x6    three bf16 pieces per operand (exact 24 bits), the six products above 2^-24       (this build's default engine),
-  fp16x3    two fp16 pieces per operand (11 + 11 bits), a0 b0 + a0 b1 + a1 b0                 (DESIGN 10, item 2a),
+  fp16x3    two fp16 pieces per operand (11 + 11 bits), a0 b0 + a0 b1 + a1 b0                 (DESIGN 10, item 0),
   tf32      one 11-bit piece per operand                                                      (the reference's cuDNN default).
 usage: python tools/split_accuracy.py [K ...]"""
 import sys
