@@ -189,9 +189,22 @@ class SwAVClustering(ViewMixin):
         return r, c
 
     def _split_k(self, m, n, k):
-        tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        want = max(1, 1024 // tiles)
-        return int(max(1, min(want, k // 256)))
+        """k split of a long-reduction TN GEMM (m x n outputs): enough workgroups to fill the chip, and — these GEMMs run
+        the wave-specialised 256 x 128 tiles, ONE workgroup per CU — a count that fills whole rounds of the 256 CUs
+        (K = 5000, m x n = 5000 x 512: 80 tiles; 6 splits = 480 workgroups = 1.9 rounds ran 8.8 ms, 16 = 5 rounds 8.4 ms)"""
+        tiles128 = ((m + 127) // 128) * ((n + 127) // 128)
+        want = max(1, 1024 // tiles128)
+        cap = max(1, k // 256)
+        if m <= 128 or k // max(1, min(want, cap)) < 768:
+            return int(max(1, min(want, cap)))
+        tiles = ((m + 255) // 256) * ((n + 127) // 128)
+        best, best_eff = 1, 0.0
+        for s in range(max(1, want // 2), min(cap, 4 * want, max(1, k // 768)) + 1):
+            wgs = tiles * s
+            eff = wgs / (((wgs + 255) // 256) * 256.0)
+            if wgs >= 256 and eff > best_eff + 1e-9:
+                best, best_eff = s, eff
+        return int(best if best_eff > 0 else max(1, min(want, cap)))
 
     def train_step(self, images, return_aux=False):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
