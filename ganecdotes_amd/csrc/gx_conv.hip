@@ -709,7 +709,7 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
 
 // EXPERIMENTAL fp16x3 engine: B [N][K] as two fp16 pieces per element (w = p0 + 2^-11 p1 up to 2^-22),
 // tiled like the bf16 planes: per (128-row tile, 16-column chunk) two 4 KB pieces in the LDS image layout.
-__global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N, int K, long ld, int ntn, int ncc,
+__global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N, int K, long ld, int transposed, int ntn, int ncc,
                                              unsigned short* __restrict__ planes) {
     const long total = (long)ntn * ncc * 128 * 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -717,7 +717,7 @@ __global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N,
         long blk = i >> 11;
         const int cc = (int)(blk % ncc); const int tn = (int)(blk / ncc);
         const int co = tn * 128 + row, ci = cc * 16 + k;
-        const float x = (co < N && ci < K) ? B[(long)co * ld + ci] : 0.f;
+        const float x = (co < N && ci < K) ? (transposed ? B[(long)ci * ld + co] : B[(long)co * ld + ci]) : 0.f;
         const _Float16 p0 = (_Float16)x;
         const _Float16 p1 = (_Float16)((x - (float)p0) * 2048.f);
         unsigned short* base = planes + (((long)tn * ncc + cc) * 2) * 2048;
@@ -1513,12 +1513,13 @@ int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, 
 }
 
 size_t gx_gemm_weight_planes_h3_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 2 * 4096; }
-int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream) {
-    if (!B || !planes || N <= 0 || K <= 0 || ldb < K) return GX_ERR_BAD_ARG;
+int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, int transposed, unsigned short* planes, void* stream) {
+    // transposed: the source is [K][N] (row stride ldb) and the planes are those of its transpose
+    if (!B || !planes || N <= 0 || K <= 0 || ldb < (transposed ? N : K)) return GX_ERR_BAD_ARG;
     const int ntn = gx_cdiv(N, 128), ncc = gx_cdiv(K, 16);
     long want = ((long)ntn * ncc * 2048 + 255) / 256;
     hipLaunchKernelGGL(split_gemm_weights_h3_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       B, N, K, ldb, ntn, ncc, planes);
+                       B, N, K, ldb, transposed, ntn, ncc, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -8,6 +8,7 @@
 //   S6 dWp             = dz^T X                  (TN, split-K)
 // Reference op chain: hfc_with_swav/swav_clustering.py:171-175 and autograd of it (:459).
 #include "gx_mfma_x6.h"
+#include <cmath>
 #include <cstdlib>
 
 #ifndef GX_DEFAULT_GEMM_MODE
@@ -37,6 +38,7 @@ struct GemmArgs {
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
     const float* up_src; int up_shift;
     const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
+    float a_scale;        // gemm_xh_kernel: power of two applied to A before the fp16 split (1 / a_scale is folded into alpha)
     float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xh_kernel(GemmArgs g) {
     const int arow = wid * 32 + r32;
     const int af = (arow >> 2) & 3;
     const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
+    const float asc = g.a_scale;
     auto compute = [&](const char* st, const char* Bs) {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
@@ -545,10 +548,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xh_kernel(GemmArgs g) {
             for (int t = 0; t < 4; ++t)
                 b[t][q] = *reinterpret_cast<const f16x8*>(Bs + q * 4096 + x_kc_off(t * 32 + r32, hh));
         unsigned p0[4], p1[4];
-        split2h(x0[0], x0[1], p0[0], p1[0]);
-        split2h(x0[2], x0[3], p0[1], p1[1]);
-        split2h(x1[0], x1[1], p0[2], p1[2]);
-        split2h(x1[2], x1[3], p0[3], p1[3]);
+        split2h(x0[0] * asc, x0[1] * asc, p0[0], p1[0]);
+        split2h(x0[2] * asc, x0[3] * asc, p0[1], p1[1]);
+        split2h(x1[0] * asc, x1[1] * asc, p0[2], p1[2]);
+        split2h(x1[2] * asc, x1[3] * asc, p0[3], p1[3]);
         const f16x8 a0 = __builtin_bit_cast(f16x8, (u32x4){p0[0], p0[1], p0[2], p0[3]});
         const f16x8 a1 = __builtin_bit_cast(f16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
         // cross terms first (the smaller magnitudes), then a0 b0
@@ -724,7 +727,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
-    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr;
+    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.a_scale = 1.f;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -796,7 +799,7 @@ static int xw_stages() {            // GX_GEMM_XW_STAGES=2|3 (LDS ring depth: 3 
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
-                          bool h3 = false) {
+                          bool h3 = false, float a_scale = 1.f) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -813,7 +816,8 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     }
     g.A = A1; g.lda = lda1; g.A2 = K2 > 0 ? A2 : nullptr; g.lda2 = K2 > 0 ? lda2 : lda1; g.K1 = K1;
     g.B = nullptr; g.ldb = 0; g.B2 = nullptr; g.ldb2 = 0; g.N1 = N; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
-    g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
+    g.alpha = h3 ? alpha / a_scale : alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
+    g.a_scale = a_scale;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
     const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h3 ? 2 : 3) * 4096;
@@ -906,9 +910,13 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
 // engine — two fp16 pieces per operand, three MFMA products per fp32 product.  b_planes = gx_split_gemm_weights_h3.
 int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                              const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream) {
+                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, float a_scale,
+                             float* colmax_part, void* stream) {
+    // a_scale: a power of two that brings A into fp16's range before the split (its inverse is folded into alpha)
+    int e2 = 0;
+    if (!(a_scale > 0.f) || std::frexp(a_scale, &e2) != 0.5f) return GX_ERR_BAD_ARG;      // not a power of two
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, nullptr, (hipStream_t)stream, true);
+                              fine_res, colmax_part, (hipStream_t)stream, true, a_scale);
 }
 
 }  // extern "C"

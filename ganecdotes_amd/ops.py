@@ -168,6 +168,41 @@ def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
     return out
 
 
+# ---- EXPERIMENTAL fp16x3 engine: opt-in, operands with an a-priori range only ---------------------
+def split_gemm_weights_h3(b, transposed=False):
+    """two fp16 pieces per element of the weight operand; transposed: b is stored (K, N) and the planes are b.T's"""
+    _chk2d(b)
+    n, k = (b.shape[1], b.shape[0]) if transposed else b.shape
+    L = lib()
+    planes = torch.empty(L.gx_gemm_weight_planes_h3_bytes(n, k) // 2, dtype=torch.int16, device=b.device)
+    _lib.check(L.gx_split_gemm_weights_h3(_p(b), n, k, b.stride(0), int(transposed), _p(planes), _stream()),
+               "gx_split_gemm_weights_h3")
+    return planes
+
+
+def gemm_nt_planes_h3(a, b_planes, out, a_scale=1.0, alpha=1.0, col_bias=None, want_colmax=False):
+    """out = alpha * a @ B.T + col_bias on the fp16x3 engine; a_scale: power of two that brings `a` into fp16's range"""
+    _chk2d(a, out)
+    _chk(col_bias)
+    m, k = a.shape
+    n = out.shape[1]
+    L = lib()
+    part = None
+    if want_colmax:
+        g = 1 if want_colmax is True else int(want_colmax)
+        pb = L.gx_gemm_colmax_part_bytes(m, n)
+        part = workspace("gemm_colmax", pb, a.device)[:pb // 4]
+    with record("gemm_f32_kernel", 2.0 * m * n * k):
+        _lib.check(L.gx_gemm_f32_nt_planes_h3(m, n, k, _p(a), a.stride(0), 0, None, 0, _p(b_planes), _p(out), out.stride(0),
+                                              alpha, 0.0, None, _p(col_bias), None, 0, float(a_scale), _p(part), _stream()),
+                   "gx_gemm_f32_nt_planes_h3")
+    if want_colmax:
+        if g > 1:
+            return out, part.view(-1, n)[:m // 32].view(g, m // (32 * g), n).amax(1)
+        return out, part.view(-1, n).amax(0)
+    return out
+
+
 def split_gemm_weights(b):
     """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
     Made once per optimizer step: the projection / prototype weights only change there."""
@@ -993,7 +1028,8 @@ def swapped_ce_fused_ok(sk_s, d_s):
 def swapped_ce_fused(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, gb, gb_beta):
     """swapped_ce + gb = gb_beta * gb + colsum(d_s) + colsum(d_t), one pass over the two score matrices"""
     S, T = sk_s.S, sk_t.S
-    _chk(loss_out, d_s, d_t, gb)
+    _chk(loss_out, gb)
+    _chk2d(d_s, d_t)                       # row-strided dS (padded rows) is fine: the kernel takes the stride
     L = lib()
     wsb = L.gx_swapped_ce_fused_workspace_bytes(sk_s.K)
     ws = workspace("ce_fused", wsb, S.device)

@@ -54,6 +54,11 @@ class _NullLogger:
         pass
 
 
+# EXPERIMENTAL: GX_EXPERIMENTAL_FP16X3=1 routes the many-prototype score and dz GEMMs — operands whose
+# range is known a priori (unit-norm rows; dS bounded by grad_scale / 2T) — through the fp16x3 engine.  Off by default.
+FP16X3 = os.environ.get("GX_EXPERIMENTAL_FP16X3", "0") == "1"
+
+
 class SwAVClustering(ViewMixin):
 
 
@@ -288,6 +293,11 @@ class SwAVClustering(ViewMixin):
         pgroup = max(1, min(P, int(16e9 // (8.0 * rows * K)))) if mode == 'pyramid' else 1
         # generic-K scores: the prototype weights as bf16x6 planes, once per step (gemm_xw_kernel)
         wc_planes = ops.split_gemm_weights(Wc) if (not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0) else None
+        h3 = FP16X3 and wc_planes is not None and K % 4 == 0
+        if h3:
+            Kp = (K + 15) // 16 * 16
+            wc_h3 = ops.split_gemm_weights_h3(Wc)                          # scores: z_hat (unit rows) x Wc (unit rows)
+            wct_h3 = ops.split_gemm_weights_h3(Wc, transposed=True)        # dz = dS Wc as dS x (Wc^T)^T, k padded to Kp
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
@@ -318,7 +328,12 @@ class SwAVClustering(ViewMixin):
                             z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
                         X.append(x)
-                    if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
+                    if h3 and ops.gemm_planes_ok(z, None, K, sc):
+                        cm_g = (True if ngroups == 1 else ngroups) if (K > 64 and (ngroups == 1 or grows % 32 == 0)) else False
+                        res = ops.gemm_nt_planes_h3(z, wc_h3, sc, col_bias=bc, want_colmax=cm_g)
+                        if cm_g:
+                            cmax_pre[(gi, v)] = res[1]
+                    elif wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
                         # (B*N, K), Wc split once per step; the Sinkhorn column maxima come out of the epilogue
                         if K > 64 and (ngroups == 1 or grows % 32 == 0):
                             _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
@@ -356,7 +371,14 @@ class SwAVClustering(ViewMixin):
                 picks = pb.picks[pno]
                 X, Zh, Rn = keep[gi]
                 Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
-                dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
+                if h3:       # rows padded to whole 16-column chunks (zero pad) so that dS can be the A operand of the dz GEMM
+                    dSp = [torch.empty(rows, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
+                    for t_ in dSp:
+                        if Kp > K:
+                            t_[:, K:].zero_()
+                    dS = [t_[:, :K] for t_ in dSp]
+                else:
+                    dS = [torch.empty_like(Sc[0]), torch.empty_like(Sc[1])]
                 # many prototypes: loss, dS and the bias gradient in one pass over the score matrices
                 gb_in_ce = not (mode == 'pyramid' and small) and ops.swapped_ce_fused_ok(skb[0], dS[0])
                 for g in range(ngroups):
@@ -381,7 +403,13 @@ class SwAVClustering(ViewMixin):
                     ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                     if not gb_in_ce:
                         ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
-                    dz = ops.gemm(dS[v], Wc, False, False)                         # d z_hat (B*N, D)
+                    if h3 and ops.gemm_planes_ok(dSp[v], None, D, Zh[v]):
+                        # |dS| <= grad_scale / 2T: one host-computed power of two lifts it into fp16's normal range
+                        bound = max(0.5 * gscale / T, 1e-30)
+                        dz = torch.empty(rows, D, dtype=torch.float32, device=dev)
+                        ops.gemm_nt_planes_h3(dSp[v], wct_h3, dz, a_scale=2.0 ** math.floor(math.log2(16384.0 / bound)))
+                    else:
+                        dz = ops.gemm(dS[v], Wc, False, False)                     # d z_hat (B*N, D)
                     if mode == 'pyramid':
                         with self._timed("scatter_rows"):
                             ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])

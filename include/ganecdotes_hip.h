@@ -108,10 +108,11 @@ size_t gx_gemm_colmax_part_bytes(int M, int N);
  * two fp16 pieces (11 + 11 bits) and three MFMA products per fp32 product — per-product error 2^-22 instead of 2^-24,
  * operands within fp16's range.  Exists so that the precision question can be answered with measurements. */
 size_t gx_gemm_weight_planes_h3_bytes(int N, int K);
-int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream);
+int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, int transposed, unsigned short* planes, void* stream);
 int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                              const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, void* stream);
+                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, float a_scale,
+                             float* colmax_part, void* stream);   /* a_scale: power of two applied to A before the split */
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110

@@ -695,10 +695,10 @@ def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
             w = dev(torch.randn(n, k1 + k2) / (k1 + k2) ** 0.5)
             co = dev(torch.randn(m // 4, n)) if up else None
             pl = torch.empty(L.gx_gemm_weight_planes_h3_bytes(n, k1 + k2) // 2, dtype=torch.int16, device="cuda")
-            _lib.check(L.gx_split_gemm_weights_h3(_p(w), n, k1 + k2, w.stride(0), _p(pl), _stream()), "split_h3")
+            _lib.check(L.gx_split_gemm_weights_h3(_p(w), n, k1 + k2, w.stride(0), 0, _p(pl), _stream()), "split_h3")
             out = torch.empty(m, n, device="cuda")
             _lib.check(L.gx_gemm_f32_nt_planes_h3(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
-                                                  _p(pl), _p(out), n, 1.0, 0.0, None, None, _p(co), up, _stream()), "h3")
+                                                  _p(pl), _p(out), n, 1.0, 0.0, None, None, _p(co), up, 1.0, None, _stream()), "h3")
             acat = a1 if a2 is None else torch.cat([a1, a2], 1)
             ref = acat.double() @ w.double().t()
             if up:
@@ -710,6 +710,16 @@ def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
             ops.set_gemm_mode(1)
             e3, e32 = rel_err(out, ref), rel_err(exact, ref)
             assert e3 < 3e-6 and e3 <= 1.5 * e32 + 1e-7, (e3, e32)
+        # tiny operands (a gradient matrix) lifted by a power of two, weights given transposed, column maxima
+        a = dev(torch.randn(600, 208) * 3e-7)
+        a[:, 200:] = 0
+        wt = dev(torch.randn(200, 96) / 14.0)                     # stored (K, N)
+        out = torch.empty(600, 96, device="cuda")
+        _, cm = ops.gemm_nt_planes_h3(a, ops.split_gemm_weights_h3(wt, transposed=True), out, a_scale=2.0 ** 35, want_colmax=True)
+        ref = a[:, :200].double() @ wt.double()
+        assert rel_err(out, ref) < 3e-6 and torch.equal(cm, out.amax(0))
+        with pytest.raises(RuntimeError):                          # the scale must be a power of two
+            ops.gemm_nt_planes_h3(a, ops.split_gemm_weights_h3(wt, transposed=True), out, a_scale=3.0)
     finally:
         ops.set_gemm_mode(prev)
 
