@@ -38,6 +38,7 @@ struct GemmArgs {
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
     const float* up_src; int up_shift;
     const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
+    int n_group;          // gemm_xw / gemm_xh: N tiles per group of the tile order (xw_tile_of)
     float a_scale;        // gemm_xh_kernel: power of two applied to A before the fp16 split (1 / a_scale is folded into alpha)
     float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
@@ -341,6 +342,19 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (tm, tn) of logical tile `logical` for the weight-plane kernels: the N tiles go in groups of g.n_group, and within a
+// group the pixel tiles are swept with the group's N tiles innermost.  An XCD's contiguous run of logical tiles then
+// reads an A tile from HBM once per GROUP (the group's other tiles find it in L2) and keeps only the group's weight
+// planes hot.  With tn simply fastest, a 5000-column score GEMM kept all 40 weight slices (15 MB against 4 MB of L2) in
+// flight per XCD and fetched 23 GB per launch for 0.65 GB of activations (profiles/r02_k5000_traffic.json history).
+__device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& tm, int& tn) {
+    const int per_group = g.tiles_m * g.n_group;
+    const int grp = logical / per_group, rem = logical - grp * per_group;
+    const int width = min(g.n_group, g.tiles_n - grp * g.n_group);      // the last group may be narrower
+    tm = rem / width;
+    tn = grp * g.n_group + (rem - tm * width);
+}
+
 // NT contraction with the weight operand PRE-SPLIT (gx_split_gemm_weights: the projection / prototype weights change
 // once per step, their planes are made once per step) — "xw".  What the kernel above strings in series per 16-deep
 // k-tile (global loads -> registers -> split -> six LDS plane stores -> barrier) becomes, as in modconv_xp_kernel,
@@ -360,7 +374,8 @@ __global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = g.tiles_m * g.tiles_n;
     const int logical = xcd_remap((int)blockIdx.x, ntile);
-    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    int tm, tn;
+    xw_tile_of(g, logical, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;                      // K, K1 are multiples of 16
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -491,7 +506,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xh_kernel(GemmArgs g) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = g.tiles_m * g.tiles_n;
     const int logical = xcd_remap((int)blockIdx.x, ntile);
-    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    int tm, tn;
+    xw_tile_of(g, logical, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -727,7 +743,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
-    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.a_scale = 1.f;
+    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.a_scale = 1.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -823,6 +839,13 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h3 ? 2 : 3) * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
+    {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
+        static const int forced = [] { const char* e = getenv("GX_GEMM_XW_NGROUP"); return e ? atoi(e) : 0; }();
+        const long per_tile = (long)K * 128 * (h3 ? 4 : 6);
+        long gn = forced > 0 ? forced : (2L << 20) / per_tile;
+        gn = gn < 1 ? 1 : (gn > g.tiles_n ? g.tiles_n : gn);
+        g.n_group = (int)gn;
+    }
     if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;
     g.colmax_part = colmax_part;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
