@@ -696,6 +696,111 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, split);
 }
 
+// EXPERIMENTAL fp16x3 form of the wave-specialised TN GEMM (opt-in): C = alpha * A^T B with A [K][M]
+// and B [K][N] both m-contiguous, every element split into two fp16 pieces by the producer waves (A after a
+// power-of-two lift g.a_scale), three MFMA products per fp32 product in the consumers (a0 b0 into one accumulator set,
+// the cross terms into a second).  128 x 128 tile: four consumer waves 2 x 2 of 64 x 64, four producer waves.
+constexpr int XH_WS_SLOT = 4 * XImg<128>::MC_PLANE;                  // A pieces + B pieces: 17408 B
+__global__ __launch_bounds__(WS_THREADS, 1) void gemm_xhws_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * XH_WS_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = g.tiles_m * g.tiles_n;
+    int logical, split;
+    gemm_tile_of_block(ntile, logical, split);
+    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nkt = (kend - kbeg + XK - 1) / XK;
+    char* slot0 = lds;
+    char* slot1 = lds + XH_WS_SLOT;
+    constexpr int PL = XImg<128>::MC_PLANE, RW = XImg<128>::MC_ROWW;
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int p = tid - 256;
+        const float asc = g.a_scale;
+        f32x4 ra0[2], rb0[2], ra1[2], rb1[2];
+        auto load_tiles = [&](int t, f32x4 (&ra)[2], f32x4 (&rb)[2]) {     // tiles past kend load as zeros
+            const int k0 = kbeg + t * XK;
+            x6_load_tile<false, true, 128>(g.A, g.lda, m0, g.M, k0, kend, ra, p);
+            x6_load_tile<false, true, 128>(g.B, g.ldb, n0, g.N, k0, kend, rb, p);
+        };
+        auto stage_one = [&](char* S, const f32x4 (&v)[2], float sc) {     // (k, k + 1) of one m -> one word per piece
+            unsigned q0[4], q1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2h(v[0][e] * sc, v[1][e] * sc, q0[e], q1[e]);
+            char* d = S + ((p >> 5) * RW + (p & 31) * 4) * 4;
+            *reinterpret_cast<u32x4*>(d) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
+            *reinterpret_cast<u32x4*>(d + PL) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
+        };
+        auto stage = [&](char* slot, const f32x4 (&ra)[2], const f32x4 (&rb)[2]) {
+            stage_one(slot, ra, asc);
+            stage_one(slot + 2 * PL, rb, 1.f);
+        };
+        load_tiles(0, ra0, rb0);
+        load_tiles(1, ra1, rb1);
+        if (nkt > 0) stage(slot0, ra0, rb0);
+        __syncthreads();                                             // barrier 0: tile 0 visible
+        for (int t = 0; t < nkt; t += 2) {
+            load_tiles(t + 2, ra0, rb0);
+            if (t + 1 < nkt) stage(slot1, ra1, rb1);
+            __syncthreads();                                         // barrier t+1
+            if (t + 1 >= nkt) break;
+            load_tiles(t + 3, ra1, rb1);
+            if (t + 2 < nkt) stage(slot0, ra0, rb0);
+            __syncthreads();                                         // barrier t+2
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    const int wr = wid >> 1, wc = wid & 1;
+    f32x16 acc[2][2], crs[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; crs[mt][nt][r] = 0.f; }
+    const int r32 = lane & 31, hh = lane >> 5;
+    __syncthreads();                                                 // barrier 0
+    for (int t = 0; t < nkt; ++t) {
+        const char* As = (t & 1) ? slot1 : slot0;
+        const char* Bs = As + 2 * PL;
+        f16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][q] = __builtin_bit_cast(f16x8, x6_frag<false, 128>(As, q, wr * 64 + i * 32 + r32, hh));
+                b[i][q] = __builtin_bit_cast(f16x8, x6_frag<false, 128>(Bs, q, wc * 64 + i * 32 + r32, hh));
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1], b[nt][0], crs[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][1], crs[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][0], acc[mt][nt], 0, 0, 0);
+        __syncthreads();                                             // barrier t+1
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(crs[mt][nt][r], 1.f / 2048.f, acc[mt][nt][r]);
+    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
+}
+
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int splits, float* __restrict__ C,
                                           int M, int N, long ldc, float alpha, float beta,
@@ -740,7 +845,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1) {
+                       int N1 = -1, float h3_a_scale = 0.f) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.a_scale = 1.f; g.n_group = 1;
@@ -761,7 +866,11 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
-    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= ws_min_k();
+    const bool h3 = h3_a_scale > 0.f;         // EXPERIMENTAL fp16x3 TN (gemm_xhws_kernel): 128 x 128 tiles
+    if (h3 && (!x6 || !transA || transB || !g.vec_ok || A2 || B2 || up_src)) return GX_ERR_BAD_ARG;
+    g.a_scale = h3 ? h3_a_scale : 1.f;
+    if (h3) { alpha /= h3_a_scale; g.alpha = alpha; }
+    const bool ws = !h3 && x6 && M > BM && (split_k > 1 ? K / split_k : K) >= ws_min_k();
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -789,7 +898,8 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         else if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, g);              \
     } while (0)
-    if (!transA && transB) GX_LAUNCH_GEMM(false, true);
+    if (h3) hipLaunchKernelGGL(gemm_xhws_kernel, grid, dim3(WS_THREADS), 0, stream, g);
+    else if (!transA && transB) GX_LAUNCH_GEMM(false, true);
     else if (!transA && !transB) GX_LAUNCH_GEMM(false, false);
     else if (transA && !transB) GX_LAUNCH_GEMM(true, false);
     else GX_LAUNCH_GEMM(true, true);
@@ -940,6 +1050,16 @@ int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, i
     if (!(a_scale > 0.f) || std::frexp(a_scale, &e2) != 0.5f) return GX_ERR_BAD_ARG;      // not a power of two
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
                               fine_res, colmax_part, (hipStream_t)stream, true, a_scale);
+}
+
+// EXPERIMENTAL: C = alpha * A^T B + beta * C on the fp16x3 engine, A [K][M] lifted by the power of
+// two a_scale before the split (B inside fp16's range as it is).  Split-K as gx_gemm_f32.
+int gx_gemm_f32_tn_h3(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float alpha,
+                      float beta, float a_scale, int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+    int e2 = 0;
+    if (!(a_scale > 0.f) || std::frexp(a_scale, &e2) != 0.5f) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
+                           workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1, a_scale);
 }
 
 }  // extern "C"

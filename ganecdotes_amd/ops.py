@@ -203,6 +203,22 @@ def gemm_nt_planes_h3(a, b_planes, out, a_scale=1.0, alpha=1.0, col_bias=None, w
     return out
 
 
+def gemm_tn_h3(a, b, out, a_scale, alpha=1.0, beta=0.0, split_k=1):
+    """out = alpha * a.T @ b + beta*out on the fp16x3 engine (a stored (K, M), lifted by the power of two a_scale)"""
+    _chk2d(a, b, out)
+    k, m = a.shape
+    n = b.shape[1]
+    L = lib()
+    ws, wsb = None, 0
+    if split_k > 1:
+        wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
+        ws = workspace("gemm", wsb, a.device)
+    with record("gemm_f32_kernel", 2.0 * m * n * k):
+        _lib.check(L.gx_gemm_f32_tn_h3(m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), alpha, beta,
+                                       float(a_scale), split_k, _p(ws), wsb, _stream()), "gx_gemm_f32_tn_h3")
+    return out
+
+
 def split_gemm_weights(b):
     """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
     Made once per optimizer step: the projection / prototype weights only change there."""

@@ -211,6 +211,18 @@ class SwAVClustering(ViewMixin):
                 best, best_eff = s, eff
         return int(best if best_eff > 0 else max(1, min(want, cap)))
 
+    @staticmethod
+    def _split_k_h3(m, n, k):
+        """k split for the experimental fp16x3 TN kernel (128 x 128 tiles, one workgroup per CU): whole rounds of 256"""
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        best, best_eff = 1, 0.0
+        for s in range(1, max(1, min(64, k // 768)) + 1):
+            wgs = tiles * s
+            eff = wgs / (((wgs + 255) // 256) * 256.0)
+            if wgs >= 256 and eff > best_eff + 1e-9:
+                best, best_eff = s, eff
+        return best
+
     def train_step(self, images, return_aux=False):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
         as a 1-element HIP tensor (global mean; no host sync)."""
@@ -400,7 +412,12 @@ class SwAVClustering(ViewMixin):
                             ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
                         first_acc = False
                         continue
-                    ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
+                    if h3:
+                        bound = max(0.5 * gscale / T, 1e-30)
+                        ops.gemm_tn_h3(dS[v], Zh[v], gWc, 2.0 ** math.floor(math.log2(16384.0 / bound)), beta=beta,
+                                       split_k=self._split_k_h3(K, D, rows))
+                    else:
+                        ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                     if not gb_in_ce:
                         ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
                     if h3 and ops.gemm_planes_ok(dSp[v], None, D, Zh[v]):

@@ -113,6 +113,8 @@ int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, i
                              const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                              const float* row_scale, const float* col_bias, const float* coarse, int fine_res, float a_scale,
                              float* colmax_part, void* stream);   /* a_scale: power of two applied to A before the split */
+int gx_gemm_f32_tn_h3(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float alpha,
+                      float beta, float a_scale, int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110

@@ -720,6 +720,17 @@ def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
         assert rel_err(out, ref) < 3e-6 and torch.equal(cm, out.amax(0))
         with pytest.raises(RuntimeError):                          # the scale must be a power of two
             ops.gemm_nt_planes_h3(a, ops.split_gemm_weights_h3(wt, transposed=True), out, a_scale=3.0)
+        # the TN form (a prototype-gradient GEMM: tiny dS lifted by a power of two, unit-range z_hat), split-K, beta
+        for (k, m, n, split) in ((5000, 200, 96, 3), (4096, 520, 512, 4), (700, 132, 260, 1)):
+            at, b = dev(torch.randn(k, m) * 3e-7), dev(torch.nn.functional.normalize(torch.randn(k, n), dim=1))
+            prior = torch.randn(m, n) * 1e-6
+            out = dev(prior.clone())
+            ops.gemm_tn_h3(at, b, out, 2.0 ** 35, alpha=0.5, beta=1.0, split_k=split)
+            want = prior.double() + 0.5 * (at.double().t() @ b.double()).cpu()
+            ref6 = dev(prior.clone())
+            ops.gemm(at, b, True, False, out=ref6, alpha=0.5, beta=1.0, split_k=split)
+            e3, e6 = rel_err(out, want), rel_err(ref6, want)
+            assert e3 < 3e-6 and e3 <= 1.5 * e6 + 1e-7, (e3, e6)
     finally:
         ops.set_gemm_mode(prev)
 
