@@ -324,9 +324,12 @@ def main():
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ("fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (fp32-level error, "
-                       "tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
-                       if ops.get_gemm_mode() == 1 else "fp32 MFMA (exact fmaf chains)"),
+        "arithmetic": (("fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (fp32-level error, "
+                        "tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
+                        if ops.get_gemm_mode() == 1 else "fp32 MFMA (exact fmaf chains)") +
+                       ("; EXPERIMENTAL GX_EXPERIMENTAL_FP16X3=1: the many-prototype score / dz / prototype-gradient GEMMs "
+                        "(K > 16 only) as two fp16 pieces per operand, three products per fp32 product — NOT the default "
+                        "arithmetic (DESIGN.md par. 10 item 0)" if os.environ.get("GX_EXPERIMENTAL_FP16X3", "0") == "1" else "")),
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
