@@ -54,8 +54,9 @@ class _NullLogger:
         pass
 
 
-# EXPERIMENTAL: GX_EXPERIMENTAL_FP16X3=1 routes the many-prototype score and dz GEMMs — operands whose
-# range is known a priori (unit-norm rows; dS bounded by grad_scale / 2T) — through the fp16x3 engine.  Off by default.
+# EXPERIMENTAL: GX_EXPERIMENTAL_FP16X3=1 routes the three many-prototype GEMMs (scores, dz, prototype
+# gradient; K > 64) — operands whose range is known a priori: unit-norm rows, dS bounded by grad_scale / 2T — through the
+# fp16x3 engine (two fp16 pieces per operand, three MFMA products per fp32 product).  Off by default.
 FP16X3 = os.environ.get("GX_EXPERIMENTAL_FP16X3", "0") == "1"
 
 
@@ -304,8 +305,10 @@ class SwAVClustering(ViewMixin):
         # descriptor panel per view alive until its backward, so it goes patch by patch.
         pgroup = max(1, min(P, int(16e9 // (8.0 * rows * K)))) if mode == 'pyramid' else 1
         # generic-K scores: the prototype weights as bf16x6 planes, once per step (gemm_xw_kernel)
-        wc_planes = ops.split_gemm_weights(Wc) if (not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0) else None
-        h3 = FP16X3 and wc_planes is not None and K % 4 == 0
+        wc_planes = None
+        if not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0:
+            wc_planes = ops.split_gemm_weights(Wc)
+        h3 = FP16X3 and wc_planes is not None and K % 4 == 0 and K > 64
         if h3:
             Kp = (K + 15) // 16 * 16
             wc_h3 = ops.split_gemm_weights_h3(Wc)                          # scores: z_hat (unit rows) x Wc (unit rows)
