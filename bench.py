@@ -153,31 +153,181 @@ def cpu_baseline(nproto, threads=None):
                        f"({t_patches:.1f} s); oracle (torch CPU fp32, {threads} threads)")
 
 
-def self_launch(n):
+def self_launch(n, argv=None, poll_s=0.2, grace_s=5.0):
     """Run this script as n ranks on one node (what `torch.distributed.run --nproc-per-node n` would do):
     one child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  The parent touches
-    no GPU; children are ordinary subprocesses (never an exec of a process that has initialised HIP)."""
+    no GPU; children are ordinary subprocesses (never an exec of a process that has initialised HIP).
+    All children are polled: the first one that exits non-zero takes the others down (terminate, then kill
+    after `grace_s`) and its code is returned within seconds — a rank that dies during start-up must not leave
+    its peers waiting in the rendezvous or in a collective until the backend's timeout.  Every rank's stderr
+    (and the stdout of ranks > 0) is relayed line by line with a `[rank r]` prefix; rank 0's JSON line is
+    printed last."""
     import socket
     import subprocess
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    argv = sys.argv[1:] if argv is None else argv
+    procs, readers, out0 = [], [], []
+
+    def relay(stream, prefix, keep):
+        for raw in iter(stream.readline, b""):
+            line = raw.decode(errors="replace").rstrip("\n")
+            if keep is not None and line.startswith("{"):
+                keep.append(line)                                   # rank 0's JSON line(s)
+            else:
+                print(f"{prefix}{line}", file=sys.stderr, flush=True)
+        stream.close()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # dmabuf IPC: the pool's host driver has no legacy IPC, and without this RCCL's peer-memory exchange fails
+        # with `hipIpcGetMemHandle: invalid argument` (the image exports it already; kept for a bare environment)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    for line in out.decode().splitlines():          # ONE JSON line (backends may chat on stdout: "[Gloo] Rank 0 is ...")
-        if line.startswith("{"):
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        procs.append(p)
+        for stream, keep in ((p.stdout, out0 if r == 0 else None), (p.stderr, None)):
+            t = threading.Thread(target=relay, args=(stream, f"[rank {r}] ", keep), daemon=True)
+            t.start()
+            readers.append(t)
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr, flush=True)
+        if live and rc == 0:
+            time.sleep(poll_s)
+    if live:                                                        # a rank failed: take the rest down
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + grace_s
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    for t in readers:
+        t.join(timeout=5.0)
+    if rc == 0:
+        for line in out0:           # ONE JSON line (backends may chat on stdout: "[Gloo] Rank 0 is ..." goes to stderr)
             print(line, flush=True)
     return rc
+
+
+def measure(sw, args, steps, warmup, dev, world):
+    """`warmup` untimed steps, then exactly `steps` steps bracketed by barrier + synchronize on both sides;
+    returns (seconds = max over ranks, per-tag HIP-event statistics, last loss)."""
+    import queue
+    import threading
+    from ganecdotes_amd import ops
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def feed(n):
+        """Background producer: host draws (reference RNG order) + pinned upload of batch i+1
+        overlap the kernels of batch i.  Started INSIDE the timed region for the timed steps."""
+        q = queue.Queue(maxsize=2)
+
+        def run():
+            torch.cuda.set_device(dev)             # a new thread starts on device 0: stage on this rank's GPU
+            for _ in range(n):
+                q.put(sw.prepare_batch(sw.draw_batch(args.batch)))
+        threading.Thread(target=run, daemon=True).start()
+        return q
+
+    q = feed(warmup)
+    for _ in range(warmup):
+        sw.train_step(q.get())
+    ops.PROFILE = {}
+    sync()
+    t0 = time.perf_counter()
+    q = feed(steps)
+    for _ in range(steps):
+        loss = sw.train_step(q.get())
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    # HIP events on the launch stream over the timed region (ops.record brackets the launches of the MFMA kernels with
+    # their algorithmic FLOPs and of the large HBM-bound passes with their algorithmic bytes: SURVEY par. 8d figures x the
+    # units the launch processes)
+    prof, ops.PROFILE = ops.PROFILE, None
+    stats = {}
+    for tag, evs in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b, *_ in evs)
+        stats[tag] = dict(ms_per_step=ms / steps, launches_per_step=sum(e[4] for e in evs) / steps,
+                          flops_per_step=sum(e[2] for e in evs) / steps, bytes_per_step=sum(e[3] for e in evs) / steps)
+    return dt, stats, float(loss.item())
+
+
+def roofline_of(stats, ms_per_step, traffic_file):
+    """The `roofline` object of the JSON line: the dominant MFMA kernel (algorithmic FLOPs per launch / its average
+    launch time, HIP events), the whole step against the same peak, and the largest HBM-bound pass."""
+    from ganecdotes_amd import ops
+    kern = {k: v for k, v in stats.items() if not k.startswith("phase:") and v["flops_per_step"] > 0}
+    if not kern:
+        return None
+    name = max(kern, key=lambda k: kern[k]["ms_per_step"])
+    v = kern[name]
+    ach = v["flops_per_step"] / (v["ms_per_step"] * 1e-3)
+    x6 = ops.get_gemm_mode() == 1
+    eng = ("bf16 MFMA, bf16x6: each fp32 operand split exactly into three bf16, six MFMA products per fp32 "
+           "product, fp32 accumulate" if x6 else "fp32 MFMA")
+    what = {"modconv_kernel": f"gx::modconv_xp_kernel / gx::modconv_kernel (3x3 modulated conv, implicit GEMM on {eng}; "
+                              "the modulated activations are split once by their producer and both operands reach LDS by "
+                              "LDS-DMA; algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
+            "gemm_f32_kernel": f"gx::gemm kernels (pyramid projection / prototype / gradient GEMMs on {eng}; "
+                               "algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
+    # peak for ALGORITHMIC fp32 FLOPs: the fp32 MFMA peak, or (bf16x6) the dense bf16 MFMA peak / 6
+    peak = PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA
+    # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
+    traffic = None
+    if traffic_file and os.path.exists(traffic_file):
+        stem = {"modconv_kernel": "modconv", "gemm_f32_kernel": "gemm"}.get(name, name)
+        cands = [t for k, t in json.load(open(traffic_file)).items() if stem in k]
+        if cands:
+            traffic = max(cands, key=lambda t: t["launches"])["hbm_bytes_per_launch"]
+    step_flops = sum(x["flops_per_step"] for x in kern.values())
+    roof = dict(bound="mfma", achieved=ach / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                frac=ach / peak, traffic=traffic, kernel=what,
+                engine="bf16x6" if x6 else "f32mfma",
+                mfma_tflops_issued=(6.0 if x6 else 1.0) * ach / 1e12,
+                mfma_peak=(PEAK_BF16_MFMA if x6 else PEAK_F32_MFMA) / 1e12,
+                fp32_mfma_peak=PEAK_F32_MFMA / 1e12,
+                launches_per_step=v["launches_per_step"],
+                avg_launch_ms=v["ms_per_step"] / v["launches_per_step"],
+                gflop_per_launch=v["flops_per_step"] / v["launches_per_step"] / 1e9,
+                # the whole step against the same peak: the algorithmic FLOPs of every contraction the step EXECUTES
+                # (conv + GEMM launches; restructurings that remove products lower this count) / wall time per step
+                step_tflop=step_flops / 1e12, step_frac=step_flops / (ms_per_step * 1e-3) / peak,
+                ms_per_step_by_kernel={k: round(x["ms_per_step"], 3) for k, x in stats.items()})
+    hb = {k: x for k, x in stats.items() if not k.startswith("phase:") and x["flops_per_step"] == 0 and x["bytes_per_step"] > 0}
+    if hb:
+        hname = max(hb, key=lambda k: hb[k]["ms_per_step"])
+        h = hb[hname]
+        gbs = h["bytes_per_step"] / (h["ms_per_step"] * 1e-3)
+        roof["hbm"] = dict(kernel=hname, bound="hbm", achieved=gbs / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=gbs / PEAK_HBM,
+                           gbytes_per_step=h["bytes_per_step"] / 1e9, ms_per_step=h["ms_per_step"],
+                           launches_per_step=h["launches_per_step"])
+    return roof
 
 
 def main():
@@ -192,8 +342,13 @@ def main():
                          "across ranks by all-reduce as BASELINE.json's north_star asks (default); 'image' = one problem per "
                          "image, view and patch (the reference's batch-1 semantics, no Sinkhorn collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-faithful", default="auto", choices=["auto", "on", "off"],
+                    help="also time the reference's own nprototypes = 5000 (hfc_with_swav_ffhq_config.py:52) for a few steps and "
+                         "nest the result in the JSON line; auto = on one GPU with the default 8 prototypes only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")
+    ap.add_argument("--dry-rendezvous", action="store_true",
+                    help="launcher check: every rank joins the process group, runs one barrier and exits (no GPU work)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -205,8 +360,29 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GX_BENCH_FAIL_RANK") == str(rank):          # test hook: a rank that dies during start-up
+        print(f"rank {rank}: GX_BENCH_FAIL_RANK set, exiting with code 3", file=sys.stderr, flush=True)
+        sys.exit(3)
+    from datetime import timedelta
+    pg_timeout = timedelta(seconds=120)
+    if args.dry_rendezvous:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_rendezvous": True, "world": world}), flush=True)
+        return
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))   # the box's CPU share
-    local = local % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"--backend nccl needs one GPU per rank: {world} ranks but {ndev} visible device(s) "
+                         f"(use --backend gloo to rehearse several ranks on one GPU)")
+    local = local % ndev                     # gloo rehearsal: several ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
@@ -214,131 +390,83 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         group = dist.group.WORLD
 
+    from ganecdotes_amd import ops
     from ganecdotes_amd.swav_clustering import SwAVClustering
     g = build_generator(256, dev)
-    wl = workload(args.batch, args.prototypes, scope=args.scope)
-    sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
-    torch.manual_seed(42 + rank)
-    np.random.seed(42 + rank)
-    sw.build_heads()
-    if world > 1:   # replicated heads: rank 0's init everywhere
-        import torch.distributed as dist
-        for p in sw._params():
-            dist.broadcast(p, 0)
 
-    def sync():
-        if world > 1:
+    def make(nproto):
+        wl = workload(args.batch, nproto, scope=args.scope)
+        sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
+        torch.manual_seed(42 + rank)
+        np.random.seed(42 + rank)
+        sw.build_heads()
+        if world > 1:   # replicated heads: rank 0's init everywhere
             import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
+            for p in sw._params():
+                dist.broadcast(p, 0)
+        return sw
 
-    import queue
-    import threading
-
-    def feed(n):
-        """Background producer: host draws (reference RNG order) + pinned upload of batch i+1
-        overlap the kernels of batch i.  Started INSIDE the timed region for the timed steps."""
-        q = queue.Queue(maxsize=2)
-
-        def run():
-            torch.cuda.set_device(dev)             # a new thread starts on device 0: stage on this rank's GPU
-            for _ in range(n):
-                q.put(sw.prepare_batch(sw.draw_batch(args.batch)))
-        threading.Thread(target=run, daemon=True).start()
-        return q
-
-    q = feed(args.warmup)
-    for _ in range(args.warmup):
-        sw.train_step(q.get())
-    from ganecdotes_amd import ops
-    ops.PROFILE = {}
-    sync()
-    t0 = time.perf_counter()
-    q = feed(args.steps)
-    for _ in range(args.steps):
-        loss = sw.train_step(q.get())
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    sw = make(args.prototypes)
+    dt, stats, loss = measure(sw, args, args.steps, args.warmup, dev, world)
     images = args.steps * args.batch * world
-
-    # roofline of the dominant kernel, measured live with HIP events on the launch stream over
-    # the timed region (ops.record brackets every launch of the MFMA kernels with its
-    # algorithmic FLOPs: SURVEY par. 8d figures x the units the launch processes)
-    prof, ops.PROFILE = ops.PROFILE, None
-    stats = {}
-    for tag, evs in prof.items():
-        ms = sum(a.elapsed_time(b) for a, b, *_ in evs)
-        stats[tag] = dict(ms_per_step=ms / args.steps, launches_per_step=sum(e[4] for e in evs) / args.steps,
-                          flops_per_step=sum(e[2] for e in evs) / args.steps,
-                          bytes_per_step=sum(e[3] for e in evs) / args.steps)
+    ms_step = 1e3 * dt / args.steps
     if os.environ.get("GX_BENCH_EVENTS"):
         for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms_per_step"]):
             print(f"# {k:24s} {v['ms_per_step']:9.2f} ms/step  {v['launches_per_step']:7.1f} launches  "
-                  f"{v['flops_per_step'] / max(v['ms_per_step'], 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
-    roof = None
-    kern = {k: v for k, v in stats.items() if not k.startswith("phase:") and v["flops_per_step"] > 0}
-    if kern:
-        name = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        v = kern[name]
-        ach = v["flops_per_step"] / (v["ms_per_step"] * 1e-3)
-        x6 = ops.get_gemm_mode() == 1
-        eng = ("bf16 MFMA, bf16x6: each fp32 operand split exactly into three bf16, six MFMA products per fp32 "
-               "product, fp32 accumulate" if x6 else "fp32 MFMA")
-        what = {"modconv_kernel": f"gx::modconv_xp_kernel / gx::modconv_kernel (3x3 modulated conv, implicit GEMM on {eng}; "
-                                  "the modulated activations are split once by their producer and both operands reach LDS by "
-                                  "LDS-DMA; algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
-                "gemm_f32_kernel": f"gx::gemm kernels (pyramid projection / prototype / gradient GEMMs on {eng}; "
-                                   "algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
-        # peak for ALGORITHMIC fp32 FLOPs: the fp32 MFMA peak, or (bf16x6) the dense bf16 MFMA peak / 6
-        peak = PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA
-        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tfile):
-            stem = {"modconv_kernel": "modconv", "gemm_f32_kernel": "gemm"}.get(name, name)
-            cands = [t for k, t in json.load(open(tfile)).items() if stem in k]
-            if cands:
-                traffic = max(cands, key=lambda t: t["launches"])["hbm_bytes_per_launch"]
-        roof = dict(bound="mfma", achieved=ach / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                    frac=ach / peak, traffic=traffic, kernel=what,
-                    engine="bf16x6" if x6 else "f32mfma",
-                    mfma_tflops_issued=(6.0 if x6 else 1.0) * ach / 1e12,
-                    mfma_peak=(PEAK_BF16_MFMA if x6 else PEAK_F32_MFMA) / 1e12,
-                    fp32_mfma_peak=PEAK_F32_MFMA / 1e12,
-                    launches_per_step=v["launches_per_step"],
-                    avg_launch_ms=v["ms_per_step"] / v["launches_per_step"],
-                    gflop_per_launch=v["flops_per_step"] / v["launches_per_step"] / 1e9,
-                    ms_per_step_by_kernel={k: round(x["ms_per_step"], 3) for k, x in stats.items()})
+                  f"{v['flops_per_step'] / max(v['ms_per_step'], 1e-9) / 1e9:8.1f} TFLOP/s  "
+                  f"{v['bytes_per_step'] / max(v['ms_per_step'], 1e-9) / 1e6:8.1f} GB/s", file=sys.stderr)
+    roof = roofline_of(stats, ms_step, os.path.join(ROOT, "profiles", "r03_traffic.json"))
+    x6 = ops.get_gemm_mode() == 1
     out = {
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": (("fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (fp32-level error, "
-                        "tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
-                        if ops.get_gemm_mode() == 1 else "fp32 MFMA (exact fmaf chains)") +
-                       ("; EXPERIMENTAL GX_EXPERIMENTAL_FP16X3=1: the many-prototype score / dz / prototype-gradient GEMMs "
-                        "(K > 16 only) as two fp16 pieces per operand, three products per fp32 product — NOT the default "
-                        "arithmetic (DESIGN.md par. 10 item 0)" if os.environ.get("GX_EXPERIMENTAL_FP16X3", "0") == "1" else "")),
+        "arithmetic": ("fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (every operand bit kept: fp32-level "
+                       "error, tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
+                       if x6 else "fp32 MFMA (exact fmaf chains)"),
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
                                f"the device generator (= the set randperm[:N] selects); views = the 13 feature taps of both "
                                f"perturbed latents (the RGB image, which enters no loss term, is not rendered)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": float(loss.item())},
+                   "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": loss},
         "roofline": roof,
     }
+    # the reference's own configuration (nprototypes = 5000): a second, short measurement inside the same line, so that
+    # the number the reference actually ships is timed by whoever runs this script and not only by the builder
+    want_rf = args.reference_faithful == "on" or (args.reference_faithful == "auto" and world == 1 and args.prototypes == 8)
+    if want_rf:
+        del sw
+        torch.cuda.empty_cache()
+        rf_steps, rf_warm = 8, 2
+        sw5 = make(5000)
+        dt5, st5, loss5 = measure(sw5, args, rf_steps, rf_warm, dev, world)
+        ms5 = 1e3 * dt5 / rf_steps
+        r5 = roofline_of(st5, ms5, None)
+        peak = (PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA)
+        gemm = st5.get("gemm_f32_kernel")
+        hb = (r5 or {}).get("hbm")
+        out["reference_faithful"] = {
+            "workload": f"ffhq-256 hfc_with_swav, 5000 prototypes (hfc_with_swav_ffhq_config.py:52), batch={args.batch}/GPU, "
+                        f"otherwise the configuration of this line", "prototypes": 5000, "steps": rf_steps, "warmup": rf_warm,
+            "ms_per_step": ms5, "value": rf_steps * args.batch * world / dt5, "unit": "images/s", "loss": loss5,
+            "roofline": {
+                "kernel": "gx::gemm kernels (score NT / prototype-gradient TN / dz GEMMs of the 10 view-patches + the pyramid)",
+                "mfma_tflops": None if not gemm else gemm["flops_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12,
+                "mfma_frac": None if not gemm else gemm["flops_per_step"] / (gemm["ms_per_step"] * 1e-3) / peak,
+                "gemm_ms_per_step": None if not gemm else gemm["ms_per_step"],
+                "step_tflop": None if not r5 else r5["step_tflop"], "step_frac": None if not r5 else r5["step_frac"],
+                "hbm_kernel": None if not hb else hb["kernel"], "hbm_gbs": None if not hb else hb["achieved"],
+                "hbm_frac": None if not hb else hb["frac"], "hbm_ms_per_step": None if not hb else hb["ms_per_step"],
+                "ms_per_step_by_kernel": None if not r5 else r5["ms_per_step_by_kernel"]}}
+        del sw5
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.prototypes)

@@ -52,11 +52,6 @@ SIGNATURES = {
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
                                     c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
-    "gx_gemm_f32_tn_h3": (c_i, [c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_f, c_i, c_p, c_sz, c_p]),
-    "gx_gemm_weight_planes_h3_bytes": (c_sz, [c_i, c_i]),
-    "gx_split_gemm_weights_h3": (c_i, [c_p, c_i, c_i, c_l, c_i, c_p, c_p]),
-    "gx_gemm_f32_nt_planes_h3": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_f,
-                                       c_p, c_p]),
     "gx_gemm_f32_upadd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p]),
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "gx_sumpool2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

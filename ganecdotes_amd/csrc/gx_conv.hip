@@ -707,26 +707,6 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
     }
 }
 
-// EXPERIMENTAL fp16x3 engine: B [N][K] as two fp16 pieces per element (w = p0 + 2^-11 p1 up to 2^-22),
-// tiled like the bf16 planes: per (128-row tile, 16-column chunk) two 4 KB pieces in the LDS image layout.
-__global__ void split_gemm_weights_h3_kernel(const float* __restrict__ B, int N, int K, long ld, int transposed, int ntn, int ncc,
-                                             unsigned short* __restrict__ planes) {
-    const long total = (long)ntn * ncc * 128 * 16;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
-        long blk = i >> 11;
-        const int cc = (int)(blk % ncc); const int tn = (int)(blk / ncc);
-        const int co = tn * 128 + row, ci = cc * 16 + k;
-        const float x = (co < N && ci < K) ? (transposed ? B[(long)ci * ld + co] : B[(long)co * ld + ci]) : 0.f;
-        const _Float16 p0 = (_Float16)x;
-        const _Float16 p1 = (_Float16)((x - (float)p0) * 2048.f);
-        unsigned short* base = planes + (((long)tn * ncc + cc) * 2) * 2048;
-        const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
-        base[off] = __builtin_bit_cast(unsigned short, p0);
-        base[2048 + off] = __builtin_bit_cast(unsigned short, p1);
-    }
-}
-
 // Latents of one view of a batch (swav_clustering.py:599-640 + image_augmentor.py:42-53 + the truncation of
 // model.py:594-602): lat[b][l][:] = keep * (m + psi (w_b - m)) + mix[b][l][0] nw[b][0][:] + mix[b][l][1] nw[b][1][:]
 // with keep = 1 - mix[b][l][0] - mix[b][l][1]  (mix is sigma at the two perturbed latents of image b, else 0).
@@ -1301,11 +1281,10 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         const size_t pb = (size_t)g.B * (g.IH + 2) * (g.IW + 2) * 32;
         if (pb >= 0x7FFFFFF0ull) return GX_ERR_BAD_ARG;
         g.xp_plane_bytes = (unsigned)pb;
-        // MFMA shape of the six products: 16x16x32 (plane pairs along K, default) or 32x32x16 (GX_CONV_MFMA16=0).  Equal pipe
-        // cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
-        // 243-246 -> 256-260 TFLOP/s, same-process A/B (tools/bench_conv_xp.py)
-        static const bool m16 = [] { const char* e = getenv("GX_CONV_MFMA16"); return !(e && e[0] == '0'); }();
-        if (m16 && (g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
+        // MFMA shape of the six products: 16x16x32 (plane pairs along K) where Cout allows its epilogue, else 32x32x16.  Equal
+        // pipe cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
+        // 243-246 -> 256-260 TFLOP/s, same-process A/B (round 2, tools/bench_conv_xp.py)
+        if ((g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
         else hipLaunchKernelGGL(modconv_xp_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
         GX_CHECK_LAUNCH();
         return GX_OK;
@@ -1512,18 +1491,6 @@ int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, 
     return launch_conv(g, nullptr, 0, (hipStream_t)stream);
 }
 
-size_t gx_gemm_weight_planes_h3_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 2 * 4096; }
-int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, int transposed, unsigned short* planes, void* stream) {
-    // transposed: the source is [K][N] (row stride ldb) and the planes are those of its transpose
-    if (!B || !planes || N <= 0 || K <= 0 || ldb < (transposed ? N : K)) return GX_ERR_BAD_ARG;
-    const int ntn = gx_cdiv(N, 128), ncc = gx_cdiv(K, 16);
-    long want = ((long)ntn * ncc * 2048 + 255) / 256;
-    hipLaunchKernelGGL(split_gemm_weights_h3_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       B, N, K, ldb, transposed, ntn, ncc, planes);
-    GX_CHECK_LAUNCH();
-    return GX_OK;
-}
-
 // Upsampling StyledConv: conv_transpose2d(stride 2, pad 0) -> (2H+1)^2 scratch T, then blur
 // pad (1,1) + demod + noise + bias + act -> out [B][2H][2W][Cout].
 //   T: caller-allocated scratch of B*(2H+1)*(2W+1)*Cout floats; kf: flipped 4x4 FIR (device, 16 floats)
@@ -1547,8 +1514,7 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
     long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
     if (planes_out && (C & 15) == 0) total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * ((OW + 15) / 16) * (C >> 4) * 64;
     long want = (total + 255) / 256;
-    static const bool lds_planes = [] { const char* e = getenv("GX_BLUR_LDS"); return !(e && e[0] == '0'); }();
-    if (planes_out && lds_planes && (C & 63) == 0 && (OW & 15) == 0 &&
+    if (planes_out && (C & 63) == 0 && (OW & 15) == 0 &&
         ((((uintptr_t)T | (uintptr_t)out | (uintptr_t)planes_out) & 15) == 0)) {
         const long nblk = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * (OW >> 4) * (C >> 6);
         hipLaunchKernelGGL(blur_act_xp_kernel, dim3((int)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, (hipStream_t)stream, T, B,

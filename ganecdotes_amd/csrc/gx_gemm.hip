@@ -38,8 +38,7 @@ struct GemmArgs {
     // (the upsample-add of the pyramid projection, fused).  Not with split-K.
     const float* up_src; int up_shift;
     const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
-    int n_group;          // gemm_xw / gemm_xh: N tiles per group of the tile order (xw_tile_of)
-    float a_scale;        // gemm_xh_kernel: power of two applied to A before the fp16 split (1 / a_scale is folded into alpha)
+    int n_group;          // gemm_xw_kernel: N tiles per group of the tile order (xw_tile_of)
     float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
@@ -366,8 +365,8 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
 // Products and their order equal x6_mfma_tile's, so results are bitwise those of gemm_x6_kernel.
 //   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
 constexpr int XW_A = 8192, XW_B = 3 * 4096;                          // one A tile (raw fp32), one B tile (planes)
-template <int NS>
-__global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
+    constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
     __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // A ring of NS tiles, B ring of 2
     char* const ldsB = lds + NS * XW_A;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -483,132 +482,6 @@ __global__ __launch_bounds__(GEMM_THREADS, NS == 2 ? 3 : 2) void gemm_xw_kernel(
     }
 }
 
-// ---- EXPERIMENTAL engine "fp16x3" (opt-in, never the default): the NT contraction of gemm_xw_kernel
-// with every operand as TWO fp16 pieces a = a0 + 2^-11 a1 (11 + 11 bits) and a b ~ a0 b0 + 2^-11 (a0 b1 + a1 b0): three
-// MFMA products per fp32 product instead of six, per-product error 2^-22 instead of 2^-24 (tools/split_accuracy.py).
-// Same structure as gemm_xw_kernel (A raw fp32 by LDS-DMA, split at the fragment read; B planes by LDS-DMA); the two
-// orders of magnitude accumulate separately (acc0: a0 b0, acc1: the cross terms) and meet in the epilogue.
-// Operands must lie in fp16's range (|x| < 65504; below 6e-5 the relative precision of a piece degrades).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned& p0, unsigned& p1) {
-    const f16x2 h = __builtin_convertvector((f32x2){x0, x1}, f16x2);
-    p0 = __builtin_bit_cast(unsigned, h);
-    const f32x2 back = __builtin_convertvector(h, f32x2);
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){(x0 - back[0]) * 2048.f, (x1 - back[1]) * 2048.f}, f16x2));
-}
-constexpr int XH_B = 2 * 4096;                                       // one B tile: two fp16 pieces
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xh_kernel(GemmArgs g) {
-    constexpr int NS = 2;
-    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // (sized as gemm_xw_kernel: the epilogue stage)
-    char* const ldsB = lds + NS * XW_A;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int logical = xcd_remap((int)blockIdx.x, ntile);
-    int tm, tn;
-    xw_tile_of(g, logical, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    unsigned aoff1[2], aoff2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = i * 256 + tid;
-        int row = p >> 2;
-        const int q = (p & 3) ^ ((p >> 4) & 3);
-        row = min(row, g.M - 1 - m0);
-        aoff1[i] = ((unsigned)row * (unsigned)g.lda + (unsigned)q * 4u) * 4u;
-        aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
-    }
-    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A + (long)m0 * g.lda, 0x7FFFFFF0u);
-    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A, 0x7FFFFFF0u);
-    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
-    const unsigned boff = (unsigned)tid * 16u;
-    const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * 2u * 4096u;
-    auto issue_b = [&](int kt, char* dst) {
-        const unsigned blk = bblk0 + (unsigned)kt * 2u * 4096u;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)boff,
-                                                     (int)(blk + p * 4096u), 0, 0);
-    };
-    auto issue_a = [&](int kt, char* dst) {
-        const bool second = kt >= nkt1;
-        const int ks = (second ? kt - nkt1 : kt) * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff1[i], ks, 0, 0);
-        }
-    };
-    f32x16 acc0[1][2], acc1[1][2], crs0[2], crs1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; crs0[j][r] = 0.f; crs1[j][r] = 0.f; }
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int arow = wid * 32 + r32;
-    const int af = (arow >> 2) & 3;
-    const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
-    const float asc = g.a_scale;
-    auto compute = [&](const char* st, const char* Bs) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
-        f16x8 b[4][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                b[t][q] = *reinterpret_cast<const f16x8*>(Bs + q * 4096 + x_kc_off(t * 32 + r32, hh));
-        unsigned p0[4], p1[4];
-        split2h(x0[0] * asc, x0[1] * asc, p0[0], p1[0]);
-        split2h(x0[2] * asc, x0[3] * asc, p0[1], p1[1]);
-        split2h(x1[0] * asc, x1[1] * asc, p0[2], p1[2]);
-        split2h(x1[2] * asc, x1[3] * asc, p0[3], p1[3]);
-        const f16x8 a0 = __builtin_bit_cast(f16x8, (u32x4){p0[0], p0[1], p0[2], p0[3]});
-        const f16x8 a1 = __builtin_bit_cast(f16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
-        // cross terms first (the smaller magnitudes), then a0 b0
-        crs0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0][0], crs0[0], 0, 0, 0);
-        crs0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[1][0], crs0[1], 0, 0, 0);
-        crs1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2][0], crs1[0], 0, 0, 0);
-        crs1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[3][0], crs1[1], 0, 0, 0);
-        crs0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0][1], crs0[0], 0, 0, 0);
-        crs0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1][1], crs0[1], 0, 0, 0);
-        crs1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2][1], crs1[0], 0, 0, 0);
-        crs1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3][1], crs1[1], 0, 0, 0);
-        acc0[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0][0], acc0[0][0], 0, 0, 0);
-        acc0[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1][0], acc0[0][1], 0, 0, 0);
-        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2][0], acc1[0][0], 0, 0, 0);
-        acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3][0], acc1[0][1], 0, 0, 0);
-    };
-    if (nkt > 0) { issue_b(0, ldsB); issue_a(0, lds); }
-    for (int t = 0; t < nkt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nkt) { issue_b(t + 1, ldsB + ((t + 1) & 1) * XW_B); issue_a(t + 1, lds + ((t + 1) & 1) * XW_A); }
-        compute(lds + (t & 1) * XW_A, ldsB + (t & 1) * XW_B);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc0[0][j][r] = fmaf(crs0[j][r], 1.f / 2048.f, acc0[0][j][r]);
-            acc1[0][j][r] = fmaf(crs1[j][r], 1.f / 2048.f, acc1[0][j][r]);
-        }
-    float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
-    if (g.beta != 0.f) {
-        gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
-        gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
-    } else {
-        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
-        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
-    }
-}
-
 // Wave-specialised bf16x6 GEMM.  A 16-deep k-tile is only 768 MFMA cycles per wave — less than the
 // split arithmetic, the LDS round trip and a barrier that the 4-wave kernel above strings in series
 // with it (its MFMA pipe is busy 55 % of the time).  Here a workgroup of 512 threads owns a 256 x 128
@@ -696,111 +569,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         gemm_epilogue_t<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, split);
 }
 
-// EXPERIMENTAL fp16x3 form of the wave-specialised TN GEMM (opt-in): C = alpha * A^T B with A [K][M]
-// and B [K][N] both m-contiguous, every element split into two fp16 pieces by the producer waves (A after a
-// power-of-two lift g.a_scale), three MFMA products per fp32 product in the consumers (a0 b0 into one accumulator set,
-// the cross terms into a second).  128 x 128 tile: four consumer waves 2 x 2 of 64 x 64, four producer waves.
-constexpr int XH_WS_SLOT = 4 * XImg<128>::MC_PLANE;                  // A pieces + B pieces: 17408 B
-__global__ __launch_bounds__(WS_THREADS, 1) void gemm_xhws_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * XH_WS_SLOT];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntile = g.tiles_m * g.tiles_n;
-    int logical, split;
-    gemm_tile_of_block(ntile, logical, split);
-    const int tm = logical / g.tiles_n, tn = logical - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = split * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
-    const int nkt = (kend - kbeg + XK - 1) / XK;
-    char* slot0 = lds;
-    char* slot1 = lds + XH_WS_SLOT;
-    constexpr int PL = XImg<128>::MC_PLANE, RW = XImg<128>::MC_ROWW;
-    if (wid >= 4) {
-        // ------------------------------------------------------------------ producers
-        const int p = tid - 256;
-        const float asc = g.a_scale;
-        f32x4 ra0[2], rb0[2], ra1[2], rb1[2];
-        auto load_tiles = [&](int t, f32x4 (&ra)[2], f32x4 (&rb)[2]) {     // tiles past kend load as zeros
-            const int k0 = kbeg + t * XK;
-            x6_load_tile<false, true, 128>(g.A, g.lda, m0, g.M, k0, kend, ra, p);
-            x6_load_tile<false, true, 128>(g.B, g.ldb, n0, g.N, k0, kend, rb, p);
-        };
-        auto stage_one = [&](char* S, const f32x4 (&v)[2], float sc) {     // (k, k + 1) of one m -> one word per piece
-            unsigned q0[4], q1[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2h(v[0][e] * sc, v[1][e] * sc, q0[e], q1[e]);
-            char* d = S + ((p >> 5) * RW + (p & 31) * 4) * 4;
-            *reinterpret_cast<u32x4*>(d) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
-            *reinterpret_cast<u32x4*>(d + PL) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
-        };
-        auto stage = [&](char* slot, const f32x4 (&ra)[2], const f32x4 (&rb)[2]) {
-            stage_one(slot, ra, asc);
-            stage_one(slot + 2 * PL, rb, 1.f);
-        };
-        load_tiles(0, ra0, rb0);
-        load_tiles(1, ra1, rb1);
-        if (nkt > 0) stage(slot0, ra0, rb0);
-        __syncthreads();                                             // barrier 0: tile 0 visible
-        for (int t = 0; t < nkt; t += 2) {
-            load_tiles(t + 2, ra0, rb0);
-            if (t + 1 < nkt) stage(slot1, ra1, rb1);
-            __syncthreads();                                         // barrier t+1
-            if (t + 1 >= nkt) break;
-            load_tiles(t + 3, ra1, rb1);
-            if (t + 2 < nkt) stage(slot0, ra0, rb0);
-            __syncthreads();                                         // barrier t+2
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------- consumers
-    const int wr = wid >> 1, wc = wid & 1;
-    f32x16 acc[2][2], crs[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; crs[mt][nt][r] = 0.f; }
-    const int r32 = lane & 31, hh = lane >> 5;
-    __syncthreads();                                                 // barrier 0
-    for (int t = 0; t < nkt; ++t) {
-        const char* As = (t & 1) ? slot1 : slot0;
-        const char* Bs = As + 2 * PL;
-        f16x8 a[2][2], b[2][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i][q] = __builtin_bit_cast(f16x8, x6_frag<false, 128>(As, q, wr * 64 + i * 32 + r32, hh));
-                b[i][q] = __builtin_bit_cast(f16x8, x6_frag<false, 128>(Bs, q, wc * 64 + i * 32 + r32, hh));
-            }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1], b[nt][0], crs[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][1], crs[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][0], acc[mt][nt], 0, 0, 0);
-        __syncthreads();                                             // barrier t+1
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(crs[mt][nt][r], 1.f / 2048.f, acc[mt][nt][r]);
-    gemm_epilogue(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
-}
-
 // Sum split-K slabs in a fixed order (bitwise reproducible) and apply the epilogue.
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int splits, float* __restrict__ C,
                                           int M, int N, long ldc, float alpha, float beta,
@@ -831,24 +599,17 @@ static int gemm_mode() {
     return g_gemm_mode;
 }
 
-static int ws_min_k() {             // GX_WS_MINK: shortest k extent (per split) that takes the wave-specialised kernel
-    static const int v = [] { const char* e = getenv("GX_WS_MINK"); return e ? atoi(e) : 768; }();
-    return v;
-}
-static bool ep_scalar() {          // GX_GEMM_EPILOGUE=scalar: the dword epilogue (A/B measurements)
-    static const bool v = [] { const char* e = getenv("GX_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
-    return v;
-}
+constexpr int WS_MIN_K = 768;      // shortest k extent (per split) that takes the wave-specialised kernel (256: 7.4 -> 9.0 ms)
 
 static int launch_gemm(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
                        long ldb, float* C, long ldc, float alpha, float beta, const float* row_scale,
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1, float h3_a_scale = 0.f) {
+                       int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
-    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.a_scale = 1.f; g.n_group = 1;
+    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -866,11 +627,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
-    const bool h3 = h3_a_scale > 0.f;         // EXPERIMENTAL fp16x3 TN (gemm_xhws_kernel): 128 x 128 tiles
-    if (h3 && (!x6 || !transA || transB || !g.vec_ok || A2 || B2 || up_src)) return GX_ERR_BAD_ARG;
-    g.a_scale = h3 ? h3_a_scale : 1.f;
-    if (h3) { alpha /= h3_a_scale; g.alpha = alpha; }
-    const bool ws = !h3 && x6 && M > BM && (split_k > 1 ? K / split_k : K) >= ws_min_k();
+    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= WS_MIN_K;
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -886,7 +643,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         const bool direct = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
         const bool slab_ok = (((uintptr_t)workspace & 15) == 0);
         const bool up_ok = !up_src || (((uintptr_t)up_src & 15) == 0);
-        g.ep_vec = (N % 4 == 0) && (g.slab ? slab_ok : (direct && up_ok)) && !ep_scalar();
+        g.ep_vec = (N % 4 == 0) && (g.slab ? slab_ok : (direct && up_ok));
     }
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
 #define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
@@ -898,8 +655,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
         else if (g.vec_ok) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, g);              \
     } while (0)
-    if (h3) hipLaunchKernelGGL(gemm_xhws_kernel, grid, dim3(WS_THREADS), 0, stream, g);
-    else if (!transA && transB) GX_LAUNCH_GEMM(false, true);
+    if (!transA && transB) GX_LAUNCH_GEMM(false, true);
     else if (!transA && !transB) GX_LAUNCH_GEMM(false, false);
     else if (transA && !transB) GX_LAUNCH_GEMM(true, false);
     else GX_LAUNCH_GEMM(true, true);
@@ -918,14 +674,9 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 
 // C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C (+ upsample2(coarse)) with B given as pre-split planes
 // (gx_split_gemm_weights of the [N][K1 + K2] weight).  bf16x6 engine only; K1, K2 multiples of 16, rows 16-B aligned.
-static int xw_stages() {            // GX_GEMM_XW_STAGES=2|3 (LDS ring depth: 3 workgroups/CU at 2, 2 at 3)
-    static const int v = [] { const char* e = getenv("GX_GEMM_XW_STAGES"); return (e && e[0] == '3') ? 3 : (e && e[0] == '4') ? 4 : 2; }();
-    return v;
-}
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
-                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
-                          bool h3 = false, float a_scale = 1.f) {
+                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -942,27 +693,22 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     }
     g.A = A1; g.lda = lda1; g.A2 = K2 > 0 ? A2 : nullptr; g.lda2 = K2 > 0 ? lda2 : lda1; g.K1 = K1;
     g.B = nullptr; g.ldb = 0; g.B2 = nullptr; g.ldb2 = 0; g.N1 = N; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
-    g.alpha = h3 ? alpha / a_scale : alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
-    g.a_scale = a_scale;
+    g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
-    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h3 ? 2 : 3) * 4096;
+    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
     {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
-        static const int forced = [] { const char* e = getenv("GX_GEMM_XW_NGROUP"); return e ? atoi(e) : 0; }();
-        const long per_tile = (long)K * 128 * (h3 ? 4 : 6);
-        long gn = forced > 0 ? forced : (2L << 20) / per_tile;
+        const long per_tile = (long)K * 128 * 6;
+        long gn = (2L << 20) / per_tile;
         gn = gn < 1 ? 1 : (gn > g.tiles_n ? g.tiles_n : gn);
         g.n_group = (int)gn;
     }
     if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;
     g.colmax_part = colmax_part;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
-    if (h3) hipLaunchKernelGGL(gemm_xh_kernel, grid, block, 0, stream, g);
-    else if (xw_stages() == 3) hipLaunchKernelGGL(gemm_xw_kernel<3>, grid, block, 0, stream, g);
-    else if (xw_stages() == 4) hipLaunchKernelGGL(gemm_xw_kernel<4>, grid, block, 0, stream, g);
-    else hipLaunchKernelGGL(gemm_xw_kernel<2>, grid, block, 0, stream, g);
+    hipLaunchKernelGGL(gemm_xw_kernel, grid, block, 0, stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1037,29 +783,6 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
     if (!B2 || N2 <= 0) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(1, 0, M, N1 + N2, K, A, lda, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
                            workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1);
-}
-
-// EXPERIMENTAL (nothing in the product path calls it): gx_gemm_f32_nt_planes on the "fp16x3"
-// engine — two fp16 pieces per operand, three MFMA products per fp32 product.  b_planes = gx_split_gemm_weights_h3.
-int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
-                             const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, float a_scale,
-                             float* colmax_part, void* stream) {
-    // a_scale: a power of two that brings A into fp16's range before the split (its inverse is folded into alpha)
-    int e2 = 0;
-    if (!(a_scale > 0.f) || std::frexp(a_scale, &e2) != 0.5f) return GX_ERR_BAD_ARG;      // not a power of two
-    return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, colmax_part, (hipStream_t)stream, true, a_scale);
-}
-
-// EXPERIMENTAL: C = alpha * A^T B + beta * C on the fp16x3 engine, A [K][M] lifted by the power of
-// two a_scale before the split (B inside fp16's range as it is).  Split-K as gx_gemm_f32.
-int gx_gemm_f32_tn_h3(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float alpha,
-                      float beta, float a_scale, int split_k, float* workspace, size_t workspace_bytes, void* stream) {
-    int e2 = 0;
-    if (!(a_scale > 0.f) || std::frexp(a_scale, &e2) != 0.5f) return GX_ERR_BAD_ARG;
-    return gx::launch_gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
-                           workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1, a_scale);
 }
 
 }  // extern "C"

@@ -1088,8 +1088,7 @@ int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_p
     if (!workspace || workspace_bytes < (size_t)npair * nb * sizeof(float)) return GX_ERR_WORKSPACE;
     const long vs = rows_per_patch * K;                       // view stride
     CePairs pr{ngroups, 2 * vs, rows * K, (long)2 * ngroups * K, (long)K};
-    static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
-    const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (rows_per_patch * K) % 4 == 0 &&
+    const bool rowlane = K <= 16 && (K & 3) == 0 && (rows_per_patch * K) % 4 == 0 &&
                          ((((uintptr_t)S_all | (uintptr_t)dS_all) & 15) == 0);
 #define GX_CE_ROWLANE(KQ_)                                                                                                     \
     hipLaunchKernelGGL(swapped_ce_rowlane_kernel<KQ_>, dim3(nb, (unsigned)npair), dim3(256), 0, (hipStream_t)stream, S_all,     \
@@ -1530,8 +1529,7 @@ int gx_sinkhorn_small_batch(const float* S, int nprob, long sprob, long rows, in
     GX_CHECK_LAUNCH();
     const float c_uniform = 1.f / (float)rows;
     // a row per lane for K in {4, 8, 12, 16} with 16-B aligned rows (GX_SK_ROWLANE=0: the team form, for A/B runs)
-    static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
-    const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
+    const bool rowlane = K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
     for (int it = 0; it < niters; ++it) {
         float* up_prev = part + (size_t)((it + 1) & 1) * nb * PK;
         float* up_cur = part + (size_t)(it & 1) * nb * PK;
@@ -1618,8 +1616,7 @@ int gx_sinkhorn_small_batch_pass(const float* S, int nprob, long sprob, long row
         GX_CHECK_LAUNCH();
     }
     {   // the sharded form of the pass takes the same row-per-lane kernel (gx_sinkhorn_small_batch)
-        static const bool rowlane_on = [] { const char* e = getenv("GX_SK_ROWLANE"); return !(e && e[0] == '0'); }();
-        const bool rowlane = rowlane_on && K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
+        const bool rowlane = K <= 16 && (K & 3) == 0 && (ld & 3) == 0 && (sprob & 3) == 0 && (((uintptr_t)S) & 15) == 0;
         const float* up = u_prev ? u_prev : part;
         float* la_p = labuf + (size_t)((it + 1) & 1) * PK;
         float* la_c = labuf + (size_t)(it & 1) * PK;

@@ -168,57 +168,6 @@ def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
     return out
 
 
-# ---- EXPERIMENTAL fp16x3 engine: opt-in, operands with an a-priori range only ---------------------
-def split_gemm_weights_h3(b, transposed=False):
-    """two fp16 pieces per element of the weight operand; transposed: b is stored (K, N) and the planes are b.T's"""
-    _chk2d(b)
-    n, k = (b.shape[1], b.shape[0]) if transposed else b.shape
-    L = lib()
-    planes = torch.empty(L.gx_gemm_weight_planes_h3_bytes(n, k) // 2, dtype=torch.int16, device=b.device)
-    _lib.check(L.gx_split_gemm_weights_h3(_p(b), n, k, b.stride(0), int(transposed), _p(planes), _stream()),
-               "gx_split_gemm_weights_h3")
-    return planes
-
-
-def gemm_nt_planes_h3(a, b_planes, out, a_scale=1.0, alpha=1.0, col_bias=None, want_colmax=False):
-    """out = alpha * a @ B.T + col_bias on the fp16x3 engine; a_scale: power of two that brings `a` into fp16's range"""
-    _chk2d(a, out)
-    _chk(col_bias)
-    m, k = a.shape
-    n = out.shape[1]
-    L = lib()
-    part = None
-    if want_colmax:
-        g = 1 if want_colmax is True else int(want_colmax)
-        pb = L.gx_gemm_colmax_part_bytes(m, n)
-        part = workspace("gemm_colmax", pb, a.device)[:pb // 4]
-    with record("gemm_f32_kernel", 2.0 * m * n * k):
-        _lib.check(L.gx_gemm_f32_nt_planes_h3(m, n, k, _p(a), a.stride(0), 0, None, 0, _p(b_planes), _p(out), out.stride(0),
-                                              alpha, 0.0, None, _p(col_bias), None, 0, float(a_scale), _p(part), _stream()),
-                   "gx_gemm_f32_nt_planes_h3")
-    if want_colmax:
-        if g > 1:
-            return out, part.view(-1, n)[:m // 32].view(g, m // (32 * g), n).amax(1)
-        return out, part.view(-1, n).amax(0)
-    return out
-
-
-def gemm_tn_h3(a, b, out, a_scale, alpha=1.0, beta=0.0, split_k=1):
-    """out = alpha * a.T @ b + beta*out on the fp16x3 engine (a stored (K, M), lifted by the power of two a_scale)"""
-    _chk2d(a, b, out)
-    k, m = a.shape
-    n = b.shape[1]
-    L = lib()
-    ws, wsb = None, 0
-    if split_k > 1:
-        wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
-        ws = workspace("gemm", wsb, a.device)
-    with record("gemm_f32_kernel", 2.0 * m * n * k):
-        _lib.check(L.gx_gemm_f32_tn_h3(m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), alpha, beta,
-                                       float(a_scale), split_k, _p(ws), wsb, _stream()), "gx_gemm_f32_tn_h3")
-    return out
-
-
 def split_gemm_weights(b):
     """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
     Made once per optimizer step: the projection / prototype weights only change there."""
@@ -290,7 +239,8 @@ def sumpool2(fine):
     _chk(fine)
     b, rf, _, d = fine.shape
     out = torch.empty(b, rf // 2, rf // 2, d, dtype=torch.float32, device=fine.device)
-    _lib.check(lib().gx_sumpool2(_p(fine), _p(out), b, rf // 2, d, _stream()), "gx_sumpool2")
+    with record("sumpool2_kernel", 0.0, 5.0 * b * rf * rf * d):
+        _lib.check(lib().gx_sumpool2(_p(fine), _p(out), b, rf // 2, d, _stream()), "gx_sumpool2")
     return out
 
 
@@ -438,8 +388,10 @@ def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False):
         pool = torch.empty(b, h // 2, w // 2, d, dtype=torch.float32, device=z.device)
     wsb = L.gx_proto_small_workspace_bytes(k, d)
     ws = workspace("protosmall", wsb, z.device)
-    _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), b * h * w, h // 2, d, _p(wc), k, _p(g), _p(pool), _p(gwc),
-                                         beta, _p(ws), wsb, _stream()), "gx_proto_lowrank_finish")
+    npix = b * h * w
+    with record("proto_lowrank_finish_kernel", 0.0, 4.0 * npix * (d * (2.25 if want_pool else 2.0) + coeffs.shape[1])):
+        _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), npix, h // 2, d, _p(wc), k, _p(g), _p(pool), _p(gwc),
+                                             beta, _p(ws), wsb, _stream()), "gx_proto_lowrank_finish")
     return (g, pool) if want_pool else g
 
 
@@ -452,8 +404,10 @@ def upsample2_add_scores_(coarse, fine, wc, bias):
     k = wc.shape[0]
     rn = torch.empty(b * 4 * r * r, dtype=torch.float32, device=fine.device)
     sc = torch.empty(b * 4 * r * r, k, dtype=torch.float32, device=fine.device)
-    _lib.check(lib().gx_upsample2_add_scores(_p(coarse), _p(fine), b, r, d, _p(wc), _p(bias), k, _p(rn), _p(sc),
-                                             _stream()), "gx_upsample2_add_scores")
+    npix = b * 4 * r * r
+    with record("upsample2_add_scores_kernel", 0.0, 4.0 * npix * ((d if coarse is None else 2.25 * d) + k + 1)):
+        _lib.check(lib().gx_upsample2_add_scores(_p(coarse), _p(fine), b, r, d, _p(wc), _p(bias), k, _p(rn), _p(sc),
+                                                 _stream()), "gx_upsample2_add_scores")
     return rn, sc
 
 
@@ -823,7 +777,8 @@ def row_argmax(z):
 
 
 def colsum(x, out, alpha=1.0, beta=0.0):
-    _chk(x, out)
+    _chk2d(x)
+    _chk(out)
     L = lib()
     k = x.shape[1]
     wsb = L.gx_colsum_workspace_bytes(k)
@@ -939,6 +894,14 @@ class SinkhornBatch:
         return self.probs[i]
 
     def run(self, reduce=None):
+        if reduce is not None:
+            return self._run(reduce)
+        # one read of every score matrix per half-iteration (+ the column maxima unless the score GEMM left them behind)
+        npass = self.niters + (0 if all(p.cmax_preset is not None for p in self.probs) else 1)
+        with record("sinkhorn_pass_kernel", 0.0, 4.0 * self.nprob * self.rows * self.K * npass, launches=npass):
+            return self._run(None)
+
+    def _run(self, reduce):
         if reduce is None and self.c_uniform == 1.0 / self.rows and self.K <= 64 and self.rows >= 4096:
             L = lib()
             wsb = self.nprob * L.gx_sinkhorn_workspace_bytes(self.K)
@@ -1023,7 +986,10 @@ def swapped_ce(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, loss_b
     """Fused Sinkhorn-codes + swapped-prediction CE forward (+ d scores).  sk_* are run()
     Sinkhorn states of the two views; loss_out is a 1-element HIP tensor (accumulated)."""
     S, T = sk_s.S, sk_t.S
-    _chk(loss_out, d_s, d_t)
+    _chk(loss_out)
+    _chk2d(d_s, d_t)                       # row-strided dS (rows padded to whole 16-column chunks): the kernel takes the stride
+    if d_s is not None and d_t is not None and d_s.stride(0) != d_t.stride(0):
+        raise RuntimeError("swapped_ce: d_s and d_t must share their row stride")
     L = lib()
     wsb = L.gx_swapped_ce_workspace_bytes(sk_s.rows, sk_s.K)
     ws = workspace("ce", wsb, S.device)
@@ -1049,9 +1015,10 @@ def swapped_ce_fused(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, 
     L = lib()
     wsb = L.gx_swapped_ce_fused_workspace_bytes(sk_s.K)
     ws = workspace("ce_fused", wsb, S.device)
-    _lib.check(L.gx_swapped_ce_fused(_p(S), _p(T), sk_s.rows, sk_s.K, S.stride(0), sk_s.eps, temperature, _p(sk_s.la),
-                                     _p(sk_t.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), loss_scale, loss_beta,
-                                     _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()), "gx_swapped_ce_fused")
+    with record("ce_fused_bigk_kernel", 0.0, 16.0 * sk_s.rows * sk_s.K):        # two score matrices read, two dS written
+            _lib.check(L.gx_swapped_ce_fused(_p(S), _p(T), sk_s.rows, sk_s.K, S.stride(0), sk_s.eps, temperature, _p(sk_s.la),
+                                         _p(sk_t.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), loss_scale, loss_beta,
+                                         _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()), "gx_swapped_ce_fused")
     return loss_out
 
 

@@ -10,15 +10,9 @@ the exact adjoint (scatter-add, 2x2 sum-pooling, one TN GEMM per tap).  Same rea
 as swav_clustering.py:108-130 + :160-171 (and autograd of them); only the fp32 summation order
 differs (13 partial dot products instead of one 5376-long chain).
 """
-import os
-
 import torch
 
 from . import ops
-
-FUSE_UP = os.environ.get("GX_PYRAMID_FUSE", "1") != "0"      # 0: separate upsample-add passes (A/B measurements)
-TN_CAT = os.environ.get("GX_PYRAMID_TNCAT", "1") != "0"      # 0: one weight-gradient GEMM per tap (A/B measurements)
-WP_PLANES = os.environ.get("GX_PYRAMID_PLANES", "1") != "0"  # 0: in-kernel weight split (gemm_x6_kernel; A/B measurements)
 
 
 class Pyramid:
@@ -49,10 +43,10 @@ class Pyramid:
             p = torch.empty(self.B * r * r, d, dtype=torch.float32, device=wp.device)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
             # the level below rides on the epilogue of this level's (first) GEMM: p = taps . Wp^T + upsample2(prev)
-            up = prev.reshape(-1, d) if (FUSE_UP and prev is not None and used and (r & (r - 1)) == 0) else None
+            up = prev.reshape(-1, d) if (prev is not None and used and (r & (r - 1)) == 0) else None
             if not used:
                 p.zero_()
-            elif (WP_PLANES and len(used) <= 2 and used[0][2] == used[0][0].shape[1] and
+            elif (len(used) <= 2 and used[0][2] == used[0][0].shape[1] and
                   (len(used) == 1 or used[1][1] == used[0][1] + used[0][2]) and
                   ops.gemm_planes_ok(used[0][0], used[1][0][:, :used[1][2]] if len(used) == 2 else None, d, p)):
                 # the level's weight columns as bf16x6 planes, split once per call (Wp changes once per step):
@@ -98,7 +92,7 @@ class Pyramid:
             rows = self.B * r * r
             g2 = g.reshape(rows, -1)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
-            if (TN_CAT and len(used) == 2 and used[0][2] % 128 == 0 and used[1][1] == used[0][1] + used[0][2]):
+            if (len(used) == 2 and used[0][2] % 128 == 0 and used[1][1] == used[0][1] + used[0][2]):
                 # both taps of the level against ONE pass over the level's dZ
                 (ta, off, ca), (tb, _, cb) = used
                 tiles = ((g2.shape[1] + 127) // 128) * ((ca + cb + 127) // 128)

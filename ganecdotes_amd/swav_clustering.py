@@ -54,12 +54,6 @@ class _NullLogger:
         pass
 
 
-# EXPERIMENTAL: GX_EXPERIMENTAL_FP16X3=1 routes the three many-prototype GEMMs (scores, dz, prototype
-# gradient; K > 64) — operands whose range is known a priori: unit-norm rows, dS bounded by grad_scale / 2T — through the
-# fp16x3 engine (two fp16 pieces per operand, three MFMA products per fp32 product).  Off by default.
-FP16X3 = os.environ.get("GX_EXPERIMENTAL_FP16X3", "0") == "1"
-
-
 class SwAVClustering(ViewMixin):
 
 
@@ -212,18 +206,6 @@ class SwAVClustering(ViewMixin):
                 best, best_eff = s, eff
         return int(best if best_eff > 0 else max(1, min(want, cap)))
 
-    @staticmethod
-    def _split_k_h3(m, n, k):
-        """k split for the experimental fp16x3 TN kernel (128 x 128 tiles, one workgroup per CU): whole rounds of 256"""
-        tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        best, best_eff = 1, 0.0
-        for s in range(1, max(1, min(64, k // 768)) + 1):
-            wgs = tiles * s
-            eff = wgs / (((wgs + 255) // 256) * 256.0)
-            if wgs >= 256 and eff > best_eff + 1e-9:
-                best, best_eff = s, eff
-        return best
-
     def train_step(self, images, return_aux=False):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
         as a 1-element HIP tensor (global mean; no host sync)."""
@@ -308,15 +290,11 @@ class SwAVClustering(ViewMixin):
         wc_planes = None
         if not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0:
             wc_planes = ops.split_gemm_weights(Wc)
-        h3 = FP16X3 and wc_planes is not None and K % 4 == 0 and K > 64
         # dz = dS Wc as the NT contraction dS x (Wc^T)^T on the weight-plane kernel: dS rows padded to whole 16-column
         # chunks (zero pad), planes of Wc^T once per step (many prototypes; 7.95 -> 7.45 ms at K = 5000)
         pad_ds = wc_planes is not None and K % 4 == 0 and K > 64
         Kp = (K + 15) // 16 * 16
-        wct_planes = ops.split_gemm_weights(Wc.t().contiguous()) if (pad_ds and not h3) else None
-        if h3:
-            wc_h3 = ops.split_gemm_weights_h3(Wc)                          # scores: z_hat (unit rows) x Wc (unit rows)
-            wct_h3 = ops.split_gemm_weights_h3(Wc, transposed=True)
+        wct_planes = ops.split_gemm_weights(Wc.t().contiguous()) if pad_ds else None
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
@@ -347,12 +325,7 @@ class SwAVClustering(ViewMixin):
                             z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
                         X.append(x)
-                    if h3 and ops.gemm_planes_ok(z, None, K, sc):
-                        cm_g = (True if ngroups == 1 else ngroups) if (K > 64 and (ngroups == 1 or grows % 32 == 0)) else False
-                        res = ops.gemm_nt_planes_h3(z, wc_h3, sc, col_bias=bc, want_colmax=cm_g)
-                        if cm_g:
-                            cmax_pre[(gi, v)] = res[1]
-                    elif wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
+                    if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
                         # (B*N, K), Wc split once per step; the Sinkhorn column maxima come out of the epilogue
                         if K > 64 and (ngroups == 1 or grows % 32 == 0):
                             _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
@@ -419,20 +392,10 @@ class SwAVClustering(ViewMixin):
                             ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
                         first_acc = False
                         continue
-                    if h3:
-                        bound = max(0.5 * gscale / T, 1e-30)
-                        ops.gemm_tn_h3(dS[v], Zh[v], gWc, 2.0 ** math.floor(math.log2(16384.0 / bound)), beta=beta,
-                                       split_k=self._split_k_h3(K, D, rows))
-                    else:
-                        ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
+                    ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                     if not gb_in_ce:
                         ops.colsum(dS[v], gb, alpha=1.0, beta=beta)
-                    if h3 and ops.gemm_planes_ok(dSp[v], None, D, Zh[v]):
-                        # |dS| <= grad_scale / 2T: one host-computed power of two lifts it into fp16's normal range
-                        bound = max(0.5 * gscale / T, 1e-30)
-                        dz = torch.empty(rows, D, dtype=torch.float32, device=dev)
-                        ops.gemm_nt_planes_h3(dSp[v], wct_h3, dz, a_scale=2.0 ** math.floor(math.log2(16384.0 / bound)))
-                    elif pad_ds and ops.gemm_planes_ok(dSp[v], None, D, Zh[v]):
+                    if pad_ds and ops.gemm_planes_ok(dSp[v], None, D, Zh[v]):
                         dz = torch.empty(rows, D, dtype=torch.float32, device=dev)
                         ops.gemm_nt_planes(dSp[v], None, wct_planes, dz)
                     else:

@@ -104,17 +104,6 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
-/* EXPERIMENTAL, not used by the product path (DESIGN.md par. 10, item 0): the same NT contraction with every operand as
- * two fp16 pieces (11 + 11 bits) and three MFMA products per fp32 product — per-product error 2^-22 instead of 2^-24,
- * operands within fp16's range.  Exists so that the precision question can be answered with measurements. */
-size_t gx_gemm_weight_planes_h3_bytes(int N, int K);
-int gx_split_gemm_weights_h3(const float* B, int N, int K, long ldb, int transposed, unsigned short* planes, void* stream);
-int gx_gemm_f32_nt_planes_h3(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
-                             const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
-                             const float* row_scale, const float* col_bias, const float* coarse, int fine_res, float a_scale,
-                             float* colmax_part, void* stream);   /* a_scale: power of two applied to A before the split */
-int gx_gemm_f32_tn_h3(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float alpha,
-                      float beta, float a_scale, int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110

@@ -150,3 +150,36 @@ def test_sharded_sinkhorn_two_ranks_equals_oracle_on_concatenation():
         q[lo:hi] = qr
     assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
     np.testing.assert_allclose(q, q1, rtol=2e-4, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- bench.py's own launcher
+def _bench(*args, env=None, timeout=120):
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], cwd=root, capture_output=True, text=True,
+                       timeout=timeout, env=dict(os.environ, **(env or {})))
+    return p, time.time() - t0
+
+
+def test_bench_self_launch_rendezvous_two_ranks():
+    """`python bench.py --gpus 2` starts its own two ranks (fresh child processes); with --dry-rendezvous they only join
+    the gloo group, pass one barrier and leave: rc 0, ONE JSON line from rank 0, the other ranks' chatter on stderr."""
+    import json
+    p, _ = _bench("--gpus", "2", "--dry-rendezvous")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_rendezvous": True, "world": 2}
+
+
+def test_bench_self_launch_returns_fast_when_a_rank_dies():
+    """A rank that dies during start-up must not leave its peers (and the parent) waiting in the rendezvous until the
+    backend's timeout: the launcher polls every child, stops the others on the first non-zero exit and returns that
+    code within seconds; the dead rank's stderr is relayed with its rank prefix."""
+    p, dt = _bench("--gpus", "2", "--dry-rendezvous", env={"GX_BENCH_FAIL_RANK": "1"})
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert dt < 30.0, dt
+    assert "[rank 1] rank 1: GX_BENCH_FAIL_RANK set" in p.stderr and "stopping the other ranks" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

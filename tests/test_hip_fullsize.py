@@ -406,8 +406,15 @@ def test_bench_cli_contract_one_json_line(gpu):
     assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert 0.0 < r["step_frac"] < 1.0 and r["step_tflop"] > 0                  # the whole step against the same peak
+    h = r["hbm"]                                                                # the largest HBM-bound pass
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and 0.0 < h["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
+    rf = d["reference_faithful"]                                                # the reference's own nprototypes, same line
+    assert rf["prototypes"] == 5000 and rf["unit"] == d["unit"] and rf["value"] > 0
+    assert abs(rf["value"] - 16 * 1e3 / rf["ms_per_step"]) < 1e-3 * rf["value"]
+    assert 0.0 < rf["roofline"]["mfma_frac"] < 1.0 and 0.0 < rf["roofline"]["hbm_frac"] < 1.0
     d2 = run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
-    assert d2["n_gpus"] == 2 and d2["cpu_baseline"] is None
+    assert d2["n_gpus"] == 2 and d2["cpu_baseline"] is None and "reference_faithful" not in d2
     assert abs(d2["value"] - 2 * 16 * 1e3 / d2["ms_per_step"]) < 1e-3 * d2["value"]

@@ -680,61 +680,6 @@ def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
                         torch.empty(32, 48, device="cuda"))
 
 
-def test_experimental_fp16x3_nt_gemm_error_vs_fp64(ops):
-    """gx_gemm_f32_nt_planes_h3 (EXPERIMENTAL, not on the product path): two fp16 pieces per operand,
-    three MFMA products per fp32 product.  On operands inside fp16's range its error against fp64 is no larger than
-    the exact-fp32 MFMA engine's; the upsample-add / dual-A epilogue is the shared one."""
-    from ganecdotes_amd import _lib
-    from ganecdotes_amd.ops import _p, _stream, lib
-    L = lib()
-    torch.manual_seed(31)
-    prev = ops.set_gemm_mode(1)
-    try:
-        for (m, n, k1, k2, up) in ((2048, 512, 256, 0, 0), (1024, 260, 64, 48, 8), (300, 132, 4608, 0, 0)):
-            a1, a2 = dev(torch.randn(m, k1)), (dev(torch.randn(m, k2)) if k2 else None)
-            w = dev(torch.randn(n, k1 + k2) / (k1 + k2) ** 0.5)
-            co = dev(torch.randn(m // 4, n)) if up else None
-            pl = torch.empty(L.gx_gemm_weight_planes_h3_bytes(n, k1 + k2) // 2, dtype=torch.int16, device="cuda")
-            _lib.check(L.gx_split_gemm_weights_h3(_p(w), n, k1 + k2, w.stride(0), 0, _p(pl), _stream()), "split_h3")
-            out = torch.empty(m, n, device="cuda")
-            _lib.check(L.gx_gemm_f32_nt_planes_h3(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
-                                                  _p(pl), _p(out), n, 1.0, 0.0, None, None, _p(co), up, 1.0, None, _stream()), "h3")
-            acat = a1 if a2 is None else torch.cat([a1, a2], 1)
-            ref = acat.double() @ w.double().t()
-            if up:
-                ref = ref + co.reshape(-1, up // 2, up // 2, n).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(m, n).double()
-            ops.set_gemm_mode(0)
-            exact = ops.gemm(acat.contiguous(), w, False, True)
-            if up:
-                exact = exact + (ref - acat.double() @ w.double().t()).float()
-            ops.set_gemm_mode(1)
-            e3, e32 = rel_err(out, ref), rel_err(exact, ref)
-            assert e3 < 3e-6 and e3 <= 1.5 * e32 + 1e-7, (e3, e32)
-        # tiny operands (a gradient matrix) lifted by a power of two, weights given transposed, column maxima
-        a = dev(torch.randn(600, 208) * 3e-7)
-        a[:, 200:] = 0
-        wt = dev(torch.randn(200, 96) / 14.0)                     # stored (K, N)
-        out = torch.empty(600, 96, device="cuda")
-        _, cm = ops.gemm_nt_planes_h3(a, ops.split_gemm_weights_h3(wt, transposed=True), out, a_scale=2.0 ** 35, want_colmax=True)
-        ref = a[:, :200].double() @ wt.double()
-        assert rel_err(out, ref) < 3e-6 and torch.equal(cm, out.amax(0))
-        with pytest.raises(RuntimeError):                          # the scale must be a power of two
-            ops.gemm_nt_planes_h3(a, ops.split_gemm_weights_h3(wt, transposed=True), out, a_scale=3.0)
-        # the TN form (a prototype-gradient GEMM: tiny dS lifted by a power of two, unit-range z_hat), split-K, beta
-        for (k, m, n, split) in ((5000, 200, 96, 3), (4096, 520, 512, 4), (700, 132, 260, 1)):
-            at, b = dev(torch.randn(k, m) * 3e-7), dev(torch.nn.functional.normalize(torch.randn(k, n), dim=1))
-            prior = torch.randn(m, n) * 1e-6
-            out = dev(prior.clone())
-            ops.gemm_tn_h3(at, b, out, 2.0 ** 35, alpha=0.5, beta=1.0, split_k=split)
-            want = prior.double() + 0.5 * (at.double().t() @ b.double()).cpu()
-            ref6 = dev(prior.clone())
-            ops.gemm(at, b, True, False, out=ref6, alpha=0.5, beta=1.0, split_k=split)
-            e3, e6 = rel_err(out, want), rel_err(ref6, want)
-            assert e3 < 3e-6 and e3 <= 1.5 * e6 + 1e-7, (e3, e6)
-    finally:
-        ops.set_gemm_mode(prev)
-
-
 def test_pyramid_pieces(ops):
     torch.manual_seed(12)
     b, r, d = 2, 8, 24

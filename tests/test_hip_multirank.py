@@ -207,25 +207,3 @@ def test_pretrain_two_ranks_draw_different_images_and_stay_replicated():
     for a, b in zip(p0, p1):
         np.testing.assert_array_equal(a, b)               # replicas identical
     assert l0 == l1 and all(np.isfinite(l0))
-
-
-@pytest.mark.parametrize("scope", ["global", "image"])
-def test_experimental_fp16x3_generic_path_equals_default(scope, monkeypatch):
-    """GX_EXPERIMENTAL_FP16X3 (off by default): the many-prototype score and dz GEMMs on the fp16x3
-    engine — operands with an a-priori range, dS lifted by one host-computed power of two — give the default engine's
-    step (loss and updated parameters) to fp32-level differences."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    import ganecdotes_amd.swav_clustering as sc
-    sd = golden_sd(load_golden("gv10_pretrain"))
-    outs = []
-    for flag in (False, True):
-        monkeypatch.setattr(sc, "FP16X3", flag)
-        sw = _build(sd, None, scope, "uniform", 200)
-        imgs = _images(4)
-        for _ in range(2):
-            loss = sw.train_step(imgs)
-        outs.append((float(loss.item()), [p.cpu().numpy() for p in sw._params()]))
-    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-5)
-    for a, b in zip(outs[1][1], outs[0][1]):
-        np.testing.assert_allclose(a, b, rtol=1e-3, atol=2e-6 * np.abs(b).max())

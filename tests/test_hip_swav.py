@@ -254,6 +254,38 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
+@pytest.mark.parametrize("nproto", [6148, 7001])
+def test_train_step_past_the_fused_ce_limit_vs_oracle(gpu, tmp_path, nproto):
+    """More prototypes than the one-pass CE takes (K > 6144): the step falls back to gx_swapped_ce + gx_colsum.  With
+    K % 4 == 0 its dS rows are padded to whole 16-column chunks (row-strided views, the A operand of the dz GEMM) — both
+    kernels take the stride (this shape raised 'expected a contiguous tensor'); K = 7001 is the unpadded
+    form.  One step against the oracle."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    sw = make_swav(g, gpu, tmp_path, sinkhorn_scope="global", batch_size=2, nprototypes=nproto, nclasses=16)
+    torch.manual_seed(321)
+    np.random.seed(321)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(16, 7, 3, 32 * 32, 2, transforms=True) for _ in range(2)]
+    loss = sw.train_step(images)
+    oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                             ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
+                                 for v in im.views], im.picks) for im in images]
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
+        patch_size=300, num_patches=2, temperature=0.1, eps=0.05, niters=10, source_pdf="uniform", sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < 2e-3
+
+
 @pytest.mark.parametrize("mode", ["pyramid", "panel"])
 def test_patch_sampling_vs_oracle(gpu, tmp_path, mode):
     """sampling_method='patch' (swav_clustering.py:150-158, :383-385): one np.random.choice(h - patch_size)
