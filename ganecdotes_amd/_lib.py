@@ -52,6 +52,14 @@ SIGNATURES = {
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
                                     c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
+    "gx_gemm_f32_tn_gram": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f,
+                                  c_i, c_p, c_sz, c_p]),
+    "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
+    "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "gx_fineq_bwd_pool_workspace_bytes": (c_sz, [c_i, c_i]),
+    "gx_fineq_bwd_pool": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_proto_raw_tables": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p]),
     "gx_gemm_f32_upadd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p]),
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "gx_sumpool2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
@@ -64,12 +72,12 @@ SIGNATURES = {
     "gx_lowrank_stride": (c_i, [c_i]),
     "gx_gather_scores": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_fwd_lowrank": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
-    "gx_gather_scores_batch": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
-    "gx_proto_bwd_lowrank_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,
+    "gx_gather_scores_batch": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "gx_proto_bwd_lowrank_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz,
                                          c_p]),
     "gx_swapped_ce_batch": (c_i, [c_p, c_i, c_i, c_l, c_l, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "gx_proto_bwd_lowrank": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
-    "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz, c_p]),
     "gx_upsample2_add_scores": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),

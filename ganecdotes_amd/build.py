@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libganecdotes_hip.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_simclr.hip", "gx_head.hip", "gx_kmeans.hip"]
+SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_fineq.hip", "gx_simclr.hip", "gx_head.hip", "gx_kmeans.hip"]
 ARCH = "gfx950"
 
 
@@ -30,6 +30,8 @@ def _hipcc():
 def _src_hash():
     h = hashlib.sha256()
     for d in (CSRC, INCLUDE):
+        if not os.path.isdir(d):           # a package copied next to a prebuilt .so without the repo's include/
+            continue
         for name in sorted(os.listdir(d)):
             if name.endswith((".hip", ".h")):
                 with open(os.path.join(d, name), "rb") as f:

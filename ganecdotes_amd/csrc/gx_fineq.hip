@@ -1,0 +1,390 @@
+// The finest pyramid level of the low-rank (K <= 16 prototypes) path WITHOUT its projected table.
+//
+// Reference maths (hfc_with_swav/swav_clustering.py:120-128 upsample + concat, :171-175 projection, normalise,
+// prototypes): a pixel q of the finest level with tap vector t(q) (CF channels) and parent p = (y/2, x/2) has
+//     z(q) = Wf t(q) + Zc[p]          Wf = Wp[:, finest columns] (D x CF), Zc = the finished table of the level below
+// and the loss only ever sees   <Wc_k, z(q)>   and   |z(q)|^2.   Both are CF-wide forms of t(q):
+//     <Wc_k, z> = (Wc Wf)_k . t  +  Ac[p][k]                      Ac = Zc Wc^T            (rows/4 x K)
+//     |z|^2     = t^T (Wf^T Wf) t  +  t . Y2[p]  +  nc[p]         Y2 = 2 Zc Wf (rows/4 x CF),  nc = |Zc[p]|^2
+// so the level is ONE contraction  U = t . Bq^T  with Bq = [ tri(Wf^T Wf) ; Wc Wf ]  ((CF + 16) x CF instead of the
+// D = 512-wide projection), whose epilogue reduces a row to its K scores and its 1 / |z| — the (rows x D) table Z of
+// the finest level (4.3 GB at the bench batch) is never written, read back for the score tables, or read by the dense
+// finish.  tri(M) = 2 strict-lower + diagonal (t^T M t is unchanged for symmetric M): k-tile kt only meets the
+// column blocks nb >= kt / 2, 56 % of the MFMA products of the quadratic form.
+//
+// Backward (autograd of the same lines): with the coefficient grid C of the low-rank path (gx_swav.hip:
+// G[q] = C[q][:K] Wc + e[q] z(q), e = C[q][K]) the level's share of every gradient is again CF-wide:
+//     dWf  = Wc^T P + Wf S + Zc^T Tt        P = C[:, :K]^T t (K x CF),  S = sum_q e[q] t(q) t(q)^T (CF x CF),
+//                                           Tt[p] = sum_{q in p} e[q] t(q)               (rows/4 x CF)
+//     Gc   = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc        (the gradient that reaches the level below)
+//     gWc  = P Wf^T + Cpool[:, :K]^T Zc
+// gx_fineq_bwd_pool makes Tt, Cpool and P in one pass over the taps; S is the k-scaled TN GEMM gx_gemm_f32_tn_gram.
+#include "gx_mfma_x6.h"
+
+namespace gx {
+
+struct FineqArgs {
+    const float* A1; const float* A2;      // the level's taps [rows][K1], [rows][K2] (K2 = 0: one tap)
+    long lda1, lda2;
+    int K1, K2;
+    const unsigned short* Bp;              // gx_split_gemm_weights planes of Bq [CF + 16][CF]
+    unsigned Bp_bytes;
+    const float* Y2;                       // [rows / 4][CF]
+    const float* Ac;                       // [rows / 4][K]
+    const float* nc;                       // [rows / 4]
+    const float* bias;                     // [K] or null
+    float* rn_table;                       // [rows]
+    float* sc_table;                       // [rows][K]
+    int M, K, shift;                       // rows, prototypes, log2(fine resolution)
+};
+
+#ifndef FQ_ABL
+#define FQ_ABL 0                           // lab ablations (tools/lab/fineq_abl.sh): 1 no Y2 loads, 2 no MFMAs, 3 no A DMA, 4 no B DMA
+#endif
+constexpr int FQ_A = 8192;                 // one A tile: 128 rows x 16 raw fp32
+constexpr int FQ_NSA = 3;                  // A ring: the tile before the current one stays readable (block finalisation)
+
+// 128 rows per workgroup, four waves stacked along M (32 rows x all CF + 16 columns each): every A element is split by
+// exactly one lane, as in gemm_xw_kernel, and a row's whole U lives in one wave's accumulators.  NBQ = CF / 32 column
+// blocks + the score block.  Bq is lower triangular, so column block nb is FINAL after k-tile 2 nb + 1 — the two k-tiles
+// that hold the block's own tap columns, and both still sit in the A ring: the block is folded into the row sums
+//     sp[r] += t[row_r][j] * (U[row_r][j] + Y2[parent(row_r)][j])          (accumulator layout: lane = column j, 16 rows)
+// right there, with t read back from LDS, and its 16 accumulator registers are free for the rest of the loop.  Nothing of
+// U is staged or stored, and the taps are read from HBM exactly once.  (First version: U parked in LDS after the loop and
+// t / Y2 re-read row-wise from global — 4.2 GB of L2 misses with little in flight: 2.4 ms against 1.2 ms without them.)
+template <int NBQ>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void fineq_fwd_kernel(FineqArgs g) {
+    constexpr int CF = 32 * NBQ, NKT = CF / 16, FT = NBQ / 4;              // full 128-row weight tiles
+    constexpr int PST = (NBQ + 1) * 1024;                                   // one plane of a B stage: CF + 32 rows x 32 B
+    constexpr int FQ_B = 3 * PST;
+    __shared__ __attribute__((aligned(16))) char lds[FQ_NSA * FQ_A + 2 * FQ_B];
+    char* const ldsB = lds + FQ_NSA * FQ_A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (g.M + 127) >> 7;
+    const int tm = xcd_remap((int)blockIdx.x, ntile);
+    const int m0 = tm * 128;
+    const int nkt1 = g.K1 >> 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    unsigned aoff1[2], aoff2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 256 + tid;
+        int row = p >> 2;
+        const int q = (p & 3) ^ ((p >> 4) & 3);
+        row = min(row, g.M - 1 - m0);
+        aoff1[i] = ((unsigned)row * (unsigned)g.lda1 + (unsigned)q * 4u) * 4u;
+        aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A1 + (long)m0 * g.lda1, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A1, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
+    const unsigned boff = (unsigned)tid * 16u;
+
+    auto issue_b = [&](int kt, char* dst) {
+        if (FQ_ABL == 4) return;
+#pragma unroll
+        for (int tn = 0; tn < FT; ++tn) {
+            if (4 * tn + 3 < (kt >> 1)) continue;                          // every block of this tile is above the diagonal
+            const unsigned blk = ((unsigned)tn * NKT + (unsigned)kt) * 3u * 4096u;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * PST + tn * 4096 + wid * 1024), 16, (int)boff,
+                                                         (int)(blk + p * 4096u), 0, 0);
+        }
+        if (wid < 3) {                                                     // the score rows: 32 rows of tile FT, plane `wid`
+            const unsigned blk = ((unsigned)FT * NKT + (unsigned)kt) * 3u * 4096u + (unsigned)wid * 4096u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + wid * PST + FT * 4096), 16, (int)(lane * 16), (int)blk, 0, 0);
+        }
+    };
+    auto issue_a = [&](int kt, char* dst) {
+        if (FQ_ABL == 3) return;
+        const bool second = kt >= nkt1;
+        const int ks = (second ? kt - nkt1 : kt) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff1[i], ks, 0, 0);
+        }
+    };
+
+    f32x16 acc[NBQ + 1];
+#pragma unroll
+    for (int j = 0; j <= NBQ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int arow = wid * 32 + r32;
+    const int af = (arow >> 2) & 3;
+    const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
+
+    // Accumulator layout of this lane: column r32 of a block, rows (r & 3) + 8 (r >> 2) + 4 hh of the wave's 32.  The
+    // fine resolution is >= 32 (host check), so a wave's 32 rows are 32 consecutive x of ONE image row starting at an even
+    // x: row r's parent is pbase + ((r & 3) >> 1) + 4 (r >> 2) + 2 hh — rows r = 0, 1 (mod 4) share one, r = 2, 3 the next.
+    const int s = g.shift, rc = 1 << (s - 1), msk = (1 << s) - 1;
+    const int row0 = m0 + wid * 32;                                       // wave-uniform
+    const long pbase = ((long)(row0 >> (2 * s)) * rc + (((row0 >> s) & msk) >> 1)) * rc + ((row0 & msk) >> 1);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(g.Y2 + pbase * CF, 16u * CF * 4u);     // the wave's 16 parents
+    const unsigned yoff = ((unsigned)(2 * hh) * CF + (unsigned)r32) * 4u;
+    // t[row_r][column r32 of block nb] in the A ring: k-tile 2 nb + (r32 >> 4), k = r32 & 15; unit = row * 4 + (k-quad ^
+    // ((row >> 2) & 3)), and (row >> 2) & 3 = hh for even r >> 2, 2 + hh for odd: two bases + compile-time offsets
+    const int tk = r32 & 15;
+    const int tbase = wid * 2048 + hh * 256 + (tk & 3) * 4;
+    const int tb_e = tbase + (((tk >> 2) ^ hh) << 4), tb_o = tbase + (((tk >> 2) ^ (2 + hh)) << 4);
+    float sp[16], y2c[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sp[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) y2c[r] = 0.f;
+
+    issue_b(0, ldsB);
+    issue_a(0, lds);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < NKT) {
+            issue_b(t + 1, ldsB + ((t + 1) & 1) * FQ_B);
+            issue_a(t + 1, lds + ((t + 1) % FQ_NSA) * FQ_A);
+        }
+        asm volatile("" ::: "memory");
+        if ((t & 1) == 0 && FQ_ABL != 1) {                               // Y2 of block t / 2, consumed one k-tile later
+#pragma unroll
+            for (int i = 0; i < 8; ++i)                                   // parent (i & 1) + 4 (i >> 1) (+ 2 hh in yoff)
+                y2c[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_y, (int)yoff, (((i & 1) + 4 * (i >> 1)) * CF + (t >> 1) * 32) * 4, 0));
+        }
+        asm volatile("" ::: "memory");
+        const char* st = lds + (t % FQ_NSA) * FQ_A;
+        const char* Bs = ldsB + (t & 1) * FQ_B;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
+        unsigned h[4], m[4], l[4];
+        split3(x0[0], x0[1], h[0], m[0], l[0]);
+        split3(x0[2], x0[3], h[1], m[1], l[1]);
+        split3(x1[0], x1[1], h[2], m[2], l[2]);
+        split3(x1[2], x1[3], h[3], m[3], l[3]);
+        const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]}),
+                             __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
+                             __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})};
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
+        const int nb0 = t >> 1;
+        // the block that becomes final in this k-tile goes first, so that its MFMAs have retired when it is folded below
+#pragma unroll
+        for (int gb = nb0; gb <= NBQ; gb += 2) {                            // column blocks in pairs
+            bf16x8 b[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nb = gb + j;
+                if (nb > NBQ) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * PST + x_kc_off(nb * 32 + r32, hh));
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = gb + j;
+                    if (nb > NBQ || FQ_ABL == 2) continue;
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[j][TB[u]], acc[nb], 0, 0, 0);
+                }
+        }
+        if (t & 1) {                                                        // block nb0 is final: fold it into the row sums
+            const char* tsrc = lds + (((t - 1) + (r32 >> 4)) % FQ_NSA) * FQ_A;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float tv = *reinterpret_cast<const float*>(tsrc + (((r >> 2) & 1) ? tb_o : tb_e) + (r & 3) * 64 + (r >> 2) * 512);
+                sp[r] = fmaf(tv, acc[nb0][r] + y2c[((r & 3) >> 1) + 2 * (r >> 2)], sp[r]);
+            }
+        }
+    }
+
+    // ---- rows: |z|^2 = sum over the columns (the 32 lanes of this half-wave) + nc[parent]; the K scores are the score block
+    const int k = r32;
+    const bool kok = k < g.K;
+    const float myb = (kok && g.bias) ? g.bias[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long par = pbase + ((r & 3) >> 1) + 4 * (r >> 2) + 2 * hh;
+        const float nsq = gx_team_sum(sp[r], 32) + g.nc[par];
+        const float rn = 1.f / fmaxf(sqrtf(fmaxf(nsq, 0.f)), 1e-12f);
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.M) {
+            if (kok) g.sc_table[(long)row * g.K + k] = fmaf(acc[NBQ][r] + g.Ac[par * g.K + k], rn, myb);
+            if (k == 0) g.rn_table[row] = rn;
+        }
+    }
+}
+
+// Bq [CF + 16][CF] (row stride CF) for fineq_fwd_kernel: rows j < CF = the lower-triangular form of the symmetric
+// M = Wf^T Wf (2 M[j][i] for i < j, M[j][j], 0 above: sum_j t_j (Bq t)_j = t^T M t), rows CF .. CF + K - 1 = Wcf = Wc Wf,
+// the rest zero.
+__global__ void fineq_pack_kernel(const float* __restrict__ Mg, const float* __restrict__ Wcf, int CF, int K,
+                                  float* __restrict__ Bq) {
+    const int total = (CF + 16) * CF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i / CF, c = i - j * CF;
+        float v = 0.f;
+        if (j < CF) {
+            const float mv = Mg[(long)j * CF + c];
+            v = c < j ? 2.f * mv : (c == j ? mv : 0.f);
+        } else if (j - CF < K) {
+            v = Wcf[(long)(j - CF) * CF + c];
+        }
+        Bq[i] = v;
+    }
+}
+
+// One pass over the finest taps for the backward: a wave per parent pixel p (its 2 x 2 children q), lane l owns columns
+// 4 l .. 4 l + 3 of the CF <= 256 tap channels.
+//   Tt[p]    = sum_q e[q] t(q)                  e = C[q][K]
+//   Cpool[p] = sum_q C[q][:]                    (stride ls)
+//   part_w[block][k][:] = sum over the block's pixels of C[q][k] t(q)        (-> P = C[:, :K]^T t by a fixed-order reduce)
+template <int KP>
+__global__ __launch_bounds__(256) void fineq_bwd_pool_kernel(const float* __restrict__ C, const float* __restrict__ A1, long lda1,
+                                                             int K1, const float* __restrict__ A2, long lda2, int CF, long ncoarse,
+                                                             int rc, int K, float* __restrict__ Tt, float* __restrict__ Cpool,
+                                                             float* __restrict__ part_w) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane * 4;
+    const bool cok = col < CF;
+    const bool second = col >= K1;
+    const float* src = second ? A2 + (col - K1) : A1 + col;
+    const long ld = second ? lda2 : lda1;
+    const long wave0 = (long)blockIdx.x * 4 + wid;
+    const long nwave = (long)gridDim.x * 4;
+    const int ls = (K + 1 + 3) & ~3, rf = 2 * rc;
+    const long per = (long)rc * rc;
+    f32x4 gw[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gw[k] = zero4();
+    for (long p = wave0; p < ncoarse; p += nwave) {
+        const long b = p / per, rem = p - b * per;
+        const long cy = rem / rc, cx = rem - cy * rc;
+        long pq[4];
+        pq[0] = (b * rf + 2 * cy) * rf + 2 * cx;
+        pq[1] = pq[0] + 1; pq[2] = pq[0] + rf; pq[3] = pq[2] + 1;
+        float cv[4];
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cv[j] = lane < ls ? C[pq[j] * ls + lane] : 0.f;
+            t[j] = cok ? *reinterpret_cast<const f32x4*>(src + pq[j] * ld) : zero4();
+        }
+        f32x4 tt = zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tt += __shfl(cv[j], K, 64) * t[j];
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[j]), k));
+                gw[k] += c * t[j];
+            }
+        if (cok) *reinterpret_cast<f32x4*>(Tt + p * CF + col) = tt;
+        if (lane < ls) Cpool[p * ls + lane] = (cv[0] + cv[1]) + (cv[2] + cv[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+            __syncthreads();
+            *reinterpret_cast<f32x4*>(red + wid * 256 + lane * 4) = gw[k];
+            __syncthreads();
+            for (int c2 = threadIdx.x; c2 < CF; c2 += blockDim.x)
+                part_w[((long)blockIdx.x * K + k) * CF + c2] = (red[c2] + red[256 + c2]) + (red[512 + c2] + red[768 + c2]);
+        }
+    }
+}
+
+// out[j] = beta * out[j] + sum_b part[b][j]   (fixed order)
+__global__ void fineq_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+            s0 += part[(long)b * n + j]; s1 += part[(long)(b + 1) * n + j];
+            s2 += part[(long)(b + 2) * n + j]; s3 += part[(long)(b + 3) * n + j];
+        }
+        for (; b < nblk; ++b) s0 += part[(long)b * n + j];
+        const float v = (s0 + s1) + (s2 + s3);
+        out[j] = beta != 0.f ? beta * out[j] + v : v;
+    }
+}
+
+}  // namespace gx
+
+extern "C" {
+
+// the taps a finest level must have for this path: CF = K1 + K2 = 256 channels as one tap or as two of 128 (the Gram GEMM
+// of the backward takes its 256-row tile from at most two sources split at 128), K <= 16 prototypes
+int gx_fineq_ok(int K1, int K2, int K) {
+    return K1 + K2 == 256 && (K2 == 0 || K1 == 128) && K >= 1 && K <= 16;
+}
+
+int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, float* Bq, void* stream) {
+    if (!Mg || !Wcf || !Bq || CF <= 0 || K < 1 || K > 16) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gx::fineq_pack_kernel, dim3(gx_cdiv((long)(CF + 16) * CF, 256)), dim3(256), 0, (hipStream_t)stream, Mg, Wcf,
+                       CF, K, Bq);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
+                 const unsigned short* bq_planes, const float* Y2, const float* Ac, const float* nc, const float* bias,
+                 int K, float* rn_table, float* sc_table, void* stream) {
+    if (!t1 || !bq_planes || !Y2 || !Ac || !nc || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
+    if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
+    if (gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;                   // a bf16x6 kernel
+    // >= 32: a wave's 32 rows are consecutive pixels of one image row (fineq_fwd_kernel's parent arithmetic)
+    if (fine_res < 32 || (fine_res & (fine_res - 1)) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
+    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || ld1 < K1 || (K2 > 0 && ld2 < K2) || ld1 >= (1 << 22) || ld2 >= (1 << 22) ||
+        127L * ld1 * 4 + 4L * K1 >= 0x7FFFFFF0L || 127L * ld2 * 4 + 4L * K2 >= 0x7FFFFFF0L ||
+        (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)bq_planes | (uintptr_t)Y2) & 15))
+        return GX_ERR_ALIGN;
+    const int CF = K1 + K2;
+    gx::FineqArgs g;
+    g.A1 = t1; g.A2 = K2 > 0 ? t2 : nullptr; g.lda1 = ld1; g.lda2 = K2 > 0 ? ld2 : ld1; g.K1 = K1; g.K2 = K2;
+    g.Bp = bq_planes; g.Bp_bytes = (unsigned)gx_gemm_weight_planes_bytes(CF + 16, CF);
+    g.Y2 = Y2; g.Ac = Ac; g.nc = nc; g.bias = bias; g.rn_table = rn_table; g.sc_table = sc_table;
+    g.M = rows; g.K = K; g.shift = 0;
+    while ((1 << g.shift) < fine_res) ++g.shift;
+    const dim3 grid(gx_cdiv(rows, 128)), block(gx::GEMM_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gx::fineq_fwd_kernel<8>, grid, block, 0, st, g);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF) { return (size_t)2048 * K * CF * sizeof(float); }
+int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
+                      long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (!C || !t1 || !Tt || !Cpool || !P || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
+    if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
+    if (fine_res < 2 || (fine_res & 1) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
+    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || (K1 & 3) || (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)Tt) & 15)) return GX_ERR_ALIGN;
+    const int CF = K1 + K2;
+    if (!workspace || workspace_bytes < gx_fineq_bwd_pool_workspace_bytes(K, CF)) return GX_ERR_WORKSPACE;
+    const long ncoarse = rows / 4;
+    long nb = (ncoarse + 15) / 16;
+    if (nb > 2048) nb = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 8)
+        hipLaunchKernelGGL((gx::fineq_bwd_pool_kernel<8>), dim3((int)nb), dim3(256), 0, st, C, t1, ld1, K1, K2 > 0 ? t2 : t1,
+                           K2 > 0 ? ld2 : ld1, CF, ncoarse, fine_res / 2, K, Tt, Cpool, workspace);
+    else
+        hipLaunchKernelGGL((gx::fineq_bwd_pool_kernel<16>), dim3((int)nb), dim3(256), 0, st, C, t1, ld1, K1, K2 > 0 ? t2 : t1,
+                           K2 > 0 ? ld2 : ld1, CF, ncoarse, fine_res / 2, K, Tt, Cpool, workspace);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gx::fineq_reduce_kernel, dim3(gx_cdiv((long)K * CF, 256)), dim3(256), 0, st, workspace, (int)nb, K * CF, 0.f, P);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+}  // extern "C"

@@ -1921,7 +1921,8 @@ constexpr int LR_MAXK = 16;            // low-rank path: K <= 16 prototypes
 __host__ __device__ constexpr int lr_stride(int K) { return (K + 1 + 3) & ~3; }
 
 // scores[row][k] = rn * <Z[q], Wc_k> + b_k ; rnorm[row] = rn.  One wave per row.
-template <int KP>
+// RAW: scores[row][k] = <Z[q], Wc_k>, rnorm[row] = |Z[q]|^2 (what gx_fineq_fwd needs of the level below the finest).
+template <int KP, bool RAW = false>
 __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __restrict__ Z, int HW, int D,
                                                                 const int* __restrict__ picks,
                                                                 const int* __restrict__ maps, int rows_per_img,
@@ -1962,8 +1963,8 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
         ss = gx_wave_sum(ss);
         const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
         const float sc = ps_reduce<KP>(p, lane);
-        if (owner) scores[row * K + myk] = fmaf(sc, rn, myb);
-        if (lane == 0) rnorm[row] = rn;
+        if (owner) scores[row * K + myk] = RAW ? sc : fmaf(sc, rn, myb);
+        if (lane == 0) rnorm[row] = RAW ? ss : rn;
     }
 }
 
@@ -2030,8 +2031,10 @@ __global__ void proto_bwd_lowrank_kernel(const float* __restrict__ dS, const flo
 
 // The whole step at once (low-rank path, both views in one 2B-image batch): row r enumerates
 // (patch p, view v, image b, sample n); its pixel is map(picks[p][b][n]) of image v*B + b.
+// shift > 0: the tables live `shift` pyramid levels below the picks' resolution (no taps above: every pixel of a
+// 2^shift x 2^shift block has its ancestor's descriptor); wlog2 = log2 of the picks' image width.
 __device__ __forceinline__ long lr_row_pixel(long r, int B, int N, int HW, const int* __restrict__ picks,
-                                             const int* __restrict__ maps) {
+                                             const int* __restrict__ maps, int shift, int wlog2) {
     const int n = (int)(r % N);
     const long t = r / N;
     const int b = (int)(t % B), v = (int)((t / B) & 1);
@@ -2039,17 +2042,22 @@ __device__ __forceinline__ long lr_row_pixel(long r, int B, int N, int HW, const
     const int img = v * B + b;
     int pix = picks[(p * B + b) * N + n];
     if (maps) pix = maps[(long)img * HW + pix];
-    return pix >= 0 ? (long)img * HW + pix : -1;
+    if (pix < 0) return -1;
+    if (shift > 0) {
+        const int y = pix >> wlog2, x = pix & ((1 << wlog2) - 1);
+        return (long)img * (HW >> (2 * shift)) + (((y >> shift) << (wlog2 - shift)) + (x >> shift));
+    }
+    return (long)img * HW + pix;
 }
 __global__ void gather_scores_batch_kernel(const float* __restrict__ T, const float* __restrict__ rnT,
                                            const float* __restrict__ bias, int B, int HW, int K, int N,
                                            const int* __restrict__ picks, const int* __restrict__ maps, long rows,
-                                           float* __restrict__ scores, float* __restrict__ rnorm) {
+                                           float* __restrict__ scores, float* __restrict__ rnorm, int shift, int wlog2) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * K) return;
     const long r = idx / K;
     const int k = (int)(idx - r * K);
-    const long q = lr_row_pixel(r, B, N, HW, picks, maps);
+    const long q = lr_row_pixel(r, B, N, HW, picks, maps, shift, wlog2);
     scores[idx] = q >= 0 ? T[q * K + k] : (bias ? bias[k] : 0.f);
     if (k == 0) rnorm[r] = q >= 0 ? rnT[q] : 1e12f;
 }
@@ -2057,7 +2065,7 @@ __global__ void proto_bwd_lowrank_batch_kernel(const float* __restrict__ dS, con
                                                const float* __restrict__ rnorm, const float* __restrict__ bias, int B,
                                                int HW, int K, int N, const int* __restrict__ picks,
                                                const int* __restrict__ maps, long rows, float* __restrict__ C,
-                                               float* __restrict__ part_b) {
+                                               float* __restrict__ part_b, int shift, int wlog2) {
     __shared__ float sb[LR_MAXK];
     const int ls = lr_stride(K);
     const int team = (K + 1 <= 16) ? 16 : 32;
@@ -2073,7 +2081,7 @@ __global__ void proto_bwd_lowrank_batch_kernel(const float* __restrict__ dS, con
         float d = 0.f, sc = 0.f, rn = 0.f;
         long q = -1;
         if (live) {
-            q = lr_row_pixel(row, B, N, HW, picks, maps);
+            q = lr_row_pixel(row, B, N, HW, picks, maps, shift, wlog2);
             rn = rnorm[row];
             if (tl < K) { d = dS[row * K + tl]; sc = scores[row * K + tl] - myb; }
         }
@@ -2096,7 +2104,7 @@ template <int KP, bool POOL>
 __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* __restrict__ C, const float* __restrict__ Z,
                                                                    long npix, int rc, int D, const float* __restrict__ Wc,
                                                                    int K, float* __restrict__ G, float* __restrict__ Gpool,
-                                                                   float* __restrict__ part_w) {
+                                                                   float* __restrict__ part_w, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][256] (this slab of Wc)
     const int cb = blockIdx.y * 256;
     for (int i = threadIdx.x; i < KP * 256; i += blockDim.x) wsm[i] = (i >> 8) < K ? Wc[(long)(i >> 8) * D + cb + (i & 255)] : 0.f;
@@ -2122,19 +2130,20 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
             for (int j = 0; j < 4; ++j) pq[j] = g * 4 + j;
         }
         float cv[4];
-        f32x4 z[4];
+        f32x4 z[4], g0[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = pq[j] < npix;
             cv[j] = (ok && lane < ls) ? C[pq[j] * ls + lane] : 0.f;
             z[j] = ok ? *reinterpret_cast<const f32x4*>(Z + pq[j] * D + col) : zero4();
+            g0[j] = (ok && accumulate) ? *reinterpret_cast<const f32x4*>(G + pq[j] * D + col) : zero4();
         }
         // coefficients as wave-uniform scalars (lane k of cv[j] holds C[q_j][k]); a never-sampled pixel has
         // all-zero coefficients and simply yields a zero row.  A prototype float4 is read from LDS once
         // for the four rows.
         f32x4 a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = __shfl(cv[j], K, 64) * z[j];
+        for (int j = 0; j < 4; ++j) a[j] = g0[j] + __shfl(cv[j], K, 64) * z[j];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + k * 256 + lane * 4);
@@ -2272,6 +2281,25 @@ int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks,
     return GX_OK;
 }
 
+// dots [rows][K] = Z Wc^T and sumsq [rows] = |Z[row]|^2 of a finished table Z [rows][D] — no normalisation, no bias:
+// the inputs gx_fineq_fwd takes from the level below the finest.
+int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, float* dots, void* stream) {
+    if (!Z || !Wc || !sumsq || !dots || rows <= 0 || rows > 0x7FFFFFFFL) return GX_ERR_BAD_ARG;
+    if (K < 1 || K > gx::LR_MAXK || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
+    long nb = (rows + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    const int kp = K <= 8 ? 8 : 16;
+    const size_t lds = (size_t)kp * D * sizeof(float);
+    if (kp == 8)
+        hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<8, true>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z,
+                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots);
+    else
+        hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<16, true>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z,
+                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
 // Rows of the all-pixel score table (gx_proto_fwd_lowrank with picks == NULL) for one patch.
 int gx_gather_scores(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
                      const int* picks, int rows_per_img, const int* maps, float* scores, float* rnorm, void* stream) {
@@ -2287,31 +2315,42 @@ int gx_gather_scores(const float* table, const float* rn_table, const float* bia
 // All patches and both views of a step in one launch: tables over the 2B-image batch (view v = images
 // [v*B, (v+1)*B)), picks [npatch][B][N], maps [2B][HW] or NULL; rows are ordered (patch, view, image, sample),
 // i.e. scores is [npatch][2][B*N][K].
+static int lr_wlog2(int HW, int shift) {          // log2 of the image width for a table `shift` levels below the picks; -1: bad
+    if (shift < 0) return -1;
+    if (shift == 0) return 0;
+    int w = 0;
+    while ((1L << (2 * w)) < HW) ++w;
+    return ((1L << (2 * w)) == HW && shift <= w) ? w : -1;
+}
 int gx_gather_scores_batch(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
-                           const int* picks, int npatch, int N, const int* maps, float* scores, float* rnorm,
+                           const int* picks, int npatch, int N, const int* maps, int shift, float* scores, float* rnorm,
                            void* stream) {
     if (!table || !rn_table || !picks || !scores || !rnorm || B <= 0 || HW <= 0 || K <= 0 || npatch <= 0 || N <= 0)
         return GX_ERR_BAD_ARG;
+    const int wlog2 = lr_wlog2(HW, shift);
+    if (wlog2 < 0) return GX_ERR_BAD_ARG;
     const long rows = (long)npatch * 2 * B * N;
     hipLaunchKernelGGL(gx::gather_scores_batch_kernel, dim3((unsigned)gx_cdiv(rows * K, 256)), dim3(256), 0,
-                       (hipStream_t)stream, table, rn_table, bias, B, HW, K, N, picks, maps, rows, scores, rnorm);
+                       (hipStream_t)stream, table, rn_table, bias, B, HW, K, N, picks, maps, rows, scores, rnorm, shift, wlog2);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
 // the matching coefficient scatter: C [2B*HW][gx_lowrank_stride(K)] += ..., gb = beta*gb + colsum(dS).
 // workspace >= 1024*K floats.
 int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
-                               int K, const int* picks, int npatch, int N, const int* maps, float* C, float* gb,
+                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, float* gb,
                                float beta, float* workspace, size_t workspace_bytes, void* stream) {
     if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || npatch <= 0 || N <= 0 || K < 1 ||
         K > gx::LR_MAXK)
         return GX_ERR_BAD_ARG;
+    const int wlog2 = lr_wlog2(HW, shift);
+    if (wlog2 < 0) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < (size_t)1024 * K * sizeof(float)) return GX_ERR_WORKSPACE;
     const long rows = (long)npatch * 2 * B * N;
     long nb = (rows + 15) / 16;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(gx::proto_bwd_lowrank_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores,
-                       rnorm, bias, B, HW, K, N, picks, maps, rows, C, workspace);
+                       rnorm, bias, B, HW, K, N, picks, maps, rows, C, workspace, shift, wlog2);
     GX_CHECK_LAUNCH();
     gx::launch_partial_reduce(workspace, (int)nb, K, 1.f, beta, gb, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
@@ -2343,7 +2382,7 @@ int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnor
 // sum-pooled G (what gx_sumpool2 would compute from G).  rc is ignored when Gpool == NULL.
 // workspace >= gx_proto_small_workspace_bytes(K, D).
 int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, int D, const float* Wc, int K, float* G,
-                            float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
+                            int accumulate, float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
                             void* stream) {
     if (!C || !Z || !Wc || !G || !gWc || npix <= 0 || K < 1 || K > gx::LR_MAXK || (D & 255) || D > 512)
         return GX_ERR_BAD_ARG;
@@ -2356,7 +2395,7 @@ int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, i
     hipStream_t st = (hipStream_t)stream;
 #define GX_FINISH(KP, POOL)                                                                                         \
     hipLaunchKernelGGL((gx::proto_lowrank_finish_kernel<KP, POOL>), dim3((int)nb, D / 256), dim3(256), lds, st, C, Z, \
-                       npix, rc, D, Wc, K, G, Gpool, workspace)
+                       npix, rc, D, Wc, K, G, Gpool, workspace, accumulate)
     if (kp == 8) { if (Gpool) GX_FINISH(8, true); else GX_FINISH(8, false); }
     else         { if (Gpool) GX_FINISH(16, true); else GX_FINISH(16, false); }
 #undef GX_FINISH

@@ -324,24 +324,29 @@ def gather_scores(table, rn_table, bias, picks, maps, hw, out=None):
     return rn, sc
 
 
-def gather_scores_batch(table, rn_table, bias, picks, maps, b, hw, out):
-    """all patches x both views: out (P, 2, B*N, K) scores, returns rnorm (P, 2, B*N); tables over the 2B batch"""
+def gather_scores_batch(table, rn_table, bias, picks, maps, b, hw, out, shift=0):
+    """all patches x both views: out (P, 2, B*N, K) scores, returns rnorm (P, 2, B*N); tables over the 2B batch,
+    `shift` pyramid levels below the picks' resolution (2B * hw / 4**shift rows)"""
     _chk(table, rn_table, bias, out)
     p, pb, n = picks.shape
     k = table.shape[1]
+    if table.shape[0] != 2 * b * (hw >> (2 * shift)) or rn_table.numel() != table.shape[0]:
+        raise RuntimeError("gather_scores_batch: tables do not match (2B, hw, shift)")
     rn = torch.empty(p, 2, b * n, dtype=torch.float32, device=table.device)
-    _lib.check(lib().gx_gather_scores_batch(_p(table), _p(rn_table), _p(bias), b, hw, k, _p(picks), p, n, _p(maps), _p(out),
-                                            _p(rn), _stream()), "gx_gather_scores_batch")
+    _lib.check(lib().gx_gather_scores_batch(_p(table), _p(rn_table), _p(bias), b, hw, k, _p(picks), p, n, _p(maps), shift,
+                                            _p(out), _p(rn), _stream()), "gx_gather_scores_batch")
     return rn
 
 
-def proto_bwd_lowrank_batch_(ds, scores, rnorm, bias, picks, maps, coeffs, b, hw, gb, beta):
+def proto_bwd_lowrank_batch_(ds, scores, rnorm, bias, picks, maps, coeffs, b, hw, gb, beta, shift=0):
     _chk(ds, scores, rnorm, bias, coeffs, gb)
     p, pb, n = picks.shape
     k = ds.shape[-1]
+    if coeffs.shape[0] != 2 * b * (hw >> (2 * shift)):
+        raise RuntimeError("proto_bwd_lowrank_batch_: coefficient grid does not match (2B, hw, shift)")
     ws = workspace("lowrank_b", 1024 * k * 4, ds.device)
     _lib.check(lib().gx_proto_bwd_lowrank_batch(_p(ds), _p(scores), _p(rnorm), _p(bias), b, hw, k, _p(picks), p, n, _p(maps),
-                                                _p(coeffs), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
+                                                shift, _p(coeffs), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
                "gx_proto_bwd_lowrank_batch")
 
 
@@ -373,14 +378,17 @@ def proto_bwd_lowrank_(ds, scores, rnorm, bias, picks, maps, coeffs, hw, gb, bet
                "gx_proto_bwd_lowrank")
 
 
-def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False):
+def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False, add_to=None):
     """G (B,H,W,D) rebuilt from the coefficient grid; gwc = beta*gwc + C^T Z.
-    want_pool: also return sumpool2(G) (B,H/2,W/2,D), produced in the same pass."""
-    _chk(coeffs, z, wc, gwc)
+    want_pool: also return sumpool2(G) (B,H/2,W/2,D), produced in the same pass.
+    add_to: a (B,H,W,D) table the rebuilt rows are ADDED to (it becomes G)."""
+    _chk(coeffs, z, wc, gwc, add_to)
     b, h, w, d = z.shape
     k = wc.shape[0]
     L = lib()
-    g = torch.empty_like(z)
+    if add_to is not None and tuple(add_to.shape) != tuple(z.shape):
+        raise RuntimeError("proto_lowrank_finish: add_to must have the table's shape")
+    g = torch.empty_like(z) if add_to is None else add_to
     pool = None
     if want_pool:
         if h != w or h % 2:
@@ -389,9 +397,10 @@ def proto_lowrank_finish(coeffs, z, wc, gwc, beta, want_pool=False):
     wsb = L.gx_proto_small_workspace_bytes(k, d)
     ws = workspace("protosmall", wsb, z.device)
     npix = b * h * w
-    with record("proto_lowrank_finish_kernel", 0.0, 4.0 * npix * (d * (2.25 if want_pool else 2.0) + coeffs.shape[1])):
-        _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), npix, h // 2, d, _p(wc), k, _p(g), _p(pool), _p(gwc),
-                                             beta, _p(ws), wsb, _stream()), "gx_proto_lowrank_finish")
+    passes = 2.0 + (0.25 if want_pool else 0.0) + (1.0 if add_to is not None else 0.0)
+    with record("proto_lowrank_finish_kernel", 0.0, 4.0 * npix * (d * passes + coeffs.shape[1])):
+        _lib.check(L.gx_proto_lowrank_finish(_p(coeffs), _p(z), npix, h // 2, d, _p(wc), k, _p(g), int(add_to is not None),
+                                             _p(pool), _p(gwc), beta, _p(ws), wsb, _stream()), "gx_proto_lowrank_finish")
     return (g, pool) if want_pool else g
 
 
@@ -409,6 +418,103 @@ def upsample2_add_scores_(coarse, fine, wc, bias):
         _lib.check(lib().gx_upsample2_add_scores(_p(coarse), _p(fine), b, r, d, _p(wc), _p(bias), k, _p(rn), _p(sc),
                                                  _stream()), "gx_upsample2_add_scores")
     return rn, sc
+
+
+# ---- the finest level of the low-rank path without its projected table (csrc/gx_fineq.hip) --------------------------
+def fineq_ok(k1, k2, k):
+    """taps (k1 + k2 channels) and prototype count the quadratic-form finest level takes (bf16x6 engine only)"""
+    return get_gemm_mode() == 1 and bool(lib().gx_fineq_ok(int(k1), int(k2), int(k)))
+
+
+def proto_raw_tables(z2d, wc):
+    """z2d (rows, D) finished table -> (sumsq (rows,), dots (rows, K) = z2d @ wc.T): no normalisation, no bias"""
+    _chk(z2d, wc)
+    rows, d = z2d.shape
+    k = wc.shape[0]
+    ss = torch.empty(rows, dtype=torch.float32, device=z2d.device)
+    dots = torch.empty(rows, k, dtype=torch.float32, device=z2d.device)
+    with record("proto_raw_tables_kernel", 0.0, 4.0 * rows * (d + k + 1)):
+        _lib.check(lib().gx_proto_raw_tables(_p(z2d), rows, d, _p(wc), k, _p(ss), _p(dots), _stream()), "gx_proto_raw_tables")
+    return ss, dots
+
+
+def fineq_pack_weights(mg, wcf):
+    """Bq (CF + 16, CF) = [tri(mg) ; wcf ; 0] for fineq_fwd: mg = Wf.T @ Wf (CF, CF), wcf = Wc @ Wf (K, CF)"""
+    _chk(mg, wcf)
+    cf, k = mg.shape[0], wcf.shape[0]
+    bq = torch.empty(cf + 16, cf, dtype=torch.float32, device=mg.device)
+    _lib.check(lib().gx_fineq_pack_weights(_p(mg), _p(wcf), cf, k, _p(bq), _stream()), "gx_fineq_pack_weights")
+    return bq
+
+
+def fineq_fwd(t1, t2, bq_planes, y2, ac, nc, bias, fine_res):
+    """the finest level's score / rnorm tables from its taps t1 (rows, K1) [| t2 (rows, K2)] and the level below
+    (y2 = 2 Zc Wf, ac = Zc Wc^T, nc = |Zc|^2): returns (rn_table (rows,), sc_table (rows, K))"""
+    _chk2d(t1, t2)
+    _chk(y2, ac, nc, bias)
+    rows, k1 = t1.shape
+    k2 = 0 if t2 is None else t2.shape[1]
+    k = ac.shape[1]
+    if tuple(y2.shape) != (rows // 4, k1 + k2) or ac.shape[0] != rows // 4 or nc.numel() != rows // 4 or \
+            (t2 is not None and t2.shape[0] != rows):
+        raise RuntimeError("fineq_fwd: shape mismatch")
+    L = lib()
+    if bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
+        raise RuntimeError("fineq_fwd: planes do not match (CF + 16, CF)")
+    rn = torch.empty(rows, dtype=torch.float32, device=t1.device)
+    sc = torch.empty(rows, k, dtype=torch.float32, device=t1.device)
+    cf = k1 + k2
+    flops = 2.0 * rows * 16 * 32 * (sum(cf // 32 - (t >> 1) for t in range(cf // 16)) + cf // 16)   # blocks on / below the diagonal + scores
+    with record("fineq_fwd_kernel", flops):
+        _lib.check(L.gx_fineq_fwd(rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2), 0 if t2 is None else t2.stride(0),
+                                  _p(bq_planes), _p(y2), _p(ac), _p(nc), _p(bias), k, _p(rn), _p(sc), _stream()),
+                   "gx_fineq_fwd")
+    return rn, sc
+
+
+def fineq_bwd_pool(coeffs, t1, t2, k, fine_res):
+    """coefficient grid (rows, stride) + the finest taps -> Tt (rows/4, CF), Cpool (rows/4, stride), P (K, CF)"""
+    _chk(coeffs)
+    _chk2d(t1, t2)
+    rows, k1 = t1.shape
+    k2 = 0 if t2 is None else t2.shape[1]
+    cf = k1 + k2
+    L = lib()
+    if coeffs.shape[0] != rows or coeffs.shape[1] != L.gx_lowrank_stride(k):
+        raise RuntimeError("fineq_bwd_pool: coefficient grid does not match (rows, K)")
+    tt = torch.empty(rows // 4, cf, dtype=torch.float32, device=t1.device)
+    cpool = torch.empty(rows // 4, coeffs.shape[1], dtype=torch.float32, device=t1.device)
+    pm = torch.empty(k, cf, dtype=torch.float32, device=t1.device)
+    wsb = L.gx_fineq_bwd_pool_workspace_bytes(k, cf)
+    ws = workspace("fineq_pool", wsb, t1.device)
+    with record("fineq_bwd_pool_kernel", 0.0, 4.0 * rows * (cf * 1.25 + coeffs.shape[1] * 1.25)):
+        _lib.check(L.gx_fineq_bwd_pool(_p(coeffs), rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2),
+                                       0 if t2 is None else t2.stride(0), k, _p(tt), _p(cpool), _p(pm), _p(ws), wsb, _stream()),
+                   "gx_fineq_bwd_pool")
+    return tt, cpool, pm
+
+
+def gemm_tn_gram(a1, a2, kscale, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
+    """out (M1+M2, N1+N2) = alpha * ([a1 | a2] * kscale[:, None]).T @ [b1 | b2] + beta*out; a* (K, M*), b* (K, N*),
+    kscale a 1-D (possibly strided) fp32 view of K elements or None; a2 / b2 may be None.  bf16x6 engine."""
+    _chk2d(a1, a2, b1, b2, out)
+    k, m1 = a1.shape
+    m2 = 0 if a2 is None else a2.shape[1]
+    n1 = b1.shape[1]
+    n2 = 0 if b2 is None else b2.shape[1]
+    if tuple(out.shape) != (m1 + m2, n1 + n2) or b1.shape[0] != k or (kscale is not None and (kscale.dim() != 1 or kscale.numel() != k)):
+        raise RuntimeError("gemm_tn_gram: shape mismatch")
+    L = lib()
+    ws, wsb = None, 0
+    if split_k > 1:
+        wsb = L.gx_gemm_f32_workspace_bytes(m1 + m2, n1 + n2, split_k)
+        ws = workspace("gemm", wsb, a1.device)
+    with record("gemm_f32_kernel", 2.0 * (m1 + m2) * (n1 + n2) * k):
+        _lib.check(L.gx_gemm_f32_tn_gram(m1, m2, n1, n2, k, _p(a1), a1.stride(0), _p(a2), 0 if a2 is None else a2.stride(0),
+                                         _p(kscale), 0 if kscale is None else kscale.stride(0), _p(b1), b1.stride(0), _p(b2),
+                                         0 if b2 is None else b2.stride(0), _p(out), out.stride(0), alpha, beta, split_k,
+                                         _p(ws), wsb, _stream()), "gx_gemm_f32_tn_gram")
+    return out
 
 
 # ------------------------------------------------------------------------------------- generator pieces

@@ -9,6 +9,15 @@ pyramid into one full-resolution table Z; z(p) is then a single 2 KB row of Z.  
 the exact adjoint (scatter-add, 2x2 sum-pooling, one TN GEMM per tap).  Same real-number result
 as swav_clustering.py:108-130 + :160-171 (and autograd of them); only the fp32 summation order
 differs (13 partial dot products instead of one 5376-long chain).
+
+With K <= 16 prototypes (`project_tables` / `backward_lowrank`) the loss only sees a pixel's K
+prototype scores and 1 / |z|, and the top of the pyramid is never formed:
+  * levels without taps (hlen cuts them off: a 512^2 generator at hlen = 5376) are skipped — the
+    tables live at the highest level that has taps and the pick lists index it with a shift;
+  * a finest level with taps enters through CF-wide forms of its taps (csrc/gx_fineq.hip: one
+    (CF + 16)-column contraction whose epilogue reduces every row to K + 1 numbers), so its
+    (pixels x D) table Z — 4.3 GB at 16 images of 256^2 — and the gradient table of the same size
+    are never written; the backward is a weighted Gram GEMM of the taps plus GEMMs on the level below.
 """
 import torch
 
@@ -31,15 +40,14 @@ class Pyramid:
         self.levels = [levels[r] for r in self.res]
         if any(b != 2 * a for a, b in zip(self.res, self.res[1:])) or self.res[-1] != self.size:
             raise RuntimeError("pyramid projection needs taps at successive powers of two")
+        self._lr = None
 
-    def project(self, wp, score_head=None):
-        """wp (D, hlen) -> Z (B, H, W, D): the projection of every pixel's descriptor.
-        score_head=(Wc, bias) with K <= 16: the last upsample-add also emits the prototype score
-        table of every pixel; returns (Z, (rn_table, score_table))."""
+    # ------------------------------------------------------------------------------------- forward
+    def _project_levels(self, wp, nlev):
+        """Z of level nlev - 1 (B, r, r, D): the projections of the first nlev levels summed up the pyramid"""
         d = wp.shape[0]
         prev = None
-        tables = None
-        for r, taps in zip(self.res, self.levels):
+        for r, taps in zip(self.res[:nlev], self.levels[:nlev]):
             p = torch.empty(self.B * r * r, d, dtype=torch.float32, device=wp.device)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
             # the level below rides on the epilogue of this level's (first) GEMM: p = taps . Wp^T + upsample2(prev)
@@ -69,26 +77,76 @@ class Pyramid:
                     else:
                         ops.gemm(t[:, :cu], wp[:, off:off + cu], False, True, out=p, beta=0.0 if i == 0 else 1.0)
             p = p.reshape(self.B, r, r, d)
-            if prev is not None:
-                if score_head is not None and r == self.res[-1]:
-                    tables = ops.upsample2_add_scores_(prev if up is None else None, p, *score_head)
-                elif up is None:
-                    ops.upsample2_add_(prev, p)
+            if prev is not None and up is None:
+                ops.upsample2_add_(prev, p)
             prev = p
-        if score_head is not None:
-            if tables is None:                       # single-level pyramid: no upsample pass to ride on
-                tables = ops.proto_fwd_lowrank(prev, None, None, *score_head)
-            return prev, tables
         return prev
 
-    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None):
-        """g (B, H, W, D) = d loss / d Z -> gwp (D, hlen) (+)= sum over taps of G_level^T tap.
-        g_pooled: sumpool2(g) if the caller already has it.  on_level([(off, width), ...]) is called once
-        the GEMMs of a level are queued (its columns of gwp are final: a sharded caller starts their
-        all-reduce there)."""
+    def project(self, wp):
+        """wp (D, hlen) -> Z (B, H, W, D): the projection of every pixel's descriptor."""
+        return self._project_levels(wp, len(self.res))
+
+    def _used(self, li):
+        return [(t, off, cu) for t, off, cu in self.levels[li] if cu > 0]
+
+    def project_tables(self, wp, wc, bias, quad=True):
+        """The K <= 16 path: (rn_table, sc_table, shift) — 1 / |z| and the K prototype scores of every pixel of the
+        table level, which lies `shift` levels below the finest (levels without taps are never formed).
+        quad=False keeps the finest level's projected table (the form every engine takes; A/B and parity tests)."""
+        k = wc.shape[0]
+        top = len(self.res) - 1
+        while top > 0 and not self._used(top):
+            top -= 1
+        shift = len(self.res) - 1 - top
+        used = self._used(top)
+        r = self.res[top]
+        fq = None
+        if quad and top > 0 and r >= 32 and 1 <= len(used) <= 2 and all(cu == t.shape[1] for t, _, cu in used) and \
+                (len(used) == 1 or used[1][1] == used[0][1] + used[0][2]) and (r & (r - 1)) == 0 and \
+                ops.fineq_ok(used[0][2], used[1][2] if len(used) == 2 else 0, k) and wp.shape[0] % 16 == 0 and \
+                all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t, _, _ in used):
+            fq = used
+        if fq is None:
+            z = self._project_levels(wp, top + 1)
+            if top > 0:
+                rn, sc = ops.upsample2_add_scores_(None, z, wc, bias)
+            else:                                    # single-level pyramid
+                rn, sc = ops.proto_fwd_lowrank(z, None, None, wc, bias)
+            self._lr = dict(mode="table", top=top, shift=shift, z=z)
+            return rn, sc, shift
+        # quadratic-form finest level (csrc/gx_fineq.hip): only the level below is projected
+        zc = self._project_levels(wp, top)
+        d = wp.shape[0]
+        t1, off, c1 = fq[0]
+        t2 = fq[1][0] if len(fq) == 2 else None
+        cf = c1 + (fq[1][2] if len(fq) == 2 else 0)
+        wf = wp[:, off:off + cf]                                        # (D, CF) view, row stride hlen
+        mg = ops.gemm(wf, wf, True, False)                              # Wf^T Wf (CF, CF)
+        wcf = ops.gemm(wc, wf, False, False)                            # Wc Wf (K, CF)
+        bq = ops.fineq_pack_weights(mg, wcf)
+        zc2 = zc.reshape(-1, d)
+        y2 = torch.empty(zc2.shape[0], cf, dtype=torch.float32, device=wp.device)
+        ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous()), y2, alpha=2.0)   # 2 Zc Wf
+        nc, ac = ops.proto_raw_tables(zc2, wc)
+        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq), y2, ac, nc, bias, r)
+        self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf)
+        return rn, sc, shift
+
+    def table_pixels(self):
+        """pixels per image of the table level of the last project_tables call"""
+        r = self.res[self._lr["top"]]
+        return r * r
+
+    # ------------------------------------------------------------------------------------- backward
+    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None, nlev=None):
+        """g (B, r, r, D) = d loss / d Z of level nlev - 1 (default: the finest) -> gwp (D, hlen) (+)= sum over the
+        taps of the first nlev levels of G_level^T tap.  g_pooled: sumpool2(g) if the caller already has it.
+        on_level([(off, width), ...]) is called once the GEMMs of a level are queued (its columns of gwp are final:
+        a sharded caller starts their all-reduce there)."""
         first = not accumulate
-        touched = set()
-        for r, taps in zip(reversed(self.res), reversed(self.levels)):
+        nlev = len(self.res) if nlev is None else nlev
+        res, levels = self.res[:nlev], self.levels[:nlev]
+        for r, taps in zip(reversed(res), reversed(levels)):
             rows = self.B * r * r
             g2 = g.reshape(rows, -1)
             used = [(t, off, cu) for t, off, cu in taps if cu > 0]
@@ -98,18 +156,60 @@ class Pyramid:
                 tiles = ((g2.shape[1] + 127) // 128) * ((ca + cb + 127) // 128)
                 split = int(max(1, min(512 // tiles, rows // 256)))
                 ops.gemm_tn_cat(g2, ta[:, :ca], tb[:, :cb], gwp[:, off:off + ca + cb], beta=0.0 if first else 1.0, split_k=split)
-                touched.update(((off, ca), (off + ca, cb)))
                 used = []
             for t, off, cu in used:
                 tiles = ((g2.shape[1] + 127) // 128) * ((cu + 127) // 128)
                 split = int(max(1, min(512 // tiles, rows // 256)))
                 ops.gemm(g2, t[:, :cu], True, False, out=gwp[:, off:off + cu], beta=0.0 if first else 1.0,
                          split_k=split)
-                touched.add((off, cu))
             if on_level is not None and any(cu > 0 for _, _, cu in taps):
                 on_level([(off, cu) for _, off, cu in taps if cu > 0])
-            if r != self.res[0]:
-                g = g_pooled if (g_pooled is not None and r == self.res[-1]) else ops.sumpool2(g)
-        if first:      # columns of hlen not covered by any tap cannot exist (sum C >= hlen); nothing to zero
-            pass
+            if r != res[0]:
+                g = g_pooled if (g_pooled is not None and r == res[-1]) else ops.sumpool2(g)
         return gwp
+
+    def backward_lowrank(self, coeffs, wp, wc, gwp, gwc, on_level=None, on_heads=None):
+        """The adjoint of project_tables from the coefficient grid C (table pixels x (K + 1)) of the low-rank path
+        (csrc/gx_swav.hip: G[q] = C[q][:K] Wc + C[q][K] z(q)): gwp (D, hlen) = d loss / d Wp, gwc (K, D) = d loss / d Wc
+        (both overwritten).  on_heads() is called when gwc is final, on_level as in `backward`."""
+        lr = self._lr
+        top, zc = lr["top"], lr["z"]
+        if top + 1 < len(self.res):                  # columns of levels above the table level (hlen cut them off)
+            pass                                     # carry no weight columns: nothing to zero
+        if lr["mode"] == "table":
+            pool = top > 0
+            out = ops.proto_lowrank_finish(coeffs, zc, wc, gwc, 0.0, want_pool=pool)
+            g, gp = out if pool else (out, None)
+            if on_heads is not None:
+                on_heads()
+            return self.backward(g, gwp, accumulate=False, g_pooled=gp, on_level=on_level, nlev=top + 1)
+        t1, t2, off, cf = lr["t1"], lr["t2"], lr["off"], lr["cf"]
+        r = self.res[top]
+        k, d = wc.shape[0], wp.shape[0]
+        wf = wp[:, off:off + cf]
+        zc2 = zc.reshape(-1, d)
+        tt, cpool, pm = ops.fineq_bwd_pool(coeffs, t1, t2, k, r)
+        # gradient of the level below: Gc = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc  (+ its 2x2 sum-pooling), gWc
+        gc = torch.empty_like(zc2)
+        ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
+        pool = top > 1
+        out = ops.proto_lowrank_finish(cpool, zc, wc, gwc, 0.0, want_pool=pool, add_to=gc.reshape(zc.shape))
+        gcz, gp = out if pool else (out, None)
+        ops.gemm(pm, wf, False, True, out=gwc, beta=1.0)                # gWc += P Wf^T
+        if on_heads is not None:
+            on_heads()
+        # dWf = Zc^T Tt + Wf S + Wc^T P      S = sum_q e[q] t(q) t(q)^T, e = C[:, K]
+        rows = t1.shape[0]
+        s = torch.empty(cf, cf, dtype=torch.float32, device=wp.device)
+        n1 = t1.shape[1]
+        # 2 N-tiles (one M-tile of 256) x splits: whole rounds of the 256 CUs
+        ops.gemm_tn_gram(t1, t2, coeffs[:, k], t1, t2, s, split_k=int(max(1, min(128, rows // 2048))))
+        gcols = gwp[:, off:off + cf]
+        rc_rows = zc2.shape[0]
+        tiles = ((d + 127) // 128) * ((cf + 127) // 128)
+        ops.gemm(zc2, tt, True, False, out=gcols, beta=0.0, split_k=int(max(1, min(512 // tiles, rc_rows // 256))))
+        ops.gemm(wf, s, False, False, out=gcols, beta=1.0)
+        ops.gemm(wc, pm, True, False, out=gcols, beta=1.0)
+        if on_level is not None:
+            on_level([(o, cu) for _, o, cu in self._used(top)])
+        return self.backward(gcz, gwp, accumulate=False, g_pooled=gp, on_level=on_level, nlev=top)

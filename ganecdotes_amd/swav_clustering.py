@@ -251,11 +251,14 @@ class SwAVClustering(ViewMixin):
                 # (2B, H, W, D) holds view s in [0, B) and view t in [B, 2B)
                 pyr = Pyramid(ts_all, hlen)
                 npx = B * hw * hw
-                if lowrank:      # the finest upsample-add also emits every pixel's scores (rn table, score table)
-                    Z_all, (rn_all, sc_all) = pyr.project(Wp, score_head=(Wc, bc))
+                if lowrank:
+                    # K <= 16: the score / rnorm tables of every pixel of the table level; the finest level's projected
+                    # table is never formed (pyramid.py, csrc/gx_fineq.hip) and levels without taps are skipped (`lshift`)
+                    rn_all, sc_all, lshift = pyr.project_tables(Wp, Wc, bc, quad=sa.get('fineq', True))
+                    Z_all = Zt = None
                 else:
                     Z_all = pyr.project(Wp)
-                Zt = [Z_all[v * B:(v + 1) * B] for v in range(2)]              # (B, H, W, D) per view
+                    Zt = [Z_all[v * B:(v + 1) * B] for v in range(2)]          # (B, H, W, D) per view
             if lowrank:
                 maps_all = None
                 if views[0][1] is not None or views[1][1] is not None:        # (2B, HW) rotate / flip index maps
@@ -263,7 +266,7 @@ class SwAVClustering(ViewMixin):
                     if views[0][1] is None or views[1][1] is None:
                         ident = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
                     maps_all = torch.cat([m if m is not None else ident for m in (views[0][1], views[1][1])])
-                Ct_all = ops.lowrank_coeffs(2 * B, hw * hw, K, dev)            # (2B*HW, K+1 padded) coefficient grid
+                Ct_all = ops.lowrank_coeffs(2 * B, pyr.table_pixels(), K, dev)   # (2B * table pixels, K+1 padded) coefficient grid
                 G_all = None
             else:
                 G_all = torch.zeros_like(Z_all)
@@ -304,7 +307,7 @@ class SwAVClustering(ViewMixin):
             batched = lowrank                    # K <= 16: gather / loss / scatter of all patches in single launches
             if batched:      # every patch and both views in single launches (tables over the 2B-image batch)
                 gpicks = pb.picks[pnos[0]:pnos[-1] + 1].contiguous()
-                Rn_all = ops.gather_scores_batch(sc_all, rn_all, bc, gpicks, maps_all, B, hw * hw, Sc_all)
+                Rn_all = ops.gather_scores_batch(sc_all, rn_all, bc, gpicks, maps_all, B, hw * hw, Sc_all, shift=lshift)
             for gi, pno in enumerate(pnos if not batched else []):
                 picks = pb.picks[pno]
                 X, Zh, Rn = [], [], []
@@ -356,7 +359,7 @@ class SwAVClustering(ViewMixin):
                                q_s=skb[0].codes(), q_t=skb[ngroups].codes())
                 with self._timed("proto_bwd_lowrank"):
                     ops.proto_bwd_lowrank_batch_(dS_all, Sc_all, Rn_all, bc, gpicks, maps_all, Ct_all, B, hw * hw, gb,
-                                                 0.0 if first_acc else 1.0)
+                                                 0.0 if first_acc else 1.0, shift=lshift)
                 first_acc = False
                 del dS_all, Rn_all
             for gi, pno in enumerate(pnos if not batched else []):
@@ -413,21 +416,20 @@ class SwAVClustering(ViewMixin):
             del keep, Sc_all, skb
         pending = []
         if mode == 'pyramid':
-            Gp = None
-            if lowrank:
-                with self._timed("lowrank_finish"):
-                    pool = len(pyr.res) > 1
-                    out = ops.proto_lowrank_finish(Ct_all, Z_all, Wc, gWc, 0.0, want_pool=pool)
-                    G_all, Gp = out if pool else (out, None)
-            on_level = None
+            on_level = on_heads = None
             if self.sharded:
-                # the prototype gradients and the loss are final here: their all-reduce travels while the
+                # once the prototype gradients and the loss are final their all-reduce travels while the
                 # pyramid backward runs, and every pyramid level's slice of dWp follows as soon as its GEMMs
                 # are queued (finest levels first), so only the coarsest levels' message is exposed
-                pending.append(sharded.allreduce_flat_async([gWc, gb, loss], self.dist_group))
+                on_heads = lambda: pending.append(sharded.allreduce_flat_async([gWc, gb, loss], self.dist_group))
                 on_level = lambda cols: pending.append(sharded.allreduce_cols_async(gWp, cols, self.dist_group))
             with self._timed("pyramid_bwd"):
-                pyr.backward(G_all, gWp, accumulate=False, g_pooled=Gp, on_level=on_level)
+                if lowrank:      # from the coefficient grid: dense finish at the table level, the finest level's Gram forms
+                    pyr.backward_lowrank(Ct_all, Wp, Wc, gWp, gWc, on_level=on_level, on_heads=on_heads)
+                else:
+                    if on_heads is not None:
+                        on_heads()
+                    pyr.backward(G_all, gWp, accumulate=False, on_level=on_level)
             del Zt, Z_all, G_all
         elif self.sharded:
             pending.append(sharded.allreduce_flat_async(list(self._grads) + [loss], self.dist_group))

@@ -105,6 +105,41 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
 
+/* The weighted Gram form of the TN contraction (bf16x6 engine): C (M1 + M2, N1 + N2) = alpha * ([A1 | A2] .* s)^T [B1 | B2] +
+ * beta * C with A1 [K][M1], A2 [K][M2] (M1 = 128 when M2 > 0, 128 < M1 + M2 <= 256), s[k] = kscale[k * kscale_ld] (NULL: 1),
+ * B1 [K][N1], B2 [K][N2] (N1 a multiple of 128 when N2 > 0).  Autograd of the finest level's share of |z|^2
+ * (swav_clustering.py:171-173): S = sum_q e[q] t(q) t(q)^T, see gx_fineq_*. */
+int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, long lda1, const float* A2, long lda2,
+                        const float* kscale, long kscale_ld, const float* B1, long ldb1, const float* B2, long ldb2, float* C,
+                        long ldc, float alpha, float beta, int split_k, float* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the finest pyramid level of the low-rank (K <= 16) path without its projected table (csrc/gx_fineq.hip) ----
+ * Reference: swav_clustering.py:120-128 (nearest upsample + concat), :171-175 (projection, F.normalize, prototypes) and
+ * autograd of them.  A finest-level pixel q with taps t(q) (CF = K1 + K2 channels) and parent p has z(q) = Wf t(q) + Zc[p];
+ * the loss needs only <Wc_k, z> = (Wc Wf)_k . t + Ac[p][k] and |z|^2 = t^T (Wf^T Wf) t + t . Y2[p] + nc[p]
+ * (Ac = Zc Wc^T, Y2 = 2 Zc Wf, nc = |Zc|^2: gx_proto_raw_tables and one gx_gemm_f32_nt_planes on the level below).
+ *   gx_fineq_ok            shapes this path takes: CF = 256 as one tap or as two taps of 128, K <= 16
+ *   gx_fineq_pack_weights  Bq [CF + 16][CF] = [tri(Mg) ; Wcf ; 0] from Mg = Wf^T Wf [CF][CF] and Wcf = Wc Wf [K][CF]
+ *                          (tri: 2 x strict lower + diagonal — t^T tri(M) t = t^T M t, k-tile kt only meets the column
+ *                          blocks >= kt / 2 and a block is final two k-tiles after its first)
+ *   gx_fineq_fwd           rn_table [rows], sc_table [rows][K] (= gx_upsample2_add_scores' tables) from the taps, the planes
+ *                          gx_split_gemm_weights(Bq) and the three coarse tables; rows = B * fine_res^2 pixels in (b, y, x)
+ *                          order, fine_res a power of two >= 32
+ *   gx_fineq_bwd_pool      from the coefficient grid C [rows][gx_lowrank_stride(K)] (gx_proto_bwd_lowrank*): Tt [rows/4][CF] =
+ *                          sum over the 2x2 children of C[q][K] t(q), Cpool [rows/4][stride] = the children's coefficient sums,
+ *                          P [K][CF] = C[:, :K]^T t.  workspace: gx_fineq_bwd_pool_workspace_bytes(K, CF) */
+int gx_fineq_ok(int K1, int K2, int K);
+int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, float* Bq, void* stream);
+int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
+                 const unsigned short* bq_planes, const float* Y2, const float* Ac, const float* nc, const float* bias,
+                 int K, float* rn_table, float* sc_table, void* stream);
+size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF);
+int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
+                      long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,
+                      void* stream);
+/* dots [rows][K] = Z Wc^T, sumsq [rows] = |Z[row]|^2 of a finished table Z [rows][D] (no normalisation, no bias) */
+int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, float* dots, void* stream);
+
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110
  * gx_bias_act        EqualLinear epilogue / fused_leaky_relu     model.py:32-43, :242-252;
@@ -270,19 +305,22 @@ int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks,
 int gx_gather_scores(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
                      const int* picks, int rows_per_img, const int* maps, float* scores, float* rnorm, void* stream);
 /* the whole step in single launches (both views = one 2B-image batch, all patches; rows ordered
- * (patch, view, image, sample)): gather, coefficient scatter, and — gx_swapped_ce_batch below — the loss */
+ * (patch, view, image, sample)): gather, coefficient scatter, and — gx_swapped_ce_batch below — the loss.
+ * shift > 0: the tables / the coefficient grid live `shift` pyramid levels below the picks' resolution (HW a square of
+ * a power of two): with no tap above that level every pixel of a 2^shift x 2^shift block has its ancestor's descriptor
+ * (swav_clustering.py:120-128: nearest upsampling), so the tables are [2B * HW / 4^shift] rows */
 int gx_gather_scores_batch(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
-                           const int* picks, int npatch, int N, const int* maps, float* scores, float* rnorm,
+                           const int* picks, int npatch, int N, const int* maps, int shift, float* scores, float* rnorm,
                            void* stream);
 int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
-                               int K, const int* picks, int npatch, int N, const int* maps, float* C, float* gb,
+                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, float* gb,
                                float beta, float* workspace, size_t workspace_bytes, void* stream);
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream);
 int gx_proto_lowrank_finish(const float* C, const float* Z, long npix, int rc, int D, const float* Wc, int K, float* G,
-                            float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
-                            void* stream);   /* Gpool != NULL: also the 2x2 sum-pooled G (B*rc*rc, D) */
+                            int accumulate, float* Gpool, float* gWc, float beta, float* workspace, size_t workspace_bytes,
+                            void* stream);   /* Gpool != NULL: also the 2x2 sum-pooled G (B*rc*rc, D); accumulate: G += */
 /* finest pyramid level + score table in one pass: fine += upsample2(coarse); rn_table, sc_table as
  * gx_proto_fwd_lowrank(picks = NULL) on the result.  coarse == NULL: fine is already finished
  * (gx_gemm_f32_upadd) and only the tables are written */

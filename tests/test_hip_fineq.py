@@ -1,0 +1,165 @@
+"""The finest pyramid level of the K <= 16 path without its projected table (csrc/gx_fineq.hip, pyramid.py):
+the quadratic-form route against the route that forms Z (itself pinned by the oracle / golden tests), kernel by kernel
+and through Pyramid.project_tables / backward_lowrank, and the shifted tables of a pyramid whose top levels have no taps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ganecdotes_amd import ops as o
+    o.lib()
+    prev = o.set_gemm_mode(1)
+    yield o
+    o.set_gemm_mode(prev)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _taps(b, res_top, chans, seed=5, scale=1.0):
+    """NHWC taps of a pyramid: chans = {res: [c, ...]}; values grow towards the fine levels like generator activations"""
+    g = torch.Generator().manual_seed(seed)
+    taps = []
+    for r in sorted(chans):
+        for c in chans[r]:
+            taps.append((torch.randn(b, r, r, c, generator=g) * scale * (1.0 + 0.5 * np.log2(r))).cuda())
+    return taps
+
+
+@pytest.mark.parametrize("k,two_taps", [(8, True), (16, True), (5, False)])
+def test_fineq_tables_equal_the_projected_table_route(ops, k, two_taps):
+    """rn / score tables of every pixel: gx_fineq_fwd (CF-wide forms of the finest taps + three tables of the level below)
+    against the tables computed from the projected table Z (gx_upsample2_add_scores), and against fp64."""
+    from ganecdotes_amd.pyramid import Pyramid
+    b, d = 3, 512
+    chans = {16: [64], 32: [128, 128], 64: [128, 128] if two_taps else [256]}
+    taps = _taps(b, 64, chans)
+    hlen = sum(sum(v) for v in chans.values())
+    torch.manual_seed(11)
+    wp = (torch.randn(d, hlen) / hlen ** 0.5).cuda()
+    wc = torch.nn.functional.normalize(torch.randn(k, d), dim=1).cuda()
+    bias = (0.1 * torch.randn(k)).cuda()
+    pyr = Pyramid(ops.TapSet(taps), hlen)
+    rn_q, sc_q, sh_q = pyr.project_tables(wp, wc, bias, quad=True)
+    assert pyr._lr["mode"] == "quad" and sh_q == 0
+    rn_t, sc_t, sh_t = Pyramid(ops.TapSet(taps), hlen).project_tables(wp, wc, bias, quad=False)
+    assert sh_t == 0
+    # fp64 truth
+    z = None
+    off = 0
+    for r in sorted(chans):
+        lv = [t for t in taps if t.shape[1] == r]
+        x = torch.cat([t.reshape(-1, t.shape[3]) for t in lv], 1).double()
+        c = x.shape[1]
+        p = (x @ wp[:, off:off + c].double().t()).reshape(b, r, r, d)
+        off += c
+        z = p if z is None else p + z.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    z = z.reshape(-1, d)
+    nrm = z.norm(dim=1)
+    sc64 = (z @ wc.double().t()) / nrm[:, None] + bias.double()
+    assert rel(rn_q, 1.0 / nrm) < 2e-5 and rel(rn_t, 1.0 / nrm) < 2e-5
+    assert rel(sc_q, sc64) < 2e-5 and rel(sc_t, sc64) < 2e-5
+    assert rel(rn_q, rn_t) < 2e-5 and rel(sc_q, sc_t) < 2e-5
+
+
+@pytest.mark.parametrize("k,two_taps", [(8, True), (16, True), (5, False)])
+def test_fineq_backward_equals_the_projected_table_route(ops, k, two_taps):
+    """d loss / d Wp and d loss / d Wc from a random coefficient grid: the Gram-form backward (gx_fineq_bwd_pool,
+    gx_gemm_f32_tn_gram, GEMMs on the level below) against the dense finish on the projected table + the pyramid adjoint."""
+    from ganecdotes_amd.pyramid import Pyramid
+    b, d = 3, 512
+    chans = {16: [64], 32: [128, 128], 64: [128, 128] if two_taps else [256]}
+    taps = _taps(b, 64, chans, seed=9)
+    hlen = sum(sum(v) for v in chans.values())
+    torch.manual_seed(13)
+    wp = (torch.randn(d, hlen) / hlen ** 0.5).cuda()
+    wc = torch.nn.functional.normalize(torch.randn(k, d), dim=1).cuda()
+    bias = torch.zeros(k).cuda()
+    ls = ops.lib().gx_lowrank_stride(k)
+    coeffs = torch.zeros(b * 64 * 64, ls)
+    hit = torch.rand(b * 64 * 64) < 0.4                       # never-sampled pixels have all-zero coefficients
+    coeffs[hit, :k + 1] = torch.randn(int(hit.sum()), k + 1) * 1e-3
+    coeffs = coeffs.cuda()
+    outs = []
+    for quad in (True, False):
+        pyr = Pyramid(ops.TapSet(taps), hlen)
+        pyr.project_tables(wp, wc, bias, quad=quad)
+        assert pyr._lr["mode"] == ("quad" if quad else "table")
+        gwp = torch.full_like(wp, 7.0)                         # overwritten, not accumulated
+        gwc = torch.full_like(wc, 7.0)
+        seen = []
+        pyr.backward_lowrank(coeffs, wp, wc, gwp, gwc, on_level=lambda cols: seen.append(tuple(cols)),
+                             on_heads=lambda: seen.append("heads"))
+        assert seen[0] == "heads" and len(seen) == 4           # heads first, then one call per level, finest first
+        outs.append((gwp, gwc, seen))
+    assert outs[0][2] == outs[1][2]
+    assert rel(outs[0][0], outs[1][0]) < 2e-5
+    assert rel(outs[0][1], outs[1][1]) < 2e-5
+
+
+def test_gemm_tn_gram_vs_fp64(ops):
+    """C = ([A1 | A2] .* s)^T [B1 | B2]: the k-scaled TN GEMM with its 256-row tile from two sources, split-K, beta"""
+    torch.manual_seed(3)
+    for (kk, split, two) in ((4096, 4, True), (1000, 1, True), (6000, 3, False)):
+        a1 = torch.randn(kk, 128 if two else 256).cuda()
+        a2 = torch.randn(kk, 128).cuda() if two else None
+        sfull = torch.randn(kk, 12).cuda()
+        sc = sfull[:, 8]                                        # strided 1-D view, like the coefficient grid's column K
+        prior = torch.randn(256, 256)
+        out = prior.clone().cuda()
+        ops.gemm_tn_gram(a1, a2, sc, a1, a2, out, alpha=0.5, beta=1.0, split_k=split)
+        a = a1 if a2 is None else torch.cat([a1, a2], 1)
+        want = prior.double() + 0.5 * ((a.double() * sc.double()[:, None]).t() @ a.double()).cpu()
+        assert rel(out, want) < 3e-6
+    with pytest.raises(RuntimeError):                          # the second A source needs the first to be 128 wide
+        ops.gemm_tn_gram(torch.randn(64, 64).cuda(), torch.randn(64, 128).cuda(), None, torch.randn(64, 128).cuda(), None,
+                         torch.empty(192, 128).cuda())
+
+
+def test_tables_shifted_below_levels_without_taps(ops):
+    """hlen cuts the finest level off (a 512^2 generator at hlen = 5376): the tables and the coefficient grid live one
+    level down and the pick lists index them through the shift — same scores, same gradients as with the upsampled table."""
+    from ganecdotes_amd.pyramid import Pyramid
+    b, d, k = 2, 256, 8
+    chans = {8: [32], 16: [64, 64], 32: [16, 16]}
+    taps = _taps(b, 32, chans, seed=21)
+    hlen = 32 + 128                                             # the 32^2 taps are cut off
+    torch.manual_seed(17)
+    wp = (torch.randn(d, hlen) / hlen ** 0.5).cuda()
+    wc = torch.nn.functional.normalize(torch.randn(k, d), dim=1).cuda()
+    bias = (0.1 * torch.randn(k)).cuda()
+    pyr = Pyramid(ops.TapSet(taps), hlen)
+    rn, sc, shift = pyr.project_tables(wp, wc, bias)
+    assert shift == 1 and pyr.table_pixels() == 16 * 16 and rn.numel() == b * 256
+    z = pyr.project(wp)                                         # the full-resolution table (what predict uses)
+    rn_f, sc_f = ops.proto_fwd_lowrank(z, None, None, wc, bias)
+    up = lambda t, c: t.reshape(b, 16, 16, c).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(-1, c)
+    assert rel(up(rn, 1).flatten(), rn_f) < 1e-6 and rel(up(sc, k), sc_f) < 1e-6
+    # gather through the shift == gather from the upsampled tables (B = 1 image per view, 2 patches)
+    n, hw = 300, 32 * 32
+    picks = torch.stack([torch.randperm(hw)[:n] for _ in range(2)]).reshape(2, 1, n).int().cuda()
+    maps = torch.stack([torch.randperm(hw), torch.arange(hw)]).int().cuda()
+    maps[0, :50] = -1                                           # rotated out of the frame
+    out_s = torch.empty(2, 2, n, k).cuda()
+    out_f = torch.empty(2, 2, n, k).cuda()
+    rn_s = ops.gather_scores_batch(sc, rn, bias, picks, maps, 1, hw, out_s, shift=1)
+    rn_g = ops.gather_scores_batch(sc_f, rn_f, bias, picks, maps, 1, hw, out_f)
+    assert rel(out_s, out_f) < 1e-6 and rel(rn_s, rn_g) < 1e-6
+    # scatter through the shift == 2x2 pooling of the full-resolution coefficient grid
+    ds = (torch.randn(2, 2, n, k) * 1e-3).cuda()
+    c_s = ops.lowrank_coeffs(2, 256, k, "cuda")
+    c_f = ops.lowrank_coeffs(2, hw, k, "cuda")
+    gb_s, gb_f = torch.zeros(k).cuda(), torch.zeros(k).cuda()
+    ops.proto_bwd_lowrank_batch_(ds, out_s, rn_s, bias, picks, maps, c_s, 1, hw, gb_s, 0.0, shift=1)
+    ops.proto_bwd_lowrank_batch_(ds, out_f, rn_g, bias, picks, maps, c_f, 1, hw, gb_f, 0.0)
+    ls = c_s.shape[1]
+    pooled = c_f.reshape(2, 16, 2, 16, 2, ls).sum((2, 4)).reshape(-1, ls)
+    assert rel(c_s, pooled) < 1e-5 and rel(gb_s, gb_f) < 1e-6

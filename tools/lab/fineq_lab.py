@@ -1,0 +1,79 @@
+"""The pieces of the finest pyramid level at the bench shape (2B = 32 images of 256^2, CF = 128 + 128, D = 512, K = 8):
+quadratic-form route (csrc/gx_fineq.hip) against the projected-table route, kernel by kernel.
+    python tools/lab/fineq_lab.py [piece ...]      (no argument: everything)"""
+import sys
+import torch
+sys.path.insert(0, "/root/repo")
+from ganecdotes_amd import ops
+
+dev = "cuda"
+which = set(sys.argv[1:])
+B2, R, D, K, CF = 32, 256, 512, 8, 256
+rows, rc = B2 * R * R, B2 * R * R // 4
+torch.manual_seed(0)
+t1 = torch.randn(rows, 128, device=dev)
+t2 = torch.randn(rows, 128, device=dev)
+zc = torch.randn(B2, R // 2, R // 2, D, device=dev)
+zc2 = zc.reshape(-1, D)
+wp = torch.randn(D, CF, device=dev) / 16
+wc = torch.nn.functional.normalize(torch.randn(K, D, device=dev), dim=1)
+bias = torch.zeros(K, device=dev)
+ls = ops.lib().gx_lowrank_stride(K)
+coeffs = torch.randn(rows, ls, device=dev) * 1e-3
+
+
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def show(name, ms, flops=0.0, nbytes=0.0):
+    print(f"{name:44s} {ms:7.3f} ms" + (f"  {flops / ms / 1e9:7.1f} TFLOP/s" if flops else "") +
+          (f"  {nbytes / ms / 1e6:7.1f} GB/s" if nbytes else ""), flush=True)
+
+
+def want(name):
+    return not which or name in which
+
+
+mg = ops.gemm(wp, wp, True, False)
+wcf = ops.gemm(wc, wp, False, False)
+y2 = torch.empty(rc, CF, device=dev)
+wft_planes = ops.split_gemm_weights(wp.t().contiguous())
+wf_planes = ops.split_gemm_weights(wp)
+if want("fwd"):
+    show("y2 = 2 Zc Wf (0.5M x 512 -> 256)", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, y2, alpha=2.0)), 2.0 * rc * D * CF)
+    show("raw tables of Zc", timeit(lambda: ops.proto_raw_tables(zc2, wc)), 0, 4.0 * rc * (D + K + 1))
+    nc, ac = ops.proto_raw_tables(zc2, wc)
+    pl = ops.split_gemm_weights(ops.fineq_pack_weights(mg, wcf))
+    nblk = sum(8 - (t >> 1) for t in range(16)) + 16
+    show("fineq_fwd", timeit(lambda: ops.fineq_fwd(t1, t2, pl, y2, ac, nc, bias, R)), 2.0 * rows * 512 * nblk)
+    # the projected-table route
+    z = torch.empty(rows, D, device=dev)
+    wpl = ops.split_gemm_weights(torch.randn(D, CF, device=dev) / 16)
+    show("old: finest projection GEMM (+ upadd)", timeit(lambda: ops.gemm_nt_planes(t1, t2, wpl, z, coarse=zc2, fine_res=R)), 2.0 * rows * D * CF)
+    z4 = z.reshape(B2, R, R, D)
+    show("old: score tables pass", timeit(lambda: ops.upsample2_add_scores_(None, z4, wc, bias)), 0, 4.0 * rows * (D + K + 1))
+if want("bwd"):
+    show("fineq_bwd_pool", timeit(lambda: ops.fineq_bwd_pool(coeffs, t1, t2, K, R)), 0, 4.0 * rows * (CF * 1.25 + ls * 1.25))
+    tt, cpool, pm = ops.fineq_bwd_pool(coeffs, t1, t2, K, R)
+    s = torch.empty(CF, CF, device=dev)
+    for split in (64, 128, 256):
+        show(f"gram S (split {split})", timeit(lambda: ops.gemm_tn_gram(t1, t2, coeffs[:, K], t1, t2, s, split_k=split)), 2.0 * rows * CF * CF)
+    gc = torch.empty(rc, D, device=dev)
+    show("Gc = Tt Wf^T (0.5M x 256 -> 512)", timeit(lambda: ops.gemm_nt_planes(tt, None, wf_planes, gc)), 2.0 * rc * D * CF)
+    gwc = torch.empty(K, D, device=dev)
+    show("finish at the coarse level (add_to, pool)", timeit(lambda: ops.proto_lowrank_finish(cpool, zc, wc, gwc, 0.0, want_pool=True, add_to=gc.reshape(zc.shape))),
+         0, 4.0 * rc * D * 3.25)
+    gw = torch.empty(D, CF, device=dev)
+    show("dWf: Zc^T Tt (512 x 256, k = 0.5M)", timeit(lambda: ops.gemm(zc2, tt, True, False, out=gw, split_k=64)), 2.0 * rc * D * CF)
+    # the projected-table route
+    z = torch.randn(B2, R, R, D, device=dev)
+    show("old: dense finish at the fine level", timeit(lambda: ops.proto_lowrank_finish(coeffs, z, wc, gwc, 0.0, want_pool=True)), 0, 4.0 * rows * D * 2.25)
+    g2 = z.reshape(rows, D)
+    show("old: finest TN (512 x 256, k = 2M)", timeit(lambda: ops.gemm_tn_cat(g2, t1, t2, gw, split_k=64)), 2.0 * rows * D * CF)
