@@ -301,6 +301,271 @@ __global__ __launch_bounds__(256) void fineq_bwd_pool_kernel(const float* __rest
     }
 }
 
+// ---- the backward of the finest level in ONE pass over its taps -------------------------------------------------------------
+// S = sum_q e[q] t(q) t(q)^T (CF x CF, symmetric), P = C[:, :K]^T t (K x CF), Tt[p] = sum over the 2x2 children of e[q] t(q),
+// Cpool[p] = the children's coefficient sums.  A wave-specialised TN contraction (the shape of gemm_x6ws_kernel): a
+// workgroup owns a run of k-tiles, a k-tile = one 2 x 8 pixel block (4 parents x 4 children), so that a parent's four
+// children meet in one producer wave:
+//   producer wave w (threads 512 + 64 w ..): lanes 0-31 hold the pixel pair (y, x0 + 2 w), (y, x0 + 2 w + 1), lanes 32-63
+//     the pair below it — the same parent; a thread owns tap columns 4 (l & 31) .. + 3 (+ 128).  It scales its taps by e,
+//     splits t and e t into bf16 planes (B and A images of the k-tile), sums e t over its pair, adds the partner lane's
+//     (lane ^ 32) and writes Tt; lanes l & 31 < stride do the same for the coefficients (Cpool) and put C[q][:K] into rows
+//     256 .. 271 of the A image, so that P comes out of the same MFMA loop;
+//   consumer waves 0-7: the ten 64 x 64 blocks on or above the diagonal of S + two 32 x 128 blocks of P = 48 MFMA tiles,
+//     six per wave, two consumer waves per SIMD (each hides the other's LDS latency) — 75 % of the products of the full Gram matrix, none of the plain TN GEMM's second pass
+//     over the taps (the k-scaled gx_gemm_f32_tn_gram + the separate pool pass read them 2.5 times: 2.6 ms against ...).
+// Each workgroup leaves its partial [272][256] in the slab; fineq_bwd_reduce_kernel sums the slabs in a fixed order and
+// mirrors the upper blocks of S.
+constexpr int FB_RA = 288, FB_RB = 256;                                  // rows of the A image (256 + the 16 coefficient rows, padded) and of B
+constexpr int FB_SLOT = XImg<FB_RA>::BYTES + XImg<FB_RB>::BYTES;         // 28416 + 25344 B
+struct FineqBwdArgs {
+    const float* C; int ls;                // coefficient grid [rows][ls]
+    const float* T1; const float* T2;      // tap columns 0..127 and 128..255 (T2 = T1 + 128 for a single 256-channel tap)
+    long ld1, ld2;
+    int K, shift;                          // prototypes, log2(fine resolution)
+    long nkt;                              // k-tiles in all = rows / 16
+    int kt_per;                            // k-tiles per workgroup
+    float* slab;                           // [gridDim][272][256]
+    float* Tt;                             // [rows / 4][256]
+    float* Cpool;                          // [rows / 4][ls]
+};
+
+// Consumer wave W of fineq_bwd_kernel.  Tasks (row block of the A image, column block of the B image), four MFMA tiles each:
+//   W = 0: (0,0) (0,64) (0,128)    W = 1: (0,192) (64,192) (128,192)    W = 2: (64,64) (64,128) (128,128)   — 64 x 64 blocks of S
+//   W = 3: (192,192), then the coefficient rows 256.. against columns 128..255 and 0..127 (32 x 128 each: P)
+// The twelve MFMA tiles of a k-tile are walked in an order in which only ONE operand fragment changes from tile to tile
+// (FB_GA / FB_GB); the changing fragment of tile n + 1 is read from LDS before tile n's six products issue, so its
+// latency hides under them.  Each list is cut in two: eight consumer waves of six tiles (96 accumulators + 36 fragment
+// registers; with sched_barrier pinning the order nothing spills — hoisted freely, the four-wave form spilled ~90
+// registers per k-tile: 2.4 ms instead of 1.6).
+constexpr int FB_TA0[4][3] = {{0, 0, 0}, {0, 64, 128}, {64, 64, 128}, {192, 256, 256}};
+constexpr int FB_TB0[4][3] = {{0, 64, 128}, {192, 192, 192}, {64, 128, 128}, {192, 0, 128}};
+constexpr int FB_GA[4][12] = {{0, 32, 32, 0, 0, 32, 32, 0, 0, 32, 32, 0},
+                              {0, 32, 32, 0, 64, 96, 96, 64, 128, 160, 160, 128},
+                              {64, 96, 96, 64, 64, 96, 96, 64, 128, 160, 160, 128},
+                              {192, 224, 224, 192, 256, 256, 256, 256, 256, 256, 256, 256}};
+constexpr int FB_GB[4][12] = {{0, 0, 32, 32, 64, 64, 96, 96, 128, 128, 160, 160},
+                              {192, 192, 224, 224, 224, 224, 192, 192, 192, 192, 224, 224},
+                              {64, 64, 96, 96, 128, 128, 160, 160, 160, 160, 128, 128},
+                              {192, 192, 224, 224, 224, 192, 160, 128, 96, 64, 32, 0}};
+struct FbFrag { bf16x8 p[3]; };
+// x (lanes 0-31) + x (lanes 32-63) in every lane: v_permlane32_swap (swaps a's upper half-wave with b's lower one, in place),
+// one VALU instruction instead of a ds_bpermute.  Inline asm: hipcc 7.2 returns the FIRST register for both elements of
+// __builtin_amdgcn_permlane32_swap's result (tools/lab history: r[0] + r[1] came out as 2 r[0]).
+__device__ __forceinline__ float fb_half_sum(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return a + b;
+}
+template <int W8>
+__device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* lds, int nkt, int lane) {
+    constexpr int W = W8 >> 1, N0 = 6 * (W8 & 1);                     // this wave: tiles N0 .. N0 + 5 of list W
+    constexpr int AIMG = XImg<FB_RA>::BYTES;
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int r32 = lane & 31, hh = lane >> 5;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
+    auto load_a = [&](const char* As, int row) {
+        FbFrag f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.p[q] = x6_frag<false, FB_RA>(As, q, row + r32, hh);
+        return f;
+    };
+    auto load_b = [&](const char* Bs, int row) {
+        FbFrag f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.p[q] = x6_frag<false, FB_RB>(Bs, q, row + r32, hh);
+        return f;
+    };
+    __syncthreads();                                                 // barrier 0
+    for (int t = 0; t < nkt; ++t) {
+        const char* As = lds + (t & 1) * FB_SLOT;
+        const char* Bs = As + AIMG;
+        FbFrag a = load_a(As, FB_GA[W][N0]), b = load_b(Bs, FB_GB[W][N0]), nx;
+#pragma unroll
+        for (int n = N0; n < N0 + 6; ++n) {
+            const bool last = n == N0 + 5;
+            const bool a_changes = !last && FB_GA[W][n + 1 > 11 ? 11 : n + 1] != FB_GA[W][n];
+            if (!last) nx = a_changes ? load_a(As, FB_GA[W][n + 1 > 11 ? 11 : n + 1]) : load_b(Bs, FB_GB[W][n + 1 > 11 ? 11 : n + 1]);
+            const int ai = n - N0;
+#pragma unroll
+            for (int u = 0; u < (FQ_ABL == 11 ? 1 : 6); ++u)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[u]], b.p[TB[u]], acc[ai], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                        // the order above is the schedule
+            if (!last) { if (a_changes) a = nx; else b = nx; }
+        }
+        __syncthreads();                                             // barrier t + 1
+    }
+    float* out = g.slab + (long)blockIdx.x * (272 * 256);
+#pragma unroll
+    for (int n = N0; n < N0 + 6; ++n) {
+        const int ai = n - N0;
+        const int col = FB_GB[W][n] + r32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = FB_GA[W][n] + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (row < 272) out[row * 256 + col] = acc[ai][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * FB_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long kt0 = (long)blockIdx.x * g.kt_per;
+    const int nkt = (int)max(0L, min((long)g.kt_per, g.nkt - kt0));
+    char* slot0 = lds;
+    char* slot1 = lds + FB_SLOT;
+    constexpr int APL = XImg<FB_RA>::MC_PLANE, ARW = XImg<FB_RA>::MC_ROWW, AIMG = XImg<FB_RA>::BYTES;
+    constexpr int BPL = XImg<FB_RB>::MC_PLANE, BRW = XImg<FB_RB>::MC_ROWW;
+    // rows 272 .. 287 of the A image are never written by the producers: zero them once (both slots, all planes)
+    for (int i = tid; i < 2 * 3 * 8 * 16; i += 768) {
+        const int sl = i / (3 * 8 * 16), r = i % (3 * 8 * 16);
+        const int pl = r / (8 * 16), kp = (r / 16) & 7, m = 272 + (r & 15);
+        *reinterpret_cast<unsigned*>(lds + sl * FB_SLOT + pl * APL + (kp * ARW + m) * 4) = 0u;
+    }
+
+    if (wid >= 8) {
+        // ------------------------------------------------------------------ producers
+        const int p = tid - 512, pw = p >> 6, half = (p >> 5) & 1, c4 = (p & 31) * 4, mm = p & 31;
+        const int s = g.shift, res = 1 << s, rc = res >> 1;
+        const int xbs = s - 3;                                              // x-blocks per image row = res / 8
+        struct Tile { f32x4 v[4]; float c0, c1, e0, e1; long q0, par; bool live; };
+        auto load_tile = [&](int t, Tile& T) {
+            T.live = t < nkt;
+            const long bid = kt0 + min(t, max(nkt - 1, 0));
+            const long per_img = (long)1 << (2 * s - 4);
+            const long img = bid >> (2 * s - 4), rem = bid & (per_img - 1);
+            const int yp = (int)(rem >> xbs), xb = (int)(rem & ((1 << xbs) - 1));
+            T.q0 = (img * res + 2 * yp + half) * res + 8 * xb + 2 * pw;    // the pair q0, q0 + 1
+            T.par = (img * rc + yp) * rc + 4 * xb + pw;
+            if (T.live) {
+                T.v[0] = *reinterpret_cast<const f32x4*>(g.T1 + T.q0 * g.ld1 + c4);
+                T.v[1] = *reinterpret_cast<const f32x4*>(g.T1 + (T.q0 + 1) * g.ld1 + c4);
+                T.v[2] = *reinterpret_cast<const f32x4*>(g.T2 + T.q0 * g.ld2 + c4);
+                T.v[3] = *reinterpret_cast<const f32x4*>(g.T2 + (T.q0 + 1) * g.ld2 + c4);
+                T.c0 = mm < g.ls ? g.C[T.q0 * g.ls + mm] : 0.f;
+                T.c1 = mm < g.ls ? g.C[(T.q0 + 1) * g.ls + mm] : 0.f;
+                T.e0 = g.C[T.q0 * g.ls + g.K];                           // one address per half-wave: a broadcast load
+                T.e1 = g.C[(T.q0 + 1) * g.ls + g.K];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T.v[i] = zero4();
+                T.c0 = T.c1 = T.e0 = T.e1 = 0.f;
+            }
+        };
+        auto stage = [&](char* slot, const Tile& T) {
+            if (FQ_ABL == 12) return;
+            const int kp = p >> 5;                                          // k-pair of this thread: pixels q0, q0 + 1
+            const float e0 = T.e0, e1 = T.e1;
+            char* A = slot;
+            char* B = slot + AIMG;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 t0 = T.v[2 * j], t1 = T.v[2 * j + 1];
+                const f32x4 s0 = e0 * t0, s1 = e1 * t1;
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(t0[e], t1[e], h[e], m[e], l[e]);
+                char* pb = B + (kp * BRW + c4 + 128 * j) * 4;
+                *reinterpret_cast<u32x4*>(pb) = (u32x4){h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(pb + BPL) = (u32x4){m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<u32x4*>(pb + 2 * BPL) = (u32x4){l[0], l[1], l[2], l[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(s0[e], s1[e], h[e], m[e], l[e]);
+                char* pa = A + (kp * ARW + c4 + 128 * j) * 4;
+                *reinterpret_cast<u32x4*>(pa) = (u32x4){h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(pa + APL) = (u32x4){m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<u32x4*>(pa + 2 * APL) = (u32x4){l[0], l[1], l[2], l[3]};
+                // Tt: this pair + the pair below / above it (the partner lane holds the same columns of the same parent)
+                f32x4 tt = s0 + s1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tt[e] = fb_half_sum(tt[e]);
+                if (half == 0 && T.live) *reinterpret_cast<f32x4*>(g.Tt + T.par * 256 + c4 + 128 * j) = tt;
+            }
+            if (mm < 16) {                                                   // coefficient rows 256 .. 271 of the A image
+                const bool kok = mm < g.K;
+                unsigned h, m, l;
+                split3(kok ? T.c0 : 0.f, kok ? T.c1 : 0.f, h, m, l);
+                char* pa = A + (kp * ARW + 256 + mm) * 4;
+                *reinterpret_cast<unsigned*>(pa) = h;
+                *reinterpret_cast<unsigned*>(pa + APL) = m;
+                *reinterpret_cast<unsigned*>(pa + 2 * APL) = l;
+            }
+            const float cp = fb_half_sum(T.c0 + T.c1);
+            if (half == 0 && mm < g.ls && T.live) g.Cpool[T.par * g.ls + mm] = cp;
+        };
+        // Four k-tiles (64 KB per workgroup = per CU) stay in flight: the taps stream from HBM exactly once and nothing else
+        // hides their latency (two tiles in flight ran the kernel at 2.4 ms: 1.1 TB/s)
+        Tile T0, T1, T2, T3;
+        load_tile(0, T0);
+        load_tile(1, T1);
+        load_tile(2, T2);
+        load_tile(3, T3);
+        __syncthreads();                                             // the zero rows are in place
+        if (nkt > 0) stage(slot0, T0);
+        load_tile(4, T0);
+        __syncthreads();                                             // barrier 0: tile 0 visible
+        for (int t = 0; t < nkt; t += 4) {
+            if (t + 1 < nkt) stage(slot1, T1);
+            load_tile(t + 5, T1);
+            __syncthreads();                                         // barrier t + 1
+            if (t + 1 >= nkt) break;
+            if (t + 2 < nkt) stage(slot0, T2);
+            load_tile(t + 6, T2);
+            __syncthreads();                                         // barrier t + 2
+            if (t + 2 >= nkt) break;
+            if (t + 3 < nkt) stage(slot1, T3);
+            load_tile(t + 7, T3);
+            __syncthreads();                                         // barrier t + 3
+            if (t + 3 >= nkt) break;
+            if (t + 4 < nkt) stage(slot0, T0);
+            load_tile(t + 8, T0);
+            __syncthreads();                                         // barrier t + 4
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    __syncthreads();                                                 // (zero rows)
+    switch (wid) {
+        case 0: fineq_bwd_consume<0>(g, lds, nkt, lane); break;
+        case 1: fineq_bwd_consume<1>(g, lds, nkt, lane); break;
+        case 2: fineq_bwd_consume<2>(g, lds, nkt, lane); break;
+        case 3: fineq_bwd_consume<3>(g, lds, nkt, lane); break;
+        case 4: fineq_bwd_consume<4>(g, lds, nkt, lane); break;
+        case 5: fineq_bwd_consume<5>(g, lds, nkt, lane); break;
+        case 6: fineq_bwd_consume<6>(g, lds, nkt, lane); break;
+        default: fineq_bwd_consume<7>(g, lds, nkt, lane); break;
+    }
+}
+
+// S [256][256] (row stride lds_) and P [K][256] from the workgroups' partials: fixed order; the blocks of S below the
+// diagonal (64 x 64 granularity) are the mirror images of the ones above it
+__global__ void fineq_bwd_reduce_kernel(const float* __restrict__ slab, int nslab, int K, float* __restrict__ S, float* __restrict__ P) {
+#pragma clang fp contract(off)
+    const int total = (256 + K) * 256;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int row = i >> 8, col = i & 255;
+        int sr = row, sc = col;
+        if (row < 256 && (row >> 6) > (col >> 6)) { sr = col; sc = row; }
+        const float* src = slab + sr * 256 + sc;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 3 < nslab; b += 4) {
+            s0 += src[(long)b * (272 * 256)]; s1 += src[(long)(b + 1) * (272 * 256)];
+            s2 += src[(long)(b + 2) * (272 * 256)]; s3 += src[(long)(b + 3) * (272 * 256)];
+        }
+        for (; b < nslab; ++b) s0 += src[(long)b * (272 * 256)];
+        const float v = (s0 + s1) + (s2 + s3);
+        if (row < 256) S[i] = v;
+        else P[(row - 256) * 256 + col] = v;
+    }
+}
+
 // out[j] = beta * out[j] + sum_b part[b][j]   (fixed order)
 __global__ void fineq_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta, float* __restrict__ out) {
 #pragma clang fp contract(off)
@@ -357,6 +622,36 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
     const dim3 grid(gx_cdiv(rows, 128)), block(gx::GEMM_THREADS);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gx::fineq_fwd_kernel<8>, grid, block, 0, st, g);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// One pass over the finest taps for the whole backward of the level (fineq_bwd_kernel): S [256][256] = sum_q e[q] t t^T,
+// P [K][256], Tt [rows / 4][256], Cpool [rows / 4][stride].  bf16x6 engine; fine_res a power of two >= 16.
+#define GX_FINEQ_BWD_WGS 256
+size_t gx_fineq_bwd_workspace_bytes(void) { return (size_t)GX_FINEQ_BWD_WGS * 272 * 256 * sizeof(float); }
+int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
+                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!C || !t1 || !S || !P || !Tt || !Cpool || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
+    if (!gx_fineq_ok(K1, K2, K) || gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;
+    if (fine_res < 16 || (fine_res & (fine_res - 1)) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
+    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)Tt) & 15)) return GX_ERR_ALIGN;
+    if (!workspace || workspace_bytes < gx_fineq_bwd_workspace_bytes()) return GX_ERR_WORKSPACE;
+    gx::FineqBwdArgs g;
+    g.C = C; g.ls = (K + 1 + 3) & ~3;
+    g.T1 = t1; g.ld1 = ld1;
+    g.T2 = K2 > 0 ? t2 : t1 + 128; g.ld2 = K2 > 0 ? ld2 : ld1;
+    g.K = K; g.shift = 0;
+    while ((1 << g.shift) < fine_res) ++g.shift;
+    g.nkt = rows / 16;
+    int nwg = (int)(g.nkt < GX_FINEQ_BWD_WGS ? g.nkt : GX_FINEQ_BWD_WGS);
+    g.kt_per = (int)((g.nkt + nwg - 1) / nwg);
+    nwg = (int)((g.nkt + g.kt_per - 1) / g.kt_per);
+    g.slab = workspace; g.Tt = Tt; g.Cpool = Cpool;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gx::fineq_bwd_kernel, dim3(nwg), dim3(768), 0, st, g);
+    GX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gx::fineq_bwd_reduce_kernel, dim3(gx_cdiv((256 + K) * 256, 256)), dim3(256), 0, st, workspace, nwg, K, S, P);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

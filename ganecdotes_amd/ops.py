@@ -494,6 +494,32 @@ def fineq_bwd_pool(coeffs, t1, t2, k, fine_res):
     return tt, cpool, pm
 
 
+def fineq_bwd(coeffs, t1, t2, k, fine_res):
+    """coefficient grid (rows, stride) + the finest taps, ONE pass over the taps -> S (256, 256) = sum_q e[q] t t^T,
+    P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride)"""
+    _chk(coeffs)
+    _chk2d(t1, t2)
+    rows, k1 = t1.shape
+    k2 = 0 if t2 is None else t2.shape[1]
+    cf = k1 + k2
+    L = lib()
+    if coeffs.shape[0] != rows or coeffs.shape[1] != L.gx_lowrank_stride(k) or cf != 256:
+        raise RuntimeError("fineq_bwd: coefficient grid / taps do not match (rows, K, 256 channels)")
+    dev = t1.device
+    s = torch.empty(cf, cf, dtype=torch.float32, device=dev)
+    pm = torch.empty(k, cf, dtype=torch.float32, device=dev)
+    tt = torch.empty(rows // 4, cf, dtype=torch.float32, device=dev)
+    cpool = torch.empty(rows // 4, coeffs.shape[1], dtype=torch.float32, device=dev)
+    wsb = L.gx_fineq_bwd_workspace_bytes()
+    ws = workspace("fineq_bwd", wsb, dev)
+    # the 10 of 16 64x64 blocks of S on / above the diagonal + the 32 coefficient rows (K of them live)
+    with record("fineq_bwd_kernel", 2.0 * rows * 64 * 64 * 12, 4.0 * rows * (cf * 1.25 + coeffs.shape[1] * 1.25)):
+        _lib.check(L.gx_fineq_bwd(_p(coeffs), rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2),
+                                  0 if t2 is None else t2.stride(0), k, _p(s), _p(pm), _p(tt), _p(cpool), _p(ws), wsb,
+                                  _stream()), "gx_fineq_bwd")
+    return s, pm, tt, cpool
+
+
 def gemm_tn_gram(a1, a2, kscale, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
     """out (M1+M2, N1+N2) = alpha * ([a1 | a2] * kscale[:, None]).T @ [b1 | b2] + beta*out; a* (K, M*), b* (K, N*),
     kscale a 1-D (possibly strided) fp32 view of K elements or None; a2 / b2 may be None.  bf16x6 engine."""

@@ -188,7 +188,8 @@ class Pyramid:
         k, d = wc.shape[0], wp.shape[0]
         wf = wp[:, off:off + cf]
         zc2 = zc.reshape(-1, d)
-        tt, cpool, pm = ops.fineq_bwd_pool(coeffs, t1, t2, k, r)
+        # ONE pass over the level's taps: S = sum_q e[q] t t^T (e = C[:, K]), P = C[:, :K]^T t, Tt = 2x2-pooled e t, Cpool
+        s, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, k, r)
         # gradient of the level below: Gc = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc  (+ its 2x2 sum-pooling), gWc
         gc = torch.empty_like(zc2)
         ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
@@ -198,12 +199,7 @@ class Pyramid:
         ops.gemm(pm, wf, False, True, out=gwc, beta=1.0)                # gWc += P Wf^T
         if on_heads is not None:
             on_heads()
-        # dWf = Zc^T Tt + Wf S + Wc^T P      S = sum_q e[q] t(q) t(q)^T, e = C[:, K]
-        rows = t1.shape[0]
-        s = torch.empty(cf, cf, dtype=torch.float32, device=wp.device)
-        n1 = t1.shape[1]
-        # 2 N-tiles (one M-tile of 256) x splits: whole rounds of the 256 CUs
-        ops.gemm_tn_gram(t1, t2, coeffs[:, k], t1, t2, s, split_k=int(max(1, min(128, rows // 2048))))
+        # dWf = Zc^T Tt + Wf S + Wc^T P
         gcols = gwp[:, off:off + cf]
         rc_rows = zc2.shape[0]
         tiles = ((d + 127) // 128) * ((cf + 127) // 128)

@@ -133,6 +133,12 @@ int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, floa
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* Y2, const float* Ac, const float* nc, const float* bias,
                  int K, float* rn_table, float* sc_table, void* stream);
+/* gx_fineq_bwd: the whole backward of the level in ONE pass over its taps — S [256][256] = sum_q C[q][K] t(q) t(q)^T (the
+ * weighted Gram matrix: only the blocks on / above the diagonal are contracted), P [K][256] = C[:, :K]^T t, Tt, Cpool as
+ * gx_fineq_bwd_pool.  workspace: gx_fineq_bwd_workspace_bytes(); fine_res a power of two >= 16 */
+size_t gx_fineq_bwd_workspace_bytes(void);
+int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
+                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream);
 size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF);
 int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
                       long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,

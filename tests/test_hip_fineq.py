@@ -105,6 +105,31 @@ def test_fineq_backward_equals_the_projected_table_route(ops, k, two_taps):
     assert rel(outs[0][1], outs[1][1]) < 2e-5
 
 
+@pytest.mark.parametrize("k,two_taps,res", [(8, True, 64), (16, True, 32), (5, False, 16)])
+def test_fineq_bwd_one_pass_vs_fp64(ops, k, two_taps, res):
+    """gx_fineq_bwd: the weighted Gram matrix S (upper blocks contracted, lower mirrored), P, the pooled e t and the pooled
+    coefficients from one pass over the taps — against fp64 and against the two-kernel form (gx_fineq_bwd_pool + tn_gram)"""
+    torch.manual_seed(29)
+    b = 3
+    rows = b * res * res
+    t1 = torch.randn(rows, 128 if two_taps else 256).cuda()
+    t2 = torch.randn(rows, 128).cuda() if two_taps else None
+    ls = ops.lib().gx_lowrank_stride(k)
+    c = torch.zeros(rows, ls)
+    c[:, :k + 1] = torch.randn(rows, k + 1) * 1e-2
+    c = c.cuda()
+    s, pm, tt, cpool = ops.fineq_bwd(c, t1, t2, k, res)
+    t = (t1 if t2 is None else torch.cat([t1, t2], 1)).double()
+    e = c[:, k].double()
+    assert rel(s, (t * e[:, None]).t() @ t) < 3e-6
+    assert rel(s, s.t()) < 1e-6                     # mirrored across the diagonal blocks; inside one, (e t)^T t both ways
+    assert rel(pm, c[:, :k].double().t() @ t) < 3e-6
+    pool = lambda x: x.reshape(b, res // 2, 2, res // 2, 2, -1).sum((2, 4)).reshape(rows // 4, -1)
+    assert rel(tt, pool(t * e[:, None])) < 2e-6 and rel(cpool, pool(c.double())) < 2e-6
+    tt2, cpool2, pm2 = ops.fineq_bwd_pool(c, t1, t2, k, res)
+    assert rel(tt2, tt) < 2e-6 and rel(cpool2, cpool) < 2e-6 and rel(pm2, pm) < 3e-6
+
+
 def test_gemm_tn_gram_vs_fp64(ops):
     """C = ([A1 | A2] .* s)^T [B1 | B2]: the k-scaled TN GEMM with its 256-row tile from two sources, split-K, beta"""
     torch.manual_seed(3)

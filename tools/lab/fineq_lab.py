@@ -60,6 +60,7 @@ if want("fwd"):
     z4 = z.reshape(B2, R, R, D)
     show("old: score tables pass", timeit(lambda: ops.upsample2_add_scores_(None, z4, wc, bias)), 0, 4.0 * rows * (D + K + 1))
 if want("bwd"):
+    show("fineq_bwd (S, P, Tt, Cpool in one pass)", timeit(lambda: ops.fineq_bwd(coeffs, t1, t2, K, R)), 2.0 * rows * 64 * 64 * 12, 4.0 * rows * CF * 1.25)
     show("fineq_bwd_pool", timeit(lambda: ops.fineq_bwd_pool(coeffs, t1, t2, K, R)), 0, 4.0 * rows * (CF * 1.25 + ls * 1.25))
     tt, cpool, pm = ops.fineq_bwd_pool(coeffs, t1, t2, K, R)
     s = torch.empty(CF, CF, device=dev)
