@@ -20,6 +20,7 @@
 //     gWc  = P Wf^T + Cpool[:, :K]^T Zc
 // gx_fineq_bwd_pool makes Tt, Cpool and P in one pass over the taps; S is the k-scaled TN GEMM gx_gemm_f32_tn_gram.
 #include "gx_mfma_x6.h"
+#include <type_traits>
 
 namespace gx {
 
@@ -29,196 +30,244 @@ struct FineqArgs {
     int K1, K2;
     const unsigned short* Bp;              // gx_split_gemm_weights planes of Bq [CF + 16][CF]
     unsigned Bp_bytes;
-    const float* Y2;                       // [rows / 4][CF]
-    const float* Ac;                       // [rows / 4][K]
-    const float* nc;                       // [rows / 4]
+    const float* Yx;                       // [rows / 4][FQ_YLD]: Y2 | Ac | nc (gx_fineq_ytable_ld())
     const float* bias;                     // [K] or null
     float* rn_table;                       // [rows]
     float* sc_table;                       // [rows][K]
     int M, K, shift;                       // rows, prototypes, log2(fine resolution)
+    int ntile;                             // 128-row tiles
 };
 
 #ifndef FQ_ABL
-#define FQ_ABL 0                           // lab ablations (tools/lab/fineq_abl.sh): 1 no Y2 loads, 2 no MFMAs, 3 no A DMA, 4 no B DMA
+#define FQ_ABL 0                           // lab ablations (tools/lab/fineq_abl.sh): 2 no MFMAs, 11 / 12 the backward kernel's
 #endif
+// The coarse tables travel as ONE table of FQ_YLD floats per parent pixel: columns 0 .. 255 = Y2 = 2 Zc Wf, 256 .. 271 =
+// Ac = Zc Wc^T (K of them live), 272 = nc = |Zc|^2 — so that the score block's share is a ninth "column block" of it.
+constexpr int FQ_YLD = 288;
 constexpr int FQ_A = 8192;                 // one A tile: 128 rows x 16 raw fp32
-constexpr int FQ_NSA = 3;                  // A ring: the tile before the current one stays readable (block finalisation)
+constexpr int FQ_NSA = 4;                  // A ring: prefetch distance 2, and the tile before the current one stays readable
+constexpr int FQ_NSB = 3;                  // B ring: prefetch distance 2
+constexpr int FQ_PST = 9 * 1024;           // one plane of a B stage: 9 column blocks x 32 rows x 32 B
+constexpr int FQ_B = 3 * FQ_PST;           // 27 KB
+constexpr int FQ_Y = 8192;                 // one Y block: 4 row groups x 16 parents x 32 columns
+constexpr int FQ_LDS = FQ_NSA * FQ_A + FQ_NSB * FQ_B + 3 * FQ_Y + 512;
 
-// 128 rows per workgroup, four waves stacked along M (32 rows x all CF + 16 columns each): every A element is split by
-// exactly one lane, as in gemm_xw_kernel, and a row's whole U lives in one wave's accumulators.  NBQ = CF / 32 column
-// blocks + the score block.  Bq is lower triangular, so column block nb is FINAL after k-tile 2 nb + 1 — the two k-tiles
-// that hold the block's own tap columns, and both still sit in the A ring: the block is folded into the row sums
+// per-wave DMA instruction counts of k-tile kt (compile-time): B = the 1 KB chunks (plane, column block >= kt / 2) dealt to
+// 8 waves; Y = one per wave at odd k-tiles (block (kt + 1) / 2 of this / the next tile) and at kt = 12 (the score block)
+__host__ __device__ constexpr int fq_nblk(int kt) { return 9 - ((kt & 15) >> 1); }
+__host__ __device__ constexpr int fq_nb_dma(int kt) { return (3 * fq_nblk(kt) + 7) / 8; }
+__host__ __device__ constexpr int fq_ny_dma(int kt) { return ((kt & 1) || (kt & 15) == 12) ? 1 : 0; }
+// outstanding vector-memory operations allowed at the top of k-tile t: everything issued in k-tile t - 1 (the DMAs of
+// k-tile t itself were issued in t - 2, before them, and complete in order)
+__host__ __device__ constexpr int fq_vmcnt(int t) { return fq_ny_dma(t + 15) + fq_nb_dma(t + 1) + 1; }
+__device__ __forceinline__ void fq_wait_vm(int n) {        // n is a constant once the k loop is unrolled: one case survives
+    switch (n) {
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Workgroup barrier WITHOUT the fences of __syncthreads(): those make hipcc drain every outstanding vector-memory operation
+// (s_waitcnt vmcnt(0)) — i.e. the DMAs of the NEXT k-tiles — in front of every barrier.  LDS writes of this wave are
+// retired (lgkmcnt(0)), the DMAs it must see are covered by the counted vmcnt wait before it, and the "memory" clobber
+// keeps the compiler from moving LDS accesses across.
+__device__ __forceinline__ void fq_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Persistent: one 512-thread workgroup per CU walks 128-row tiles; 16 k-tiles per tile, ONE barrier per k-tile, and the
+// rings run on across tile boundaries (k-tile t issues the DMAs of k-tile t + 2, possibly of the next tile), so no
+// workgroup ever ramps up again after its first tile.  Roles: waves 0-3 ("L") own column blocks 0 .. 5 of their 32 rows,
+// waves 4-7 ("R") blocks 6, 7 and the score block — 42 against 46 block-k-tiles, a pair (w, w + 4) shares a SIMD.
+// Bq is lower triangular, so column block nb is FINAL after k-tile 2 nb + 1 — the two k-tiles that hold the block's own tap
+// columns, both still in the A ring: its owner folds it into the row sums
 //     sp[r] += t[row_r][j] * (U[row_r][j] + Y2[parent(row_r)][j])          (accumulator layout: lane = column j, 16 rows)
-// right there, with t read back from LDS, and its 16 accumulator registers are free for the rest of the loop.  Nothing of
-// U is staged or stored, and the taps are read from HBM exactly once.  (First version: U parked in LDS after the loop and
-// t / Y2 re-read row-wise from global — 4.2 GB of L2 misses with little in flight: 2.4 ms against 1.2 ms without them.)
-template <int NBQ>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void fineq_fwd_kernel(FineqArgs g) {
-    constexpr int CF = 32 * NBQ, NKT = CF / 16, FT = NBQ / 4;              // full 128-row weight tiles
-    constexpr int PST = (NBQ + 1) * 1024;                                   // one plane of a B stage: CF + 32 rows x 32 B
-    constexpr int FQ_B = 3 * PST;
-    __shared__ __attribute__((aligned(16))) char lds[FQ_NSA * FQ_A + 2 * FQ_B];
+// right there (t and Y2 from LDS).  Nothing of U is staged or stored and the taps leave HBM exactly once.  History: U parked
+// in LDS after the loop with t / Y2 re-read from global 2.4 ms (4.2 GB of L2 misses with little in flight); folding in the
+// loop, 4 waves x all 9 blocks, 2 workgroups per CU 1.7 ms (256 VGPRs: the Y2 loads spilled one by one behind vmcnt(0)).
+__global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
+    constexpr int CF = 256, NKT = 16;
+    __shared__ __attribute__((aligned(16))) char lds[FQ_LDS];
     char* const ldsB = lds + FQ_NSA * FQ_A;
+    char* const ldsY = ldsB + FQ_NSB * FQ_B;
+    float* const xs = reinterpret_cast<float*>(ldsY + 3 * FQ_Y);           // [4 row groups][32 rows]: L's share of the row sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntile = (g.M + 127) >> 7;
-    const int tm = xcd_remap((int)blockIdx.x, ntile);
-    const int m0 = tm * 128;
+    const int rg = wid & 3;
+    const bool isL = wid < 4;
     const int nkt1 = g.K1 >> 4;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int my_tiles = ((int)blockIdx.x < g.ntile) ? (g.ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (my_tiles == 0) return;
 
-    unsigned aoff1[2], aoff2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = i * 256 + tid;
-        int row = p >> 2;
-        const int q = (p & 3) ^ ((p >> 4) & 3);
-        row = min(row, g.M - 1 - m0);
-        aoff1[i] = ((unsigned)row * (unsigned)g.lda1 + (unsigned)q * 4u) * 4u;
-        aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
-    }
-    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A1 + (long)m0 * g.lda1, 0x7FFFFFF0u);
-    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A1, 0x7FFFFFF0u);
+    // ---- DMA sources.  A: unit p = tid holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3) (the layout of gemm_xw_kernel)
+    const unsigned arow = (unsigned)(tid >> 2), aq = (unsigned)((tid & 3) ^ ((tid >> 4) & 3));
+    const unsigned aoff1 = (arow * (unsigned)g.lda1 + aq * 4u) * 4u, aoff2 = (arow * (unsigned)g.lda2 + aq * 4u) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A1, 0xFFFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 : g.A1, 0xFFFFFFF0u);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
-    const unsigned boff = (unsigned)tid * 16u;
-
-    auto issue_b = [&](int kt, char* dst) {
-        if (FQ_ABL == 4) return;
-#pragma unroll
-        for (int tn = 0; tn < FT; ++tn) {
-            if (4 * tn + 3 < (kt >> 1)) continue;                          // every block of this tile is above the diagonal
-            const unsigned blk = ((unsigned)tn * NKT + (unsigned)kt) * 3u * 4096u;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * PST + tn * 4096 + wid * 1024), 16, (int)boff,
-                                                         (int)(blk + p * 4096u), 0, 0);
-        }
-        if (wid < 3) {                                                     // the score rows: 32 rows of tile FT, plane `wid`
-            const unsigned blk = ((unsigned)FT * NKT + (unsigned)kt) * 3u * 4096u + (unsigned)wid * 4096u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + wid * PST + FT * 4096), 16, (int)(lane * 16), (int)blk, 0, 0);
-        }
-    };
-    auto issue_a = [&](int kt, char* dst) {
-        if (FQ_ABL == 3) return;
-        const bool second = kt >= nkt1;
-        const int ks = (second ? kt - nkt1 : kt) * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff1[i], ks, 0, 0);
-        }
-    };
-
-    f32x16 acc[NBQ + 1];
-#pragma unroll
-    for (int j = 0; j <= NBQ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int arow = wid * 32 + r32;
-    const int af = (arow >> 2) & 3;
-    const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
-
-    // Accumulator layout of this lane: column r32 of a block, rows (r & 3) + 8 (r >> 2) + 4 hh of the wave's 32.  The
-    // fine resolution is >= 32 (host check), so a wave's 32 rows are 32 consecutive x of ONE image row starting at an even
-    // x: row r's parent is pbase + ((r & 3) >> 1) + 4 (r >> 2) + 2 hh — rows r = 0, 1 (mod 4) share one, r = 2, 3 the next.
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(g.Yx, 0xFFFFFFF0u);
     const int s = g.shift, rc = 1 << (s - 1), msk = (1 << s) - 1;
-    const int row0 = m0 + wid * 32;                                       // wave-uniform
-    const long pbase = ((long)(row0 >> (2 * s)) * rc + (((row0 >> s) & msk) >> 1)) * rc + ((row0 & msk) >> 1);
-    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(g.Y2 + pbase * CF, 16u * CF * 4u);     // the wave's 16 parents
-    const unsigned yoff = ((unsigned)(2 * hh) * CF + (unsigned)r32) * 4u;
-    // t[row_r][column r32 of block nb] in the A ring: k-tile 2 nb + (r32 >> 4), k = r32 & 15; unit = row * 4 + (k-quad ^
-    // ((row >> 2) & 3)), and (row >> 2) & 3 = hh for even r >> 2, 2 + hh for odd: two bases + compile-time offsets
-    const int tk = r32 & 15;
-    const int tbase = wid * 2048 + hh * 256 + (tk & 3) * 4;
-    const int tb_e = tbase + (((tk >> 2) ^ hh) << 4), tb_o = tbase + (((tk >> 2) ^ (2 + hh)) << 4);
-    float sp[16], y2c[8];
+    // first parent of row group rg of tile tm (a row group = 32 consecutive x of one image row, x even: host checks res >= 32)
+    auto pbase_of = [&](int tm) -> unsigned {
+        const int row0 = tm * 128 + rg * 32;
+        return (unsigned)(((row0 >> (2 * s)) * rc + (((row0 >> s) & msk) >> 1)) * rc + ((row0 & msk) >> 1));
+    };
+    auto issue_a = [&](int tm, int kt, int slot) {
+        const bool second = kt >= nkt1;
+        const unsigned so = (unsigned)tm * 128u * (unsigned)(second ? g.lda2 : g.lda1) * 4u + (unsigned)((second ? kt - nkt1 : kt) * 64);
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(lds + slot * FQ_A + wid * 1024), 16, (int)aoff2, (int)so, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(lds + slot * FQ_A + wid * 1024), 16, (int)aoff1, (int)so, 0, 0);
+    };
+    // B: the 1 KB chunks (plane p, column block nb >= kt / 2) of k-tile kt, chunk c = wave + 8 i (clamped: a few duplicates)
+    auto issue_b = [&](int kt, int slot) {
+        const int nblk = fq_nblk(kt), nch = 3 * nblk, nbmin = 9 - nblk;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sp[r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) y2c[r] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= fq_nb_dma(kt)) continue;
+            const int c = min(wid + 8 * i, nch - 1);
+            const int p = c / nblk, nb = nbmin + c - p * nblk;
+            const unsigned src = (unsigned)(((nb >> 2) * NKT + kt) * 3 + p) * 4096u + (unsigned)(nb & 3) * 1024u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(ldsB + slot * FQ_B + p * FQ_PST + nb * 1024), 16,
+                                                     (int)(lane * 16), (int)src, 0, 0);
+        }
+    };
+    // Y: block nb (8 = the Ac | nc columns) of tile tm for this wave's row group: parents 8 (wid >> 2) .. + 7, 128 B each
+    const unsigned yoff = ((unsigned)(8 * (wid >> 2) + (lane >> 3)) * FQ_YLD) * 4u + (unsigned)(lane & 7) * 16u;
+    auto issue_y = [&](int tm, int nb, int slot) {
+        const unsigned so = (pbase_of(tm) * FQ_YLD + (unsigned)nb * 32u) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr_t)(ldsY + slot * FQ_Y + rg * 2048 + (wid >> 2) * 1024), 16, (int)yoff,
+                                                 (int)so, 0, 0);
+    };
 
-    issue_b(0, ldsB);
-    issue_a(0, lds);
+    // ---- per-lane constants
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int afr = rg * 32 + r32, af = (afr >> 2) & 3;                     // A fragment: row r32 of the row group, k = 8 hh ..
+    const int au0 = (afr * 4 + ((2 * hh) ^ af)) * 16, au1 = (afr * 4 + ((2 * hh + 1) ^ af)) * 16;
+    // t[row_r][column r32 of block nb] in the A ring: k-tile 2 nb + (r32 >> 4), k = r32 & 15 (see gemm_xw_kernel's unit map)
+    const int tk = r32 & 15;
+    const int tbase = rg * 2048 + hh * 256 + (tk & 3) * 4;
+    const int tb_e = tbase + (((tk >> 2) ^ hh) << 4), tb_o = tbase + (((tk >> 2) ^ (2 + hh)) << 4);
+    const int ybase = rg * 2048 + (2 * hh) * 128 + r32 * 4;                 // Y[parent ((r & 3) >> 1) + 4 (r >> 2) + 2 hh][r32]
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
+    const float myb = (r32 < g.K && g.bias) ? g.bias[r32] : 0.f;
+
+    // ---- prologue: what k-tiles -2 and -1 of a previous tile would have issued
+    int tm = (int)blockIdx.x;
+    int sb = 0;                                                          // B ring slot of the current k-tile (runtime: 16 % 3 != 0)
+    issue_b(0, 0); issue_a(tm, 0, 0);
+    issue_y(tm, 0, 0); issue_b(1, 1); issue_a(tm, 1, 1);
+
+    f32x16 acc[6];
+    float sp[16];
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tn = (it + 1 < my_tiles) ? tm + (int)gridDim.x : tm;        // next tile (the last one prefetches itself: unused)
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < NKT) {
-            issue_b(t + 1, ldsB + ((t + 1) & 1) * FQ_B);
-            issue_a(t + 1, lds + ((t + 1) % FQ_NSA) * FQ_A);
-        }
-        asm volatile("" ::: "memory");
-        if ((t & 1) == 0 && FQ_ABL != 1) {                               // Y2 of block t / 2, consumed one k-tile later
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)                                   // parent (i & 1) + 4 (i >> 1) (+ 2 hh in yoff)
-                y2c[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rs_y, (int)yoff, (((i & 1) + 4 * (i >> 1)) * CF + (t >> 1) * 32) * 4, 0));
-        }
-        asm volatile("" ::: "memory");
-        const char* st = lds + (t % FQ_NSA) * FQ_A;
-        const char* Bs = ldsB + (t & 1) * FQ_B;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
-        unsigned h[4], m[4], l[4];
-        split3(x0[0], x0[1], h[0], m[0], l[0]);
-        split3(x0[2], x0[3], h[1], m[1], l[1]);
-        split3(x1[0], x1[1], h[2], m[2], l[2]);
-        split3(x1[2], x1[3], h[3], m[3], l[3]);
-        const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]}),
-                             __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
-                             __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})};
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
-        const int nb0 = t >> 1;
-        // the block that becomes final in this k-tile goes first, so that its MFMAs have retired when it is folded below
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
-        for (int gb = nb0; gb <= NBQ; gb += 2) {                            // column blocks in pairs
-            bf16x8 b[2][3];
+        for (int r = 0; r < 16; ++r) sp[r] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nb = gb + j;
-                if (nb > NBQ) continue;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * PST + x_kc_off(nb * 32 + r32, hh));
+        for (int t = 0; t < NKT; ++t) {
+            fq_wait_vm(fq_vmcnt(t));
+            fq_barrier();
+            // issue: [Y] B(t + 2) A(t + 2) — Y first: its consumer (two k-tiles on) only waits for the A / B issued after it
+            if (t & 1) issue_y(t == 15 ? tn : tm, ((t + 1) >> 1) & 7, ((t + 1) >> 1) & 1);
+            if (t == 12) issue_y(tm, 8, 2);
+            {
+                const int sb2 = sb + 2 >= FQ_NSB ? sb + 2 - FQ_NSB : sb + 2;
+                issue_b((t + 2) & 15, sb2);
+                issue_a(t + 2 >= NKT ? tn : tm, (t + 2) & 15, (t + 2) & 3);
             }
+            const int nb0 = t >> 1;
+            const bool active = isL ? (nb0 <= 5) : true;
+            if (active) {
+                const char* st = lds + (t & 3) * FQ_A;
+                const char* Bs = ldsB + sb * FQ_B;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
+                unsigned h[4], m[4], l[4];
+                split3(x0[0], x0[1], h[0], m[0], l[0]);
+                split3(x0[2], x0[3], h[1], m[1], l[1]);
+                split3(x1[0], x1[1], h[2], m[2], l[2]);
+                split3(x1[2], x1[3], h[3], m[3], l[3]);
+                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]}),
+                                     __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
+                                     __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})};
+                // this wave's column blocks that k-tile t still meets: L: nb0 .. 5 -> acc[nb]; R: max(nb0, 6) .. 8 -> acc[nb - 6]
+                auto run = [&](auto role) {
+                    constexpr bool L = decltype(role)::value;
+                    constexpr int lo = L ? 0 : 6, hi = L ? 5 : 8;
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
+                    for (int gb = lo; gb <= hi; gb += 2) {
+                        bf16x8 b[2][3];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int nb = gb + j;
-                    if (nb > NBQ || FQ_ABL == 2) continue;
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[j][TB[u]], acc[nb], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) {
+                            const int nb = gb + j;
+                            if (nb > hi || nb < nb0) continue;
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * FQ_PST + x_kc_off(nb * 32 + r32, hh));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int nb = gb + j;
+                                if (nb > hi || nb < nb0 || FQ_ABL == 2) continue;
+                                acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[j][TB[u]], acc[nb - lo], 0, 0, 0);
+                            }
+                    }
+                };
+                if (isL) run(std::integral_constant<bool, true>{});
+                else run(std::integral_constant<bool, false>{});
+            }
+            if ((t & 1) && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
+                const char* tsrc = lds + (((t - 1) + (r32 >> 4)) & 3) * FQ_A;
+                const char* ysrc = ldsY + (nb0 & 1) * FQ_Y + ybase;
+                auto fold = [&](const f32x16& u) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float tv = *reinterpret_cast<const float*>(tsrc + (((r >> 2) & 1) ? tb_o : tb_e) + (r & 3) * 64 + (r >> 2) * 512);
+                        const float yv = *reinterpret_cast<const float*>(ysrc + (((r & 3) >> 1) + 4 * (r >> 2)) * 128);
+                        sp[r] = fmaf(tv, u[r] + yv, sp[r]);
+                    }
+                };
+                if (isL) fold(acc[nb0 <= 5 ? nb0 : 5]);
+                else fold(acc[nb0 >= 6 ? nb0 - 6 : 0]);
+                if (isL && nb0 == 5) {                                      // L's share of the row sums is complete
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = gx_team_sum(sp[r], 32);
+                        if (r32 == 0) xs[rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = v;
+                    }
                 }
+            }
+            sb = sb + 1 >= FQ_NSB ? 0 : sb + 1;
         }
-        if (t & 1) {                                                        // block nb0 is final: fold it into the row sums
-            const char* tsrc = lds + (((t - 1) + (r32 >> 4)) % FQ_NSA) * FQ_A;
+        if (!isL) {
+            // ---- rows: |z|^2 = L's share + R's + nc[parent]; scores from the score block + Ac[parent]
+            // (the score block of Y arrived at k-tile 12 + 2; xs was written at k-tile 11: four barriers ago)
+            const char* ysc = ldsY + 2 * FQ_Y + rg * 2048 + (2 * hh) * 128;
+            const int row0 = tm * 128 + rg * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float tv = *reinterpret_cast<const float*>(tsrc + (((r >> 2) & 1) ? tb_o : tb_e) + (r & 3) * 64 + (r >> 2) * 512);
-                sp[r] = fmaf(tv, acc[nb0][r] + y2c[((r & 3) >> 1) + 2 * (r >> 2)], sp[r]);
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const char* yp = ysc + (((r & 3) >> 1) + 4 * (r >> 2)) * 128;
+                const float nsq = gx_team_sum(sp[r], 32) + xs[rg * 32 + rr] + *reinterpret_cast<const float*>(yp + 16 * 4);
+                const float rn = 1.f / fmaxf(sqrtf(fmaxf(nsq, 0.f)), 1e-12f);
+                const int row = row0 + rr;
+                if (r32 < g.K) g.sc_table[(long)row * g.K + r32] = fmaf(acc[2][r] + *reinterpret_cast<const float*>(yp + r32 * 4), rn, myb);
+                if (r32 == 0) g.rn_table[row] = rn;
             }
         }
+        tm = tn;
     }
-
-    // ---- rows: |z|^2 = sum over the columns (the 32 lanes of this half-wave) + nc[parent]; the K scores are the score block
-    const int k = r32;
-    const bool kok = k < g.K;
-    const float myb = (kok && g.bias) ? g.bias[k] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long par = pbase + ((r & 3) >> 1) + 4 * (r >> 2) + 2 * hh;
-        const float nsq = gx_team_sum(sp[r], 32) + g.nc[par];
-        const float rn = 1.f / fmaxf(sqrtf(fmaxf(nsq, 0.f)), 1e-12f);
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < g.M) {
-            if (kok) g.sc_table[(long)row * g.K + k] = fmaf(acc[NBQ][r] + g.Ac[par * g.K + k], rn, myb);
-            if (k == 0) g.rn_table[row] = rn;
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last tile's look-ahead DMAs still target this LDS
+    __syncthreads();
 }
 
 // Bq [CF + 16][CF] (row stride CF) for fineq_fwd_kernel: rows j < CF = the lower-triangular form of the symmetric
@@ -600,28 +649,39 @@ int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, floa
     return GX_OK;
 }
 
+int gx_fineq_ytable_ld(void) { return gx::FQ_YLD; }
+static int fineq_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
-                 const unsigned short* bq_planes, const float* Y2, const float* Ac, const float* nc, const float* bias,
-                 int K, float* rn_table, float* sc_table, void* stream) {
-    if (!t1 || !bq_planes || !Y2 || !Ac || !nc || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
+                 const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
+                 float* sc_table, void* stream) {
+    if (!t1 || !bq_planes || !ytable || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
     if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
     if (gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;                   // a bf16x6 kernel
-    // >= 32: a wave's 32 rows are consecutive pixels of one image row (fineq_fwd_kernel's parent arithmetic)
+    // >= 32: a wave's 32 rows are consecutive pixels of one image row (fineq_fwd_kernel's parent arithmetic); rows is then
+    // a multiple of 1024: whole 128-row tiles
     if (fine_res < 32 || (fine_res & (fine_res - 1)) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
-    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || ld1 < K1 || (K2 > 0 && ld2 < K2) || ld1 >= (1 << 22) || ld2 >= (1 << 22) ||
-        127L * ld1 * 4 + 4L * K1 >= 0x7FFFFFF0L || 127L * ld2 * 4 + 4L * K2 >= 0x7FFFFFF0L ||
-        (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)bq_planes | (uintptr_t)Y2) & 15))
+    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || ld1 < K1 || (K2 > 0 && ld2 < K2) ||
+        (long)rows * ld1 * 4 >= 0xFFFFFFF0L || (long)rows * ld2 * 4 >= 0xFFFFFFF0L ||           // 32-bit buffer offsets
+        (long)(rows / 4) * gx::FQ_YLD * 4 >= 0xFFFFFFF0L ||
+        (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)bq_planes | (uintptr_t)ytable) & 15))
         return GX_ERR_ALIGN;
     const int CF = K1 + K2;
     gx::FineqArgs g;
     g.A1 = t1; g.A2 = K2 > 0 ? t2 : nullptr; g.lda1 = ld1; g.lda2 = K2 > 0 ? ld2 : ld1; g.K1 = K1; g.K2 = K2;
     g.Bp = bq_planes; g.Bp_bytes = (unsigned)gx_gemm_weight_planes_bytes(CF + 16, CF);
-    g.Y2 = Y2; g.Ac = Ac; g.nc = nc; g.bias = bias; g.rn_table = rn_table; g.sc_table = sc_table;
+    g.Yx = ytable; g.bias = bias; g.rn_table = rn_table; g.sc_table = sc_table;
     g.M = rows; g.K = K; g.shift = 0;
     while ((1 << g.shift) < fine_res) ++g.shift;
-    const dim3 grid(gx_cdiv(rows, 128)), block(gx::GEMM_THREADS);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gx::fineq_fwd_kernel<8>, grid, block, 0, st, g);
+    g.ntile = rows / 128;
+    const int nwg = g.ntile < fineq_num_cus() ? g.ntile : fineq_num_cus();
+    hipLaunchKernelGGL(gx::fineq_fwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

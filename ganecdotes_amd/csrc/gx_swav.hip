@@ -1928,7 +1928,8 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
                                                                 const int* __restrict__ maps, int rows_per_img,
                                                                 long rows, const float* __restrict__ Wc,
                                                                 const float* __restrict__ bias, int K,
-                                                                float* __restrict__ rnorm, float* __restrict__ scores) {
+                                                                float* __restrict__ rnorm, float* __restrict__ scores,
+                                                                long ld_rn = 1, long ld_sc = 0) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] (rows >= K are zero)
     for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
     __syncthreads();
@@ -1938,6 +1939,7 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
     const int myk = ps_lane_k<KP>(lane);
     const bool owner = ps_lane_owner<KP>(lane) && myk < K;
     const float myb = (owner && bias) ? bias[myk] : 0.f;
+    if (ld_sc == 0) ld_sc = K;
     for (long row = wave0; row < rows; row += nwave) {
         const int b = (int)(row / rows_per_img);
         int pix = picks ? picks[row] : (int)(row - (long)b * rows_per_img);   // no picks: the whole table, in order
@@ -1963,8 +1965,8 @@ __global__ __launch_bounds__(256) void proto_fwd_lowrank_kernel(const float* __r
         ss = gx_wave_sum(ss);
         const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
         const float sc = ps_reduce<KP>(p, lane);
-        if (owner) scores[row * K + myk] = RAW ? sc : fmaf(sc, rn, myb);
-        if (lane == 0) rnorm[row] = RAW ? ss : rn;
+        if (owner) scores[row * ld_sc + myk] = RAW ? sc : fmaf(sc, rn, myb);
+        if (lane == 0) rnorm[row * ld_rn] = RAW ? ss : rn;
     }
 }
 
@@ -2283,8 +2285,9 @@ int gx_proto_fwd_lowrank(const float* Z, int B, int HW, int D, const int* picks,
 
 // dots [rows][K] = Z Wc^T and sumsq [rows] = |Z[row]|^2 of a finished table Z [rows][D] — no normalisation, no bias:
 // the inputs gx_fineq_fwd takes from the level below the finest.
-int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, float* dots, void* stream) {
-    if (!Z || !Wc || !sumsq || !dots || rows <= 0 || rows > 0x7FFFFFFFL) return GX_ERR_BAD_ARG;
+int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, long ld_sumsq, float* dots,
+                        long ld_dots, void* stream) {
+    if (!Z || !Wc || !sumsq || !dots || rows <= 0 || rows > 0x7FFFFFFFL || ld_sumsq < 1 || ld_dots < K) return GX_ERR_BAD_ARG;
     if (K < 1 || K > gx::LR_MAXK || (D & 255) || D > 256 * gx::PS_MAXV) return GX_ERR_BAD_ARG;
     long nb = (rows + 3) / 4;
     if (nb > 2048) nb = 2048;
@@ -2292,10 +2295,10 @@ int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K
     const size_t lds = (size_t)kp * D * sizeof(float);
     if (kp == 8)
         hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<8, true>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z,
-                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots);
+                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots, ld_sumsq, ld_dots);
     else
         hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<16, true>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z,
-                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots);
+                           (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots, ld_sumsq, ld_dots);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

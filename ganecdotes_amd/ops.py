@@ -426,15 +426,28 @@ def fineq_ok(k1, k2, k):
     return get_gemm_mode() == 1 and bool(lib().gx_fineq_ok(int(k1), int(k2), int(k)))
 
 
-def proto_raw_tables(z2d, wc):
-    """z2d (rows, D) finished table -> (sumsq (rows,), dots (rows, K) = z2d @ wc.T): no normalisation, no bias"""
-    _chk(z2d, wc)
+def fineq_ytable(rows_coarse, device):
+    """the coarse table of fineq_fwd: (rows/4, ld) fp32 — columns [0, 256) Y2 = 2 Zc Wf, [256, 256 + K) Ac = Zc Wc^T,
+    272 nc = |Zc|^2 — so that every share of a parent pixel reaches the kernel as a 128-B column block of one row"""
+    return torch.zeros(rows_coarse, lib().gx_fineq_ytable_ld(), dtype=torch.float32, device=device)
+
+
+def proto_raw_tables(z2d, wc, ytable=None):
+    """z2d (rows, D) finished table -> (sumsq (rows,), dots (rows, K) = z2d @ wc.T): no normalisation, no bias.
+    ytable: write them into columns 272 and [256, 256 + K) of a fineq_ytable instead (returns views of it)"""
+    _chk(z2d, wc, ytable)
     rows, d = z2d.shape
     k = wc.shape[0]
-    ss = torch.empty(rows, dtype=torch.float32, device=z2d.device)
-    dots = torch.empty(rows, k, dtype=torch.float32, device=z2d.device)
+    if ytable is None:
+        ss = torch.empty(rows, dtype=torch.float32, device=z2d.device)
+        dots = torch.empty(rows, k, dtype=torch.float32, device=z2d.device)
+    else:
+        if ytable.shape[0] != rows or ytable.shape[1] < 273:
+            raise RuntimeError("proto_raw_tables: ytable does not match")
+        ss, dots = ytable[:, 272], ytable[:, 256:256 + k]
     with record("proto_raw_tables_kernel", 0.0, 4.0 * rows * (d + k + 1)):
-        _lib.check(lib().gx_proto_raw_tables(_p(z2d), rows, d, _p(wc), k, _p(ss), _p(dots), _stream()), "gx_proto_raw_tables")
+        _lib.check(lib().gx_proto_raw_tables(_p(z2d), rows, d, _p(wc), k, _p(ss), ss.stride(0), _p(dots), dots.stride(0),
+                                             _stream()), "gx_proto_raw_tables")
     return ss, dots
 
 
@@ -447,18 +460,16 @@ def fineq_pack_weights(mg, wcf):
     return bq
 
 
-def fineq_fwd(t1, t2, bq_planes, y2, ac, nc, bias, fine_res):
-    """the finest level's score / rnorm tables from its taps t1 (rows, K1) [| t2 (rows, K2)] and the level below
-    (y2 = 2 Zc Wf, ac = Zc Wc^T, nc = |Zc|^2): returns (rn_table (rows,), sc_table (rows, K))"""
+def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
+    """the finest level's score / rnorm tables from its taps t1 (rows, K1) [| t2 (rows, K2)] and the coarse table of the
+    level below (fineq_ytable: y2 = 2 Zc Wf | ac = Zc Wc^T | nc = |Zc|^2): returns (rn_table (rows,), sc_table (rows, K))"""
     _chk2d(t1, t2)
-    _chk(y2, ac, nc, bias)
+    _chk(ytable, bias)
     rows, k1 = t1.shape
     k2 = 0 if t2 is None else t2.shape[1]
-    k = ac.shape[1]
-    if tuple(y2.shape) != (rows // 4, k1 + k2) or ac.shape[0] != rows // 4 or nc.numel() != rows // 4 or \
-            (t2 is not None and t2.shape[0] != rows):
-        raise RuntimeError("fineq_fwd: shape mismatch")
     L = lib()
+    if tuple(ytable.shape) != (rows // 4, L.gx_fineq_ytable_ld()) or (t2 is not None and t2.shape[0] != rows):
+        raise RuntimeError("fineq_fwd: shape mismatch")
     if bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
         raise RuntimeError("fineq_fwd: planes do not match (CF + 16, CF)")
     rn = torch.empty(rows, dtype=torch.float32, device=t1.device)
@@ -467,7 +478,7 @@ def fineq_fwd(t1, t2, bq_planes, y2, ac, nc, bias, fine_res):
     flops = 2.0 * rows * 16 * 32 * (sum(cf // 32 - (t >> 1) for t in range(cf // 16)) + cf // 16)   # blocks on / below the diagonal + scores
     with record("fineq_fwd_kernel", flops):
         _lib.check(L.gx_fineq_fwd(rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2), 0 if t2 is None else t2.stride(0),
-                                  _p(bq_planes), _p(y2), _p(ac), _p(nc), _p(bias), k, _p(rn), _p(sc), _stream()),
+                                  _p(bq_planes), _p(ytable), _p(bias), k, _p(rn), _p(sc), _stream()),
                    "gx_fineq_fwd")
     return rn, sc
 

@@ -125,10 +125,10 @@ class Pyramid:
         wcf = ops.gemm(wc, wf, False, False)                            # Wc Wf (K, CF)
         bq = ops.fineq_pack_weights(mg, wcf)
         zc2 = zc.reshape(-1, d)
-        y2 = torch.empty(zc2.shape[0], cf, dtype=torch.float32, device=wp.device)
-        ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous()), y2, alpha=2.0)   # 2 Zc Wf
-        nc, ac = ops.proto_raw_tables(zc2, wc)
-        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq), y2, ac, nc, bias, r)
+        yt = ops.fineq_ytable(zc2.shape[0], wp.device)                  # per parent pixel: 2 Zc Wf | Zc Wc^T | |Zc|^2
+        ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous()), yt[:, :cf], alpha=2.0)
+        ops.proto_raw_tables(zc2, wc, ytable=yt)
+        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq), yt, bias, k, r)
         self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf)
         return rn, sc, shift
 

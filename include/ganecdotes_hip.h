@@ -117,7 +117,8 @@ int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, 
  * Reference: swav_clustering.py:120-128 (nearest upsample + concat), :171-175 (projection, F.normalize, prototypes) and
  * autograd of them.  A finest-level pixel q with taps t(q) (CF = K1 + K2 channels) and parent p has z(q) = Wf t(q) + Zc[p];
  * the loss needs only <Wc_k, z> = (Wc Wf)_k . t + Ac[p][k] and |z|^2 = t^T (Wf^T Wf) t + t . Y2[p] + nc[p]
- * (Ac = Zc Wc^T, Y2 = 2 Zc Wf, nc = |Zc|^2: gx_proto_raw_tables and one gx_gemm_f32_nt_planes on the level below).
+ * (Ac = Zc Wc^T, Y2 = 2 Zc Wf, nc = |Zc|^2: gx_proto_raw_tables and one gx_gemm_f32_nt_planes on the level below, both
+ * writing into ONE table of gx_fineq_ytable_ld() floats per parent pixel).
  *   gx_fineq_ok            shapes this path takes: CF = 256 as one tap or as two taps of 128, K <= 16
  *   gx_fineq_pack_weights  Bq [CF + 16][CF] = [tri(Mg) ; Wcf ; 0] from Mg = Wf^T Wf [CF][CF] and Wcf = Wc Wf [K][CF]
  *                          (tri: 2 x strict lower + diagonal — t^T tri(M) t = t^T M t, k-tile kt only meets the column
@@ -130,9 +131,10 @@ int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, 
  *                          P [K][CF] = C[:, :K]^T t.  workspace: gx_fineq_bwd_pool_workspace_bytes(K, CF) */
 int gx_fineq_ok(int K1, int K2, int K);
 int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, float* Bq, void* stream);
+int gx_fineq_ytable_ld(void);   /* floats per parent pixel of the coarse table: [0, 256) Y2 | [256, 272) Ac | 272 nc | pad */
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
-                 const unsigned short* bq_planes, const float* Y2, const float* Ac, const float* nc, const float* bias,
-                 int K, float* rn_table, float* sc_table, void* stream);
+                 const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
+                 float* sc_table, void* stream);
 /* gx_fineq_bwd: the whole backward of the level in ONE pass over its taps — S [256][256] = sum_q C[q][K] t(q) t(q)^T (the
  * weighted Gram matrix: only the blocks on / above the diagonal are contracted), P [K][256] = C[:, :K]^T t, Tt, Cpool as
  * gx_fineq_bwd_pool.  workspace: gx_fineq_bwd_workspace_bytes(); fine_res a power of two >= 16 */
@@ -143,8 +145,10 @@ size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF);
 int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
                       long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,
                       void* stream);
-/* dots [rows][K] = Z Wc^T, sumsq [rows] = |Z[row]|^2 of a finished table Z [rows][D] (no normalisation, no bias) */
-int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, float* dots, void* stream);
+/* dots[row * ld_dots + k] = (Z Wc^T)[row][k], sumsq[row * ld_sumsq] = |Z[row]|^2 of a finished table Z [rows][D] (no
+ * normalisation, no bias); the strides let both land inside the coarse table of gx_fineq_fwd */
+int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, long ld_sumsq, float* dots,
+                        long ld_dots, void* stream);
 
 /* ---- generator forward (models/stylegan2/model.py) ------------------------------------------
  * gx_pixel_norm      PixelNorm                                   model.py:105-110

@@ -43,16 +43,17 @@ def want(name):
 
 mg = ops.gemm(wp, wp, True, False)
 wcf = ops.gemm(wc, wp, False, False)
-y2 = torch.empty(rc, CF, device=dev)
+yt = ops.fineq_ytable(rc, dev)
+y2 = yt[:, :CF]
 wft_planes = ops.split_gemm_weights(wp.t().contiguous())
 wf_planes = ops.split_gemm_weights(wp)
 if want("fwd"):
     show("y2 = 2 Zc Wf (0.5M x 512 -> 256)", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, y2, alpha=2.0)), 2.0 * rc * D * CF)
     show("raw tables of Zc", timeit(lambda: ops.proto_raw_tables(zc2, wc)), 0, 4.0 * rc * (D + K + 1))
-    nc, ac = ops.proto_raw_tables(zc2, wc)
+    ops.proto_raw_tables(zc2, wc, ytable=yt)
     pl = ops.split_gemm_weights(ops.fineq_pack_weights(mg, wcf))
     nblk = sum(8 - (t >> 1) for t in range(16)) + 16
-    show("fineq_fwd", timeit(lambda: ops.fineq_fwd(t1, t2, pl, y2, ac, nc, bias, R)), 2.0 * rows * 512 * nblk)
+    show("fineq_fwd", timeit(lambda: ops.fineq_fwd(t1, t2, pl, yt, bias, K, R)), 2.0 * rows * 512 * nblk)
     # the projected-table route
     z = torch.empty(rows, D, device=dev)
     wpl = ops.split_gemm_weights(torch.randn(D, CF, device=dev) / 16)
