@@ -282,6 +282,8 @@ class SwAVClustering(ViewMixin):
                 marg = [[self._marginals(imgs[v][b:b + 1].contiguous(), K, N) for b in range(B)] for v in range(2)]
                 r_one = torch.stack([torch.stack([m[0] for m in mv]) for mv in marg])   # (2, B, K)
                 c_one = torch.stack([torch.stack([m[1] for m in mv]) for mv in marg])   # (2, B, N)
+        if return_aux and marg is not None:                       # what the 'image' pdf prescribes (tests)
+            aux.update(norm_map_s=imgs[0], norm_map_t=imgs[1], r_marginals=r_one, c_marginals=c_one)
         ngroups = 1 if scope == 'global' else B                  # Sinkhorn problems per (patch, view)
         grows = rows // ngroups
         nglob = grows * (self.world if scope == 'global' else 1)

@@ -377,6 +377,87 @@ def test_bench_step_properties(gpu, bench_state, nproto):
         assert rel(a_, b_) < 1e-4
 
 
+def test_cat256_per_rank_step_properties(gpu, bench_state):
+    """configs[2]'s per-rank shape exactly as hfc_with_swav_cat_config.py:52-65 sets it: 16 images, 16 prototypes,
+    source_pdf='image', eps = 0.003.  The marginals the step prescribes are the reference's histograms of the whole norm
+    map (oracle image_marginals: K bins for the prototypes, one bin per sample), the codes are a transport plan onto
+    them (rows exactly — the last half-iteration —, prototype mass to Sinkhorn's residual), and the loss is the swapped
+    cross-entropy of those codes."""
+    from oracle import swav_ref as S
+    g, ml, make = bench_state
+    sw = make(16, batch=16, num_patches=1)
+    sw.sinkhorn_args.update(source_pdf="image", eps=0.003)
+    sw.eps = 0.003
+    torch.manual_seed(12)
+    np.random.seed(12)
+    images = sw.draw_batch(16)
+    torch.manual_seed(22)
+    loss, aux = sw.train_step(images, return_aux=True)
+    rows = 16 * 20000
+    assert np.isfinite(loss.item())
+    for v, tag in enumerate("st"):
+        img = aux[f"norm_map_{tag}"].cpu()
+        assert img.shape == (16, 256, 256)
+        r_ref, c_ref = S.image_marginals(img, 16, rows)
+        r, c = aux["r_marginals"][v].cpu(), aux["c_marginals"][v].cpu()
+        # a sample on a bin edge may fall either side of it in fp32: a few counts out of 1 M
+        assert float((r - r_ref).abs().max()) < 8.0 / img.numel() and float((c - c_ref).abs().max()) < 8.0 / img.numel()
+        q = aux[f"q_{tag}"].double().cpu()
+        assert q.shape == (rows, 16) and bool((q >= 0).all())
+        assert float((q.sum(1) - 1).abs().max()) < 1e-4
+        mass = (q * c.double()[:, None]).sum(0)                    # prototype mass of the plan diag(c) q
+        assert abs(float(mass.sum()) - 1) < 1e-5
+        assert float((mass - r.double()).abs().max()) < 0.3 * float(r.max()), (mass, r)   # Sinkhorn's residual after 10 iterations (random heads)
+    ps = torch.log_softmax(aux["scores_s"].double() / 0.01, 1)
+    pt = torch.log_softmax(aux["scores_t"].double() / 0.01, 1)
+    want = -0.5 * ((aux["q_t"].double() * ps).sum(1).mean() + (aux["q_s"].double() * pt).sum(1).mean())
+    np.testing.assert_allclose(loss.item(), float(want), rtol=1e-4)
+
+
+def test_car512_per_rank_step_properties(gpu):
+    """configs[3]'s per-rank shape (hfc_with_swav_car_config.py:52-65): a true 512^2 generator, 4 images, 16 prototypes,
+    eps = 0.01, all 5 patches of 20 000 of 262 144 pixels.  hlen = 5376 cuts the 512^2 taps off, so the score tables
+    live at 256^2 and the picks index them through the shift (pyramid.py); transport-plan, loss and reproducibility
+    properties as in test_bench_step_properties."""
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    g, _ = full_generator(512, seed=9)
+    g = g.to(gpu)
+    torch.manual_seed(2)
+    ml = g.mean_latent(64)
+
+    def make():
+        a = ffhq_args(4, 16)
+        a["perturb_args"] = dict(truncation=0.7, n_layers=7, n_samples=1, layer_no=None, perturb_std=[1.0] * 7)
+        a["sinkhorn_args"] = dict(source_pdf="uniform", niters=10, eps=0.01)
+        sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", **a)
+        sw.mean_latent = ml
+        torch.manual_seed(78)
+        sw.build_heads()
+        return sw
+    sw = make()
+    torch.manual_seed(14)
+    np.random.seed(14)
+    images = sw.draw_batch(4)
+    torch.manual_seed(24)
+    loss, aux = sw.train_step(images, return_aux=True)
+    rows = 4 * 20000
+    for tag in "st":
+        q = aux[f"q_{tag}"].double()
+        assert q.shape == (rows, 16) and bool((q >= 0).all())
+        assert float((q.sum(1) - 1).abs().max()) < 1e-4
+        col = q.sum(0) / rows
+        assert float((col * 16 - 1).abs().max()) < 0.2
+    assert np.isfinite(loss.item())
+    g0 = [x.clone() for x in sw._grads]
+    assert all(bool(torch.isfinite(x).all()) for x in g0)
+    sw2 = make()
+    torch.manual_seed(24)
+    loss2 = sw2.train_step(images)
+    np.testing.assert_allclose(loss2.item(), loss.item(), rtol=1e-5)
+    for a_, b_ in zip(sw2._grads, g0):
+        assert rel(a_, b_) < 1e-4
+
+
 def test_bench_cli_contract_one_json_line(gpu):
     """`python bench.py --gpus N --steps K --warmup W` as the driver runs it: exactly one JSON line on stdout with the
     contract's keys (metric / unit of BASELINE.json, whole-job value, roofline of the dominant kernel with
