@@ -398,3 +398,21 @@ def test_gv16_remaining_test_metrics():
     np.testing.assert_allclose([pdv[c] for c in classes], d["met_pd"])
     curve = O.iou_vs_pd_curve(mi, classes)
     np.testing.assert_allclose(np.array([curve[c] for c in classes + ["Mean"]]), d["met_curve"], atol=1e-15)
+
+
+def test_fixtures_regenerate_from_the_reference():
+    """tools/verify_golden.py: every capture script, run against /root/reference into a scratch directory, reproduces the
+    tracked tests/golden/*.npz array for array (only GV10's wall-clock log string may differ) and leaves the tracked files
+    untouched.  The reference exists in the build container only; elsewhere the fixtures are the pin."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/hfc_with_swav"):
+        pytest.skip("the reference tree is not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    before = {n: os.path.getmtime(os.path.join(golden, n)) for n in os.listdir(golden)}
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "verify_golden.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 unexpected difference(s)" in p.stdout
+    assert before == {n: os.path.getmtime(os.path.join(golden, n)) for n in os.listdir(golden)}

@@ -106,6 +106,16 @@ def _np(t):
     return t.detach().cpu().numpy().copy()
 
 
+def out_dir_arg(description=None):
+    """`--out DIR` of every capture script (default: tests/golden): capturing into a scratch directory leaves the
+    tracked fixtures untouched (tools/verify_golden.py compares the two)"""
+    ap = argparse.ArgumentParser(description=description)
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    return args.out
+
+
 class _Logger:
     def __init__(self):
         self.lines = []

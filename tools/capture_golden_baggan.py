@@ -14,11 +14,11 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from capture_golden import REF, _install_placeholders, _np   # noqa: E402
+from capture_golden import REF, _install_placeholders, _np, out_dir_arg   # noqa: E402
 
 
 def main():
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    out_dir = out_dir_arg(__doc__.splitlines()[0])
     _install_placeholders()
     sys.path.insert(0, REF)
     import matplotlib

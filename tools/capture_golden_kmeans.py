@@ -22,7 +22,7 @@ import tempfile
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from capture_golden import REF, _Logger, _install_placeholders, _np   # noqa: E402
+from capture_golden import REF, _Logger, _install_placeholders, _np, out_dir_arg   # noqa: E402
 
 
 def blobs(seed, n=700, c=24, k=5):
@@ -33,13 +33,19 @@ def blobs(seed, n=700, c=24, k=5):
 
 
 def main():
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    out_dir = out_dir_arg(__doc__.splitlines()[0])
     _install_placeholders()
+    # one thread everywhere: sklearn's threaded chunk sums (and torch's) round differently from run to run otherwise
+    # (A_*_inertia +-0.004, centres +-5e-7 between two captures), and the fixture must regenerate bit for bit
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
     import torch
     import torch.nn.functional as F
-    torch.set_num_threads(4)
+    torch.set_num_threads(1)
     import sklearn
     from sklearn.cluster import KMeans, kmeans_plusplus
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(1)
 
     arrs = dict(sklearn_version=np.asarray(sklearn.__version__))
     # ------------------------------------------------------------------ A: sklearn itself

@@ -18,7 +18,7 @@ import types
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from capture_golden import REF, _install_placeholders, _np   # noqa: E402
+from capture_golden import REF, _install_placeholders, _np, out_dir_arg   # noqa: E402
 
 UPFIRDN_CASES = [   # (major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
     (3, 9, 9, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1),        # mode 1 (blur after the transposed conv)
@@ -31,7 +31,7 @@ UPFIRDN_CASES = [   # (major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, dow
 
 
 def main():
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    out_dir = out_dir_arg(__doc__.splitlines()[0])
     _install_placeholders()
     for name in ("skimage.segmentation", "skimage.metrics"):
         sys.modules[name] = types.ModuleType(name)
