@@ -2183,13 +2183,16 @@ __global__ __launch_bounds__(256) void proto_lowrank_finish_kernel(const float* 
 // of the finished rows in the same pass.  One wave per coarse pixel = 2x2 block of fine pixels:
 // one coarse row + four fine rows in flight per lane.  ADD = false: the table is already finished (the
 // upsample-add rode on the projection GEMM's epilogue, gx_gemm_f32_upadd): tables only, nothing stored back.
-template <int KP, bool ADD>
+// RAW (with ADD = false): sc_table[q * ld_sc + k] = <fine[q], Wc_k>, rn_table[q * ld_rn] = |fine[q]|^2 — no normalisation,
+// no bias: the shares of the level below the finest that gx_fineq_fwd takes (gx_proto_raw_tables).
+template <int KP, bool ADD, bool RAW = false>
 __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* __restrict__ coarse, float* __restrict__ fine,
                                                                    long ncoarse, int rc, int D,
                                                                    const float* __restrict__ Wc,
                                                                    const float* __restrict__ bias, int K,
                                                                    float* __restrict__ rn_table,
-                                                                   float* __restrict__ sc_table) {
+                                                                   float* __restrict__ sc_table, long ld_rn = 1,
+                                                                   long ld_sc = 0) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];          // [KP][D] (rows >= K are zero)
     for (int i = threadIdx.x; i < KP * D; i += blockDim.x) wsm[i] = (i / D) < K ? Wc[i] : 0.f;
     __syncthreads();
@@ -2200,6 +2203,7 @@ __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* 
     const bool owner = ps_lane_owner<KP>(lane) && myk < K;
     const float myb = (owner && bias) ? bias[myk] : 0.f;
     const long per = (long)rc * rc;
+    if (ld_sc == 0) ld_sc = K;
     for (long g = wave0; g < ncoarse; g += nwave) {
         const long b = g / per, rem = g - b * per;
         const long cy = rem / rc, cx = rem - cy * rc;
@@ -2250,8 +2254,8 @@ __global__ __launch_bounds__(256) void upsample2_add_scores_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < KP; ++k) pj[k] = p[j][k];
             const float sc = ps_reduce<KP>(pj, lane);
-            if (owner) sc_table[pq[j] * K + myk] = fmaf(sc, rn, myb);
-            if (lane == 0) rn_table[pq[j]] = rn;
+            if (owner) sc_table[pq[j] * ld_sc + myk] = RAW ? sc : fmaf(sc, rn, myb);
+            if (lane == 0) rn_table[pq[j] * ld_rn] = RAW ? sj : rn;
         }
     }
 }
@@ -2293,6 +2297,25 @@ int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K
     if (nb > 2048) nb = 2048;
     const int kp = K <= 8 ? 8 : 16;
     const size_t lds = (size_t)kp * D * sizeof(float);
+    if (D <= 512 && rows % 4 == 0) {
+        // four rows in flight per wave (upsample2_add_scores_kernel's row loop: 4.8 TB/s against 2.3 with one): rows are
+        // independent here, so ANY grouping by four will do — the kernel's 2 x 2 blocks of a (1 x 2) x (rows / 2) "image"
+        const long ncoarse = rows / 4;
+        long nbk = (ncoarse + 3) / 4;
+        if (nbk > 4096) nbk = 4096;
+        // B = 1 image of 2 rc x 2 rc pixels needs a square; use the degenerate geometry rc = rows / 4, rf = 2 rc with
+        // per = rc * rc > ncoarse: every group g < ncoarse then has b = 0, cy = 0, cx = g: pixels 2 g, 2 g + 1, rf + 2 g, rf + 2 g + 1
+        // -> rows {2g, 2g+1} of the first half and {2g, 2g+1} + rows/2 of the second: all rows exactly once
+        const int rcq = (int)ncoarse;
+        if (kp == 8)
+            hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<8, false, true>), dim3((int)nbk), dim3(256), lds, (hipStream_t)stream,
+                               nullptr, const_cast<float*>(Z), ncoarse, rcq, D, Wc, nullptr, K, sumsq, dots, ld_sumsq, ld_dots);
+        else
+            hipLaunchKernelGGL((gx::upsample2_add_scores_kernel<16, false, true>), dim3((int)nbk), dim3(256), lds, (hipStream_t)stream,
+                               nullptr, const_cast<float*>(Z), ncoarse, rcq, D, Wc, nullptr, K, sumsq, dots, ld_sumsq, ld_dots);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     if (kp == 8)
         hipLaunchKernelGGL((gx::proto_fwd_lowrank_kernel<8, true>), dim3((int)nb), dim3(256), lds, (hipStream_t)stream, Z,
                            (int)rows, D, nullptr, nullptr, (int)rows, rows, Wc, nullptr, K, sumsq, dots, ld_sumsq, ld_dots);

@@ -134,11 +134,13 @@ class Generator(nn.Module):
             cin = cout
         self.n_latent = self.log_size * 2 - 2
         self._derived = None
+        self._xplanes = {}              # this generator's x-planes buffers, one per styled conv (ops.xplanes_buffer)
         self.want_image = True          # ToRGB branch can be skipped by feature-only callers
 
     # ------------------------------------------------------------------ derived (frozen) weights
     def _invalidate(self):
         self._derived = None
+        self._xplanes = {}
 
     def load_state_dict(self, *a, **k):
         self._invalidate()
@@ -274,12 +276,12 @@ class Generator(nn.Module):
         wtp = d[key + ".wtp"]
         cout = d[key + ".wt"].shape[1]
         if xp is None and self._uses_xp(m, key, bsz, h, w, d):
-            xp = ops.modsplit(x, s, out=ops.xplanes_buffer(bsz, h, w, cin, x.device, key))
+            xp = ops.modsplit(x, s, out=ops.xplanes_buffer(bsz, h, w, cin, x.device, key, cache=self._xplanes))
         oh, ow = (2 * h, 2 * w) if m.upsample else (h, w)
         ns = npl = None
         if nxt is not None and self._uses_xp(nxt[0], nxt[1], bsz, oh, ow, d):
             ns = self._slab(sp, bsz, d[nxt[1] + ".soff"])
-            npl = ops.xplanes_buffer(bsz, oh, ow, cout, x.device, nxt[1])
+            npl = ops.xplanes_buffer(bsz, oh, ow, cout, x.device, nxt[1], cache=self._xplanes)
         if m.upsample:
             out = ops.modconv_up(x, d[key + ".wt"], s, dm, d[key + ".kf"], noise, nw, b, True, wt_planes=wtp, x_planes=xp,
                                  next_style=ns, next_planes=npl)

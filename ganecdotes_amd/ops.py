@@ -647,14 +647,20 @@ def split_conv_weights(wt):
 _XPLANES = {}
 
 
-def xplanes_buffer(b, h, w, cin, device, slot=""):
+def xplanes_buffer(b, h, w, cin, device, slot="", cache=None):
     """A persistent x-planes buffer for (b, h, w, cin) (gx_xplanes_bytes; int16 view).  Its zero border is written
-    here, once; kernels only ever write the interior, so the buffer is reused step after step."""
-    key = (b, h, w, cin, str(device), slot)
-    buf = _XPLANES.get(key)
-    if buf is None:
-        buf = torch.zeros(lib().gx_xplanes_bytes(b, h, w, cin) // 2, dtype=torch.int16, device=device)
-        _XPLANES[key] = buf
+    here, once; kernels only ever write the interior, so the buffer is reused step after step.
+    cache: the owner's dict (a Generator keeps its own: two generators, or one generator on two streams, must not
+    share planes) holding ONE buffer per slot — a request with another shape (a different batch size) replaces it, so a
+    process that alternates between batch sizes does not pin a full set of planes per size.  Without `cache` a
+    module-wide dict keyed by the full shape is used (lab scripts).  Users of one cache are ordered on one stream."""
+    shape = (b, h, w, cin, str(device))
+    store, key = (_XPLANES, shape + (slot,)) if cache is None else (cache, slot)
+    hit = store.get(key)
+    if hit is not None and hit[0] == shape:
+        return hit[1]
+    buf = torch.zeros(lib().gx_xplanes_bytes(b, h, w, cin) // 2, dtype=torch.int16, device=device)
+    store[key] = (shape, buf)
     return buf
 
 

@@ -131,10 +131,14 @@ def test_generator_xp_path_equals_in_kernel_split(gpu):
         img0, taps0 = g([w], **kw)
         taps0 = [t.clone() for t in taps0]
         GM.CONV_XP = True
-        ops._XPLANES.clear()
+        g._xplanes.clear()
         img1, taps1 = g([w], **kw)
-        users = {k[-1] for k in ops._XPLANES}               # consumer layers that read x planes
+        users = set(g._xplanes)                              # consumer layers that read x planes (the generator's own buffers)
         assert {"convs.4", "convs.5", "convs.6", "convs.7"} <= users, users
+        # one buffer per layer: another batch size replaces it instead of pinning a second set
+        g([w[:4]], **kw)
+        assert set(g._xplanes) == users and any(shape[0] == 4 for shape, _ in g._xplanes.values())
+        img1, taps1 = g([w], **kw)
         assert rel(img1, img0) < 1e-5
         for a, b in zip(taps1, taps0):
             assert rel(a, b) < 1e-5
