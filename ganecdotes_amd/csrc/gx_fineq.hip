@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
         return (unsigned)(((row0 >> (2 * s)) * rc + (((row0 >> s) & msk) >> 1)) * rc + ((row0 & msk) >> 1));
     };
     auto issue_a = [&](int tm, int kt, int slot) {
+        if (FQ_ABL == 3) return;
         const bool second = kt >= nkt1;
         const unsigned so = (unsigned)tm * 128u * (unsigned)(second ? g.lda2 : g.lda1) * 4u + (unsigned)((second ? kt - nkt1 : kt) * 64);
         if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(lds + slot * FQ_A + wid * 1024), 16, (int)aoff2, (int)so, 0, 0);
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     };
     // B: the 1 KB chunks (plane p, column block nb >= kt / 2) of k-tile kt, chunk c = wave + 8 i (clamped: a few duplicates)
     auto issue_b = [&](int kt, int slot) {
+        if (FQ_ABL == 4) return;
         const int nblk = fq_nblk(kt), nch = 3 * nblk, nbmin = 9 - nblk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     // Y: block nb (8 = the Ac | nc columns) of tile tm for this wave's row group: parents 8 (wid >> 2) .. + 7, 128 B each
     const unsigned yoff = ((unsigned)(8 * (wid >> 2) + (lane >> 3)) * FQ_YLD) * 4u + (unsigned)(lane & 7) * 16u;
     auto issue_y = [&](int tm, int nb, int slot) {
+        if (FQ_ABL == 5) return;
         const unsigned so = (pbase_of(tm) * FQ_YLD + (unsigned)nb * 32u) * 4u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr_t)(ldsY + slot * FQ_Y + rg * 2048 + (wid >> 2) * 1024), 16, (int)yoff,
                                                  (int)so, 0, 0);
@@ -172,8 +175,9 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
         for (int r = 0; r < 16; ++r) sp[r] = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            fq_wait_vm(fq_vmcnt(t));
-            fq_barrier();
+            if (FQ_ABL >= 3 && FQ_ABL <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else fq_wait_vm(fq_vmcnt(t));
+            if (FQ_ABL != 7) fq_barrier();
             // issue: [Y] B(t + 2) A(t + 2) — Y first: its consumer (two k-tiles on) only waits for the A / B issued after it
             if (t & 1) issue_y(t == 15 ? tn : tm, ((t + 1) >> 1) & 7, ((t + 1) >> 1) & 1);
             if (t == 12) issue_y(tm, 8, 2);
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                 if (isL) run(std::integral_constant<bool, true>{});
                 else run(std::integral_constant<bool, false>{});
             }
-            if ((t & 1) && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
+            if ((t & 1) && FQ_ABL != 6 && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
                 const char* tsrc = lds + (((t - 1) + (r32 >> 4)) & 3) * FQ_A;
                 const char* ysrc = ldsY + (nb0 & 1) * FQ_Y + ybase;
                 auto fold = [&](const f32x16& u) {

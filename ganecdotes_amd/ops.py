@@ -429,7 +429,8 @@ def fineq_ok(k1, k2, k):
 def fineq_ytable(rows_coarse, device):
     """the coarse table of fineq_fwd: (rows/4, ld) fp32 — columns [0, 256) Y2 = 2 Zc Wf, [256, 256 + K) Ac = Zc Wc^T,
     272 nc = |Zc|^2 — so that every share of a parent pixel reaches the kernel as a 128-B column block of one row"""
-    return torch.zeros(rows_coarse, lib().gx_fineq_ytable_ld(), dtype=torch.float32, device=device)
+    # (not zeroed: the pad columns travel to LDS with their block but nothing reads them)
+    return torch.empty(rows_coarse, lib().gx_fineq_ytable_ld(), dtype=torch.float32, device=device)
 
 
 def proto_raw_tables(z2d, wc, ytable=None):
