@@ -741,7 +741,8 @@ def modconv_up(x, wt, s, dmod, kf, noise, noise_w, bias, act=True, wt_planes=Non
         else:
             _lib.check(L.gx_modconv_up_convt_p(_p(x), b, h, w, cin, _p(wt), _p(wt_planes), cout, _p(s), _p(scratch),
                                                _p(slab), sbytes, _stream()), "gx_modconv_up_convt_p")
-    tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
+    # T read once, the fp32 tap written once, and (when the next conv reads planes) the three bf16 planes of out * s_next
+    tbytes = 4.0 * b * cout * ((2 * h + 1) * (2 * w + 1) + 4 * h * w) + (6.0 * b * cout * 4 * h * w if next_planes is not None else 0.0)
     with record("blur_act_kernel", 0.0, tbytes):
         _lib.check(L.gx_blur_act_fwd_xp(_p(scratch), b, 2 * h + 1, 2 * w + 1, cout, _p(kf), _p(dmod), _p(nz), nbs,
                                         _p(noise_w), _p(bias), int(act), _p(out), _p(next_style), _p(next_planes),
