@@ -52,16 +52,12 @@ SIGNATURES = {
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
                                     c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
-    "gx_gemm_f32_tn_gram": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f,
-                                  c_i, c_p, c_sz, c_p]),
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gx_fineq_ytable_ld": (c_i, []),
     "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_fineq_bwd_workspace_bytes": (c_sz, []),
     "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
-    "gx_fineq_bwd_pool_workspace_bytes": (c_sz, [c_i, c_i]),
-    "gx_fineq_bwd_pool": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_proto_raw_tables": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p]),
     "gx_gemm_f32_upadd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p]),
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -18,7 +18,7 @@
 //                                           Tt[p] = sum_{q in p} e[q] t(q)               (rows/4 x CF)
 //     Gc   = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc        (the gradient that reaches the level below)
 //     gWc  = P Wf^T + Cpool[:, :K]^T Zc
-// gx_fineq_bwd_pool makes Tt, Cpool and P in one pass over the taps; S is the k-scaled TN GEMM gx_gemm_f32_tn_gram.
+// gx_fineq_bwd makes S, P, Tt and Cpool in ONE wave-specialised pass over the taps.
 #include "gx_mfma_x6.h"
 #include <type_traits>
 
@@ -293,67 +293,6 @@ __global__ void fineq_pack_kernel(const float* __restrict__ Mg, const float* __r
     }
 }
 
-// One pass over the finest taps for the backward: a wave per parent pixel p (its 2 x 2 children q), lane l owns columns
-// 4 l .. 4 l + 3 of the CF <= 256 tap channels.
-//   Tt[p]    = sum_q e[q] t(q)                  e = C[q][K]
-//   Cpool[p] = sum_q C[q][:]                    (stride ls)
-//   part_w[block][k][:] = sum over the block's pixels of C[q][k] t(q)        (-> P = C[:, :K]^T t by a fixed-order reduce)
-template <int KP>
-__global__ __launch_bounds__(256) void fineq_bwd_pool_kernel(const float* __restrict__ C, const float* __restrict__ A1, long lda1,
-                                                             int K1, const float* __restrict__ A2, long lda2, int CF, long ncoarse,
-                                                             int rc, int K, float* __restrict__ Tt, float* __restrict__ Cpool,
-                                                             float* __restrict__ part_w) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 256];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane * 4;
-    const bool cok = col < CF;
-    const bool second = col >= K1;
-    const float* src = second ? A2 + (col - K1) : A1 + col;
-    const long ld = second ? lda2 : lda1;
-    const long wave0 = (long)blockIdx.x * 4 + wid;
-    const long nwave = (long)gridDim.x * 4;
-    const int ls = (K + 1 + 3) & ~3, rf = 2 * rc;
-    const long per = (long)rc * rc;
-    f32x4 gw[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) gw[k] = zero4();
-    for (long p = wave0; p < ncoarse; p += nwave) {
-        const long b = p / per, rem = p - b * per;
-        const long cy = rem / rc, cx = rem - cy * rc;
-        long pq[4];
-        pq[0] = (b * rf + 2 * cy) * rf + 2 * cx;
-        pq[1] = pq[0] + 1; pq[2] = pq[0] + rf; pq[3] = pq[2] + 1;
-        float cv[4];
-        f32x4 t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cv[j] = lane < ls ? C[pq[j] * ls + lane] : 0.f;
-            t[j] = cok ? *reinterpret_cast<const f32x4*>(src + pq[j] * ld) : zero4();
-        }
-        f32x4 tt = zero4();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tt += __shfl(cv[j], K, 64) * t[j];
-#pragma unroll
-        for (int k = 0; k < KP; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[j]), k));
-                gw[k] += c * t[j];
-            }
-        if (cok) *reinterpret_cast<f32x4*>(Tt + p * CF + col) = tt;
-        if (lane < ls) Cpool[p * ls + lane] = (cv[0] + cv[1]) + (cv[2] + cv[3]);
-    }
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        if (k < K) {
-            __syncthreads();
-            *reinterpret_cast<f32x4*>(red + wid * 256 + lane * 4) = gw[k];
-            __syncthreads();
-            for (int c2 = threadIdx.x; c2 < CF; c2 += blockDim.x)
-                part_w[((long)blockIdx.x * K + k) * CF + c2] = (red[c2] + red[256 + c2]) + (red[512 + c2] + red[768 + c2]);
-        }
-    }
-}
-
 // ---- the backward of the finest level in ONE pass over its taps -------------------------------------------------------------
 // S = sum_q e[q] t(q) t(q)^T (CF x CF, symmetric), P = C[:, :K]^T t (K x CF), Tt[p] = sum over the 2x2 children of e[q] t(q),
 // Cpool[p] = the children's coefficient sums.  A wave-specialised TN contraction (the shape of gemm_x6ws_kernel): a
@@ -363,14 +302,22 @@ __global__ __launch_bounds__(256) void fineq_bwd_pool_kernel(const float* __rest
 //     the pair below it — the same parent; a thread owns tap columns 4 (l & 31) .. + 3 (+ 128).  It scales its taps by e,
 //     splits t and e t into bf16 planes (B and A images of the k-tile), sums e t over its pair, adds the partner lane's
 //     (lane ^ 32) and writes Tt; lanes l & 31 < stride do the same for the coefficients (Cpool) and put C[q][:K] into rows
-//     256 .. 271 of the A image, so that P comes out of the same MFMA loop;
+//     256 .. 271 (columns of its [k][m] image) of the A operand, so that P comes out of the same MFMA loop;
 //   consumer waves 0-7: the ten 64 x 64 blocks on or above the diagonal of S + two 32 x 128 blocks of P = 48 MFMA tiles,
-//     six per wave, two consumer waves per SIMD (each hides the other's LDS latency) — 75 % of the products of the full Gram matrix, none of the plain TN GEMM's second pass
-//     over the taps (the k-scaled gx_gemm_f32_tn_gram + the separate pool pass read them 2.5 times: 2.6 ms against ...).
+//     six per wave, two consumer waves per SIMD (each hides the other's LDS latency) — 75 % of the products of the full
+//     Gram matrix, and none of a plain TN GEMM's extra passes over the taps (round 3's first cut, a k-scaled TN GEMM + a
+//     separate pool pass, read them 2.5 times: 2.6 ms against 1.3).
 // Each workgroup leaves its partial [272][256] in the slab; fineq_bwd_reduce_kernel sums the slabs in a fixed order and
 // mirrors the upper blocks of S.
-constexpr int FB_RA = 288, FB_RB = 256;                                  // rows of the A image (256 + the 16 coefficient rows, padded) and of B
-constexpr int FB_SLOT = XImg<FB_RA>::BYTES + XImg<FB_RB>::BYTES;         // 28416 + 25344 B
+// LDS images of a k-tile, one per operand and plane: plain [16 k rows][m columns] bf16, exactly as the m-contiguous taps
+// arrive, read back TRANSPOSED by ds_read_b64_tr_b16 (guide T10): per 16-lane group a block of 4 k rows x 16 m columns, lane
+// i receiving column i — two of them are one 32x32x16 operand fragment (m = lane & 31, k = 8 (lane >> 5) .. + 7).  The
+// k-pair-packed image they replace needed four ds_read_b32 per fragment, at half the LDS rate (128 B/clk/CU, and far less at
+// two waves per SIMD: MI355X_MICROARCH.md, LDS) — it was what the producers and consumers of this kernel fought over.
+// Row stride 576 B = 64 (mod 256): the four rows of a block and the two blocks of a half-wave cover all 64 banks once.
+// A: 256 tap columns + the 16 coefficient columns + 16 zero columns = 288 columns = 576 B; B: 256 columns + 64 B of padding.
+constexpr int FB_RS = 576, FB_PL = 16 * FB_RS, FB_IMG = 3 * FB_PL;        // row stride, one plane, one operand image (27 KB)
+constexpr int FB_SLOT = 2 * FB_IMG;
 struct FineqBwdArgs {
     const float* C; int ls;                // coefficient grid [rows][ls]
     const float* T1; const float* T2;      // tap columns 0..127 and 128..255 (T2 = T1 + 128 for a single 256-channel tap)
@@ -402,6 +349,17 @@ constexpr int FB_GB[4][12] = {{0, 0, 32, 32, 64, 64, 96, 96, 128, 128, 160, 160}
                               {64, 64, 96, 96, 128, 128, 160, 160, 160, 160, 128, 128},
                               {192, 192, 224, 224, 224, 192, 160, 128, 96, 64, 32, 0}};
 struct FbFrag { bf16x8 p[3]; };
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// fragment (32 rows starting at column `col0` of the image, plane `pl`) for lane `lane`: toff = this lane's byte offset
+// inside a 4 x 16 block = (8 h + q) * FB_RS + (16 (g & 1) + 4 p) * 2 with g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, p = lane & 3
+__device__ __forceinline__ bf16x8 fb_frag(const char* img, int pl, int col0, int toff) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const char* a = img + pl * FB_PL + col0 * 2 + toff;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + 4 * FB_RS));
+    return __builtin_bit_cast(bf16x8, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
 // x (lanes 0-31) + x (lanes 32-63) in every lane: v_permlane32_swap (swaps a's upper half-wave with b's lower one, in place),
 // one VALU instruction instead of a ds_bpermute.  Inline asm: hipcc 7.2 returns the FIRST register for both elements of
 // __builtin_amdgcn_permlane32_swap's result (tools/lab history: r[0] + r[1] came out as 2 r[0]).
@@ -413,7 +371,8 @@ __device__ __forceinline__ float fb_half_sum(float x) {
 template <int W8>
 __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* lds, int nkt, int lane) {
     constexpr int W = W8 >> 1, N0 = 6 * (W8 & 1);                     // this wave: tiles N0 .. N0 + 5 of list W
-    constexpr int AIMG = XImg<FB_RA>::BYTES;
+    constexpr int AIMG = FB_IMG;
+    const int toff = (8 * (lane >> 5) + ((lane & 15) >> 2)) * FB_RS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     f32x16 acc[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j)
@@ -424,13 +383,13 @@ __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* l
     auto load_a = [&](const char* As, int row) {
         FbFrag f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.p[q] = x6_frag<false, FB_RA>(As, q, row + r32, hh);
+        for (int q = 0; q < 3; ++q) f.p[q] = fb_frag(As, q, row, toff);
         return f;
     };
     auto load_b = [&](const char* Bs, int row) {
         FbFrag f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.p[q] = x6_frag<false, FB_RB>(Bs, q, row + r32, hh);
+        for (int q = 0; q < 3; ++q) f.p[q] = fb_frag(Bs, q, row, toff);
         return f;
     };
     __syncthreads();                                                 // barrier 0
@@ -473,13 +432,13 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
     const int nkt = (int)max(0L, min((long)g.kt_per, g.nkt - kt0));
     char* slot0 = lds;
     char* slot1 = lds + FB_SLOT;
-    constexpr int APL = XImg<FB_RA>::MC_PLANE, ARW = XImg<FB_RA>::MC_ROWW, AIMG = XImg<FB_RA>::BYTES;
-    constexpr int BPL = XImg<FB_RB>::MC_PLANE, BRW = XImg<FB_RB>::MC_ROWW;
-    // rows 272 .. 287 of the A image are never written by the producers: zero them once (both slots, all planes)
-    for (int i = tid; i < 2 * 3 * 8 * 16; i += 768) {
-        const int sl = i / (3 * 8 * 16), r = i % (3 * 8 * 16);
-        const int pl = r / (8 * 16), kp = (r / 16) & 7, m = 272 + (r & 15);
-        *reinterpret_cast<unsigned*>(lds + sl * FB_SLOT + pl * APL + (kp * ARW + m) * 4) = 0u;
+    constexpr int AIMG = FB_IMG;
+    // columns 272 .. 287 of the A image are never written by the producers: zero them once (both slots, all planes, 16 k rows
+    // x 32 B = 8 words each)
+    for (int i = tid; i < 2 * 3 * 16 * 8; i += 768) {
+        const int sl = i / (3 * 16 * 8), r = i % (3 * 16 * 8);
+        const int pl = r / (16 * 8), k = (r / 8) & 15, w = r & 7;
+        *reinterpret_cast<unsigned*>(lds + sl * FB_SLOT + pl * FB_PL + k * FB_RS + 272 * 2 + w * 4) = 0u;
     }
 
     if (wid >= 8) {
@@ -517,37 +476,44 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
             const float e0 = T.e0, e1 = T.e1;
             char* A = slot;
             char* B = slot + AIMG;
+            // k rows 2 kp (pixel q0) and 2 kp + 1 (pixel q0 + 1) of the images; four columns = 8 B per row and plane
+            auto put = [&](char* img, int col, const f32x4& v0, const f32x4& v1) {
+                unsigned h[4], m[4], l[4];
+                split3(v0[0], v0[1], h[0], m[0], l[0]);
+                split3(v0[2], v0[3], h[1], m[1], l[1]);
+                split3(v1[0], v1[1], h[2], m[2], l[2]);
+                split3(v1[2], v1[3], h[3], m[3], l[3]);
+                char* d = img + (2 * kp) * FB_RS + col * 2;
+                *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+                *reinterpret_cast<u32x2*>(d + FB_PL) = (u32x2){m[0], m[1]};
+                *reinterpret_cast<u32x2*>(d + 2 * FB_PL) = (u32x2){l[0], l[1]};
+                *reinterpret_cast<u32x2*>(d + FB_RS) = (u32x2){h[2], h[3]};
+                *reinterpret_cast<u32x2*>(d + FB_RS + FB_PL) = (u32x2){m[2], m[3]};
+                *reinterpret_cast<u32x2*>(d + FB_RS + 2 * FB_PL) = (u32x2){l[2], l[3]};
+            };
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 t0 = T.v[2 * j], t1 = T.v[2 * j + 1];
                 const f32x4 s0 = e0 * t0, s1 = e1 * t1;
-                unsigned h[4], m[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3(t0[e], t1[e], h[e], m[e], l[e]);
-                char* pb = B + (kp * BRW + c4 + 128 * j) * 4;
-                *reinterpret_cast<u32x4*>(pb) = (u32x4){h[0], h[1], h[2], h[3]};
-                *reinterpret_cast<u32x4*>(pb + BPL) = (u32x4){m[0], m[1], m[2], m[3]};
-                *reinterpret_cast<u32x4*>(pb + 2 * BPL) = (u32x4){l[0], l[1], l[2], l[3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3(s0[e], s1[e], h[e], m[e], l[e]);
-                char* pa = A + (kp * ARW + c4 + 128 * j) * 4;
-                *reinterpret_cast<u32x4*>(pa) = (u32x4){h[0], h[1], h[2], h[3]};
-                *reinterpret_cast<u32x4*>(pa + APL) = (u32x4){m[0], m[1], m[2], m[3]};
-                *reinterpret_cast<u32x4*>(pa + 2 * APL) = (u32x4){l[0], l[1], l[2], l[3]};
+                put(B, c4 + 128 * j, t0, t1);
+                put(A, c4 + 128 * j, s0, s1);
                 // Tt: this pair + the pair below / above it (the partner lane holds the same columns of the same parent)
                 f32x4 tt = s0 + s1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tt[e] = fb_half_sum(tt[e]);
                 if (half == 0 && T.live) *reinterpret_cast<f32x4*>(g.Tt + T.par * 256 + c4 + 128 * j) = tt;
             }
-            if (mm < 16) {                                                   // coefficient rows 256 .. 271 of the A image
+            if (mm < 16) {                                                   // coefficient columns 256 .. 271 of the A image
                 const bool kok = mm < g.K;
-                unsigned h, m, l;
+                unsigned h, m, l;                                            // low half: pixel q0's, high half: pixel q0 + 1's
                 split3(kok ? T.c0 : 0.f, kok ? T.c1 : 0.f, h, m, l);
-                char* pa = A + (kp * ARW + 256 + mm) * 4;
-                *reinterpret_cast<unsigned*>(pa) = h;
-                *reinterpret_cast<unsigned*>(pa + APL) = m;
-                *reinterpret_cast<unsigned*>(pa + 2 * APL) = l;
+                char* d = A + (2 * kp) * FB_RS + (256 + mm) * 2;
+                *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h & 0xffffu);
+                *reinterpret_cast<unsigned short*>(d + FB_PL) = (unsigned short)(m & 0xffffu);
+                *reinterpret_cast<unsigned short*>(d + 2 * FB_PL) = (unsigned short)(l & 0xffffu);
+                *reinterpret_cast<unsigned short*>(d + FB_RS) = (unsigned short)(h >> 16);
+                *reinterpret_cast<unsigned short*>(d + FB_RS + FB_PL) = (unsigned short)(m >> 16);
+                *reinterpret_cast<unsigned short*>(d + FB_RS + 2 * FB_PL) = (unsigned short)(l >> 16);
             }
             const float cp = fb_half_sum(T.c0 + T.c1);
             if (half == 0 && mm < g.ls && T.live) g.Cpool[T.par * g.ls + mm] = cp;
@@ -616,22 +582,6 @@ __global__ void fineq_bwd_reduce_kernel(const float* __restrict__ slab, int nsla
         const float v = (s0 + s1) + (s2 + s3);
         if (row < 256) S[i] = v;
         else P[(row - 256) * 256 + col] = v;
-    }
-}
-
-// out[j] = beta * out[j] + sum_b part[b][j]   (fixed order)
-__global__ void fineq_reduce_kernel(const float* __restrict__ part, int nblk, int n, float beta, float* __restrict__ out) {
-#pragma clang fp contract(off)
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int b = 0;
-        for (; b + 3 < nblk; b += 4) {
-            s0 += part[(long)b * n + j]; s1 += part[(long)(b + 1) * n + j];
-            s2 += part[(long)(b + 2) * n + j]; s3 += part[(long)(b + 3) * n + j];
-        }
-        for (; b < nblk; ++b) s0 += part[(long)b * n + j];
-        const float v = (s0 + s1) + (s2 + s3);
-        out[j] = beta != 0.f ? beta * out[j] + v : v;
     }
 }
 
@@ -716,32 +666,6 @@ int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1
     hipLaunchKernelGGL(gx::fineq_bwd_kernel, dim3(nwg), dim3(768), 0, st, g);
     GX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gx::fineq_bwd_reduce_kernel, dim3(gx_cdiv((256 + K) * 256, 256)), dim3(256), 0, st, workspace, nwg, K, S, P);
-    GX_CHECK_LAUNCH();
-    return GX_OK;
-}
-
-size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF) { return (size_t)2048 * K * CF * sizeof(float); }
-int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
-                      long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,
-                      void* stream) {
-    if (!C || !t1 || !Tt || !Cpool || !P || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
-    if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
-    if (fine_res < 2 || (fine_res & 1) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
-    if ((ld1 & 3) || (K2 > 0 && (ld2 & 3)) || (K1 & 3) || (((uintptr_t)t1 | (uintptr_t)t2 | (uintptr_t)Tt) & 15)) return GX_ERR_ALIGN;
-    const int CF = K1 + K2;
-    if (!workspace || workspace_bytes < gx_fineq_bwd_pool_workspace_bytes(K, CF)) return GX_ERR_WORKSPACE;
-    const long ncoarse = rows / 4;
-    long nb = (ncoarse + 15) / 16;
-    if (nb > 2048) nb = 2048;
-    hipStream_t st = (hipStream_t)stream;
-    if (K <= 8)
-        hipLaunchKernelGGL((gx::fineq_bwd_pool_kernel<8>), dim3((int)nb), dim3(256), 0, st, C, t1, ld1, K1, K2 > 0 ? t2 : t1,
-                           K2 > 0 ? ld2 : ld1, CF, ncoarse, fine_res / 2, K, Tt, Cpool, workspace);
-    else
-        hipLaunchKernelGGL((gx::fineq_bwd_pool_kernel<16>), dim3((int)nb), dim3(256), 0, st, C, t1, ld1, K1, K2 > 0 ? t2 : t1,
-                           K2 > 0 ? ld2 : ld1, CF, ncoarse, fine_res / 2, K, Tt, Cpool, workspace);
-    GX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gx::fineq_reduce_kernel, dim3(gx_cdiv((long)K * CF, 256)), dim3(256), 0, st, workspace, (int)nb, K * CF, 0.f, P);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -41,10 +41,6 @@ struct GemmArgs {
     int n_group;          // gemm_xw_kernel: N tiles per group of the tile order (xw_tile_of)
     float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
-    // TN "gram" form (gemm_x6ws_kernel only): A = [A | A2m] along M (the first 128 rows of the 256-row tile from A, the rest
-    // from A2m) and every k row of A scaled by kscale[k * kscale_ld] on its way into the split
-    const float* A2m; long lda2m;
-    const float* kscale; long kscale_ld;
 };
 
 // (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
@@ -528,20 +524,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         auto load_tiles = [&](int t, f32x4 (&ra)[4], f32x4 (&rb)[2]) {     // tiles past kend load as zeros
             const int k0 = kbeg + t * XK;
             const bool second = !TA && k0 >= g.K1;
-            if (TA && VEC && g.A2m) {      // gram form: rows 0..127 of the tile from A, 128.. from A2m (tiles_m == 1)
-                x6_load_tile<false, true, 128>(g.A, g.lda, 0, 128, k0, kend, reinterpret_cast<f32x4(&)[2]>(ra[0]), p);
-                x6_load_tile<false, true, 128>(g.A2m, g.lda2m, 0, g.M - 128, k0, kend, reinterpret_cast<f32x4(&)[2]>(ra[2]), p);
-            } else {
-                x6_load_tile<A_KC, VEC, WS_BM>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M,
-                                               second ? k0 - g.K1 : k0,
-                                               second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, p);
-            }
-            if (TA && g.kscale) {          // ra[2 j + i] holds k = k0 + 2 (p >> 5) + i
-                const int kk = k0 + 2 * (p >> 5);
-                const float s0 = kk < kend ? g.kscale[(long)kk * g.kscale_ld] : 0.f;
-                const float s1 = kk + 1 < kend ? g.kscale[(long)(kk + 1) * g.kscale_ld] : 0.f;
-                ra[0] *= s0; ra[1] *= s1; ra[2] *= s0; ra[3] *= s1;
-            }
+            x6_load_tile<A_KC, VEC, WS_BM>(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M,
+                                           second ? k0 - g.K1 : k0,
+                                           second ? kend - g.K1 : (TA ? kend : min(kend, g.K1)), ra, p);
             x6_load_tile<B_KC, VEC, WS_BN>(Bsrc, ldbs, nb0, nbN, k0, kend, rb, p);
         };
         auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
@@ -621,12 +606,10 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1, const float* A2m = nullptr, long lda2m = 0, const float* kscale = nullptr,
-                       long kscale_ld = 0) {
+                       int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.n_group = 1;
-    g.A2m = A2m; g.lda2m = lda2m; g.kscale = kscale; g.kscale_ld = kscale_ld;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -644,11 +627,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool x6 = gemm_mode() == 1;
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
-    const bool gram = A2m != nullptr || kscale != nullptr;      // only the wave-specialised kernel's producers know these
-    if (gram && (!x6 || !transA || transB || !g.vec_ok || A2 || up_src || M <= BM || M > WS_BM || (A2m && (lda2m & 3)) ||
-                 (((uintptr_t)A2m) & 15)))
-        return GX_ERR_BAD_ARG;
-    const bool ws = gram || (x6 && M > BM && (split_k > 1 ? K / split_k : K) >= WS_MIN_K);
+    const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= WS_MIN_K;
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -716,7 +695,6 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     g.B = nullptr; g.ldb = 0; g.B2 = nullptr; g.ldb2 = 0; g.N1 = N; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
-    g.A2m = nullptr; g.lda2m = 0; g.kscale = nullptr; g.kscale_ld = 0;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
     const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
@@ -805,20 +783,6 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
     if (!B2 || N2 <= 0) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(1, 0, M, N1 + N2, K, A, lda, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
                            workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1);
-}
-
-// The weighted Gram form of the TN contraction: C (M1 + M2, N1 + N2) = alpha * ([A1 | A2] .* s)^T [B1 | B2] + beta * C with
-// A1 [K][M1], A2 [K][M2] (M1 = 128 when M2 > 0; M1 + M2 in (128, 256]), s[k] = kscale[k * kscale_ld] (kscale = NULL: 1),
-// B as gx_gemm_f32_tn_cat.  bf16x6 engine, 16-B aligned operands.  With A = B = the finest taps and s = the normalisation
-// coefficient of every pixel this is S = sum_q e[q] t(q) t(q)^T of gx_fineq.hip (autograd of swav_clustering.py:171-173).
-int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, long lda1, const float* A2, long lda2,
-                        const float* kscale, long kscale_ld, const float* B1, long ldb1, const float* B2, long ldb2, float* C,
-                        long ldc, float alpha, float beta, int split_k, float* workspace, size_t workspace_bytes, void* stream) {
-    if (M2 < 0 || N2 < 0 || (M2 > 0 && (!A2 || M1 != 128)) || (N2 > 0 && !B2) || (kscale && kscale_ld <= 0)) return GX_ERR_BAD_ARG;
-    if (!kscale && M2 == 0) return GX_ERR_BAD_ARG;                        // nothing of the gram form asked for: gx_gemm_f32
-    return gx::launch_gemm(1, 0, M1 + M2, N1 + N2, K, A1, lda1, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
-                           workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, N2 > 0 ? B2 : nullptr, ldb2,
-                           N2 > 0 ? N1 : -1, M2 > 0 ? A2 : nullptr, lda2, kscale, kscale_ld);
 }
 
 }  // extern "C"

@@ -484,28 +484,6 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
     return rn, sc
 
 
-def fineq_bwd_pool(coeffs, t1, t2, k, fine_res):
-    """coefficient grid (rows, stride) + the finest taps -> Tt (rows/4, CF), Cpool (rows/4, stride), P (K, CF)"""
-    _chk(coeffs)
-    _chk2d(t1, t2)
-    rows, k1 = t1.shape
-    k2 = 0 if t2 is None else t2.shape[1]
-    cf = k1 + k2
-    L = lib()
-    if coeffs.shape[0] != rows or coeffs.shape[1] != L.gx_lowrank_stride(k):
-        raise RuntimeError("fineq_bwd_pool: coefficient grid does not match (rows, K)")
-    tt = torch.empty(rows // 4, cf, dtype=torch.float32, device=t1.device)
-    cpool = torch.empty(rows // 4, coeffs.shape[1], dtype=torch.float32, device=t1.device)
-    pm = torch.empty(k, cf, dtype=torch.float32, device=t1.device)
-    wsb = L.gx_fineq_bwd_pool_workspace_bytes(k, cf)
-    ws = workspace("fineq_pool", wsb, t1.device)
-    with record("fineq_bwd_pool_kernel", 0.0, 4.0 * rows * (cf * 1.25 + coeffs.shape[1] * 1.25)):
-        _lib.check(L.gx_fineq_bwd_pool(_p(coeffs), rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2),
-                                       0 if t2 is None else t2.stride(0), k, _p(tt), _p(cpool), _p(pm), _p(ws), wsb, _stream()),
-                   "gx_fineq_bwd_pool")
-    return tt, cpool, pm
-
-
 def fineq_bwd(coeffs, t1, t2, k, fine_res):
     """coefficient grid (rows, stride) + the finest taps, ONE pass over the taps -> S (256, 256) = sum_q e[q] t t^T,
     P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride)"""
@@ -530,29 +508,6 @@ def fineq_bwd(coeffs, t1, t2, k, fine_res):
                                   0 if t2 is None else t2.stride(0), k, _p(s), _p(pm), _p(tt), _p(cpool), _p(ws), wsb,
                                   _stream()), "gx_fineq_bwd")
     return s, pm, tt, cpool
-
-
-def gemm_tn_gram(a1, a2, kscale, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
-    """out (M1+M2, N1+N2) = alpha * ([a1 | a2] * kscale[:, None]).T @ [b1 | b2] + beta*out; a* (K, M*), b* (K, N*),
-    kscale a 1-D (possibly strided) fp32 view of K elements or None; a2 / b2 may be None.  bf16x6 engine."""
-    _chk2d(a1, a2, b1, b2, out)
-    k, m1 = a1.shape
-    m2 = 0 if a2 is None else a2.shape[1]
-    n1 = b1.shape[1]
-    n2 = 0 if b2 is None else b2.shape[1]
-    if tuple(out.shape) != (m1 + m2, n1 + n2) or b1.shape[0] != k or (kscale is not None and (kscale.dim() != 1 or kscale.numel() != k)):
-        raise RuntimeError("gemm_tn_gram: shape mismatch")
-    L = lib()
-    ws, wsb = None, 0
-    if split_k > 1:
-        wsb = L.gx_gemm_f32_workspace_bytes(m1 + m2, n1 + n2, split_k)
-        ws = workspace("gemm", wsb, a1.device)
-    with record("gemm_f32_kernel", 2.0 * (m1 + m2) * (n1 + n2) * k):
-        _lib.check(L.gx_gemm_f32_tn_gram(m1, m2, n1, n2, k, _p(a1), a1.stride(0), _p(a2), 0 if a2 is None else a2.stride(0),
-                                         _p(kscale), 0 if kscale is None else kscale.stride(0), _p(b1), b1.stride(0), _p(b2),
-                                         0 if b2 is None else b2.stride(0), _p(out), out.stride(0), alpha, beta, split_k,
-                                         _p(ws), wsb, _stream()), "gx_gemm_f32_tn_gram")
-    return out
 
 
 # ------------------------------------------------------------------------------------- generator pieces

@@ -105,14 +105,6 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
 
-/* The weighted Gram form of the TN contraction (bf16x6 engine): C (M1 + M2, N1 + N2) = alpha * ([A1 | A2] .* s)^T [B1 | B2] +
- * beta * C with A1 [K][M1], A2 [K][M2] (M1 = 128 when M2 > 0, 128 < M1 + M2 <= 256), s[k] = kscale[k * kscale_ld] (NULL: 1),
- * B1 [K][N1], B2 [K][N2] (N1 a multiple of 128 when N2 > 0).  Autograd of the finest level's share of |z|^2
- * (swav_clustering.py:171-173): S = sum_q e[q] t(q) t(q)^T, see gx_fineq_*. */
-int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, long lda1, const float* A2, long lda2,
-                        const float* kscale, long kscale_ld, const float* B1, long ldb1, const float* B2, long ldb2, float* C,
-                        long ldc, float alpha, float beta, int split_k, float* workspace, size_t workspace_bytes, void* stream);
-
 /* ---- the finest pyramid level of the low-rank (K <= 16) path without its projected table (csrc/gx_fineq.hip) ----
  * Reference: swav_clustering.py:120-128 (nearest upsample + concat), :171-175 (projection, F.normalize, prototypes) and
  * autograd of them.  A finest-level pixel q with taps t(q) (CF = K1 + K2 channels) and parent p has z(q) = Wf t(q) + Zc[p];
@@ -126,25 +118,20 @@ int gx_gemm_f32_tn_gram(int M1, int M2, int N1, int N2, int K, const float* A1, 
  *   gx_fineq_fwd           rn_table [rows], sc_table [rows][K] (= gx_upsample2_add_scores' tables) from the taps, the planes
  *                          gx_split_gemm_weights(Bq) and the three coarse tables; rows = B * fine_res^2 pixels in (b, y, x)
  *                          order, fine_res a power of two >= 32
- *   gx_fineq_bwd_pool      from the coefficient grid C [rows][gx_lowrank_stride(K)] (gx_proto_bwd_lowrank*): Tt [rows/4][CF] =
- *                          sum over the 2x2 children of C[q][K] t(q), Cpool [rows/4][stride] = the children's coefficient sums,
- *                          P [K][CF] = C[:, :K]^T t.  workspace: gx_fineq_bwd_pool_workspace_bytes(K, CF) */
+ *   gx_fineq_bwd           from the coefficient grid C [rows][gx_lowrank_stride(K)] (gx_proto_bwd_lowrank*), ONE pass over the
+ *                          taps: S [256][256] = sum_q C[q][K] t(q) t(q)^T (the weighted Gram matrix; only the blocks on /
+ *                          above the diagonal are contracted, the rest mirrored), P [K][256] = C[:, :K]^T t, Tt [rows/4][256]
+ *                          = sum over the 2x2 children of C[q][K] t(q), Cpool [rows/4][stride] = the children's coefficient
+ *                          sums.  workspace: gx_fineq_bwd_workspace_bytes(); fine_res a power of two >= 16 */
 int gx_fineq_ok(int K1, int K2, int K);
 int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, float* Bq, void* stream);
 int gx_fineq_ytable_ld(void);   /* floats per parent pixel of the coarse table: [0, 256) Y2 | [256, 272) Ac | 272 nc | pad */
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
                  float* sc_table, void* stream);
-/* gx_fineq_bwd: the whole backward of the level in ONE pass over its taps — S [256][256] = sum_q C[q][K] t(q) t(q)^T (the
- * weighted Gram matrix: only the blocks on / above the diagonal are contracted), P [K][256] = C[:, :K]^T t, Tt, Cpool as
- * gx_fineq_bwd_pool.  workspace: gx_fineq_bwd_workspace_bytes(); fine_res a power of two >= 16 */
 size_t gx_fineq_bwd_workspace_bytes(void);
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream);
-size_t gx_fineq_bwd_pool_workspace_bytes(int K, int CF);
-int gx_fineq_bwd_pool(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2,
-                      long ld2, int K, float* Tt, float* Cpool, float* P, float* workspace, size_t workspace_bytes,
-                      void* stream);
 /* dots[row * ld_dots + k] = (Z Wc^T)[row][k], sumsq[row * ld_sumsq] = |Z[row]|^2 of a finished table Z [rows][D] (no
  * normalisation, no bias); the strides let both land inside the coarse table of gx_fineq_fwd */
 int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, long ld_sumsq, float* dots,

@@ -72,8 +72,8 @@ def test_fineq_tables_equal_the_projected_table_route(ops, k, two_taps):
 
 @pytest.mark.parametrize("k,two_taps", [(8, True), (16, True), (5, False)])
 def test_fineq_backward_equals_the_projected_table_route(ops, k, two_taps):
-    """d loss / d Wp and d loss / d Wc from a random coefficient grid: the Gram-form backward (gx_fineq_bwd_pool,
-    gx_gemm_f32_tn_gram, GEMMs on the level below) against the dense finish on the projected table + the pyramid adjoint."""
+    """d loss / d Wp and d loss / d Wc from a random coefficient grid: the Gram-form backward (gx_fineq_bwd,
+    GEMMs on the level below) against the dense finish on the projected table + the pyramid adjoint."""
     from ganecdotes_amd.pyramid import Pyramid
     b, d = 3, 512
     chans = {16: [64], 32: [128, 128], 64: [128, 128] if two_taps else [256]}
@@ -108,7 +108,7 @@ def test_fineq_backward_equals_the_projected_table_route(ops, k, two_taps):
 @pytest.mark.parametrize("k,two_taps,res", [(8, True, 64), (16, True, 32), (5, False, 16)])
 def test_fineq_bwd_one_pass_vs_fp64(ops, k, two_taps, res):
     """gx_fineq_bwd: the weighted Gram matrix S (upper blocks contracted, lower mirrored), P, the pooled e t and the pooled
-    coefficients from one pass over the taps — against fp64 and against the two-kernel form (gx_fineq_bwd_pool + tn_gram)"""
+    coefficients from one pass over the taps — against fp64"""
     torch.manual_seed(29)
     b = 3
     rows = b * res * res
@@ -126,27 +126,6 @@ def test_fineq_bwd_one_pass_vs_fp64(ops, k, two_taps, res):
     assert rel(pm, c[:, :k].double().t() @ t) < 3e-6
     pool = lambda x: x.reshape(b, res // 2, 2, res // 2, 2, -1).sum((2, 4)).reshape(rows // 4, -1)
     assert rel(tt, pool(t * e[:, None])) < 2e-6 and rel(cpool, pool(c.double())) < 2e-6
-    tt2, cpool2, pm2 = ops.fineq_bwd_pool(c, t1, t2, k, res)
-    assert rel(tt2, tt) < 2e-6 and rel(cpool2, cpool) < 2e-6 and rel(pm2, pm) < 3e-6
-
-
-def test_gemm_tn_gram_vs_fp64(ops):
-    """C = ([A1 | A2] .* s)^T [B1 | B2]: the k-scaled TN GEMM with its 256-row tile from two sources, split-K, beta"""
-    torch.manual_seed(3)
-    for (kk, split, two) in ((4096, 4, True), (1000, 1, True), (6000, 3, False)):
-        a1 = torch.randn(kk, 128 if two else 256).cuda()
-        a2 = torch.randn(kk, 128).cuda() if two else None
-        sfull = torch.randn(kk, 12).cuda()
-        sc = sfull[:, 8]                                        # strided 1-D view, like the coefficient grid's column K
-        prior = torch.randn(256, 256)
-        out = prior.clone().cuda()
-        ops.gemm_tn_gram(a1, a2, sc, a1, a2, out, alpha=0.5, beta=1.0, split_k=split)
-        a = a1 if a2 is None else torch.cat([a1, a2], 1)
-        want = prior.double() + 0.5 * ((a.double() * sc.double()[:, None]).t() @ a.double()).cpu()
-        assert rel(out, want) < 3e-6
-    with pytest.raises(RuntimeError):                          # the second A source needs the first to be 128 wide
-        ops.gemm_tn_gram(torch.randn(64, 64).cuda(), torch.randn(64, 128).cuda(), None, torch.randn(64, 128).cuda(), None,
-                         torch.empty(192, 128).cuda())
 
 
 def test_tables_shifted_below_levels_without_taps(ops):

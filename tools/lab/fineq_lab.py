@@ -62,11 +62,7 @@ if want("fwd"):
     show("old: score tables pass", timeit(lambda: ops.upsample2_add_scores_(None, z4, wc, bias)), 0, 4.0 * rows * (D + K + 1))
 if want("bwd"):
     show("fineq_bwd (S, P, Tt, Cpool in one pass)", timeit(lambda: ops.fineq_bwd(coeffs, t1, t2, K, R)), 2.0 * rows * 64 * 64 * 12, 4.0 * rows * CF * 1.25)
-    show("fineq_bwd_pool", timeit(lambda: ops.fineq_bwd_pool(coeffs, t1, t2, K, R)), 0, 4.0 * rows * (CF * 1.25 + ls * 1.25))
-    tt, cpool, pm = ops.fineq_bwd_pool(coeffs, t1, t2, K, R)
-    s = torch.empty(CF, CF, device=dev)
-    for split in (64, 128, 256):
-        show(f"gram S (split {split})", timeit(lambda: ops.gemm_tn_gram(t1, t2, coeffs[:, K], t1, t2, s, split_k=split)), 2.0 * rows * CF * CF)
+    s_, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, K, R)
     gc = torch.empty(rc, D, device=dev)
     show("Gc = Tt Wf^T (0.5M x 256 -> 512)", timeit(lambda: ops.gemm_nt_planes(tt, None, wf_planes, gc)), 2.0 * rc * D * CF)
     gwc = torch.empty(K, D, device=dev)
