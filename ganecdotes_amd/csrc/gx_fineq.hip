@@ -349,8 +349,6 @@ constexpr int FB_GB[4][12] = {{0, 0, 32, 32, 64, 64, 96, 96, 128, 128, 160, 160}
                               {64, 64, 96, 96, 128, 128, 160, 160, 160, 160, 128, 128},
                               {192, 192, 224, 224, 224, 192, 160, 128, 96, 64, 32, 0}};
 struct FbFrag { bf16x8 p[3]; };
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 // fragment (32 rows starting at column `col0` of the image, plane `pl`) for lane `lane`: toff = this lane's byte offset
 // inside a 4 x 16 block = (8 h + q) * FB_RS + (16 (g & 1) + 4 p) * 2 with g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, p = lane & 3
 __device__ __forceinline__ bf16x8 fb_frag(const char* img, int pl, int col0, int toff) {

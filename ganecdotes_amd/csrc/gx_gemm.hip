@@ -218,8 +218,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
 // The same contraction on the bf16 matrix cores (gx_mfma_x6.h): 128 x 128 x 16 tiles, every operand
 // element split into three bf16 on its way into LDS, six MFMA products per fp32 product.
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_x6_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (!TA && TB) ? 3 : 2) void gemm_x6_kernel(GemmArgs g) {   // (an m-contiguous operand image is 15 KB: two workgroups per CU)
     constexpr bool A_KC = !TA, B_KC = TB;
+    constexpr int X_TILE_BYTES = (A_KC && B_KC) ? gx::X_TILE_BYTES : X_TILE_BYTES_MC;     // (shadows the KC-only size)
     __shared__ __attribute__((aligned(16))) char lds[4 * X_TILE_BYTES];   // A0 B0 A1 B1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int ntile = g.tiles_m * g.tiles_n;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
 // while the producers fill slot (t+1)&1.  One producer and one consumer wave share each SIMD, so
 // the split arithmetic issues in the gaps of the other wave's MFMAs.
 constexpr int WS_BM = 256, WS_BN = 128, WS_THREADS = 512;
-constexpr int WS_SLOT = XImg<WS_BM>::BYTES + XImg<WS_BN>::BYTES;          // 25344 + 13056 B
+constexpr int WS_SLOT = XImg<WS_BM>::BYTES + XImg<WS_BN>::BYTES;          // 27648 + 15360 B
 
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {

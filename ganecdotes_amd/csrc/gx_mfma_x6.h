@@ -13,8 +13,11 @@
 //   KC image (k-contiguous source):  plane [128 rows][16 bf16], unpadded    — fragment = one ds_read_b128
 //        (32-B rows; the two 16-B halves of rows 8..15 (mod 16) are swapped, so the 16 lanes of a
 //        ds_read_b128 group fall in 16 distinct 4-bank slots)
-//   MC image (m-contiguous source):  plane [8 k-pairs][128 + 8 words]      — fragment = four ds_read_b32
-//        (a word = bf16 of k, k+1 for one m; lanes 0-31 / 32-63 land 32 banks apart)
+//   MC image (m-contiguous source):  plane [16 k rows][R bf16 + 64 B]      — the source's own layout, read back TRANSPOSED:
+//        fragment = two ds_read_b64_tr_b16 (per 16-lane group a block of 4 k rows x 16 m columns, lane i receiving column
+//        i: cdna_hip_programming.md T10).  Row stride 2 R + 64 B = 64 (mod 256): the four rows of a block and the two
+//        blocks of a half-wave cover all 64 banks once.  (Rounds 1-2 packed k-pairs into words and read four ds_read_b32
+//        per fragment: half the LDS rate, MI355X_MICROARCH.md "LDS", and what the TN kernels stalled on.)
 // Operand lane map of v_mfma_f32_32x32x16_bf16: lane (r = l & 31, h = l >> 5) holds row r, k = 8h..8h+7.
 #pragma once
 #include "gx_mfma.h"
@@ -33,12 +36,15 @@ constexpr int X_KC_ROW = 32;                        // bytes per row of a KC pla
 // wave-specialised 256 x 128 tile), filled by 256 threads.
 template <int R> struct XImg {
     static constexpr int KC_PLANE = R * X_KC_ROW;             // R = 128: 4096 B
-    static constexpr int MC_ROWW = R + 8;                     // words per k-pair row
-    static constexpr int MC_PLANE = 8 * MC_ROWW * 4;          // R = 128: 4352 B
+    static constexpr int MC_RS = 2 * R + 64;                  // bytes per k row of an MC plane (R = 128: 320, 256: 576)
+    static constexpr int MC_PLANE = 16 * MC_RS;               // R = 128: 5120 B
     static constexpr int BYTES = 3 * MC_PLANE;                // one image (the KC form is smaller)
     static constexpr int NV = R / 64;                         // float4 per thread per tile
 };
-constexpr int X_TILE_BYTES = XImg<128>::BYTES;      // 13056 B
+constexpr int X_TILE_BYTES = 3 * XImg<128>::KC_PLANE;          // one KC image of a 128-row operand: 12288 B
+constexpr int X_TILE_BYTES_MC = XImg<128>::BYTES;              // ... when an operand may be m-contiguous: 15360 B
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 // byte offset of the 16-B half `half` of row `row` inside a KC plane
 __device__ __forceinline__ int x_kc_off(int row, int half) { return row * X_KC_ROW + ((half ^ ((row >> 3) & 1)) << 4); }
 
@@ -126,27 +132,35 @@ __device__ __forceinline__ void x6_store_tile(char* __restrict__ S, const f32x4 
             *reinterpret_cast<u32x2*>(p + 2 * XImg<R>::KC_PLANE) = (u32x2){l[0], l[1]};
         }
     } else {
+        // v[2 j + i] = rows (m) 4 (t & 31) + 128 j .. + 3 at k = 2 (t >> 5) + i: four bf16 = 8 B of k row 2 (t >> 5) + i
 #pragma unroll
-        for (int j = 0; j < NV / 2; ++j) {
-            unsigned h[4], m[4], l[4];
+        for (int j = 0; j < NV / 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split3(v[2 * j][e], v[2 * j + 1][e], h[e], m[e], l[e]);   // (k, k+1) of one m
-            char* p = S + ((t >> 5) * XImg<R>::MC_ROWW + (t & 31) * 4 + 128 * j) * 4;
-            *reinterpret_cast<u32x4*>(p) = (u32x4){h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4*>(p + XImg<R>::MC_PLANE) = (u32x4){m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<u32x4*>(p + 2 * XImg<R>::MC_PLANE) = (u32x4){l[0], l[1], l[2], l[3]};
-        }
+            for (int i = 0; i < 2; ++i) {
+                unsigned h[2], m[2], l[2];
+                split3(v[2 * j + i][0], v[2 * j + i][1], h[0], m[0], l[0]);
+                split3(v[2 * j + i][2], v[2 * j + i][3], h[1], m[1], l[1]);
+                char* p = S + (2 * (t >> 5) + i) * XImg<R>::MC_RS + ((t & 31) * 4 + 128 * j) * 2;
+                *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[1]};
+                *reinterpret_cast<u32x2*>(p + XImg<R>::MC_PLANE) = (u32x2){m[0], m[1]};
+                *reinterpret_cast<u32x2*>(p + 2 * XImg<R>::MC_PLANE) = (u32x2){l[0], l[1]};
+            }
     }
 }
 
 template <bool KC, int R = 128>
 __device__ __forceinline__ bf16x8 x6_frag(const char* __restrict__ S, int plane, int row, int h) {
     if (KC) return *reinterpret_cast<const bf16x8*>(S + plane * XImg<R>::KC_PLANE + x_kc_off(row, h));
-    const unsigned* W = reinterpret_cast<const unsigned*>(S + plane * XImg<R>::MC_PLANE) + 4 * h * XImg<R>::MC_ROWW + row;
-    u32x4 w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = W[j * XImg<R>::MC_ROWW];
-    return __builtin_bit_cast(bf16x8, w);
+    // transposed read: `row` = the fragment's first row (a multiple of 32) + (lane & 31).  Lane 4 q + p of a 16-lane group
+    // supplies the address of k row q, columns 4 p .. 4 p + 3 of its block and receives the block's column (lane & 15);
+    // groups 0 / 1 of a half-wave are the fragment's rows 0-15 / 16-31, the two reads its k = 8 h .. + 3 and 8 h + 4 .. + 7.
+    // Every lane of the wave must be active (EXEC all ones: the gather crosses lanes).
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const int r = row & 31, q = (r & 15) >> 2, p = r & 3;
+    const char* a = S + plane * XImg<R>::MC_PLANE + (8 * h + q) * XImg<R>::MC_RS + ((row - r) + 16 * (r >> 4) + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + 4 * XImg<R>::MC_RS));
+    return __builtin_bit_cast(bf16x8, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
 // One 16-deep k-tile for a wave's (32 MT) x (32 NT) sub-tile at rows a_row0 / b_row0 of the images:
