@@ -50,7 +50,10 @@ SIGNATURES = {
     "gx_gemm_weight_planes_bytes": (c_sz, [c_i, c_i]),
     "gx_split_gemm_weights": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
-                                    c_p]),
+                                    c_p, c_f, c_p]),
+    "gx_sinkhorn_first_from_parts_workspace_bytes": (c_sz, [c_i, c_i]),
+    "gx_sinkhorn_first_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_first_preset": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
@@ -141,7 +144,7 @@ SIGNATURES = {
     "gx_hist_counts": (c_i, [c_p, c_l, c_p, c_i, c_p, c_p, c_p]),
     "gx_hist_finish": (c_i, [c_p, c_i, c_p]),
     "gx_sinkhorn_bigk_batch_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
-    "gx_sinkhorn_bigk_batch": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_bigk_batch": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_swapped_ce_workspace_bytes": (c_sz, [c_l, c_i]),
     "gx_swapped_ce_fused_workspace_bytes": (c_sz, [c_i]),
     "gx_swapped_ce_fused": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_f,

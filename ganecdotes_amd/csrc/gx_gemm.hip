@@ -40,6 +40,8 @@ struct GemmArgs {
     const unsigned short* Bp; unsigned Bp_bytes;   // pre-split B planes (gemm_xw_kernel), gx_gemm_weight_planes_bytes
     int n_group;          // gemm_xw_kernel: N tiles per group of the tile order (xw_tile_of)
     float* colmax_part;   // gemm_xw_kernel: [4 tiles_m][N] maxima of the written values over each wave's 32 rows, or nullptr
+    float* usum_part;     // ... and (with colmax_part) [4 tiles_m][N] sums of exp((value - that maximum) * sk_inv_eps) over the
+    float sk_inv_eps;     //     same rows: the first Sinkhorn pass, left behind by the GEMM that writes the scores
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
 };
 
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (!TA && TB) ? 3 : 2) void gemm_x6_ker
 // gemm_epilogue_staged<1, 2>, but with every global LOAD the 8 store passes need — the coarse rows of the fused
 // upsample-add, the row scales — issued up front: issued pass by pass behind the wave barriers each one cost a full
 // memory latency before its store (16 dependent round trips per tile).
+template <bool USUM>
 __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][2], int row0, int col0, int lane, float* stage,
                                             long part_row) {
 #pragma clang fp contract(off)      // one rounding per written operation: every epilogue form gives the same bits
@@ -336,6 +339,31 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
             cm[e] = fmaxf(cm[e], __shfl_xor(cm[e], 32));
         }
         if (lane < 16 && colok) *reinterpret_cast<f32x4*>(q.colmax_part + part_row * g.N + col) = cm;
+        if (USUM) {           // ... and the first Sinkhorn pass over these 32 rows, relative to their own maxima (merged later
+                              // by log-sum-exp: gx_sinkhorn_first_from_parts): one sweep of the score matrix fewer.  The
+                              // values are rebuilt from the staging area (same operations, same bits) instead of being
+                              // held in registers: the kernel keeps its four workgroups per CU
+            float* const usum_part = q.usum_part;
+            const float ie = q.sk_inv_eps * 1.44269504088896341f;
+            f32x4 us = zero4();
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + (ps * 4 + rl) * SW + c4);
+                v *= alpha;
+                v *= rs[ps];
+                v += cb;
+                v += up[ps];
+                if (row0 + ps * 4 + rl < g.M && colok)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) us[e] += __builtin_amdgcn_exp2f((v[e] - cm[e]) * ie);      // v_exp_f32: arguments <= 0, no range fix-up
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                us[e] += __shfl_xor(us[e], 16);
+                us[e] += __shfl_xor(us[e], 32);
+            }
+            if (lane < 16 && colok) *reinterpret_cast<f32x4*>(usum_part + part_row * g.N + col) = us;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -366,6 +394,7 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
 // Products and their order equal x6_mfma_tile's, so results are bitwise those of gemm_x6_kernel.
 //   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
 constexpr int XW_A = 8192, XW_B = 3 * 4096;                          // one A tile (raw fp32), one B tile (planes)
+template <bool USUM>         // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part)
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
     __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // A ring of NS tiles, B ring of 2
@@ -478,8 +507,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
         gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
     } else {
-        xw_epilogue(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
-        xw_epilogue(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
+        xw_epilogue<USUM>(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
+        xw_epilogue<USUM>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
     }
 }
 
@@ -610,7 +639,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        int N1 = -1) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
-    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.n_group = 1;
+    g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.usum_part = nullptr; g.sk_inv_eps = 0.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (split_k > 1 || up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -677,7 +706,8 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 // (gx_split_gemm_weights of the [N][K1 + K2] weight).  bf16x6 engine only; K1, K2 multiples of 16, rows 16-B aligned.
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
-                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream) {
+                          const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
+                          float* usum_part = nullptr, float sk_eps = 0.f) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -707,9 +737,12 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
         g.n_group = (int)gn;
     }
     if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;
+    if (usum_part && (!colmax_part || !(sk_eps > 0.f) || ((uintptr_t)usum_part & 15))) return GX_ERR_BAD_ARG;
     g.colmax_part = colmax_part;
+    g.usum_part = usum_part; g.sk_inv_eps = usum_part ? 1.f / sk_eps : 0.f;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
-    hipLaunchKernelGGL(gemm_xw_kernel, grid, block, 0, stream, g);
+    if (usum_part) hipLaunchKernelGGL(gemm_xw_kernel<true>, grid, block, 0, stream, g);
+    else hipLaunchKernelGGL(gemm_xw_kernel<false>, grid, block, 0, stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -769,9 +802,9 @@ size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, void* stream) {
+                          float* colmax_part, float* usum_part, float sk_eps, void* stream) {
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, colmax_part, (hipStream_t)stream);
+                              fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps);
 }
 // bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
 size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }

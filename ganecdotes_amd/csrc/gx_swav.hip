@@ -675,6 +675,29 @@ static inline int pick_team(int K) {
     return t;
 }
 
+// cmax [groups][N], u [groups][N] from the per-32-row-slice tables of gx_gemm_f32_nt_planes (colmax_part, usum_part):
+// a group = M / groups consecutive rows (a multiple of 32); fixed order, one thread per (group, column)
+__global__ void sk_first_from_parts_kernel(const float* __restrict__ cmp, const float* __restrict__ usp, int per_group, int N,
+                                           float inv_eps, float* __restrict__ cmax, float* __restrict__ u) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, gi = blockIdx.y;
+    if (col >= N) return;
+    const float* c = cmp + (long)gi * per_group * N + col;
+    const float* s = usp + (long)gi * per_group * N + col;
+    float m = -INFINITY;
+    for (int p = 0; p < per_group; ++p) m = fmaxf(m, c[(long)p * N]);
+    float acc = 0.f;
+    for (int p = 0; p < per_group; ++p) {
+        const float cp = c[(long)p * N];
+        if (cp > -INFINITY) acc += s[(long)p * N] * expf((cp - m) * inv_eps);
+    }
+    cmax[(long)gi * N + col] = m;
+    u[(long)gi * N + col] = acc;
+}
+__global__ void sk_first_preset_kernel(const float* __restrict__ u_local, const float* __restrict__ cmax_local, int K, float inv_eps,
+                                       const unsigned* __restrict__ cmax, float* __restrict__ u) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) u[k] = u_local[k] * expf((cmax_local[k] - ord2f(cmax[k])) * inv_eps);
+}
 }  // namespace gx
 
 using namespace gx;
@@ -906,6 +929,49 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
+// (a group with many slices is merged in two stages — chunks of 64 slices, then the chunks: the merge is associative —
+// so that the 10 000 slices of a 320 000-row score matrix are not one thread's serial loop; workspace: 2 * ceil(slices / 64)
+// * N floats = gx_sinkhorn_first_from_parts_workspace_bytes)
+size_t gx_sinkhorn_first_from_parts_workspace_bytes(int M, int N) {
+    return (size_t)2 * gx_cdiv(4L * gx_cdiv(M, 128), 64) * N * sizeof(float);
+}
+int gx_sinkhorn_first_from_parts(const float* colmax_part, const float* usum_part, int M, int N, int groups, float eps,
+                                 float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!colmax_part || !usum_part || !cmax || !u || M <= 0 || N <= 0 || groups < 1 || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    if (groups > 1 && (M % (32 * groups))) return GX_ERR_BAD_ARG;          // whole 32-row slices per group
+    const int per_group = groups > 1 ? M / (32 * groups) : 4 * gx_cdiv(M, 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (groups == 1 && per_group > 256) {
+        const int nch = gx_cdiv(per_group, 64);
+        if (!workspace || workspace_bytes < (size_t)2 * nch * N * sizeof(float)) return GX_ERR_WORKSPACE;
+        float* cm1 = workspace;
+        float* u1 = workspace + (size_t)nch * N;
+        // stage 1: chunk c = slices [64 c, 64 c + 64) (the last one shorter: blockIdx.y-dependent count inside the kernel
+        // is avoided by running the full chunks and the tail as two launches)
+        const int full = per_group / 64, tail = per_group - full * 64;
+        if (full > 0)
+            hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), full), dim3(64), 0, st, colmax_part, usum_part, 64, N,
+                               1.f / eps, cm1, u1);
+        if (tail > 0)
+            hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), 1), dim3(64), 0, st, colmax_part + (size_t)full * 64 * N,
+                               usum_part + (size_t)full * 64 * N, tail, N, 1.f / eps, cm1 + (size_t)full * N, u1 + (size_t)full * N);
+        GX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), 1), dim3(64), 0, st, cm1, u1, nch, N, 1.f / eps, cmax, u);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
+    hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), groups), dim3(64), 0, st, colmax_part,
+                       usum_part, per_group, N, 1.f / eps, cmax, u);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_sinkhorn_first_preset(const float* u_local, const float* cmax_local, int K, float eps, float* workspace, void* stream) {
+    if (!u_local || !cmax_local || !workspace || K <= 0 || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_first_preset_kernel, dim3(gx_cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, u_local, cmax_local,
+                       K, 1.f / eps, (const unsigned*)workspace, workspace + K);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 // la update from the (all-reduced) column sums u; `first` uses -cmax/eps from the workspace as base.
 int gx_sinkhorn_update(const float* u, const float* r, int K, int first, const float* workspace, float eps,
                        float* la, void* stream) {
@@ -949,9 +1015,10 @@ size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K) {
 }
 int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
                            const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
-                           float* la_all, float* workspace, size_t workspace_bytes, void* stream) {
+                           const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream) {
     if (!S_all || !la_all || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || ld < K || eps <= 0.f || niters < 1)
         return GX_ERR_BAD_ARG;
+    if (u_first_all && !cmax_all) return GX_ERR_BAD_ARG;
     if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || (prob_stride & 3)) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_sinkhorn_bigk_batch_workspace_bytes(nprob, rows, K)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -974,6 +1041,12 @@ int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long
     int kx = 1;
     while (kx < 64 && kx < K) kx <<= 1;
     for (int it = 0; it < niters; ++it) {
+        if (it == 0 && u_first_all) {      // the score GEMM left the first pass behind (gx_sinkhorn_first_from_parts)
+            hipLaunchKernelGGL(sk_update_la_kernel, dim3(gx_cdiv(K, 256), nprob), dim3(256), 0, st, u_first_all, r_all, K, 1, cmax,
+                               1.f / eps, la_all, r_stride);
+            GX_CHECK_LAUNCH();
+            continue;
+        }
         if (it == 0) {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), grid, dim3(256), lds, st, S_all, rows, K,
                                                             ld, 1.f / eps, cmax, la_all, c_all, 1.f / (float)rows, nullptr, part,

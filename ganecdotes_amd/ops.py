@@ -190,11 +190,13 @@ def gemm_planes_ok(a1, a2, n, out):
 
 
 def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0,
-                   want_colmax=False):
+                   want_colmax=False, sk_eps=None):
     """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
     split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd.
     want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out); an int g > 1:
-    the maxima of g equal row groups, (g, N) (rows per group a multiple of 32)."""
+    the maxima of g equal row groups, (g, N) (rows per group a multiple of 32).
+    sk_eps (with want_colmax): also return the FIRST Sinkhorn pass, u = exp((out - colmax) / sk_eps).sum(0) (per group), from
+    per-slice sums of the same epilogue: (out, colmax, u)."""
     _chk2d(a1, a2, out, coarse)
     _chk(row_scale, col_bias)
     m, k1 = a1.shape
@@ -207,19 +209,32 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
     L = lib()
     if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(n, k1 + k2):
         raise RuntimeError("gemm_nt_planes: planes do not match (N, K)")
-    part = None
+    part = upart = None
+    if sk_eps is not None and not want_colmax:
+        raise RuntimeError("gemm_nt_planes: sk_eps needs want_colmax")
     if want_colmax:
         pb = L.gx_gemm_colmax_part_bytes(m, n)
         part = workspace("gemm_colmax", pb, a1.device)[:pb // 4]
+        if sk_eps is not None:
+            upart = workspace("gemm_usum", pb, a1.device)[:pb // 4]
     with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
         _lib.check(L.gx_gemm_f32_nt_planes(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
                                            _p(b_planes), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
-                                           _p(coarse), fine_res, _p(part), _stream()), "gx_gemm_f32_nt_planes")
+                                           _p(coarse), fine_res, _p(part), _p(upart), 0.0 if sk_eps is None else float(sk_eps),
+                                           _stream()), "gx_gemm_f32_nt_planes")
     if want_colmax:
         g = 1 if want_colmax is True else int(want_colmax)
+        if g > 1 and m % (32 * g):
+            raise RuntimeError("gemm_nt_planes: row groups must be whole 32-row slices")
+        if sk_eps is not None:          # column maxima and first-pass sums of every group, merged by log-sum-exp
+            cm = torch.empty(g, n, dtype=torch.float32, device=out.device)
+            u = torch.empty(g, n, dtype=torch.float32, device=out.device)
+            wsb = L.gx_sinkhorn_first_from_parts_workspace_bytes(m, n)
+            ws = workspace("sk_first", wsb, out.device)
+            _lib.check(L.gx_sinkhorn_first_from_parts(_p(part), _p(upart), m, n, g, float(sk_eps), _p(cm), _p(u), _p(ws), wsb,
+                                                      _stream()), "gx_sinkhorn_first_from_parts")
+            return (out, cm[0], u[0]) if g == 1 else (out, cm, u)
         if g > 1:
-            if m % (32 * g):
-                raise RuntimeError("gemm_nt_planes: row groups must be whole 32-row slices")
             return out, part.view(-1, n)[:m // 32].view(g, m // (32 * g), n).amax(1)
         return out, part.view(-1, n).amax(0)
     return out
@@ -914,6 +929,7 @@ class Sinkhorn:
         self._ws = None
         self.la = torch.empty(self.K, dtype=torch.float32, device=scores.device) if la is None else la
         self.cmax_preset = None       # (K,) column maxima of `scores` when the producer already has them (gemm_nt_planes)
+        self.u_first_preset = None    # (K,) exp((scores - cmax_preset) / eps).sum(0): the first pass, from the same producer
 
     @property
     def ws(self):
@@ -953,6 +969,12 @@ class Sinkhorn:
 
     def sweep(self, first):
         S = self.S
+        if first and self.u_first_preset is not None and self.cmax_preset is not None:
+            # the score GEMM left this pass behind, relative to ITS maxima: rescale to the maxima now in the workspace
+            # (equal on one rank; after a cross-rank MAX all-reduce possibly larger)
+            _lib.check(lib().gx_sinkhorn_first_preset(_p(self.u_first_preset), _p(self.cmax_preset), self.K, self.eps,
+                                                      _p(self.ws), _stream()), "gx_sinkhorn_first_preset")
+            return
         _lib.check(lib().gx_sinkhorn_pass(_p(S), self.rows, self.K, S.stride(0), self.eps, int(first), _p(self.la),
                                           _p(self.c), self.c_uniform, None, _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_pass")
@@ -1003,7 +1025,8 @@ class SinkhornBatch:
         if reduce is not None:
             return self._run(reduce)
         # one read of every score matrix per half-iteration (+ the column maxima unless the score GEMM left them behind)
-        npass = self.niters + (0 if all(p.cmax_preset is not None for p in self.probs) else 1)
+        npass = self.niters + (0 if all(p.cmax_preset is not None for p in self.probs) else 1) - \
+            (1 if all(p.u_first_preset is not None for p in self.probs) else 0)
         with record("sinkhorn_pass_kernel", 0.0, 4.0 * self.nprob * self.rows * self.K * npass, launches=npass):
             return self._run(None)
 
@@ -1028,10 +1051,13 @@ class SinkhornBatch:
                 wsb = L.gx_sinkhorn_bigk_batch_workspace_bytes(self.nprob, self.rows, self.K)
                 ws = workspace(self.tag + ".bigk", wsb, S.device)
                 cm = torch.stack([p.cmax_preset for p in self.probs]).contiguous() if npre else None
+                uf = None
+                if npre and all(p.u_first_preset is not None for p in self.probs):
+                    uf = torch.stack([p.u_first_preset for p in self.probs]).contiguous()
                 _lib.check(L.gx_sinkhorn_bigk_batch(
                     _p(S), self.nprob, S.stride(0), self.rows, self.K, S.stride(1), self.eps, self.niters, _p(self.r),
                     0 if self.r is None else self.r.stride(0), _p(self.c), 0 if self.c is None else self.c.stride(0),
-                    _p(cm), _p(self.la), _p(ws), wsb, _stream()), "gx_sinkhorn_bigk_batch")
+                    _p(cm), _p(uf), _p(self.la), _p(ws), wsb, _stream()), "gx_sinkhorn_bigk_batch")
                 return self
             for p in self.probs:
                 p.run()

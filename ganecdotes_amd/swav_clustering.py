@@ -331,10 +331,12 @@ class SwAVClustering(ViewMixin):
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
                         X.append(x)
                     if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
-                        # (B*N, K), Wc split once per step; the Sinkhorn column maxima come out of the epilogue
+                        # (B*N, K), Wc split once per step; the Sinkhorn column maxima AND its first pass (the column sums of
+                        # exp((scores - max) / eps)) come out of the epilogue: nine sweeps of the score matrix, not eleven
                         if K > 64 and (ngroups == 1 or grows % 32 == 0):
-                            _, cmax_pre[(gi, v)] = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
-                                                                       want_colmax=True if ngroups == 1 else ngroups)
+                            _, cm_, uf_ = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
+                                                             want_colmax=True if ngroups == 1 else ngroups, sk_eps=self.eps)
+                            cmax_pre[(gi, v)] = (cm_, uf_)
                         else:
                             ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)
                     else:
@@ -349,9 +351,11 @@ class SwAVClustering(ViewMixin):
             with self._timed("sinkhorn"):
                 skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
                                         c=c_all, c_uniform=1.0 / nglob)
-                for (gi, v), cm in cmax_pre.items():
+                for (gi, v), (cm, uf) in cmax_pre.items():
                     for g in range(ngroups):
-                        skb[(gi * 2 + v) * ngroups + g].cmax_preset = cm if ngroups == 1 else cm[g]
+                        sk_ = skb[(gi * 2 + v) * ngroups + g]
+                        sk_.cmax_preset = cm if ngroups == 1 else cm[g]
+                        sk_.u_first_preset = uf if ngroups == 1 else uf[g]
                 skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
             if batched:
                 dS_all = torch.empty_like(Sc_all)

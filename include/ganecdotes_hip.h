@@ -99,11 +99,22 @@ int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, void* stream);
+                          float* colmax_part, float* usum_part, float sk_eps, void* stream);
 /* colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N] partial column maxima of C, one row per 32 rows
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
+/* usum_part (optional, with colmax_part; same size): per 32-row slice and column the sum of exp((C - that slice's maximum) /
+ * sk_eps) — the FIRST Sinkhorn pass (swav_clustering.py:519-520: Q = exp(scores / eps), its row sums) left behind by the GEMM
+ * that writes the scores.  gx_sinkhorn_first_from_parts merges the slices of `groups` equal row groups by log-sum-exp:
+ * cmax [groups][N] = the column maxima, u [groups][N] = sum over the group's rows of exp((C - cmax) / eps). */
+size_t gx_sinkhorn_first_from_parts_workspace_bytes(int M, int N);
+int gx_sinkhorn_first_from_parts(const float* colmax_part, const float* usum_part, int M, int N, int groups, float eps,
+                                 float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream);
+/* the first pass of a Sinkhorn problem whose producer left (cmax_local, u_local) behind: u (workspace + K) = u_local *
+ * exp((cmax_local - cmax) / eps) with cmax = the maxima now in the workspace (after a cross-rank MAX all-reduce they may
+ * exceed the local ones) — replaces gx_sinkhorn_pass(first = 1) */
+int gx_sinkhorn_first_preset(const float* u_local, const float* cmax_local, int K, float eps, float* workspace, void* stream);
 
 /* ---- the finest pyramid level of the low-rank (K <= 16) path without its projected table (csrc/gx_fineq.hip) ----
  * Reference: swav_clustering.py:120-128 (nearest upsample + concat), :171-175 (projection, F.normalize, prototypes) and
@@ -392,9 +403,10 @@ int gx_hist_finish(float* hist, int bins, void* stream);
  * S_all + i * prob_stride = problem i, [rows][K]; r_all / c_all NULL = uniform marginals; cmax_all NULL or the column
  * maxima [nprob][K] (from gx_gemm_f32_nt_planes' colmax_part: no pass for them); la_all [nprob][K]. */
 size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K);
+/* (u_first_all != NULL, with cmax_all: the first pass's column sums [nprob][K] relative to cmax_all come from the producer too) */
 int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
                            const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
-                           float* la_all, float* workspace, size_t workspace_bytes, void* stream);
+                           const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).

@@ -635,6 +635,18 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
             sk2.cmax_preset = cm
             sk2.run()
             np.testing.assert_allclose(sk2.la.cpu().numpy(), sk1.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
+            # ... and the FIRST Sinkhorn pass from the same epilogue: u_k = sum_n exp((out_nk - max_k) / eps), merged from
+            # per-32-row sums relative to their own maxima; the solver fed with both skips two sweeps of `out`
+            for eps in (0.05, 0.005):
+                _, cm2, uf = ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), out, col_bias=cb, want_colmax=True, sk_eps=eps)
+                assert torch.equal(cm2, cm)
+                want = torch.exp((out.double() - cm.double()) / eps).sum(0)
+                assert rel_err(uf, want) < 2e-5
+                sk0 = ops.Sinkhorn(out, eps, 5).run()
+                sk3 = ops.Sinkhorn(out, eps, 5, tag="skf")
+                sk3.cmax_preset, sk3.u_first_preset = cm2, uf
+                sk3.run()
+                np.testing.assert_allclose(sk3.la.cpu().numpy(), sk0.la.cpu().numpy(), rtol=1e-5, atol=2e-5)
         # per row group (the per-image Sinkhorn scope): groups of whole 32-row slices, and the batched solver fed with them
         g, rows, n, k = 16, 96, 132, 32
         a, w = dev(torch.randn(g * rows, k)), dev(0.3 * torch.randn(n, k))
@@ -647,6 +659,14 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
             fed[i].cmax_preset = cm[i]
         fed.run()
         np.testing.assert_allclose(fed.la.cpu().numpy(), plain.la.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        _, cm2, uf = ops.gemm_nt_planes(a, None, ops.split_gemm_weights(w), out, want_colmax=g, sk_eps=0.05)
+        assert torch.equal(cm2, cm)
+        assert rel_err(uf, torch.exp((out.view(g, rows, n).double() - cm.double()[:, None]) / 0.05).sum(1)) < 2e-5
+        fed2 = ops.SinkhornBatch(out.view(g, rows, n), 0.05, 5, tag="skfed2")
+        for i in range(g):
+            fed2[i].cmax_preset, fed2[i].u_first_preset = cm2[i], uf[i]
+        fed2.run()
+        np.testing.assert_allclose(fed2.la.cpu().numpy(), plain.la.cpu().numpy(), rtol=1e-5, atol=2e-5)
         a, w = dev(torch.randn(64, 24)), dev(torch.randn(16, 24))            # K % 16 != 0
         assert not ops.gemm_planes_ok(a, None, 16, torch.empty(64, 16, device="cuda"))
         with pytest.raises(RuntimeError):
