@@ -676,22 +676,35 @@ static inline int pick_team(int K) {
 }
 
 // cmax [groups][N], u [groups][N] from the per-32-row-slice tables of gx_gemm_f32_nt_planes (colmax_part, usum_part):
-// a group = M / groups consecutive rows (a multiple of 32); fixed order, one thread per (group, column)
-__global__ void sk_first_from_parts_kernel(const float* __restrict__ cmp, const float* __restrict__ usp, int per_group, int N,
-                                           float inv_eps, float* __restrict__ cmax, float* __restrict__ u) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, gi = blockIdx.y;
-    if (col >= N) return;
-    const float* c = cmp + (long)gi * per_group * N + col;
-    const float* s = usp + (long)gi * per_group * N + col;
-    float m = -INFINITY;
-    for (int p = 0; p < per_group; ++p) m = fmaxf(m, c[(long)p * N]);
-    float acc = 0.f;
-    for (int p = 0; p < per_group; ++p) {
-        const float cp = c[(long)p * N];
-        if (cp > -INFINITY) acc += s[(long)p * N] * expf((cp - m) * inv_eps);
+// group gi (blockIdx.y) = slices [gi * per_group, ...) — the last group may hold fewer (`total` slices in all).  A block =
+// 64 columns x 4 slice lanes (a lane takes every fourth slice of the group), merged through LDS in a fixed order:
+//     (m, s) + (m', s') = (max, s exp((m - max) / eps) + s' exp((m' - max) / eps))      — associative, so groups of
+// many slices are merged in stages (gx_sinkhorn_first_from_parts).
+__global__ __launch_bounds__(256) void sk_first_from_parts_kernel(const float* __restrict__ cmp, const float* __restrict__ usp,
+                                                                  int per_group, int total, int N, float inv_eps,
+                                                                  float* __restrict__ cmax, float* __restrict__ u) {
+    __shared__ float sm[4][64], ss[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx, gi = blockIdx.y;
+    const int p0 = gi * per_group, p1 = min(total, p0 + per_group);
+    float m = -INFINITY, acc = 0.f;
+    if (col < N) {
+        for (int p = p0 + py; p < p1; p += 4) m = fmaxf(m, cmp[(long)p * N + col]);
+        for (int p = p0 + py; p < p1; p += 4) {
+            const float cp = cmp[(long)p * N + col];
+            if (cp > -INFINITY) acc += usp[(long)p * N + col] * expf((cp - m) * inv_eps);
+        }
     }
-    cmax[(long)gi * N + col] = m;
-    u[(long)gi * N + col] = acc;
+    sm[py][cx] = m; ss[py][cx] = acc;
+    __syncthreads();
+    if (py == 0 && col < N) {
+        float mm = fmaxf(fmaxf(sm[0][cx], sm[1][cx]), fmaxf(sm[2][cx], sm[3][cx])), a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (sm[j][cx] > -INFINITY) a += ss[j][cx] * expf((sm[j][cx] - mm) * inv_eps);
+        cmax[(long)gi * N + col] = mm;
+        u[(long)gi * N + col] = a;
+    }
 }
 __global__ void sk_first_preset_kernel(const float* __restrict__ u_local, const float* __restrict__ cmax_local, int K, float inv_eps,
                                        const unsigned* __restrict__ cmax, float* __restrict__ u) {
@@ -929,11 +942,11 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
-// (a group with many slices is merged in two stages — chunks of 64 slices, then the chunks: the merge is associative —
-// so that the 10 000 slices of a 320 000-row score matrix are not one thread's serial loop; workspace: 2 * ceil(slices / 64)
-// * N floats = gx_sinkhorn_first_from_parts_workspace_bytes)
+// (a group with many slices is merged in stages — chunks of 64 slices, then the chunks — so that the 10 000 slices of a
+// 320 000-row score matrix are not one thread's serial loop; workspace: gx_sinkhorn_first_from_parts_workspace_bytes)
 size_t gx_sinkhorn_first_from_parts_workspace_bytes(int M, int N) {
-    return (size_t)2 * gx_cdiv(4L * gx_cdiv(M, 128), 64) * N * sizeof(float);
+    const long n1 = gx_cdiv(4L * gx_cdiv(M, 128), 64);
+    return (size_t)2 * (n1 + gx_cdiv(n1, 64)) * N * sizeof(float);
 }
 int gx_sinkhorn_first_from_parts(const float* colmax_part, const float* usum_part, int M, int N, int groups, float eps,
                                  float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream) {
@@ -941,27 +954,28 @@ int gx_sinkhorn_first_from_parts(const float* colmax_part, const float* usum_par
     if (groups > 1 && (M % (32 * groups))) return GX_ERR_BAD_ARG;          // whole 32-row slices per group
     const int per_group = groups > 1 ? M / (32 * groups) : 4 * gx_cdiv(M, 128);
     hipStream_t st = (hipStream_t)stream;
-    if (groups == 1 && per_group > 256) {
-        const int nch = gx_cdiv(per_group, 64);
-        if (!workspace || workspace_bytes < (size_t)2 * nch * N * sizeof(float)) return GX_ERR_WORKSPACE;
-        float* cm1 = workspace;
-        float* u1 = workspace + (size_t)nch * N;
-        // stage 1: chunk c = slices [64 c, 64 c + 64) (the last one shorter: blockIdx.y-dependent count inside the kernel
-        // is avoided by running the full chunks and the tail as two launches)
-        const int full = per_group / 64, tail = per_group - full * 64;
-        if (full > 0)
-            hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), full), dim3(64), 0, st, colmax_part, usum_part, 64, N,
-                               1.f / eps, cm1, u1);
-        if (tail > 0)
-            hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), 1), dim3(64), 0, st, colmax_part + (size_t)full * 64 * N,
-                               usum_part + (size_t)full * 64 * N, tail, N, 1.f / eps, cm1 + (size_t)full * N, u1 + (size_t)full * N);
-        GX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), 1), dim3(64), 0, st, cm1, u1, nch, N, 1.f / eps, cmax, u);
+    const dim3 blk(256);
+    if (groups > 1 || per_group <= 256) {
+        hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), groups), blk, 0, st, colmax_part, usum_part, per_group,
+                           per_group * groups, N, 1.f / eps, cmax, u);
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
-    hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), groups), dim3(64), 0, st, colmax_part,
-                       usum_part, per_group, N, 1.f / eps, cmax, u);
+    if (!workspace || workspace_bytes < gx_sinkhorn_first_from_parts_workspace_bytes(M, N)) return GX_ERR_WORKSPACE;
+    const float* cin = colmax_part;
+    const float* uin = usum_part;
+    int parts = per_group;
+    float* w = workspace;
+    while (parts > 256) {                                                // stage: chunks of 64 -> one pair of rows per chunk
+        const int nch = gx_cdiv(parts, 64);
+        float* cm1 = w;
+        float* u1 = w + (size_t)nch * N;
+        hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), nch), blk, 0, st, cin, uin, 64, parts, N, 1.f / eps, cm1, u1);
+        GX_CHECK_LAUNCH();
+        cin = cm1; uin = u1; parts = nch;
+        w += (size_t)2 * nch * N;
+    }
+    hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(N, 64), 1), blk, 0, st, cin, uin, parts, parts, N, 1.f / eps, cmax, u);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
