@@ -26,11 +26,15 @@ from .segmentor import _PLANS, OneShotSegmentor
 
 
 def _plan(size, in_ch, n_class):
+    """[(c_in, c_out, dilation, LeakyReLU after it, taps)]: 9-tap dilated convs, or — 'Lin' — ONE 1-tap layer (a per-pixel
+    nn.Linear) that KEEPS its LeakyReLU (hfc_with_swav/swav_clustering.py:708-712)"""
+    if size == 'Lin':
+        return [(in_ch, n_class, 0, True, 1)]
     if size not in _PLANS:
-        raise NotImplementedError(f"OneShotHead: size {size!r} has no HIP path ('Lin' is used by no shipped config)")
+        raise NotImplementedError(f"OneShotHead: unknown size {size!r}")
     dil, hidden = _PLANS[size]
     widths = [in_ch] + hidden + [n_class]
-    plan = [[a, b, d, True] for d, a, b in zip(dil, widths[:-1], widths[1:])]     # zip stops at len(dil) (reference)
+    plan = [[a, b, d, True, 9] for d, a, b in zip(dil, widths[:-1], widths[1:])]     # zip stops at len(dil) (reference)
     plan[-1][3] = False
     return [tuple(p) for p in plan]
 
@@ -46,19 +50,21 @@ class OneShotHead:
         self.plan = _plan(size, in_ch, n_class)
         self.size, self.in_ch, self.n_class = size, in_ch, n_class
         self.out_ch = self.plan[-1][1]
-        self.P = max(d for _, _, d, _ in self.plan)
+        self.P = max(p[2] for p in self.plan)
         self.load_module(OneShotSegmentor(in_ch, n_class, size))          # nn.Conv2d's default init
         self._step = 0
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd):
         self.W, self.b = [], []
-        for i, (cin, cout, _, _) in enumerate(self.plan):
+        for i, (cin, cout, _, _, ntap) in enumerate(self.plan):
             w = sd[f"layers.{2 * i}.weight"].detach().float()
-            if tuple(w.shape) != (cout, cin, 3, 3):
-                raise RuntimeError(f"layers.{2 * i}.weight: expected {(cout, cin, 3, 3)}, got {tuple(w.shape)}")
-            # tap-major [9][Cout][Cin]: one contiguous (Cout, Cin) GEMM operand per tap
-            self.W.append(w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous().to(self.device))
+            want = (cout, cin, 3, 3) if ntap == 9 else (cout, cin)
+            if tuple(w.shape) != want:
+                raise RuntimeError(f"layers.{2 * i}.weight: expected {want}, got {tuple(w.shape)}")
+            # tap-major [taps][Cout][Cin]: one contiguous (Cout, Cin) GEMM operand per tap
+            w = w.permute(2, 3, 0, 1).reshape(9, cout, cin) if ntap == 9 else w.reshape(1, cout, cin)
+            self.W.append(w.contiguous().to(self.device))
             self.b.append(sd[f"layers.{2 * i}.bias"].detach().float().contiguous().to(self.device))
         self._m = self._v = None
         self._step = 0
@@ -68,8 +74,9 @@ class OneShotHead:
 
     def state_dict(self):
         sd = {}
-        for i, (cin, cout, _, _) in enumerate(self.plan):
-            sd[f"layers.{2 * i}.weight"] = self.W[i].reshape(3, 3, cout, cin).permute(2, 3, 0, 1).contiguous()
+        for i, (cin, cout, _, _, ntap) in enumerate(self.plan):
+            sd[f"layers.{2 * i}.weight"] = (self.W[i].reshape(3, 3, cout, cin).permute(2, 3, 0, 1).contiguous() if ntap == 9
+                                            else self.W[i].reshape(cout, cin).clone())
             sd[f"layers.{2 * i}.bias"] = self.b[i].clone()
         return sd
 
@@ -92,13 +99,14 @@ class OneShotHead:
         """row range [lo, hi) the GEMMs run over: it covers every row whose taps stay in the buffer,
         [s, rows - s), widened to multiples of 4 rows (16-B vector loads of the m-contiguous GEMM
         operands); the few extra rows are border rows (masked to zero), read at most 3 guard rows and
-        never reach past the buffer (hi <= rows - s + 3 <= rows because s >= 3)."""
+        never reach past the buffer's guard rows (hi <= rows - s + 3: inside the buffer when s >= 3, at most 3 guard rows
+        — zeros, G = 4 — past it for the 1-tap 'Lin' layer, whose s is 0)."""
         lo = s & ~3
         hi = lo + ((rows - s - lo + 3) & ~3)
         return lo, hi
 
-    def _shift(self, tap, d, wp):
-        return ((tap // 3) - 1) * d * wp + ((tap % 3) - 1) * d
+    def _shift(self, tap, d, wp, ntap=9):
+        return 0 if ntap == 1 else ((tap // 3) - 1) * d * wp + ((tap % 3) - 1) * d
 
     def _buf(self, rows, c):
         """zeroed flat buffer with guard rows; returns (storage, logical view of `rows` rows)"""
@@ -121,10 +129,10 @@ class OneShotHead:
         lo, hi = self._range(rows, s)
         g = self.G
         acts, x = [], xst
-        for i, (cin, cout, d, act) in enumerate(self.plan):
+        for i, (cin, cout, d, act, ntap) in enumerate(self.plan):
             yst, y = self._buf(rows, cout)
-            for tap in range(9):
-                sh = self._shift(tap, d, wp)
+            for tap in range(ntap):
+                sh = self._shift(tap, d, wp, ntap)
                 ops.gemm(x[g + lo + sh:g + hi + sh], self.W[i][tap], False, True, out=yst[g + lo:g + hi],
                          beta=0.0 if tap == 0 else 1.0, col_bias=self.b[i] if tap == 0 else None)
             _lib.check(lib().gx_head_act_mask(_p(y), b, h, w, cout, self.P, int(act), _stream()), "gx_head_act_mask")
@@ -140,24 +148,24 @@ class OneShotHead:
         grads = [None] * len(self.plan)
         dyst = dlst
         for i in reversed(range(len(self.plan))):
-            cin, cout, d, act = self.plan[i]
+            cin, cout, d, act, ntap = self.plan[i]
             x = xst if i == 0 else acts[i - 1][0]
             dy = dyst[g:g + rows]
-            if i != len(self.plan) - 1:          # through the LeakyReLU + border mask that follow layer i
+            if act:                              # through the LeakyReLU + border mask that follow layer i
                 _lib.check(lib().gx_head_act_mask_bwd(_p(dy), _p(acts[i][1]), b, h, w, cout, self.P, int(act), _stream()),
                            "gx_head_act_mask_bwd")
-            dw = torch.empty(9, cout, cin, dtype=torch.float32, device=self.device)
+            dw = torch.empty(ntap, cout, cin, dtype=torch.float32, device=self.device)
             split = int(max(1, min(256, (hi - lo) // 2048)))
-            for tap in range(9):
-                sh = self._shift(tap, d, wp)
+            for tap in range(ntap):
+                sh = self._shift(tap, d, wp, ntap)
                 ops.gemm(dyst[g + lo:g + hi], x[g + lo + sh:g + hi + sh], True, False, out=dw[tap], split_k=split)
             db = torch.empty(cout, dtype=torch.float32, device=self.device)
             ops.colsum(dy, db)
             grads[i] = (dw, db)
             if i > 0:
                 dxst, _ = self._buf(rows, cin)
-                for tap in range(9):
-                    sh = self._shift(tap, d, wp)
+                for tap in range(ntap):
+                    sh = self._shift(tap, d, wp, ntap)
                     ops.gemm(dyst[g + lo - sh:g + hi - sh], self.W[i][tap], False, False, out=dxst[g + lo:g + hi],
                              beta=0.0 if tap == 0 else 1.0)
                 dyst = dxst

@@ -5,7 +5,7 @@ Same constructor `(in_ch, n_class, size)` and layer plan as the reference's OneS
 ('XXS'..'L') or a per-pixel linear layer ('Lin').  This is the torch module the plugin surface exports
 and that `projection.pt`-style pickles / `OneShotHead.to_module()` hand back; the fine-tune and the test
 loop themselves run on HIP (ganecdotes_amd/oneshot.py `OneShotHead`, csrc/gx_head.hip — same plan, same
-`layers.{2i}.weight/bias` state_dict keys; 'Lin', used by no shipped config, has no HIP twin).
+`layers.{2i}.weight/bias` state_dict keys; 'Lin' is a single 1-tap layer there).
 """
 from torch import nn
 

@@ -17,7 +17,10 @@ import torch.nn.functional as F
 def segmentor_plan(size, in_ch, n_class):
     """[(c_in, c_out, dilation, leaky_relu_after)] of OneShotSegmentor
     (hfc_with_swav/swav_clustering.py:697-741).  zip() stops at len(dilations) and the trailing
-    LeakyReLU is dropped, so 'XXS' is ONE conv in_ch -> 12 whatever n_class is."""
+    LeakyReLU is dropped, so 'XXS' is ONE conv in_ch -> 12 whatever n_class is.  'Lin' (:708-712) is a per-pixel
+    nn.Linear(in_ch, n_class) FOLLOWED by its LeakyReLU(0.2): dilation 0 marks the 1x1 form."""
+    if size == 'Lin':
+        return [(in_ch, n_class, 0, True)]
     dil = {'XXS': [1], 'XS': [1, 2, 1], 'S': [1, 2, 1, 2, 1], 'M': [1, 2, 4, 1, 2, 4, 1],
            'L': [1, 2, 4, 8, 1, 2, 4, 8, 1]}[size]
     ch = {'XXS': [12], 'XS': [16, 8], 'S': [128, 64, 64, 32], 'M': [128, 64, 64, 64, 64, 32],
@@ -32,7 +35,11 @@ def segmentor_forward(x, params, plan):
     """OneShotSegmentor.forward (:744-758) for the conv sizes.  x (B, C, H, W); params = [w0, b0, w1, ...]
     with w (c_out, c_in, 3, 3)."""
     for i, (_, _, d, act) in enumerate(plan):
-        x = F.conv2d(x, params[2 * i], params[2 * i + 1], padding=d, dilation=d)
+        w = params[2 * i]
+        if w.dim() == 2:                      # 'Lin' (:748-755): view / permute / Linear / permute back == a 1x1 conv
+            x = F.conv2d(x, w[:, :, None, None], params[2 * i + 1])
+        else:
+            x = F.conv2d(x, w, params[2 * i + 1], padding=d, dilation=d)
         if act:
             x = F.leaky_relu(x, 0.2)
     return x

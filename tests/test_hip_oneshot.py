@@ -24,7 +24,7 @@ def rel(a, b):
     return float((a.detach() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("size", ["XXS", "XS"])
+@pytest.mark.parametrize("size", ["XXS", "XS", "Lin"])
 def test_head_finetune_golden_gv13(gpu, size):
     """the reference's OneShotSegmentor trained the run_trainer way (Adam + CrossEntropyLoss, 6 epochs):
     first forward, per-epoch losses, final weights and predictions"""

@@ -228,7 +228,7 @@ def test_gv12_simclr_trajectory_and_predict():
 
 
 # ------------------------------------------------------------------------------------- GV13: one-shot head
-@pytest.mark.parametrize("size", ["XXS", "XS"])
+@pytest.mark.parametrize("size", ["XXS", "XS", "Lin"])
 def test_oneshot_head_finetune_golden_gv13(size):
     from oracle import oneshot_ref as O
     d = load_golden("gv13_oneshot")
@@ -237,7 +237,7 @@ def test_oneshot_head_finetune_golden_gv13(size):
     keys = sorted((k for k in d if k.startswith(f"{size}_init_")),
                   key=lambda k: (int(k.split("layers.")[1].split(".")[0]), "bias" in k))
     params = [torch.from_numpy(d[k]) for k in keys]
-    assert [tuple(p.shape) for p in params[::2]] == [(b, a, 3, 3) for a, b, _, _ in plan]
+    assert [tuple(p.shape) for p in params[::2]] == [(b, a, 3, 3) if dd else (b, a) for a, b, dd, _ in plan]
     np.testing.assert_allclose(O.segmentor_forward(feats, params, plan).numpy(), d[f"{size}_out0"], rtol=1e-5, atol=1e-6)
     losses, final = O.finetune(feats, labels, params, plan, epochs=len(d[f"{size}_losses"]), lr=float(d["lr"]),
                                beta1=float(d["beta1"]), beta2=float(d["beta2"]), step_size=int(d["step_size"]),

@@ -43,8 +43,8 @@ def main():
     arrs = dict(lr=np.float64(tc.lr), beta1=np.float64(tc.beta1), beta2=np.float64(tc.beta2),
                 step_size=np.int64(tc.scheduler_args["step_size"]), gamma=np.float64(tc.scheduler_args["gamma"]))
     in_ch, n_class, hw, epochs = 16, 5, 20, 6
-    for size in ("XXS", "XS"):
-        torch.manual_seed(1300 + len(size))
+    for size in ("XXS", "XS", "Lin"):         # 'Lin': the per-pixel Linear + LeakyReLU head (used by no shipped config)
+        torch.manual_seed(1300 + len(size) + (7 if size == "Lin" else 0))
         seg = SC.OneShotSegmentor(in_ch=in_ch, n_class=n_class, size=size).train()
         feats = torch.randn(1, in_ch, hw, hw)
         labels = torch.randint(0, n_class, (1, hw, hw))
