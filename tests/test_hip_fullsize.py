@@ -27,6 +27,12 @@ def gpu():
     return torch.device("cuda")
 
 
+# north_star asks for 1e-3 relative in fp32; the step measures ~3e-7 on the loss and ~2e-6 (max-norm) on the gradients
+# against the oracle on either engine (tools/lab/step_errors.py), so the full-size tests hold it to 1e-4
+LOSS_TOL = 1e-4
+GRAD_TOL = 1e-4
+
+
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
@@ -98,11 +104,47 @@ def test_ffhq256_full_size_step_vs_oracle(gpu, engine):
         sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=5376,
         patch_size=20000, num_patches=1, temperature=0.01, eps=0.005, niters=10, source_pdf="uniform",
         sinkhorn_scope="global")
-    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)          # north_star: 1e-3 relative fp32
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_TOL)
     for got, want in zip(sw._grads, grads):
-        assert rel(got, want) < 2e-3
+        assert rel(got, want) < GRAD_TOL
     for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
-        assert rel(got, want) < 1e-4
+        assert rel(got, want) < 1e-5
+
+
+
+@pytest.mark.parametrize("nproto", [8, 5000])
+def test_ffhq256_batch2_two_patches_step_vs_oracle(gpu, engine, nproto):
+    """the batched form of the step against the oracle, not only its properties: 2 images x 2 patches x 2 views of
+    20 000 pixels in ONE global Sinkhorn problem per (patch, view) (40 000 rows), gradients averaged over images and
+    patches — BASELINE.json's 8 prototypes (quadratic-form finest level, batched gather / loss / scatter) and the
+    reference's own 5000 (Sinkhorn first pass out of the score GEMM's epilogue)."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(256)
+    g = g.to(gpu)
+    patches = 2 if nproto == 8 else 1
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
+                        **ffhq_args(2, nproto, num_patches=patches, pick_source="host"))
+    torch.manual_seed(5)
+    np.random.seed(5)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 128, 512)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(512, 13, 6, 256 * 256, patches, transforms=True) for _ in range(2)]
+    loss = sw.train_step(images)
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, _oracle_images(images, 256), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
+        use_larc=True, hlen=5376, patch_size=20000, num_patches=patches, temperature=0.01, eps=0.005, niters=10,
+        source_pdf="uniform", sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_TOL)
+    for got, want in zip(sw._grads, grads):
+        assert rel(got, want) < GRAD_TOL
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-5
 
 
 def test_car512_generator_and_cluster_map_vs_oracle(gpu, engine):
@@ -159,7 +201,11 @@ def test_cat256_full_size_step_vs_oracle(gpu, engine):
     """configs[2] (cat-256) parameters at full size: 16 prototypes, source_pdf='image' (marginals from
     the histograms of the whole 256^2 norm map, swav_clustering.py:523-532), eps = 0.003
     (configs/segmentors/hfc_with_swav_cat_config.py:52-65), one image / one patch of 20 000 pixels:
-    loss, the three gradients and the LARC update against the oracle on identical draws."""
+    loss, the three gradients and the LARC update against the oracle on identical draws.
+    Tolerance: the marginals are HISTOGRAMS of the norm map, so a norm within rounding of a bin edge moves one count
+    between two of the 20 000 / 16 bins and with it the Sinkhorn targets — a discontinuity of the reference's own
+    definition, not arithmetic error (the same step with 'uniform' marginals agrees to 3e-7): 3.3e-4 on the loss
+    measured here, held to north_star's 1e-3."""
     from oracle import swav_ref as S
     from ganecdotes_amd.draws import draw_image
     from ganecdotes_amd.swav_clustering import SwAVClustering
@@ -219,11 +265,11 @@ def test_car512_full_size_train_step_vs_oracle(gpu, nproto):
         sd, ml, 0.7, _oracle_images(images, 512), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
         use_larc=True, hlen=5376, patch_size=20000, num_patches=1, temperature=0.01, eps=0.01, niters=10,
         source_pdf="uniform", sinkhorn_scope="global")
-    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_TOL)
     for got, want in zip(sw._grads, grads):
-        assert rel(got, want) < 2e-3
+        assert rel(got, want) < GRAD_TOL
     for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
-        assert rel(got, want) < 1e-4
+        assert rel(got, want) < 1e-5
 
 
 def test_simclr_ffhq256_iteration_vs_oracle(gpu):
@@ -258,9 +304,9 @@ def test_simclr_ffhq256_iteration_vs_oracle(gpu):
     ref_loss, mean, var_u = C.simclr_step_loss(sd, ml, 0.7, oim, *leaves, hlen=5376, batch=20, temperature=1.0)
     ref_loss.backward()
     grads = [p.grad.detach().clone() for p in leaves]
-    np.testing.assert_allclose(loss.item(), float(ref_loss.detach()), rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), float(ref_loss.detach()), rtol=LOSS_TOL)
     for got, want in zip(sim._grads, grads):
-        assert rel(got, want) < 2e-3
+        assert rel(got, want) < GRAD_TOL
     for p in leaves:
         p.requires_grad_(False)
     with torch.no_grad():
@@ -268,8 +314,8 @@ def test_simclr_ffhq256_iteration_vs_oracle(gpu):
     for got, want in zip(sim._params(), leaves):
         assert rel(got, want) < 1e-4
     bn = sim.projection[1]
-    assert rel(bn.running_mean, 0.1 * mean) < 2e-3
-    assert rel(bn.running_var, 0.9 + 0.1 * var_u) < 2e-3
+    assert rel(bn.running_mean, 0.1 * mean) < GRAD_TOL
+    assert rel(bn.running_var, 0.9 + 0.1 * var_u) < GRAD_TOL
 
 
 # --------------------------------------------------------------------------- properties at the bench batch
