@@ -151,6 +151,15 @@ SIGNATURES = {
                                   c_p, c_sz, c_p]),
     "gx_swapped_ce": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p,
                             c_sz, c_p]),
+    "gx_gather_rows": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "gx_scatter_rows_add": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "gx_leaky_relu": (c_i, [c_p, c_l, c_f, c_p]),
+    "gx_leaky_relu_bwd": (c_i, [c_p, c_p, c_l, c_f, c_p]),
+    "gx_col_moment_workspace_bytes": (c_sz, [c_i]),
+    "gx_col_moment": (c_i, [c_p, c_l, c_i, c_p, c_i, c_f, c_p, c_p, c_sz, c_p]),
+    "gx_bn_act_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_i, c_f, c_p, c_p, c_p]),
+    "gx_bn_act_bwd_sums": (c_i, [c_p, c_p, c_l, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_bn_act_bwd_apply": (c_i, [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_f, c_i, c_f, c_p, c_p, c_f, c_p, c_p]),
     "gx_col_stats_workspace_bytes": (c_sz, [c_i]),
     "gx_col_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gx_bn_lrelu_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p]),

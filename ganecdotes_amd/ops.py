@@ -1154,6 +1154,100 @@ def swapped_ce_fused(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, 
     return loss_out
 
 
+# ------------------------------------------------------------------------------------- non-linear projection heads
+def gather_rows(z, picks, maps=None):
+    """z (B, H, W, D) table; picks (B, N) int32 -> the sampled rows (B*N, D), zero where the rotation zero-filled"""
+    _chk(z)
+    b, h, w, d = z.shape
+    n = picks.shape[1]
+    out = torch.empty(b * n, d, dtype=torch.float32, device=z.device)
+    _lib.check(lib().gx_gather_rows(_p(z), b, h * w, d, _p(picks), n, _p(maps), _p(out), _stream()), "gx_gather_rows")
+    return out
+
+
+def scatter_rows_add_(grows, picks, maps, g):
+    """g (B, H, W, D) += the adjoint of gather_rows on grows (B*N, D) (float atomics)"""
+    _chk(grows, g)
+    b, h, w, d = g.shape
+    _lib.check(lib().gx_scatter_rows_add(_p(grows), b, h * w, d, _p(picks), picks.shape[1], _p(maps), _p(g), _stream()),
+               "gx_scatter_rows_add")
+    return g
+
+
+def leaky_relu_(x, slope=0.01):
+    _chk(x)
+    _lib.check(lib().gx_leaky_relu(_p(x), x.numel(), slope, _stream()), "gx_leaky_relu")
+    return x
+
+
+def leaky_relu_bwd_(dy, y, slope=0.01):
+    """dy *= LeakyReLU'(.) read off the OUTPUT y (slope > 0 keeps the sign of the input)"""
+    _chk(dy, y)
+    _lib.check(lib().gx_leaky_relu_bwd(_p(dy), _p(y), dy.numel(), slope, _stream()), "gx_leaky_relu_bwd")
+    return dy
+
+
+def col_moment(x, center=None, square=False, scale=1.0):
+    """scale * sum over rows of (x - center) or its square, per column of x (rows, D)"""
+    _chk(x, center)
+    rows, d = x.shape
+    L = lib()
+    out = torch.empty(d, dtype=torch.float32, device=x.device)
+    wsb = L.gx_col_moment_workspace_bytes(d)
+    ws = workspace("colmoment", wsb, x.device)
+    _lib.check(L.gx_col_moment(_p(x), rows, d, _p(center), int(square), scale, _p(out), _p(ws), wsb, _stream()),
+               "gx_col_moment")
+    return out
+
+
+def batch_stats(x, reduce=None, world=1):
+    """BatchNorm1d's batch mean and biased variance over the rows of x — over the rows of every rank when `reduce`
+    (t, op) is given (equal row counts per rank)"""
+    n = x.shape[0] * world
+    mean = col_moment(x, None, False, 1.0 / n)
+    if reduce is not None:
+        reduce(mean, "sum")
+    var = col_moment(x, mean, True, 1.0 / n)
+    if reduce is not None:
+        reduce(var, "sum")
+    return mean, var
+
+
+BN_LRELU, BN_TANH = 0, 1
+
+
+def bn_act_fwd(x, mean, var, gamma, beta, eps, act, slope=0.01, want_xhat=True, out=None, xhat_out=None):
+    _chk(x, mean, var, gamma, beta, out, xhat_out)
+    a = torch.empty_like(x) if out is None else out
+    xhat = xhat_out if xhat_out is not None else (torch.empty_like(x) if want_xhat else None)
+    _lib.check(lib().gx_bn_act_fwd(_p(x), x.shape[0], x.shape[1], _p(mean), _p(var), _p(gamma), _p(beta), eps, act, slope,
+                                   _p(a), _p(xhat), _stream()), "gx_bn_act_fwd")
+    return a, xhat
+
+
+def bn_act_bwd(da, xhat, var, gamma, beta, eps, act, slope=0.01, reduce=None, world=1, out=None):
+    """-> (dx, dgamma, dbeta) with dgamma / dbeta THIS rank's sums (they join the step's gradient all-reduce); the
+    copies that enter dx are all-reduced first when `reduce` is given"""
+    _chk(da, xhat, var, gamma, beta, out)
+    rows, d = da.shape
+    L = lib()
+    dg = torch.empty(d, dtype=torch.float32, device=da.device)
+    db = torch.empty(d, dtype=torch.float32, device=da.device)
+    wsb = L.gx_col_moment_workspace_bytes(d)
+    ws = workspace("colmoment", wsb, da.device)
+    _lib.check(L.gx_bn_act_bwd_sums(_p(da), _p(xhat), rows, d, _p(gamma), _p(beta), act, slope, _p(dg), _p(db), _p(ws), wsb,
+                                    _stream()), "gx_bn_act_bwd_sums")
+    dg_all, db_all = dg, db
+    if reduce is not None:
+        dg_all, db_all = dg.clone(), db.clone()
+        reduce(dg_all, "sum")
+        reduce(db_all, "sum")
+    dx = torch.empty_like(da) if out is None else out
+    _lib.check(L.gx_bn_act_bwd_apply(_p(da), _p(xhat), rows, d, _p(var), _p(gamma), _p(beta), eps, act, slope, _p(dg_all),
+                                     _p(db_all), float(rows * world), _p(dx), _stream()), "gx_bn_act_bwd_apply")
+    return dx, dg, db
+
+
 # ------------------------------------------------------------------------------------- SimCLR head
 def col_stats(x):
     """(mean, biased var) over the rows of x (rows, D)"""

@@ -47,6 +47,7 @@ from . import ops, sharded
 from .draws import ImageDraws, draw_image
 from .views import PreparedBatch, ViewMixin
 from .pyramid import Pyramid
+from .projection_head import ProjectionHead, build_projection
 
 
 class _NullLogger:
@@ -133,17 +134,24 @@ class SwAVClustering(ViewMixin):
         """projection + prototype layers as torch modules (swav_clustering.py:244-271) — the
         objects that are pickled to projection.pt / prototypes.pt."""
         hlen = self.swav_args['hlen']
-        if self.swav_args['projn_nw'] != 'linear':
-            raise NotImplementedError("only projn_nw='linear' (every shipped config) has a HIP path")
-        self.projection = nn.Sequential(nn.Linear(hlen, self.nclasses, bias=False)).to(self.device)
+        self.projection = build_projection(self.swav_args['projn_nw'], hlen, self.nclasses).to(self.device)
         self.prototype = nn.Linear(self.nclasses, self.nprototypes).to(self.device)
+        self._head = None
         for p in list(self.projection.parameters()) + list(self.prototype.parameters()):
             p.requires_grad_(False)
         self._bufs = None
         self._step_no = 0
 
+    def _proj_head(self):
+        """the layers after the first Linear (projn_nw '1-layer' / '2-layer'; 'linear': none) — projection_head.py"""
+        if getattr(self, '_head', None) is None or self._head.projection is not self.projection:
+            self._head = ProjectionHead(self.projection, self.swav_args.get('projn_nw', 'linear'))
+        return self._head
+
     def _params(self):
-        return [self.projection[0].weight.data, self.prototype.weight.data, self.prototype.bias.data]
+        """[Wp, Wc, b] and, for projn_nw='2-layer', the BatchNorm affines and the second Linear after them"""
+        return [self.projection[0].weight.data, self.prototype.weight.data, self.prototype.bias.data] + \
+            self._proj_head().extra_params()
 
     # ------------------------------------------------------------------------------------- reference API
     def preprocess(self, input_latent):
@@ -217,7 +225,8 @@ class SwAVClustering(ViewMixin):
         pb = self.prepare_batch(images)
         B = pb.n
         Bg = B * self.world
-        Wp, Wc, bc = self._params()
+        Wp, Wc, bc, *extra = self._params()
+        head = self._proj_head()
         D, K = Wp.shape[0], Wc.shape[0]
         dev = self.device
 
@@ -234,17 +243,18 @@ class SwAVClustering(ViewMixin):
             imgs = [ops.norm_map(ts, hlen, maps) for ts, maps, _ in views]
 
         if self._bufs is None:
-            self._bufs = [torch.zeros_like(p) for p in (Wp, Wc, bc)]
-            self._grads = [torch.empty_like(p) for p in (Wp, Wc, bc)]
-        gWp, gWc, gb = self._grads
+            self._bufs = [torch.zeros_like(p) for p in (Wp, Wc, bc, *extra)]
+            self._grads = [torch.empty_like(p) for p in (Wp, Wc, bc, *extra)]
+        gWp, gWc, gb, *gextra = self._grads
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         rows = B * N
         gscale = 1.0 / (N * P * Bg)
         first_acc = True
         aux = {}
         mode = sa.get('projection_mode', 'pyramid')
-        small = sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D)
-        lowrank = mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D)
+        # the few-prototype routes (fused gather + scores, score tables) need a LINEAR map from descriptor to z
+        small = sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D) and head.linear
+        lowrank = mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D) and head.linear
         if mode == 'pyramid':
             with self._timed("pyramid_fwd"):
                 # ONE pyramid over the 2B images of both views: each level is one GEMM, the table Z_all
@@ -285,6 +295,7 @@ class SwAVClustering(ViewMixin):
         if return_aux and marg is not None:                       # what the 'image' pdf prescribes (tests)
             aux.update(norm_map_s=imgs[0], norm_map_t=imgs[1], r_marginals=r_one, c_marginals=c_one)
         ngroups = 1 if scope == 'global' else B                  # Sinkhorn problems per (patch, view)
+        hreduce = self._reduce if (scope == 'global' and self.sharded) else None    # BatchNorm batch = Sinkhorn problem
         grows = rows // ngroups
         nglob = grows * (self.world if scope == 'global' else 1)
         # The pyramid path holds only (rows, K) scores per patch, so all patches go through ONE
@@ -312,7 +323,7 @@ class SwAVClustering(ViewMixin):
                 Rn_all = ops.gather_scores_batch(sc_all, rn_all, bc, gpicks, maps_all, B, hw * hw, Sc_all, shift=lshift)
             for gi, pno in enumerate(pnos if not batched else []):
                 picks = pb.picks[pno]
-                X, Zh, Rn = [], [], []
+                X, Zh, Rn, Hc = [], [], [], []
                 for v, (ts, maps, _) in enumerate(views):
                     sc = Sc_all[gi, v]
                     if mode == 'pyramid' and small:
@@ -320,16 +331,24 @@ class SwAVClustering(ViewMixin):
                             z, rn, _ = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc, out=sc)
                         Zh.append(z); Rn.append(rn)
                         continue
-                    if mode == 'pyramid':
+                    if mode == 'pyramid' and head.linear:
                         with self._timed("gather_rows"):
                             z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
                     else:
-                        with self._timed("gather"):
-                            x = ops.gather_taps(ts, picks, hlen, maps)             # (B*N, hlen)
-                        with self._timed("proj_fwd"):
-                            z = ops.gemm(x, Wp, False, True)                       # (B*N, D)
+                        if mode == 'pyramid':
+                            with self._timed("gather_rows"):
+                                z = ops.gather_rows(Zt[v], picks, maps)            # rows of the first Linear's output
+                        else:
+                            with self._timed("gather"):
+                                x = ops.gather_taps(ts, picks, hlen, maps)         # (B*N, hlen)
+                            with self._timed("proj_fwd"):
+                                z = ops.gemm(x, Wp, False, True)                   # (B*N, D)
+                            X.append(x)
+                        if not head.linear:        # '1-layer' / '2-layer': one BatchNorm batch per Sinkhorn problem
+                            with self._timed("proj_head"):
+                                z, hc = head.forward(z, ngroups, hreduce, self.world if hreduce else 1)
+                            Hc.append(hc)
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
-                        X.append(x)
                     if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
                         # (B*N, K), Wc split once per step; the Sinkhorn column maxima AND its first pass (the column sums of
                         # exp((scores - max) / eps)) come out of the epilogue: nine sweeps of the score matrix, not eleven
@@ -342,7 +361,7 @@ class SwAVClustering(ViewMixin):
                     else:
                         ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)
                     Zh.append(z); Rn.append(rn)
-                keep.append((X, Zh, Rn))
+                keep.append((X, Zh, Rn, Hc))
             # S4: every (patch, view[, image]) problem of the group in one batched Sinkhorn
             r_all = c_all = None
             if marg is not None:
@@ -370,7 +389,7 @@ class SwAVClustering(ViewMixin):
                 del dS_all, Rn_all
             for gi, pno in enumerate(pnos if not batched else []):
                 picks = pb.picks[pno]
-                X, Zh, Rn = keep[gi]
+                X, Zh, Rn, Hc = keep[gi]
                 Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
                 if pad_ds:   # rows padded to whole 16-column chunks (zero pad) so that dS can be the A operand of the dz GEMM
                     dSp = [torch.empty(rows, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -409,16 +428,23 @@ class SwAVClustering(ViewMixin):
                         ops.gemm_nt_planes(dSp[v], None, wct_planes, dz)
                     else:
                         dz = ops.gemm(dS[v], Wc, False, False)                     # d z_hat (B*N, D)
-                    if mode == 'pyramid':
+                    if mode == 'pyramid' and head.linear:
                         with self._timed("scatter_rows"):
                             ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])
                     else:
                         ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
-                        with self._timed("proj_dW"):
-                            ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
+                        if not head.linear:
+                            with self._timed("proj_head"):
+                                dz = head.backward(dz, Zh[v], Hc[v], gextra, beta, split_k=self._split_k(D, D, rows))
+                        if mode == 'pyramid':
+                            with self._timed("scatter_rows"):
+                                ops.scatter_rows_add_(dz, picks, views[v][1], Gt[v])
+                        else:
+                            with self._timed("proj_dW"):
+                                ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
                     first_acc = False
                 keep[gi] = None
-                del X, Zh, Rn, Sc, dS
+                del X, Zh, Rn, Hc, Sc, dS
             del keep, Sc_all, skb
         pending = []
         if mode == 'pyramid':
@@ -427,7 +453,7 @@ class SwAVClustering(ViewMixin):
                 # once the prototype gradients and the loss are final their all-reduce travels while the
                 # pyramid backward runs, and every pyramid level's slice of dWp follows as soon as its GEMMs
                 # are queued (finest levels first), so only the coarsest levels' message is exposed
-                on_heads = lambda: pending.append(sharded.allreduce_flat_async([gWc, gb, loss], self.dist_group))
+                on_heads = lambda: pending.append(sharded.allreduce_flat_async([gWc, gb, loss] + gextra, self.dist_group))
                 on_level = lambda cols: pending.append(sharded.allreduce_cols_async(gWp, cols, self.dist_group))
             with self._timed("pyramid_bwd"):
                 if lowrank:      # from the coefficient grid: dense finish at the table level, the finest level's Gram forms
@@ -446,7 +472,7 @@ class SwAVClustering(ViewMixin):
         mom = sa['train_args'].get('momentum', 0.0)
         if sa.get('use_scheduler', False) and getattr(self, '_lr_schedule', None) is not None:
             lr = float(self._lr_schedule[min(self._step_no, len(self._lr_schedule) - 1)])
-        for p, g, buf in zip((Wp, Wc, bc), self._grads, self._bufs):
+        for p, g, buf in zip((Wp, Wc, bc, *extra), self._grads, self._bufs):
             ops.larc_sgd_(p, g, buf, lr, mom, sa['trust_coeff'], first_step=(self._step_no == 0), use_larc=use_larc)
         self._step_no += 1
         return (loss, aux) if return_aux else loss
@@ -542,6 +568,9 @@ class SwAVClustering(ViewMixin):
             picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
             x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
             z = ops.gemm(x, wp, False, True)                                   # (b*h*w, D) == NHWC
+        head = self._proj_head()
+        if not head.linear:          # BatchNorm in train mode here too (the reference never calls .eval()): per image
+            z, _ = head.forward(z.contiguous(), ts.B, want_ctx=False)
         labels = ops.row_argmax(z).reshape(ts.B, hw, hw)
         preds = z.reshape(ts.B, hw, hw, wp.shape[0]).permute(0, 3, 1, 2)
         return preds, labels

@@ -447,6 +447,31 @@ int gx_bn_lrelu_bwd(const float* da, const float* xhat, int n, int D, const floa
 int gx_simclr_ntxent(const float* out, int n, int D, float temperature, float* loss, float* dout, void* stream);
 int gx_row_div(float* z, long rows, int D, const float* nrm, void* stream);
 
+/* ---- the non-linear projection heads (hfc_with_swav/swav_clustering.py:250-269; no shipped config uses them) ----
+ * '1-layer' = Linear -> LeakyReLU(0.01); '2-layer' = Linear -> BatchNorm1d -> LeakyReLU(0.01) -> Linear -> BatchNorm1d -> Tanh,
+ * BatchNorm in train mode throughout (the reference never calls .eval()).  Row passes of the generic path:
+ * gx_gather_rows / gx_scatter_rows_add   the sampled rows of the projected table and the adjoint     :160-169, autograd
+ * gx_leaky_relu / gx_leaky_relu_bwd      nn.LeakyReLU(inplace=True) and its backward from the output  :255, :262
+ * gx_col_moment                          BatchNorm1d batch mean / biased variance (two calls)         :261, :266
+ * gx_bn_act_fwd                          BatchNorm1d + activation (0 LeakyReLU(slope), 1 tanh)        :261-267
+ * gx_bn_act_bwd_sums / _apply            their backward: column sums (all-reduced across ranks), then dx */
+int gx_gather_rows(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps, float* out,
+                   void* stream);
+int gx_scatter_rows_add(const float* g, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps, float* G,
+                        void* stream);
+int gx_leaky_relu(float* x, long total, float slope, void* stream);
+int gx_leaky_relu_bwd(float* dy, const float* y, long total, float slope, void* stream);
+size_t gx_col_moment_workspace_bytes(int D);
+int gx_col_moment(const float* x, long rows, int D, const float* center, int square, float scale, float* out,
+                  float* workspace, size_t workspace_bytes, void* stream);
+int gx_bn_act_fwd(const float* x, long rows, int D, const float* mean, const float* var, const float* gamma,
+                  const float* beta, float eps, int act, float slope, float* a, float* xhat, void* stream);
+int gx_bn_act_bwd_sums(const float* da, const float* xhat, long rows, int D, const float* gamma, const float* beta, int act,
+                       float slope, float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, void* stream);
+int gx_bn_act_bwd_apply(const float* da, const float* xhat, long rows, int D, const float* var, const float* gamma,
+                        const float* beta, float eps, int act, float slope, const float* dgamma, const float* dbeta,
+                        float n_total, float* dx, void* stream);
+
 /* ---- optimizer: apex LARC(clip=False) around SGD(momentum)   swav_clustering.py:286-292 ------ */
 size_t gx_sumsq_workspace_bytes(void);
 int gx_sumsq(const float* x, long n, float* out, float* workspace, size_t workspace_bytes, void* stream);

@@ -91,10 +91,52 @@ def sample_pixels(stack, picks, patch_size):
     return flat.t()
 
 
-def codes(x, proj_w, proto_w=None, proto_b=None, train=True):
+@dataclass
+class HeadParams:
+    """the projection network's layers after the first Linear (swav_clustering.py:250-269):
+    '1-layer' LeakyReLU(0.01); '2-layer' BatchNorm1d -> LeakyReLU(0.01) -> Linear(D, D) -> BatchNorm1d -> Tanh, both
+    BatchNorms in train mode (the reference never calls .eval()); `running` = [mean1, var1, mean2, var2, batches]
+    follows nn.BatchNorm1d's bookkeeping (momentum 0.1, unbiased variance)."""
+    kind: str
+    bn1_w: torch.Tensor = None
+    bn1_b: torch.Tensor = None
+    w2: torch.Tensor = None
+    bn2_w: torch.Tensor = None
+    bn2_b: torch.Tensor = None
+    running: list = None
+
+    def leaves(self):
+        return [] if self.kind != "2-layer" else [self.bn1_w, self.bn1_b, self.w2, self.bn2_w, self.bn2_b]
+
+    @staticmethod
+    def fresh(kind, d):
+        """as the reference constructs it: nn.Linear's default init draw for the second Linear, BatchNorm at (1, 0)"""
+        if kind != "2-layer":
+            return HeadParams(kind)
+        w2, _ = init_linear_like_torch(d, d, False)
+        return HeadParams(kind, torch.ones(d), torch.zeros(d), w2, torch.ones(d), torch.zeros(d),
+                          [torch.zeros(d), torch.ones(d), torch.zeros(d), torch.ones(d), 0])
+
+    def apply(self, z):
+        if self.kind == "1-layer":
+            return F.leaky_relu(z, 0.01)
+        if self.running is None:
+            self.running = [torch.zeros(z.shape[1]), torch.ones(z.shape[1]), torch.zeros(z.shape[1]),
+                            torch.ones(z.shape[1]), 0]
+        rm1, rv1, rm2, rv2, _ = self.running
+        z = F.leaky_relu(F.batch_norm(z, rm1, rv1, self.bn1_w, self.bn1_b, training=True, momentum=0.1, eps=1e-5), 0.01)
+        z = F.batch_norm(F.linear(z, self.w2), rm2, rv2, self.bn2_w, self.bn2_b, training=True, momentum=0.1, eps=1e-5)
+        self.running[4] += 1
+        return torch.tanh(z)
+
+
+def codes(x, proj_w, proto_w=None, proto_b=None, train=True, head=None):
     """get_swav_codes_from_hidden_features after sampling (swav_clustering.py:171-177):
-    z = x Wp^T; train: scores = normalize(z) Wc^T + b; predict: z^T (D, N)."""
+    z = projection(x) (x Wp^T, then the head's layers if projn_nw is not 'linear'); train:
+    scores = normalize(z) Wc^T + b; predict: z^T (D, N)."""
     z = F.linear(x, proj_w)
+    if head is not None and head.kind != "linear":
+        z = head.apply(z)
     if train:
         return F.linear(F.normalize(z, p=2, dim=1), proto_w, proto_b)
     return z.t()
@@ -246,6 +288,7 @@ class SwavParams:
     proj_w: torch.Tensor             # (D, C)
     proto_w: torch.Tensor            # (K, D)
     proto_b: torch.Tensor            # (K,)
+    head: "HeadParams" = None        # projn_nw '1-layer' / '2-layer' (None: 'linear')
 
 
 def swav_step_loss(sd, mean_latent, psi, images: List[ImageDraws], params: SwavParams, *, hlen,
@@ -270,10 +313,17 @@ def swav_step_loss(sd, mean_latent, psi, images: List[ImageDraws], params: SwavP
     nb = len(images)
     for pno in range(num_patches):
         sc = [[], []]
-        for b, im in enumerate(images):
+        head = params.head
+        if head is not None and head.kind == "2-layer" and sinkhorn_scope == "global":
+            # a BatchNorm batch is the rows of one Sinkhorn problem: every image's rows of that view together
             for v in range(2):
-                x = sample_pixels(stacks[b][v], im.picks[pno], patch_size)
-                sc[v].append(codes(x, proj_w, proto_w, proto_b, train=True))
+                xs = torch.cat([sample_pixels(stacks[b][v], im.picks[pno], patch_size) for b, im in enumerate(images)], 0)
+                sc[v] = list(codes(xs, proj_w, proto_w, proto_b, train=True, head=head).chunk(nb, 0))
+        else:
+            for b, im in enumerate(images):
+                for v in range(2):
+                    x = sample_pixels(stacks[b][v], im.picks[pno], patch_size)
+                    sc[v].append(codes(x, proj_w, proto_w, proto_b, train=True, head=head))
         if sinkhorn_scope == "global":
             s_all, t_all = torch.cat(sc[0], 0), torch.cat(sc[1], 0)
             with torch.no_grad():
@@ -303,7 +353,7 @@ def swav_train_step(sd, mean_latent, psi, images, params: SwavParams, bufs, *, l
     Returns (loss value, grads, new momentum buffers)."""
     with torch.no_grad():
         params.proto_w.copy_(normalize_prototypes(params.proto_w))
-    leaves = [params.proj_w, params.proto_w, params.proto_b]
+    leaves = [params.proj_w, params.proto_w, params.proto_b] + (params.head.leaves() if params.head is not None else [])
     for p in leaves:
         p.requires_grad_(True)
         p.grad = None
@@ -327,7 +377,7 @@ def init_linear_like_torch(out_f, in_f, bias):
 def pretrain_reference_order(sd, style_dim, *, num_latents_for_mean, psi, n_perturb_layers,
                              num_test_samples, num_epochs, num_patches, patch_size, hlen, nclasses,
                              nprototypes, temperature, eps, niters, lr, momentum, trust,
-                             use_larc, transforms, source_pdf="uniform"):
+                             use_larc, transforms, source_pdf="uniform", projn_nw="linear"):
     """The reference's constructor + pretrain() RNG order and update rule
     (swav_clustering.py:93-95, :224-237, :245-271, :320-460) with num_samples=1.
     Returns (losses per epoch, SwavParams)."""
@@ -341,9 +391,10 @@ def pretrain_reference_order(sd, style_dim, *, num_latents_for_mean, psi, n_pert
                 r = 2 ** ((i + 5) // 2)
                 torch.empty(1, 1, r, r).normal_()
     proj_w, _ = init_linear_like_torch(nclasses, hlen, False)
+    head = None if projn_nw == "linear" else HeadParams.fresh(projn_nw, nclasses)      # Sequential's construction order
     proto_w, proto_b = init_linear_like_torch(nprototypes, nclasses, True)
-    params = SwavParams(proj_w, proto_w, proto_b)
-    bufs = [None, None, None]
+    params = SwavParams(proj_w, proto_w, proto_b, head)
+    bufs = [None] * (3 + (len(head.leaves()) if head is not None else 0))
     size = 2 ** ((nl + 3) // 2)
     losses = []
     for _ in range(num_epochs):
@@ -359,7 +410,7 @@ def pretrain_reference_order(sd, style_dim, *, num_latents_for_mean, psi, n_pert
 
 
 # ----------------------------------------------------------------------------- P1
-def predict_swav_codes(sd, w, mean_latent, psi, proj_w, hlen):
+def predict_swav_codes(sd, w, mean_latent, psi, proj_w, hlen, head=None):
     """predict_swav_codes (swav_clustering.py:659-693): one truncation, registered noise,
     projection on every pixel, argmax over the D projection channels."""
     with torch.no_grad():
@@ -368,6 +419,6 @@ def predict_swav_codes(sd, w, mean_latent, psi, proj_w, hlen):
         stack = pixel_features(taps, hlen)
         b, c, h, wd = stack.shape
         x = torch.squeeze(stack).flatten(1).t()
-        preds = codes(x, proj_w, train=False).reshape(b, proj_w.shape[0], h, wd)
+        preds = codes(x, proj_w, train=False, head=head).reshape(b, proj_w.shape[0], h, wd)
         labels = preds.max(1)[1]
     return preds, labels

@@ -20,10 +20,10 @@ class Cfg:
     latent_dim = 16
 
 
-def _args(scope, pdf, nproto=12):
+def _args(scope, pdf, nproto=12, projn="linear"):
     swav = dict(num_epochs=1, num_samples=1, num_patches=2, sampling_method="random", patch_size=300,
                 hf_interp="nearest", warmup_epochs=1, start_warmup=0.01, use_scheduler=False, base_lr=0.01,
-                final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9), projn_nw="linear",
+                final_lr=0.0001, trust_coeff=0.01, train_args=dict(lr=0.01, momentum=0.9), projn_nw=projn,
                 temperature=0.1, nprototypes=nproto, nclasses=8 if nproto <= 16 else 16,   # D = 16: weight-plane GEMMs
                 hlen=56, add_local_loss=False, plot_test_images=False,
                 epoch_print_freq=1, max_masks=4, sinkhorn_scope=scope)
@@ -31,13 +31,13 @@ def _args(scope, pdf, nproto=12):
                 swav_args=swav, sinkhorn_args=dict(source_pdf=pdf, niters=10, eps=0.05))
 
 
-def _build(sd, group, scope, pdf, nproto=12):
+def _build(sd, group, scope, pdf, nproto=12, projn="linear"):
     from ganecdotes_amd.generator import Generator
     from ganecdotes_amd.swav_clustering import SwAVClustering
     g = Generator(32, 16, 2, channels=MINI)
     g.load_state_dict(sd, strict=False)
     g = g.eval().cuda()
-    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", dist_group=group, **_args(scope, pdf, nproto))
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", dist_group=group, **_args(scope, pdf, nproto, projn))
     torch.manual_seed(77)
     sw.mean_latent = g.style(torch.randn(64, 16).cuda()).mean(0, keepdim=True)
     torch.manual_seed(78)
@@ -52,12 +52,12 @@ def _images(n):
     return [draw_image(16, 7, 3, 32 * 32, 2) for _ in range(n)]
 
 
-def _worker(rank, world, port, sd, scope, pdf, out, nproto=12):
+def _worker(rank, world, port, sd, scope, pdf, out, nproto=12, projn="linear"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sw = _build(sd, dist.group.WORLD, scope, pdf, nproto)
+    sw = _build(sd, dist.group.WORLD, scope, pdf, nproto, projn)
     imgs = _images(4)
     loss = None
     for _ in range(2):
@@ -67,16 +67,19 @@ def _worker(rank, world, port, sd, scope, pdf, out, nproto=12):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scope,pdf,nproto", [("global", "uniform", 12), ("image", "uniform", 12), ("global", "image", 12),
-                                              ("global", "uniform", 200), ("image", "uniform", 200)])
-def test_two_ranks_equal_one_rank(scope, pdf, nproto):
+@pytest.mark.parametrize("scope,pdf,nproto,projn", [
+    ("global", "uniform", 12, "linear"), ("image", "uniform", 12, "linear"), ("global", "image", 12, "linear"),
+    ("global", "uniform", 200, "linear"), ("image", "uniform", 200, "linear"),
+    ("global", "uniform", 12, "1-layer"), ("global", "uniform", 200, "2-layer"), ("image", "uniform", 12, "2-layer")])
+def test_two_ranks_equal_one_rank(scope, pdf, nproto, projn):
     """nproto = 200: the many-prototype path (score GEMM on weight planes with the Sinkhorn column maxima from its
-    epilogue, one-pass CE with the bias gradient) under the sharded protocol"""
+    epilogue, one-pass CE with the bias gradient) under the sharded protocol; projn '2-layer' with the global scope:
+    BatchNorm statistics and backward sums all-reduced (a BatchNorm batch = the rows of one Sinkhorn problem)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     sd = golden_sd(load_golden("gv10_pretrain"))
-    sw = _build(sd, None, scope, pdf, nproto)
+    sw = _build(sd, None, scope, pdf, nproto, projn)
     imgs = _images(4)
     for _ in range(2):
         loss1 = sw.train_step(imgs)
@@ -87,7 +90,7 @@ def test_two_ranks_equal_one_rank(scope, pdf, nproto):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, sd, scope, pdf, out, nproto), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, sd, scope, pdf, out, nproto, projn), nprocs=2, join=True)
     for r in range(2):
         np.testing.assert_allclose(out[r][0], ref[0], rtol=2e-4)
         for a, b in zip(out[r][1], ref[1]):

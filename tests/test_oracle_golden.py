@@ -180,6 +180,63 @@ def test_gv11_predict():
     assert (labels.numpy() == d["labels"]).mean() > 0.999
 
 
+def _gv17_head(d, tag, kind, prefix="proj_", running_from=None):
+    """the oracle's HeadParams from a captured projection state_dict"""
+    if kind == "1-layer":
+        return S.HeadParams(kind)
+    r = running_from or prefix
+    return S.HeadParams(kind, T(d[f"{tag}_{prefix}1.weight"]), T(d[f"{tag}_{prefix}1.bias"]), T(d[f"{tag}_{prefix}3.weight"]),
+                        T(d[f"{tag}_{prefix}4.weight"]), T(d[f"{tag}_{prefix}4.bias"]),
+                        [T(d[f"{tag}_{r}1.running_mean"]).clone(), T(d[f"{tag}_{r}1.running_var"]).clone(),
+                         T(d[f"{tag}_{r}4.running_mean"]).clone(), T(d[f"{tag}_{r}4.running_var"]).clone(), 0])
+
+
+@pytest.mark.parametrize("kind", ["1-layer", "2-layer"])
+def test_gv17_projection_heads(kind):
+    """projn_nw '1-layer' / '2-layer' (swav_clustering.py:250-269): the reference's own pretrain() trajectory, final
+    modules and BatchNorm running statistics; its code calls on a fixed feature map; predict_swav_codes afterwards"""
+    d = load_golden("gv17_projection_heads")
+    tag = kind[0] + "l"
+    sd = golden_sd(d)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    losses, params, _ = S.pretrain_reference_order(
+        sd, 16, num_latents_for_mean=64, psi=0.7, n_perturb_layers=3, num_test_samples=2, num_epochs=3, num_patches=2,
+        patch_size=300, hlen=56, nclasses=8, nprototypes=12, temperature=0.1, eps=0.05, niters=10, lr=0.01, momentum=0.9,
+        trust=0.01, use_larc=False, transforms=False, projn_nw=kind)
+    np.testing.assert_allclose(losses, d[f"{tag}_losses"], rtol=1e-4)
+    close(params.proj_w, d[f"{tag}_proj_0.weight"], rtol=1e-4, atol=1e-6)
+    close(params.proto_w, d[f"{tag}_proto_weight"], rtol=1e-4, atol=1e-6)
+    close(params.proto_b, d[f"{tag}_proto_bias"], rtol=1e-4, atol=1e-6)
+    if kind == "2-layer":
+        h = params.head
+        for got, key in ((h.bn1_w, "1.weight"), (h.bn1_b, "1.bias"), (h.w2, "3.weight"), (h.bn2_w, "4.weight"),
+                         (h.bn2_b, "4.bias"), (h.running[0], "1.running_mean"), (h.running[1], "1.running_var"),
+                         (h.running[2], "4.running_mean"), (h.running[3], "4.running_var")):
+            close(got, d[f"{tag}_proj_{key}"], rtol=1e-4, atol=1e-6)
+        assert h.running[4] == int(d[f"{tag}_proj_1.num_batches_tracked"]) == 12     # 3 epochs x 2 patches x 2 views
+    # the code calls on a fixed feature map, from the CAPTURED modules
+    head = _gv17_head(d, tag, kind)
+    pw, cw, cb = T(d[f"{tag}_proj_0.weight"]), T(d[f"{tag}_proto_weight"]), T(d[f"{tag}_proto_bias"])
+    stack, picks = T(d[f"{tag}_hfeat"]), T(d[f"{tag}_picks"]).long()
+    with torch.no_grad():
+        x = S.sample_pixels(stack, picks, 300)
+        close(S.codes(x, pw, cw, cb, train=True, head=head), d[f"{tag}_scores_train"], rtol=1e-4, atol=1e-5)
+        if kind == "2-layer":
+            close(head.running[0], d[f"{tag}_proj_after_train_call_1.running_mean"], rtol=1e-4, atol=1e-6)
+            close(head.running[3], d[f"{tag}_proj_after_train_call_4.running_var"], rtol=1e-4, atol=1e-6)
+        xall = torch.squeeze(stack).flatten(1).t()
+        close(S.codes(xall, pw, train=False, head=head).reshape(1, 8, 20, 20), d[f"{tag}_scores_pred"], rtol=1e-4, atol=1e-5)
+        preds, labels = S.predict_swav_codes(sd, T(d[f"{tag}_pred_w"]), T(d[f"{tag}_mean_latent"]), 0.7, pw, hlen=56, head=head)
+    close(preds, d[f"{tag}_preds"], rtol=1e-4, atol=1e-5)
+    assert (labels.numpy() == d[f"{tag}_labels"]).mean() > 0.999
+    if kind == "2-layer":
+        close(head.running[0], d[f"{tag}_proj_after_predict_1.running_mean"], rtol=1e-4, atol=1e-6)
+        close(head.running[1], d[f"{tag}_proj_after_predict_1.running_var"], rtol=1e-4, atol=1e-6)
+        close(head.running[2], d[f"{tag}_proj_after_predict_4.running_mean"], rtol=1e-4, atol=1e-6)
+        close(head.running[3], d[f"{tag}_proj_after_predict_4.running_var"], rtol=1e-4, atol=1e-6)
+
+
 def test_rotflip_map_properties():
     m0 = S.rotflip_index_map(0.0, False, 16, 16)
     assert torch.equal(m0, torch.arange(256))

@@ -20,6 +20,7 @@ the captured functions:
 Usage:  python tools/capture_golden.py [--out tests/golden]
 """
 import argparse
+import functools
 import os
 import sys
 import types
@@ -124,6 +125,65 @@ class _Logger:
         self.lines.append(str(msg))
 
 
+def build_mini_generator(M, seed, size=32, style_dim=16, n_mlp=2, channels=None):
+    """the reference's own Generator class (M = models.stylegan2.model) with small channel counts"""
+    import torch
+    channels = channels or {4: 16, 8: 16, 16: 8, 32: 8, 64: 8}
+    torch.manual_seed(seed)
+    g = M.Generator(size, style_dim, n_mlp)        # builds the full-width net ...
+    g.channels = channels
+    g.input = M.ConstantInput(channels[4])         # ... whose blocks are replaced
+    g.conv1 = M.StyledConv(channels[4], channels[4], 3, style_dim)
+    g.to_rgb1 = M.ToRGB(channels[4], style_dim, upsample=False)
+    g.convs = torch.nn.ModuleList()
+    g.to_rgbs = torch.nn.ModuleList()
+    cin = channels[4]
+    for i in range(3, g.log_size + 1):
+        cout = channels[2 ** i]
+        g.convs.append(M.StyledConv(cin, cout, 3, style_dim, upsample=True))
+        g.convs.append(M.StyledConv(cout, cout, 3, style_dim))
+        g.to_rgbs.append(M.ToRGB(cout, style_dim))
+        cin = cout
+    # make every path numerically active
+    for m in g.modules():
+        if isinstance(m, M.NoiseInjection):
+            m.weight.data.fill_(0.1)
+        if isinstance(m, M.FusedLeakyReLU):
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, M.ToRGB):
+            m.bias.data.normal_(0, 0.2)
+    for m in g.style:
+        if isinstance(m, M.EqualLinear):
+            m.bias.data.normal_(0, 10.0)
+    g.eval()
+    return g
+
+
+class MiniCfg:
+    num_latents_for_mean = 64
+    truncation = 0.7
+    latent_dim = 16
+
+def build_swav(SC, Writer, gen, out_dir, hlen, nclasses, nproto, patch, source_pdf="uniform", eps=0.05,
+               niters=10, num_epochs=3, num_patches=2, layer_hf_dim=None, projn_nw="linear"):
+    """the reference's SwAVClustering (SC = hfc_with_swav.swav_clustering) on a mini generator, CPU"""
+    perturb_args = dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None,
+                        perturb_std=[1.0] * 3)
+    swav_args = dict(num_epochs=num_epochs, num_samples=1, num_patches=num_patches,
+                     sampling_method="random", patch_size=patch, hf_interp="nearest",
+                     warmup_epochs=num_epochs, start_warmup=0.01, use_scheduler=False,
+                     base_lr=0.01, final_lr=0.0001, trust_coeff=0.01,
+                     train_args=dict(lr=0.01, momentum=0.9), projn_nw=projn_nw,
+                     temperature=0.1, nprototypes=nproto, nclasses=nclasses, hlen=hlen,
+                     add_local_loss=False, plot_test_images=False, epoch_print_freq=1,
+                     max_masks=4)
+    sk = dict(source_pdf=source_pdf, niters=niters, eps=eps)
+    return SC.SwAVClustering(model=gen, model_config=MiniCfg, perturb_args=perturb_args,
+                             swav_args=swav_args, sinkhorn_args=sk, logger=_Logger(),
+                             train=True, out_dir=out_dir, device="cpu", tb=Writer(),
+                             layer_hf_dim=layer_hf_dim)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(
@@ -217,37 +277,7 @@ def main():
     # ---------------------------------------------------------------- GV4
     # mini generator built from the reference's own classes with small channels,
     # run through the reference's own Generator.forward.
-    def mini_generator(seed, size=32, style_dim=16, n_mlp=2,
-                       channels=None):
-        channels = channels or {4: 16, 8: 16, 16: 8, 32: 8, 64: 8}
-        torch.manual_seed(seed)
-        g = M.Generator(size, style_dim, n_mlp)        # builds the full-width net ...
-        g.channels = channels
-        g.input = M.ConstantInput(channels[4])         # ... whose blocks are replaced
-        g.conv1 = M.StyledConv(channels[4], channels[4], 3, style_dim)
-        g.to_rgb1 = M.ToRGB(channels[4], style_dim, upsample=False)
-        g.convs = torch.nn.ModuleList()
-        g.to_rgbs = torch.nn.ModuleList()
-        cin = channels[4]
-        for i in range(3, g.log_size + 1):
-            cout = channels[2 ** i]
-            g.convs.append(M.StyledConv(cin, cout, 3, style_dim, upsample=True))
-            g.convs.append(M.StyledConv(cout, cout, 3, style_dim))
-            g.to_rgbs.append(M.ToRGB(cout, style_dim))
-            cin = cout
-        # make every path numerically active
-        for m in g.modules():
-            if isinstance(m, M.NoiseInjection):
-                m.weight.data.fill_(0.1)
-            if isinstance(m, M.FusedLeakyReLU):
-                m.bias.data.normal_(0, 0.2)
-            if isinstance(m, M.ToRGB):
-                m.bias.data.normal_(0, 0.2)
-        for m in g.style:
-            if isinstance(m, M.EqualLinear):
-                m.bias.data.normal_(0, 10.0)
-        g.eval()
-        return g
+    mini_generator = functools.partial(build_mini_generator, M)
 
     g = mini_generator(104)
     torch.manual_seed(1040)
@@ -272,28 +302,8 @@ def main():
     save("gv4_mini_generator", **out)
 
     # ---------------------------------------------------------------- helper: SwAV object
-    class _Cfg:
-        num_latents_for_mean = 64
-        truncation = 0.7
-        latent_dim = 16
-
-    def make_swav(gen, out_dir, hlen, nclasses, nproto, patch, source_pdf="uniform", eps=0.05,
-                  niters=10, num_epochs=3, num_patches=2, layer_hf_dim=None):
-        perturb_args = dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None,
-                            perturb_std=[1.0] * 3)
-        swav_args = dict(num_epochs=num_epochs, num_samples=1, num_patches=num_patches,
-                         sampling_method="random", patch_size=patch, hf_interp="nearest",
-                         warmup_epochs=num_epochs, start_warmup=0.01, use_scheduler=False,
-                         base_lr=0.01, final_lr=0.0001, trust_coeff=0.01,
-                         train_args=dict(lr=0.01, momentum=0.9), projn_nw="linear",
-                         temperature=0.1, nprototypes=nproto, nclasses=nclasses, hlen=hlen,
-                         add_local_loss=False, plot_test_images=False, epoch_print_freq=1,
-                         max_masks=4)
-        sk = dict(source_pdf=source_pdf, niters=niters, eps=eps)
-        return SC.SwAVClustering(model=gen, model_config=_Cfg, perturb_args=perturb_args,
-                                 swav_args=swav_args, sinkhorn_args=sk, logger=_Logger(),
-                                 train=True, out_dir=out_dir, device="cpu", tb=Writer(),
-                                 layer_hf_dim=layer_hf_dim)
+    _Cfg = MiniCfg
+    make_swav = functools.partial(build_swav, SC, Writer)
 
     import tempfile
     tmp = tempfile.mkdtemp(prefix="gv_")

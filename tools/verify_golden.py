@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
 SCRIPTS = ["capture_golden.py", "capture_golden_oneshot.py", "capture_golden_baggan.py", "capture_golden_kmeans.py",
-           "capture_golden_native.py"]
+           "capture_golden_native.py", "capture_golden_heads.py"]
 EXPECTED = {("gv10_pretrain", "log")}
 
 
