@@ -14,8 +14,10 @@ n_init defaults to 10, the default of the scikit-learn the reference pins (1.0.2
 A layer's panel is never concatenated or moved to the host: the generator's NHWC taps already are (pixels, channels)
 matrices, the fit runs on them in HBM, and the label maps of all layers are written by one kernel in the NHWC layout
 the one-shot head consumes.  No CPU fallback: every entry point raises without a HIP device.
-Out of this build: `HierarchicalKMeansHFC` / `hier_encode=True` (the shipped config uses neither,
-configs/segmentors/hfc_kmeans_config.py:22-36).
+  * `HierarchicalKMeansHFC` (hfc_kmeans_clustering.py:212-390, `hfc_algo='hfc_kmeans_hier'`) each layer seeded from the
+                          layer before.
+`hier_encode=True` raises: it raises in the reference itself (see HFCPreprocessor.__init__; the shipped config sets
+it False, configs/segmentors/hfc_kmeans_config.py:22-36).
 """
 import ctypes
 import os
@@ -406,6 +408,60 @@ class FlatKMeansHFC(BaseHFCModel):
         return clusterer
 
 
+class HierarchicalKMeansHFC(BaseHFCModel):
+    """hfc_kmeans_clustering.py:212-390 (`hfc_algo='hfc_kmeans_hier'`): layer 0 is fitted like FlatKMeansHFC's, every
+    later layer starts Lloyd's iterations from centres propagated from the layer before — the labels of layer n,
+    nearest-resized to layer n + 1's resolution, give ONE scalar per label (the mean over that label's pixels AND all
+    channels of layer n + 1, `lbl_vect.mean()` at :380), written to every channel of the label's row and each row
+    repeated twice (:384-386) — so clusters_per_layer has to double from layer to layer, and the duplicated rows are told
+    apart by the empty-cluster relocation of the first iteration.  No `model_stats.npz` is written (only fit() does)."""
+
+    def __init__(self, kmeans_args, base_args):
+        self.kmeans_args = kmeans_args.copy()
+        BaseHFCModel.__init__(self, **base_args)
+
+    def hierarchical_fit(self, hidden_feat):
+        assert len(hidden_feat) == self.n_layer
+        self.clusterers = []
+        self._cluster_centers = None
+        for n in range(self.n_layer):
+            model = self._layerwise_fit(hidden_feat[n], n)
+            if n != self.n_layer - 1:
+                self._cluster_centers = self.calculate_cluster_centers(hidden_feat[n], hidden_feat[n + 1], model.labels_, n + 1)
+            self.clusterers.append(model)
+            self.save_model(model, n)
+            msg = f"Fitted model for Layer {n}"
+            print(msg) if self.logger is None else self.logger.info(msg)
+
+    def _layerwise_fit(self, feat, n):
+        t1, t2, _ = _pair(feat)
+        kw = dict(self.kmeans_args)
+        if getattr(self, '_cluster_centers', None) is not None:
+            kw['init'] = self._cluster_centers            # an explicit init: one run, whatever n_init says (as in scikit-learn)
+        return KMeans(n_clusters=self.clusters_per_layer[n], **kw).fit_taps(t1, t2)
+
+    def calculate_cluster_centers(self, feat_old, feat_new, labels, n):
+        """-> (2 * clusters_per_layer[n - 1], channels of layer n) float32 numpy: the init of layer n's k-means"""
+        _, _, (b, h, w) = _pair(feat_old)
+        t1, t2, (bn, hn, wn) = _pair(feat_new)
+        dev = t1.device
+        lab = torch.as_tensor(np.asarray(labels)).to(dev).reshape(b, h, w).long()
+        iy = (torch.arange(hn, device=dev) * h) // hn                 # Resize(NEAREST): source = floor(dest * in / out)
+        ix = (torch.arange(wn, device=dev) * w) // wn
+        lab = lab[:, iy][:, :, ix].reshape(-1)
+        k_old = self.clusters_per_layer[n - 1]
+        rowsum = t1.sum(1, dtype=torch.float64)
+        cn = t1.shape[1]
+        if t2 is not None:
+            rowsum = rowsum + t2.sum(1, dtype=torch.float64)
+            cn += t2.shape[1]
+        tot = torch.zeros(k_old, dtype=torch.float64, device=dev).index_add_(0, lab, rowsum)
+        cnt = torch.bincount(lab, minlength=k_old).double()
+        val = torch.where(cnt > 0, tot / (cnt.clamp(min=1) * cn), torch.zeros_like(tot))      # absent labels keep a zero row
+        centers = val.float().cpu().numpy()[:, None].repeat(cn, axis=1)
+        return np.repeat(centers, 2, axis=0)
+
+
 class HFCPreprocessor(object):
     """baseline/hfc_kmeans/segmentor.py:11-232"""
 
@@ -415,9 +471,13 @@ class HFCPreprocessor(object):
         self.hier_encode, self.hfc_algo, self.out_dir, self.train = hier_encode, hfc_algo, out_dir, train
         self.logger, self.model_config, self.hle_samples = logger, model_config, hle_samples
         assert self.hfc_algo in ['hfc_kmeans', 'hfc_kmeans_hier']
-        if self.hfc_algo != 'hfc_kmeans' or self.hier_encode:
-            raise NotImplementedError("hierarchical k-means / belief encoding are outside this build "
-                                      "(the shipped hfc_kmeans config uses neither)")
+        if self.hier_encode:
+            # the reference's own hier_encode=True cannot run: multi_sample_hierarchical_encoding
+            # (hfc_kmeans_clustering.py:484-546) builds its features without skip_const, so layer 0's clusterer is handed
+            # the constant-input conv's features and scikit-learn raises "X has 512 features, but KMeans is expecting 1024"
+            # in train_hfc_model (GV15 `D_hier_encode_outcome` holds the reference's exception on a mini generator)
+            raise NotImplementedError("hier_encode=True raises in the reference itself (feature-count mismatch in "
+                                      "multi_sample_hierarchical_encoding); the shipped hfc_kmeans config sets it False")
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError("ganecdotes_amd.kmeans runs on HIP devices only (no CPU fallback)")
@@ -425,7 +485,8 @@ class HFCPreprocessor(object):
         self.hfc_args['base_args']['logger'] = self.logger
         if presaved is not None:                             # pretrain.py / evaluate.py set hfc_prep_args['presaved']
             self.hfc_args['base_args']['presaved'] = presaved
-        self.hfc_model = FlatKMeansHFC(hfc_args['kmeans_args'], dict(hfc_args['base_args'], device=self.device))
+        cls = FlatKMeansHFC if self.hfc_algo == 'hfc_kmeans' else HierarchicalKMeansHFC
+        self.hfc_model = cls(hfc_args['kmeans_args'], dict(hfc_args['base_args'], device=self.device))
         self.trained_beliefs = None
 
     # the normal draws of the path, in the reference's order (tests feed recorded draws through this hook)
@@ -470,7 +531,10 @@ class HFCPreprocessor(object):
         hidden_features = [tuple(t[k * ns:(k + 1) * ns] for t in pairs[k]) for k in range(nl)]
         for k in range(nl):
             self.logger.info(f"Generated features for Layer: {k}") if self.logger else None
-        self.hfc_model.fit(hidden_features)
+        if self.hfc_algo == 'hfc_kmeans_hier':
+            self.hfc_model.hierarchical_fit(hidden_features)
+        else:
+            self.hfc_model.fit(hidden_features)
         if return_aug:
             return [torch.cat(p, 1) for p in hidden_features], new_latent_list
 

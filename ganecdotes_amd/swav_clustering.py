@@ -505,6 +505,13 @@ class SwAVClustering(ViewMixin):
         and saves prototypes.pt / projection.pt."""
         sa = self.swav_args
         sd = self.model.style_dim
+        if sa.get('add_local_loss', False):
+            # swav_clustering.py:420-425: `sum(self.layer_hf_dim[l_s])` sums ONE int of the configs' flat list and raises
+            # TypeError in the reference's first step; there is no defined behaviour to reproduce
+            raise NotImplementedError("add_local_loss=True raises in the reference itself (sum() of an int, "
+                                      "swav_clustering.py:424); every shipped config sets it False")
+        if sa.get('plot_test_images', False):
+            self.logger.info("plot_test_images: the tensorboard image grids (swav_clustering.py:467-500) are not drawn")
         # reference RNG order at entry: test latents + their randomized-noise forwards (:224-237)
         for _ in range(num_test_samples):
             torch.randn(1, sd)

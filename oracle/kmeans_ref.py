@@ -206,6 +206,42 @@ def flat_fit(hidden_feat, clusters_per_layer, **kmeans_args):
     return out
 
 
+def propagated_centers(feat_new, labels_old, old_shape, k_old):
+    """HierarchicalKMeansHFC.calculate_cluster_centers (:341-390): the old layer's labels, nearest-resized to the new
+    layer's resolution; per label ONE scalar — the mean over its pixels and ALL channels of the new features
+    (`lbl_vect.mean()`, :380) — in every channel of that label's row (labels that do not occur keep a zero row); every
+    row repeated twice (:384-386).  -> (2 k_old, channels) float32"""
+    feat_new = np.asarray(feat_new, np.float32)
+    b, h, w = old_shape
+    bn, cn, hn, wn = feat_new.shape
+    lab = np.asarray(labels_old).reshape(b, h, w)
+    lab = lab[:, nearest_resize_index(h, hn)][:, :, nearest_resize_index(w, wn)].reshape(-1)
+    ff = np.transpose(feat_new, (1, 0, 2, 3)).reshape(cn, -1)
+    centers = np.zeros((k_old, cn), np.float32)
+    for lbl in np.unique(lab):
+        centers[int(lbl), :] = ff[:, lab == lbl].mean(dtype=np.float32)
+    return np.repeat(centers, 2, axis=0)
+
+
+def hier_fit(hidden_feat, clusters_per_layer, **kmeans_args):
+    """HierarchicalKMeansHFC.hierarchical_fit (:235-306): k-means++ for layer 0 only; layer n + 1 starts from the centres
+    propagated from layer n's labels (one run: an explicit init overrides n_init, as scikit-learn does)"""
+    kmeans_args.pop("verbose", None)
+    out, init = [], None
+    for n, feat in enumerate(hidden_feat):
+        feat = np.asarray(feat, np.float32)
+        kw = dict(kmeans_args)
+        if init is not None:
+            kw.update(init=init, n_init=1)
+        m = kmeans_fit(panel(feat), clusters_per_layer[n], **kw)
+        m["init"] = init
+        out.append(m)
+        if n + 1 < len(hidden_feat):
+            b, _, h, w = feat.shape
+            init = propagated_centers(hidden_feat[n + 1], m["labels_"], (b, h, w), clusters_per_layer[n])
+    return out
+
+
 def flat_predict(hidden_feat, centers_per_layer, out_size):
     """FlatKMeansHFC.predict (:95-110, :169-208) -> (cluster_maps (b, sum K, out, out) in {0,1},
     [labels (b, 1, h, w) per layer])"""

@@ -377,6 +377,52 @@ def test_hfc_preprocessor_golden_gv15(gpu, tmp_path):
     assert preds.shape == g["B_pred_maps"].shape and preds.permute(0, 2, 3, 1).is_contiguous()
 
 
+def test_hierarchical_kmeans_golden_gv15(gpu, tmp_path):
+    """hfc_algo='hfc_kmeans_hier' (HierarchicalKMeansHFC, hfc_kmeans_clustering.py:212-390) against the reference's own
+    run: the centres propagated from layer to layer (one scalar per label, rows repeated twice), the fits they seed —
+    duplicated initial rows separated by the empty-cluster relocation —, the saved files and predict"""
+    from oracle import kmeans_ref as K
+    from ganecdotes_amd.kmeans import HFCPreprocessor, HierarchicalKMeansHFC
+    g = load_golden("gv15_kmeans")
+    gen = _mini(g, gpu)
+    nl, clusters = len(g["C_clusters"]), g["C_clusters"].tolist()
+    prep = HFCPreprocessor(
+        model=gen, model_config=types.SimpleNamespace(num_latents_for_mean=64),
+        perturb_args=dict(truncation=0.7, n_layers=nl, n_samples=int(g["B_n_samples"]), perturb_std=g["B_perturb_std"].tolist()),
+        hfc_args=dict(kmeans_args=dict(verbose=0, random_state=0, n_init=2),
+                      base_args=dict(out_dir=None, n_layers=nl, clusters_per_layer=clusters, out_size=int(g["B_out_size"]),
+                                     presaved=False)),
+        hfc_algo='hfc_kmeans_hier', hier_encode=False, train=True, out_dir=str(tmp_path), logger=_Log())
+    assert isinstance(prep.hfc_model, HierarchicalKMeansHFC)
+    sd, w = golden_sd(g), T(g["B_w"])
+    torch.manual_seed(int(g["C_seed_train"]))
+    _, _, draws, _ = K.train_features(sd, w[0:1], 16, num_latents_for_mean=64, truncation=0.7, n_layers=nl,
+                                      n_samples=int(g["B_n_samples"]), perturb_std=g["B_perturb_std"].tolist())
+    queue = [draws["mean_z"]] + [z for row in draws["noise"] for z in row]
+    prep._randn = lambda *shape: queue.pop(0).to(gpu)
+    feats, _ = prep.train_hfc_model(w[0:1].cuda(), return_aug=True)
+    for n in range(nl):
+        np.testing.assert_allclose(feats[n].cpu().numpy(), g[f"C_feat_{n}"], rtol=1e-3, atol=2e-4)
+        km = prep.hfc_model.clusterers[n]
+        if n:
+            np.testing.assert_allclose(np.asarray(km.init), g[f"C_init_{n}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(km.labels_, g[f"C_labels_{n}"])
+        np.testing.assert_allclose(km.cluster_centers_, g[f"C_centers_{n}"], rtol=1e-3, atol=1e-3)
+        assert abs(km.inertia_ - float(g[f"C_inertia_{n}"])) <= 1e-3 * float(g[f"C_inertia_{n}"])
+        assert km.n_iter_ == int(g[f"C_n_iter_{n}"])
+    assert sorted(os.listdir(tmp_path)) == sorted(g["C_saved_files"].tolist())
+    torch.manual_seed(int(g["C_seed_predict"]))
+    _, mean_z = K.predict_features(sd, w[1:2], 16, num_latents_for_mean=64, truncation=0.7, n_layers=nl)
+    prep._randn = lambda *shape: mean_z.to(gpu)
+    preds, labels = prep.predict_hfc_vectors(w[1:2].cuda())
+    for n in range(nl):
+        np.testing.assert_array_equal(labels[n].cpu().numpy(), g[f"C_pred_labels_{n}"])
+    np.testing.assert_array_equal(preds.cpu().numpy(), g["C_pred_maps"])
+    # the flag the reference cannot run itself (GV15 D_hier_encode_outcome) is refused, with the reason
+    with pytest.raises(NotImplementedError, match="raises in the reference itself"):
+        HFCPreprocessor(model=gen, model_config=None, perturb_args={}, hfc_args={}, hier_encode=True, out_dir=str(tmp_path))
+
+
 def test_saved_models_are_sklearn_pickles(gpu, tmp_path):
     """clusterer_layer_{n}.sav unpickles to a fitted sklearn KMeans whose CPU predict agrees with the HIP labels;
     a fresh (presaved) FlatKMeansHFC loads them back"""

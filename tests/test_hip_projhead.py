@@ -176,3 +176,11 @@ def test_unknown_projection_network_is_refused(gpu, tmp_path):
     sw = make_swav(mini_gen(sd, gpu), gpu, tmp_path, projn_nw="3-layer")
     with pytest.raises(ValueError):
         sw.build_heads()
+
+
+def test_add_local_loss_is_refused_like_the_reference(gpu, tmp_path):
+    """swav_clustering.py:420-425 raises TypeError on `sum(int)` with every shipped layer_hf_dim: refused with the reason"""
+    sd = golden_sd(load_golden("gv10_pretrain"))
+    sw = make_swav(mini_gen(sd, gpu), gpu, tmp_path, add_local_loss=True)
+    with pytest.raises(NotImplementedError, match="raises in the reference itself"):
+        sw.pretrain(None, num_test_samples=0)

@@ -426,6 +426,28 @@ def test_gv15_reference_hfc_preprocessor():
                                                    "model_stats.npz"]
 
 
+def test_gv15_reference_hierarchical_kmeans():
+    """hfc_algo='hfc_kmeans_hier' (HierarchicalKMeansHFC, hfc_kmeans_clustering.py:212-390) as the reference ran it on
+    its mini generator: the propagated initial centres, the fits they lead to and predict; and what the reference itself
+    does with hier_encode=True (it raises: the build refuses that flag with the same reason)"""
+    from oracle import kmeans_ref as K
+    g = _gv15()
+    clusters, nl = g["C_clusters"].tolist(), len(g["C_clusters"])
+    assert clusters == [3, 6, 12]
+    feats = [g[f"C_feat_{n}"] for n in range(nl)]
+    models = K.hier_fit(feats, clusters, random_state=0, n_init=2, verbose=0)
+    for n, m in enumerate(models):
+        if n:
+            np.testing.assert_allclose(m["init"], g[f"C_init_{n}"], rtol=1e-6, atol=1e-7)
+            assert np.array_equal(m["init"][0::2], m["init"][1::2]) and np.ptp(m["init"], axis=1).max() == 0
+        np.testing.assert_array_equal(m["labels_"], g[f"C_labels_{n}"])
+        np.testing.assert_allclose(m["cluster_centers_"], g[f"C_centers_{n}"], rtol=0, atol=1e-5)
+        assert abs(m["inertia_"] - float(g[f"C_inertia_{n}"])) <= 1e-5 * float(g[f"C_inertia_{n}"])
+        assert m["n_iter_"] == int(g[f"C_n_iter_{n}"])
+    assert sorted(g["C_saved_files"].tolist()) == [f"clusterer_layer_{n}.sav" for n in range(nl)]    # no model_stats.npz
+    assert str(g["D_hier_encode_outcome"]).startswith("ValueError: X has 12 features, but KMeans is expecting 16")
+
+
 # ------------------------------------------------------------------------------------- GV16: native-op signatures, metrics
 def test_gv16_upfirdn2d_general_and_fused_bias_act():
     d = load_golden("gv16_native_ops")

@@ -94,6 +94,8 @@ def main():
             self.size = size if isinstance(size, (tuple, list)) else (size, size)
 
         def __call__(self, t):
+            if not t.is_floating_point():        # torchvision's tensor path casts integer images to float32 and back
+                return F.interpolate(t.float(), size=tuple(self.size), mode="nearest").round().to(t.dtype)
             return F.interpolate(t, size=tuple(self.size), mode="nearest")
     tvt.Resize = _Resize
     from models.stylegan2 import model as M
@@ -163,6 +165,79 @@ def main():
     stats = np.load(os.path.join(tmp, "model_stats.npz"), allow_pickle=True)
     arrs["B_saved_files"] = np.asarray(sorted(os.listdir(tmp)))
     arrs["B_stats_keys"] = np.asarray(sorted(stats.files))
+
+    # ------------------------------------------------------------------ C: hfc_algo='hfc_kmeans_hier'
+    # HierarchicalKMeansHFC.hierarchical_fit (hfc_kmeans_clustering.py:212-306, :341-390): layer n + 1 starts from the
+    # centres propagated from layer n's labels (ONE scalar mean per label, every channel equal, each row repeated twice
+    # — so clusters_per_layer must double from layer to layer), k-means++ only for layer 0.
+    import warnings
+    clusters_h = [3, 6, 12]
+    tmp_h = tempfile.mkdtemp()
+    prep_h = SEG.HFCPreprocessor(
+        model=g, model_config=cfg,
+        perturb_args=dict(truncation=0.7, n_layers=n_layers, n_samples=n_samples, perturb_std=[1.0, 0.6, 1.0]),
+        hfc_args=dict(kmeans_args=dict(random_state=0, n_init=2, verbose=0),
+                      base_args=dict(out_dir=None, n_layers=n_layers, clusters_per_layer=clusters_h, out_size=out_size,
+                                     presaved=False)),
+        hfc_algo='hfc_kmeans_hier', hier_encode=False, train=True, out_dir=tmp_h, logger=_Logger())
+    arrs.update(C_clusters=np.asarray(clusters_h, np.int64), C_seed_train=np.int64(1504), C_seed_predict=np.int64(1505))
+    torch.manual_seed(1504)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")              # "Explicit initial center position passed: performing only one init"
+        feats_h, _ = prep_h.train_hfc_model(w[0:1], return_aug=True)
+    for n in range(n_layers):
+        km = prep_h.hfc_model.clusterers[n]
+        arrs[f"C_feat_{n}"] = _np(feats_h[n])
+        arrs[f"C_centers_{n}"] = km.cluster_centers_.astype(np.float32)
+        arrs[f"C_labels_{n}"] = km.labels_.astype(np.int32)
+        arrs[f"C_inertia_{n}"] = np.float64(km.inertia_)
+        arrs[f"C_n_iter_{n}"] = np.int64(km.n_iter_)
+        if n:
+            arrs[f"C_init_{n}"] = np.asarray(km.init, np.float32)          # the propagated centres that seeded this layer
+    torch.manual_seed(1505)
+    preds_h, labels_h = prep_h.predict_hfc_vectors(w[1:2])
+    arrs["C_pred_maps"] = _np(preds_h)
+    for n in range(n_layers):
+        arrs[f"C_pred_labels_{n}"] = _np(labels_h[n]).astype(np.int64)
+    arrs["C_saved_files"] = np.asarray(sorted(os.listdir(tmp_h)))
+    # ------------------------------------------------------------------ D: hier_encode=True in the reference itself
+    # multi_sample_hierarchical_encoding (hfc_kmeans_clustering.py:484-546) draws torch.randn(1, 512) (style_dim fixed at
+    # 512) and builds its features WITHOUT skip_const, so layer n's clusterer is handed the features of block n - 1 and
+    # layer 0 the constant-input conv's, whose width differs from a block pair's in every StyleGAN2 config (ffhq-256: 512
+    # against 1024).  A style_dim-512 mini generator with that property (12 against 8 + 8) records what the reference
+    # does with it.
+    torch.manual_seed(1506)
+    g5 = M.Generator(32, 512, 2)
+    ch5 = {4: 12, 8: 8, 16: 8, 32: 8}
+    g5.channels = ch5
+    g5.input = M.ConstantInput(ch5[4])
+    g5.conv1 = M.StyledConv(ch5[4], ch5[4], 3, 512)
+    g5.to_rgb1 = M.ToRGB(ch5[4], 512, upsample=False)
+    g5.convs, g5.to_rgbs = torch.nn.ModuleList(), torch.nn.ModuleList()
+    cin = ch5[4]
+    for i in range(3, g5.log_size + 1):
+        cout = ch5[2 ** i]
+        g5.convs.append(M.StyledConv(cin, cout, 3, 512, upsample=True))
+        g5.convs.append(M.StyledConv(cout, cout, 3, 512))
+        g5.to_rgbs.append(M.ToRGB(cout, 512))
+        cin = cout
+    g5.eval()
+    prep_e = SEG.HFCPreprocessor(
+        model=g5, model_config=cfg,
+        perturb_args=dict(truncation=0.7, n_layers=n_layers, n_samples=n_samples, perturb_std=[1.0, 0.6, 1.0]),
+        hfc_args=dict(kmeans_args=dict(random_state=0, n_init=2, verbose=0),
+                      base_args=dict(out_dir=None, n_layers=n_layers, clusters_per_layer=clusters, out_size=out_size,
+                                     presaved=False)),
+        hfc_algo='hfc_kmeans', hier_encode=True, hle_samples=2, train=True, out_dir=tempfile.mkdtemp(), logger=_Logger())
+    with torch.no_grad():
+        w5 = g5.style(torch.randn(1, 512))
+    try:
+        prep_e.train_hfc_model(w5)
+        outcome = "ran"
+    except Exception as e:                                                    # noqa: BLE001
+        outcome = f"{type(e).__name__}: {e}"
+    arrs["D_hier_encode_outcome"] = np.asarray(outcome)
+    print("hier_encode=True in the reference:", outcome)
 
     path = os.path.join(out_dir, "gv15_kmeans.npz")
     np.savez_compressed(path, **arrs)
