@@ -22,8 +22,10 @@ ls = ops.lib().gx_lowrank_stride(K)
 coeffs = torch.randn(rows, ls, device=dev) * 1e-3
 
 
-def timeit(f, n=5):
-    f(); torch.cuda.synchronize()
+def timeit(f, n=5, warm=10):
+    for _ in range(warm):          # the first launches after an idle spell run 10-20 % slower (clock ramp): not the kernel
+        f()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
@@ -49,6 +51,15 @@ wft_planes = ops.split_gemm_weights(wp.t().contiguous())
 wf_planes = ops.split_gemm_weights(wp)
 if want("fwd"):
     show("y2 = 2 Zc Wf (0.5M x 512 -> 256)", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, y2, alpha=2.0)), 2.0 * rc * D * CF)
+    if "y2var" in which:       # where the 154 TFLOP/s of the Y2 GEMM come from: output stride, alpha, N (three interleaved rounds)
+        yc = torch.empty(rc, CF, device=dev)
+        w512 = ops.split_gemm_weights(torch.randn(512, D, device=dev) / 16)
+        y512 = torch.empty(rc, 512, device=dev)
+        for _ in range(3):
+            show("  y2 as the step runs it (ld 288, alpha 2)", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, y2, alpha=2.0)), 2.0 * rc * D * CF)
+            show("  y2 into a contiguous (rows, 256) table", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, yc, alpha=2.0)), 2.0 * rc * D * CF)
+            show("  y2, alpha = 1", timeit(lambda: ops.gemm_nt_planes(zc2, None, wft_planes, y2, alpha=1.0)), 2.0 * rc * D * CF)
+            show("  same A, N = 512", timeit(lambda: ops.gemm_nt_planes(zc2, None, w512, y512)), 2.0 * rc * D * 512)
     show("raw tables of Zc", timeit(lambda: ops.proto_raw_tables(zc2, wc)), 0, 4.0 * rc * (D + K + 1))
     ops.proto_raw_tables(zc2, wc, ytable=yt)
     pl = ops.split_gemm_weights(ops.fineq_pack_weights(mg, wcf))
