@@ -23,6 +23,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int gx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+namespace gx {
+// out[k] = alpha * sum_b part[b][k] + beta * out[k] over nblk partial rows, in a fixed order (gx_swav.hip).  `spare`
+// (optional): >= 8 * K floats of scratch; with it many rows of many columns are reduced in two stages that fill the chip.
+void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out, hipStream_t stream,
+                           float* spare = nullptr);
+}  // namespace gx
+
 // Cross-lane exchange inside a row of 16 lanes by DPP (one VALU instruction, no LDS round trip, unlike
 // ds_bpermute behind __shfl_xor).  For a commutative reduction any pairing that joins two already
 // reduced, disjoint groups will do: xor 1 and xor 2 are quad permutes, the 8-lane step pairs lane i
@@ -50,6 +57,20 @@ __device__ __forceinline__ float gx_wave_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
+}
+// x(lane) + x(lane ^ 32) and x(lane) + x(lane ^ 16) in every lane by v_permlane32_swap / v_permlane16_swap (gfx950: swap the
+// odd half-waves / 16-lane rows of the first operand with the even ones of the second, in place): two VALU instructions
+// instead of a ds_bpermute through the LDS crossbar.  All 64 lanes must be active.  Inline asm: hipcc 7.2 returns the FIRST
+// register for both elements of __builtin_amdgcn_permlane32_swap's result.
+__device__ __forceinline__ float gx_xor32_sum(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float gx_xor16_sum(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return a + b;
 }
 // reductions over a power-of-two team of consecutive lanes (team <= 64); every lane gets the result
 __device__ __forceinline__ float gx_team_sum(float v, int team) {

@@ -43,6 +43,13 @@ struct GemmArgs {
     float* usum_part;     // ... and (with colmax_part) [4 tiles_m][N] sums of exp((value - that maximum) * sk_inv_eps) over the
     float sk_inv_eps;     //     same rows: the first Sinkhorn pass, left behind by the GEMM that writes the scores
     int ep_vec;           // C / slab / up_src rows can be written and read as aligned float4 (N % 4 == 0, ...)
+    // gemm_xw_kernel<.., FIN>: the low-rank path's dense finish in the epilogue (gx_gemm_f32_nt_planes_finish).  C's rows are
+    // the pixels of (1 << fin_rlog)^2 images; a tile is 2 image rows x 64 pixels, a wave 2 x 16 of them:
+    //   C[q] = acc[q] + sum_k fin_C[q][k] fin_Wc[k] + fin_C[q][fin_K] fin_Z[q];  fin_pool[q / 2x2] = the 2x2 sums of C;
+    //   fin_part[tile_m][k][n] = sum over the tile's 128 pixels of fin_C[q][k] fin_Z[q][n]
+    const float* fin_C; const float* fin_Z; const float* fin_Wc;
+    float* fin_pool; float* fin_part;
+    int fin_K, fin_ls, fin_rlog;
 };
 
 // (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
@@ -370,6 +377,94 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Epilogue of gemm_xw_kernel<false, true>: the dense finish of the low-rank prototype path (what proto_lowrank_finish_kernel
+// does in a pass of its own over G: read G, Z, write G, Gpool — 3.4 GB for the 128^2 level of the bench step) while the tile
+// is on the chip.  The wave's 32 rows are 2 image rows x 16 pixels (`pw` = its first pixel), so the 2x2 sums close inside
+// the wave; its coefficient rows sit in LDS (`cst`, [32][ls]); the prototype-gradient partial of the workgroup's 128 pixels
+// is summed across the four waves through the staging areas in a fixed order.
+// pixel of store pass ps of a lane whose first pixel is pl: image row ps >> 2 of the pair, x = (ps & 3) * 4 + (lane >> 4)
+#define FIN_PIX(ps) (pl + ((long)((ps) >> 2) << rlog) + ((ps) & 3) * 4)
+__device__ __forceinline__ void xw_fin_load_z(const GemmArgs& q, long N, long pl, int col, f32x4 (&z)[8]) {
+    const int rlog = q.fin_rlog;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) z[ps] = *reinterpret_cast<const f32x4*>(q.fin_Z + FIN_PIX(ps) * N + col);
+}
+__device__ __forceinline__ void xw_epilogue_fin(const GemmArgs& g, f32x16 (&acc)[1][2], const f32x4 (&z)[8], int tm, long pw,
+                                                int col0, int lane, float* stage, const float* cst, const float* stage_all) {
+    constexpr int SW = 68;
+    const GemmArgs& q = *gemm_late_args();
+    const int K = q.fin_K, ls = q.fin_ls, rlog = q.fin_rlog;
+    const int rl = lane >> 4, c4 = (lane & 15) * 4, col = col0 + c4;          // N % 128 == 0: every column is live
+    const long N = g.N;
+    const long pl = pw + rl;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SW + nt * 32 + (lane & 31)] = acc[0][nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 v[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        v[ps] = *reinterpret_cast<const f32x4*>(stage + (ps * 4 + rl) * SW + c4);
+        v[ps] += cst[(ps * 4 + rl) * ls + K] * z[ps];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // the staging area is free: it takes the wave's gWc partial [K][64]
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* const Wc = q.fin_Wc;
+    f32x4 w = *reinterpret_cast<const f32x4*>(Wc + col);
+#ifndef FIN_ABL
+#define FIN_ABL 0       // lab (tools/lab/fin_abl.sh): 1 no gWc partial, 2 no pooling, 3 no prototype term, 5 plain store only
+#endif
+    for (int k = 0; k < K && FIN_ABL != 5; ++k) {
+        const f32x4 wn = *reinterpret_cast<const f32x4*>(Wc + (long)min(k + 1, K - 1) * N + col);
+        f32x4 gw = zero4();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const float c = cst[(ps * 4 + rl) * ls + k];
+            if (FIN_ABL != 3) v[ps] += c * w;
+            if (FIN_ABL != 1) gw += c * z[ps];
+        }
+        if (FIN_ABL != 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gw[e] = gx_xor32_sum(gx_xor16_sum(gw[e]));      // over the four row lanes
+            if (lane < 16) *reinterpret_cast<f32x4*>(stage + k * 64 + c4) = gw;
+        }
+        w = wn;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f32x4*>(g.C + FIN_PIX(ps) * g.ldc + col) = v[ps];
+    if (q.fin_pool && FIN_ABL != 2 && FIN_ABL != 5) {
+        // pooled pixel of (image row pair, x / 2): the wave's 8 of them, lanes with an even row lane write
+        const long rhalf = 1L << (rlog - 1);
+        const long b = pw >> (2 * rlog), rem = pw & ((1L << (2 * rlog)) - 1);
+        const long pool0 = (b * rhalf + (rem >> (rlog + 1))) * rhalf + ((rem & ((1L << rlog) - 1)) >> 1);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            f32x4 p = v[ps] + v[ps + 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = gx_xor16_sum(p[e]);
+            if (!(rl & 1)) *reinterpret_cast<f32x4*>(q.fin_pool + (pool0 + ps * 2 + (rl >> 1)) * N + col) = p;
+        }
+    }
+    if (FIN_ABL == 1 || FIN_ABL == 5) return;
+    __syncthreads();                                     // the four waves' partials are in their staging areas
+    const int tid = threadIdx.x;
+    if (tid < K * 16) {
+        const int k = tid >> 4, c = (tid & 15) * 4;
+        const float* sp = stage_all + k * 64 + c;
+        const f32x4 s = (*reinterpret_cast<const f32x4*>(sp) + *reinterpret_cast<const f32x4*>(sp + EP_STAGE_FLOATS)) +
+                        (*reinterpret_cast<const f32x4*>(sp + 2 * EP_STAGE_FLOATS) + *reinterpret_cast<const f32x4*>(sp + 3 * EP_STAGE_FLOATS));
+        *reinterpret_cast<f32x4*>(q.fin_part + ((long)tm * K + k) * N + col0 + c) = s;
+    }
+    __syncthreads();
+}
+
+#undef FIN_PIX
+
 // (tm, tn) of logical tile `logical` for the weight-plane kernels: the N tiles go in groups of g.n_group, and within a
 // group the pixel tiles are swept with the group's N tiles innermost.  An XCD's contiguous run of logical tiles then
 // reads an A tile from HBM once per GROUP (the group's other tiles find it in L2) and keeps only the group's weight
@@ -394,10 +489,12 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
 // Products and their order equal x6_mfma_tile's, so results are bitwise those of gemm_x6_kernel.
 //   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
 constexpr int XW_A = 8192, XW_B = 3 * 4096;                          // one A tile (raw fp32), one B tile (planes)
-template <bool USUM>         // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part)
+template <bool USUM, bool FIN = false>   // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part); FIN: the
+                                         // low-rank path's dense finish in the epilogue, rows in 2 x 64-pixel tiles (xw_epilogue_fin)
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
-    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B];      // A ring of NS tiles, B ring of 2
+    // A ring of NS tiles, B ring of 2; FIN: + the four waves' coefficient rows [32][ls <= 20], DMA'd in before the k loop
+    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B + (FIN ? 4 * 32 * 20 * 4 : 0)];
     char* const ldsB = lds + NS * XW_A;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,17 +508,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
 
     // A: units p = tid and 256 + tid; tail rows re-read the last valid row (their outputs are dropped)
     unsigned aoff1[2], aoff2[2];
+    long pix0 = m0;                      // first pixel (row of A / C) of the tile
+    if (FIN) {                           // tile tm = (image, row pair, 64-pixel block): local row r = (wave, image row, x)
+        const int rlog = g.fin_rlog;
+        const int xb = tm & ((1 << (rlog - 6)) - 1), yp = (tm >> (rlog - 6)) & ((1 << (rlog - 1)) - 1);
+        pix0 = ((((long)(tm >> (2 * rlog - 7)) << rlog) + 2 * yp) << rlog) + xb * 64;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = i * 256 + tid;
         int row = p >> 2;
         const int q = (p & 3) ^ ((p >> 4) & 3);
-        row = min(row, g.M - 1 - m0);
+        if (FIN) row = (((row & 31) >> 4) << g.fin_rlog) + (row >> 5) * 16 + (row & 15);
+        else row = min(row, g.M - 1 - m0);
         aoff1[i] = ((unsigned)row * (unsigned)g.lda + (unsigned)q * 4u) * 4u;
         aoff2[i] = ((unsigned)row * (unsigned)g.lda2 + (unsigned)q * 4u) * 4u;
     }
-    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A + (long)m0 * g.lda, 0x7FFFFFF0u);
-    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + (long)m0 * g.lda2 : g.A, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.A + pix0 * g.lda, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + pix0 * g.lda2 : g.A, 0x7FFFFFF0u);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
     const unsigned boff = (unsigned)tid * 16u;
     const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * 3u * 4096u;
@@ -445,6 +549,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         }
     };
 
+    if (FIN) {      // the wave's 32 coefficient rows (2 image rows x 16 pixels = two runs of 16 * ls floats) -> LDS, 4 B per lane
+        const int ls = g.fin_ls;
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(g.fin_C + (pix0 + wid * 16) * ls, 0x7FFFFFF0u);
+        char* const cdst = lds + NS * XW_A + 2 * XW_B + wid * (32 * 20 * 4);
+        for (int dy = 0; dy < 2; ++dy)
+            for (int i = 0; i < (ls >> 2); ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_ptr_t)(cdst + (dy * 16 * ls + i * 64) * 4), 4, lane * 4,
+                                                         (int)((((long)dy << g.fin_rlog) * ls + i * 64) * 4), 0, 0);
+    }
     f32x16 acc0[1][2], acc1[1][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -503,6 +616,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     }
     __syncthreads();                                                 // every wave has read its last fragments
     float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
+    if (FIN) {
+        const GemmArgs& q = *gemm_late_args();
+        const long pw = pix0 + wid * 16;
+        const float* cst = reinterpret_cast<const float*>(lds + NS * XW_A + 2 * XW_B) + wid * (32 * 20);
+        {       // (both halves' Z rows in flight up front measured 4 % slower: 16 more live registers, spills)
+            f32x4 z[8];
+            xw_fin_load_z(q, g.N, pw + (lane >> 4), n0 + (lane & 15) * 4, z);
+            xw_epilogue_fin(g, acc0, z, tm, pw, n0, lane, stage, cst, reinterpret_cast<const float*>(lds));
+        }
+        {
+            f32x4 z[8];
+            xw_fin_load_z(q, g.N, pw + (lane >> 4), n0 + 64 + (lane & 15) * 4, z);
+            xw_epilogue_fin(g, acc1, z, tm, pw, n0 + 64, lane, stage, cst, reinterpret_cast<const float*>(lds));
+        }
+        return;
+    }
     if (g.beta != 0.f) {
         gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
         gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
@@ -707,7 +836,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
-                          float* usum_part = nullptr, float sk_eps = 0.f) {
+                          float* usum_part = nullptr, float sk_eps = 0.f, const GemmArgs* fin = nullptr) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -740,7 +869,15 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     if (usum_part && (!colmax_part || !(sk_eps > 0.f) || ((uintptr_t)usum_part & 15))) return GX_ERR_BAD_ARG;
     g.colmax_part = colmax_part;
     g.usum_part = usum_part; g.sk_inv_eps = usum_part ? 1.f / sk_eps : 0.f;
+    g.fin_C = g.fin_Z = g.fin_Wc = nullptr; g.fin_pool = g.fin_part = nullptr; g.fin_K = g.fin_ls = g.fin_rlog = 0;
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
+    if (fin) {
+        g.fin_C = fin->fin_C; g.fin_Z = fin->fin_Z; g.fin_Wc = fin->fin_Wc; g.fin_pool = fin->fin_pool; g.fin_part = fin->fin_part;
+        g.fin_K = fin->fin_K; g.fin_ls = fin->fin_ls; g.fin_rlog = fin->fin_rlog;
+        hipLaunchKernelGGL((gemm_xw_kernel<false, true>), grid, block, 0, stream, g);
+        GX_CHECK_LAUNCH();
+        return GX_OK;
+    }
     if (usum_part) hipLaunchKernelGGL(gemm_xw_kernel<true>, grid, block, 0, stream, g);
     else hipLaunchKernelGGL(gemm_xw_kernel<false>, grid, block, 0, stream, g);
     GX_CHECK_LAUNCH();
@@ -805,6 +942,35 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
                           float* colmax_part, float* usum_part, float sk_eps, void* stream) {
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
                               fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps);
+}
+// The gradient of the level below the finest one of the low-rank prototype path (K <= 16, pyramid.backward_lowrank) in ONE
+// kernel: G = A B^T (A = Tt (M, K1) from gx_fineq_bwd, B = Wf as planes) and, in the epilogue, the dense finish
+//   G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q];   gWc = beta gWc + coeffs[:, :K]^T Z;   Gpool = 2x2 sums of G (may be NULL)
+// — what gx_gemm_f32_nt_planes + gx_proto_lowrank_finish(accumulate) do in two passes over G.  The M rows are the pixels of
+// res x res images (res a power of two >= 64), coeffs (M, ls = gx_lowrank_stride(K)), Z and G (M, N) dense, N % 128 == 0.
+int gx_gemm_finish_ok(int N, int K1, int res, int K) {
+    return gx::gemm_mode() == 1 && N > 0 && (N & 127) == 0 && K1 > 0 && (K1 & 15) == 0 && res >= 64 && !(res & (res - 1)) &&
+           K >= 1 && K <= 16;
+}
+size_t gx_gemm_finish_workspace_bytes(long M, int N, int K) { return ((size_t)(M / 128) + 8) * K * N * sizeof(float); }
+int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
+                                 int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!gx_gemm_finish_ok(N, K1, res, K) || !coeffs || !Z || !Wc || !gWc || M <= 0 || M % ((long)res * res) ||
+        M >= (1L << 31) || (((uintptr_t)coeffs | (uintptr_t)Z | (uintptr_t)Wc | (uintptr_t)Gpool) & 15))
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_gemm_finish_workspace_bytes(M, N, K)) return GX_ERR_WORKSPACE;
+    gx::GemmArgs fin{};
+    fin.fin_C = coeffs; fin.fin_Z = Z; fin.fin_Wc = Wc; fin.fin_pool = Gpool; fin.fin_part = workspace;
+    fin.fin_K = K; fin.fin_ls = (K + 1 + 3) & ~3; fin.fin_rlog = 0;
+    while ((1 << fin.fin_rlog) < res) ++fin.fin_rlog;
+    const int rc = gx::launch_gemm_xw((int)M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, G, N, 1.f, 0.f, nullptr, nullptr, nullptr,
+                                      0, nullptr, (hipStream_t)stream, nullptr, 0.f, &fin);
+    if (rc) return rc;
+    const int tiles_m = (int)(M / 128);
+    gx::launch_partial_reduce(workspace, tiles_m, K * N, 1.f, beta, gWc, (hipStream_t)stream, workspace + (size_t)tiles_m * K * N);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
 }
 // bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
 size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }

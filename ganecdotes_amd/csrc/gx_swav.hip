@@ -311,8 +311,8 @@ __global__ void partial_reduce_slices_kernel(const float* __restrict__ part, int
 }
 // `spare` (optional): >= 8*K floats of scratch; with it, many partial rows of many columns are reduced in two stages
 // (8 row slices x K/64 column blocks fill the chip: one stage ran 79 blocks over 40 MB at 0.25 TB/s for K = 5000)
-static inline void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out,
-                                         hipStream_t stream, float* spare = nullptr) {
+void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out, hipStream_t stream,
+                           float* spare) {
     int kx = 1;
     while (kx < 64 && kx < K) kx <<= 1;
     if (spare && K >= 1024 && nblk >= 64) {

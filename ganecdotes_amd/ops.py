@@ -618,6 +618,29 @@ def split_conv_weights(wt):
 _XPLANES = {}
 
 
+def gemm_finish_ok(n, k1, res, k):
+    return bool(lib().gx_gemm_finish_ok(n, k1, res, k))
+
+
+def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool):
+    """G = a b^T with the low-rank path's dense finish in the GEMM's epilogue (gx_gemm_f32_nt_planes_finish):
+    G += coeffs[:, :K] wc + coeffs[:, K] .* z, gwc = beta gwc + coeffs[:, :K]^T z, and the 2x2 sums of G.
+    a (rows, K1) = pixels of res x res images, z (B, res, res, D); -> (G (B, res, res, D), Gpool (B, res/2, res/2, D) or None)"""
+    _chk(a, coeffs, z, wc, gwc)
+    bsz, r, _, d = z.shape
+    rows, k = bsz * r * r, wc.shape[0]
+    L = lib()
+    g = torch.empty_like(z)
+    gp = torch.empty(bsz, r // 2, r // 2, d, dtype=torch.float32, device=z.device) if want_pool else None
+    wsb = L.gx_gemm_finish_workspace_bytes(rows, d, k)
+    ws = workspace("gemm_finish", wsb, z.device)
+    with record("gemm_f32_kernel", 2.0 * rows * d * a.shape[1], 0.0):
+        _lib.check(L.gx_gemm_f32_nt_planes_finish(rows, d, a.shape[1], _p(a), a.stride(0), _p(b_planes), _p(g), r, _p(coeffs),
+                                                  _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _stream()),
+                   "gx_gemm_f32_nt_planes_finish")
+    return g, gp
+
+
 def xplanes_buffer(b, h, w, cin, device, slot="", cache=None):
     """A persistent x-planes buffer for (b, h, w, cin) (gx_xplanes_bytes; int16 view).  Its zero border is written
     here, once; kernels only ever write the interior, so the buffer is reused step after step.

@@ -168,7 +168,7 @@ class Pyramid:
                 g = g_pooled if (g_pooled is not None and r == res[-1]) else ops.sumpool2(g)
         return gwp
 
-    def backward_lowrank(self, coeffs, wp, wc, gwp, gwc, on_level=None, on_heads=None):
+    def backward_lowrank(self, coeffs, wp, wc, gwp, gwc, on_level=None, on_heads=None, fused_finish=True):
         """The adjoint of project_tables from the coefficient grid C (table pixels x (K + 1)) of the low-rank path
         (csrc/gx_swav.hip: G[q] = C[q][:K] Wc + C[q][K] z(q)): gwp (D, hlen) = d loss / d Wp, gwc (K, D) = d loss / d Wc
         (both overwritten).  on_heads() is called when gwc is final, on_level as in `backward`."""
@@ -191,11 +191,16 @@ class Pyramid:
         # ONE pass over the level's taps: S = sum_q e[q] t t^T (e = C[:, K]), P = C[:, :K]^T t, Tt = 2x2-pooled e t, Cpool
         s, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, k, r)
         # gradient of the level below: Gc = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc  (+ its 2x2 sum-pooling), gWc
-        gc = torch.empty_like(zc2)
-        ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
         pool = top > 1
-        out = ops.proto_lowrank_finish(cpool, zc, wc, gwc, 0.0, want_pool=pool, add_to=gc.reshape(zc.shape))
-        gcz, gp = out if pool else (out, None)
+        rc = zc.shape[1]
+        if fused_finish and ops.get_gemm_mode() == 1 and ops.gemm_finish_ok(d, cf, rc, k):
+            # ... in ONE kernel: the finish rides on the GEMM's epilogue, G is written once (csrc/gx_gemm.hip)
+            gcz, gp = ops.gemm_nt_planes_finish(tt, ops.split_gemm_weights(wf), cpool, zc, wc, gwc, 0.0, rc, pool)
+        else:
+            gc = torch.empty_like(zc2)
+            ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
+            out = ops.proto_lowrank_finish(cpool, zc, wc, gwc, 0.0, want_pool=pool, add_to=gc.reshape(zc.shape))
+            gcz, gp = out if pool else (out, None)
         ops.gemm(pm, wf, False, True, out=gwc, beta=1.0)                # gWc += P Wf^T
         if on_heads is not None:
             on_heads()

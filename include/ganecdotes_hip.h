@@ -104,6 +104,14 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
+/* gx_gemm_f32_nt_planes_finish: G = A1 B^T with the low-rank path's dense finish in the epilogue (autograd of
+ * swav_clustering.py:171-175 through the pyramid, K <= 16): G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q], gWc = beta gWc +
+ * coeffs[:, :K]^T Z, Gpool (may be NULL) = the 2x2 sums of G; rows = pixels of res x res images (DESIGN.md par. 4.14) */
+int gx_gemm_finish_ok(int N, int K1, int res, int K);
+size_t gx_gemm_finish_workspace_bytes(long M, int N, int K);
+int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
+                                 int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream);
 /* usum_part (optional, with colmax_part; same size): per 32-row slice and column the sum of exp((C - that slice's maximum) /
  * sk_eps) — the FIRST Sinkhorn pass (swav_clustering.py:519-520: Q = exp(scores / eps), its row sums) left behind by the GEMM
  * that writes the scores.  gx_sinkhorn_first_from_parts merges the slices of `groups` equal row groups by log-sum-exp:

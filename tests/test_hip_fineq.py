@@ -167,3 +167,76 @@ def test_tables_shifted_below_levels_without_taps(ops):
     ls = c_s.shape[1]
     pooled = c_f.reshape(2, 16, 2, 16, 2, ls).sum((2, 4)).reshape(-1, ls)
     assert rel(c_s, pooled) < 1e-5 and rel(gb_s, gb_f) < 1e-6
+
+
+@pytest.mark.parametrize("k,res,pool", [(8, 64, True), (16, 128, True), (5, 64, False), (1, 64, True)])
+def test_fused_finish_gemm_vs_fp64_and_the_two_kernel_route(ops, k, res, pool):
+    """gx_gemm_f32_nt_planes_finish (the dense finish in the GEMM's epilogue, rows in 2 x 64-pixel tiles): G, its 2x2 sums
+    and gWc against fp64, and against gx_gemm_f32_nt_planes + gx_proto_lowrank_finish(add_to) which it replaces"""
+    b, d, cf = 2, 512, 256
+    rows = b * res * res
+    torch.manual_seed(31 + k)
+    tt = torch.randn(rows, cf).cuda()
+    wf = (torch.randn(d, cf) / 16).cuda()
+    z = torch.randn(b, res, res, d).cuda()
+    wc = torch.nn.functional.normalize(torch.randn(k, d), dim=1).cuda()
+    ls = ops.lib().gx_lowrank_stride(k)
+    coeffs = torch.zeros(rows, ls)
+    hit = torch.rand(rows) < 0.5
+    coeffs[hit, :k + 1] = torch.randn(int(hit.sum()), k + 1)
+    coeffs = coeffs.cuda()
+    assert ops.gemm_finish_ok(d, cf, res, k)
+    planes = ops.split_gemm_weights(wf)
+    gwc = torch.full((k, d), 3.0).cuda()
+    g, gp = ops.gemm_nt_planes_finish(tt, planes, coeffs, z, wc, gwc, 0.0, res, pool)
+    # fp64
+    c64, z64 = coeffs.double(), z.double().reshape(rows, d)
+    want = tt.double() @ wf.double().t() + c64[:, :k] @ wc.double() + c64[:, k:k + 1] * z64
+    assert rel(g.reshape(rows, d), want) < 2e-6
+    assert rel(gwc, c64[:, :k].t() @ z64) < 2e-6
+    if pool:
+        wp_ = want.reshape(b, res // 2, 2, res // 2, 2, d).sum((2, 4))
+        assert rel(gp, wp_) < 2e-6
+    else:
+        assert gp is None
+    # the route it replaces
+    g2 = torch.empty(rows, d).cuda()
+    ops.gemm_nt_planes(tt, None, planes, g2)
+    gwc2 = torch.full((k, d), 3.0).cuda()
+    out = ops.proto_lowrank_finish(coeffs, z, wc, gwc2, 0.0, want_pool=pool, add_to=g2.reshape(z.shape))
+    g2f, gp2 = out if pool else (out, None)
+    assert rel(g, g2f) < 2e-6 and rel(gwc, gwc2) < 2e-6
+    if pool:
+        assert rel(gp, gp2) < 2e-6
+    # accumulate into gWc (beta = 1), and idempotence (no atomics)
+    g3, gp3 = ops.gemm_nt_planes_finish(tt, planes, coeffs, z, wc, gwc2, 1.0, res, pool)
+    assert rel(gwc2, 2.0 * gwc) < 2e-6
+    assert torch.equal(g3, g) and (not pool or torch.equal(gp3, gp))
+
+
+def test_backward_lowrank_fused_finish_equals_two_kernels(ops):
+    """Pyramid.backward_lowrank with the level below the finest at 64^2 (the fused finish applies) against the same call
+    with the finish as a pass of its own"""
+    from ganecdotes_amd.pyramid import Pyramid
+    b, d, k = 2, 512, 8
+    chans = {32: [64], 64: [128, 128], 128: [128, 128]}
+    taps = _taps(b, 128, chans, seed=11)
+    hlen = sum(sum(v) for v in chans.values())
+    torch.manual_seed(17)
+    wp = (torch.randn(d, hlen) / hlen ** 0.5).cuda()
+    wc = torch.nn.functional.normalize(torch.randn(k, d), dim=1).cuda()
+    bias = torch.zeros(k).cuda()
+    ls = ops.lib().gx_lowrank_stride(k)
+    coeffs = torch.zeros(b * 128 * 128, ls)
+    hit = torch.rand(b * 128 * 128) < 0.4
+    coeffs[hit, :k + 1] = torch.randn(int(hit.sum()), k + 1) * 1e-3
+    coeffs = coeffs.cuda()
+    outs = []
+    for fused in (True, False):
+        pyr = Pyramid(ops.TapSet(taps), hlen)
+        pyr.project_tables(wp, wc, bias)
+        assert pyr._lr["mode"] == "quad"
+        gwp, gwc = torch.full_like(wp, 7.0), torch.full_like(wc, 7.0)
+        pyr.backward_lowrank(coeffs, wp, wc, gwp, gwc, fused_finish=fused)
+        outs.append((gwp, gwc))
+    assert rel(outs[0][0], outs[1][0]) < 5e-6 and rel(outs[0][1], outs[1][1]) < 5e-6

@@ -79,6 +79,8 @@ if want("bwd"):
     gwc = torch.empty(K, D, device=dev)
     show("finish at the coarse level (add_to, pool)", timeit(lambda: ops.proto_lowrank_finish(cpool, zc, wc, gwc, 0.0, want_pool=True, add_to=gc.reshape(zc.shape))),
          0, 4.0 * rc * D * 3.25)
+    show("Gc GEMM with the finish in its epilogue", timeit(lambda: ops.gemm_nt_planes_finish(tt, wf_planes, cpool, zc, wc, gwc, 0.0, R // 2, True)),
+         2.0 * rc * D * CF, 4.0 * rc * D * 2.25)
     gw = torch.empty(D, CF, device=dev)
     show("dWf: Zc^T Tt (512 x 256, k = 0.5M)", timeit(lambda: ops.gemm(zc2, tt, True, False, out=gw, split_k=64)), 2.0 * rc * D * CF)
     # the projected-table route
