@@ -877,7 +877,10 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 // reads and the fp32 stores are then 256-B runs per pixel (the per-wave "16 pixels x one chunk" map of blur_act_kernel
 // moves them in 64-B pieces), and the three bf16 planes of an output row go through LDS ([4 chunks][3 planes][16 px][32 B],
 // double-buffered, one barrier per row) so that every (chunk, plane) image still receives one contiguous 512-B run.
-__global__ __launch_bounds__(256) void blur_act_xp_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
+#ifndef BLUR_MINB
+#define BLUR_MINB 1      // lab: workgroups per CU the register allocation is held to (tools/lab/blur_lb.sh)
+#endif
+__global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
                                                           const float* __restrict__ kf, const float* __restrict__ demod,
                                                           const float* __restrict__ noise, long noise_bstride,
                                                           const float* __restrict__ noise_w, const float* __restrict__ bias,
