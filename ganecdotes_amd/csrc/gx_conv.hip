@@ -873,13 +873,14 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 }
 
 // blur_act_kernel for layers that also write the next conv's x planes (C % 64 == 0, OW % 16 == 0): a WORKGROUP owns
-// 16 consecutive pixels x 64 channels of a BLUR_ROWS-row strip, thread t = (pixel t >> 4, channel quad t & 15).  The T
+// 16 consecutive pixels x 64 channels of a ROWS-row strip, thread t = (pixel t >> 4, channel quad t & 15).  The T
 // reads and the fp32 stores are then 256-B runs per pixel (the per-wave "16 pixels x one chunk" map of blur_act_kernel
 // moves them in 64-B pieces), and the three bf16 planes of an output row go through LDS ([4 chunks][3 planes][16 px][32 B],
 // double-buffered, one barrier per row) so that every (chunk, plane) image still receives one contiguous 512-B run.
 #ifndef BLUR_MINB
 #define BLUR_MINB 1      // lab: workgroups per CU the register allocation is held to (tools/lab/blur_lb.sh)
 #endif
+template <int ROWS>      // output rows per strip: 32 on the large layers (vertical halo 35 / 32 instead of 19 / 16), 16 on the small
 __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
                                                           const float* __restrict__ kf, const float* __restrict__ demod,
                                                           const float* __restrict__ noise, long noise_bstride,
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
                                                           const float* __restrict__ s_next, unsigned short* __restrict__ xp_out) {
     __shared__ __attribute__((aligned(16))) char stage[2][12 * 512];
     const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
-    const int nseg = (OH + BLUR_ROWS - 1) / BLUR_ROWS, nxb = OW >> 4, ncg = C >> 6;
+    const int nseg = (OH + ROWS - 1) / ROWS, nxb = OW >> 4, ncg = C >> 6;
     const int tid = threadIdx.x, px = tid >> 4, c4 = tid & 15;
     float k[16];
 #pragma unroll
@@ -897,12 +898,14 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
     const long nblk = (long)B * nseg * nxb * ncg;
     int par = 0;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        long rest = blk;
+        // neighbouring tiles share their 3-pixel halos of T: an XCD takes a contiguous run of tiles, so the halo a
+        // neighbour already fetched is found in that XCD's L2 (dispatch order deals consecutive blocks to different XCDs)
+        long rest = (nblk == (long)gridDim.x) ? (long)xcd_remap((int)blk, (int)nblk) : blk;
         const int cg = (int)(rest % ncg); rest /= ncg;
         const int xb = (int)(rest % nxb); rest /= nxb;
         const int seg = (int)(rest % nseg);
         const int b = (int)(rest / nseg);
-        const int c = cg * 64 + c4 * 4, x = xb * 16 + px, y0 = seg * BLUR_ROWS;
+        const int c = cg * 64 + c4 * 4, x = xb * 16 + px, y0 = seg * ROWS;
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f}, sn4 = {1.f, 1.f, 1.f, 1.f};
         if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
         if (demod) dm4 = *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
@@ -922,11 +925,11 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
             }
         };
 #pragma unroll 1
-        for (int g4 = 0; g4 < BLUR_ROWS / 4 + 1; ++g4) {
+        for (int g4 = 0; g4 < ROWS / 4 + 1; ++g4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g4 + j;                 // input row y0 - 1 + r
-                if (r > BLUR_ROWS + 2) break;
+                if (r > ROWS + 2) break;
                 f32x4 v[4];
                 load_row(r, v);       // (loading row r + 1 ahead of this row's barrier measured 10 % slower: 16 more registers)
 #pragma unroll
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
                 }
                 const int o = r - 3;                      // this output row is now complete
                 const int y = y0 + o;
-                if (o >= 0 && o < BLUR_ROWS && y < OH) {  // block-uniform
+                if (o >= 0 && o < ROWS && y < OH) {  // block-uniform
                     const f32x4 a = acc[(j + 1) & 3];
                     const float nz = noise ? nw * noise[(long)b * noise_bstride + (long)y * OW + x] : 0.f;
                     f32x4 ov;
@@ -1519,8 +1522,18 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
     long want = (total + 255) / 256;
     if (planes_out && (C & 63) == 0 && (OW & 15) == 0 &&
         ((((uintptr_t)T | (uintptr_t)out | (uintptr_t)planes_out) & 15) == 0)) {
+        // strips of 32 rows where that still leaves every CU several workgroups (the 64^2 outputs and up at the bench batch);
+        // same-process A/B (round 3): the XCD-contiguous tile order 0.467 -> 0.435 ms on the 128^2 output, 0.790 -> 0.782 on 256^2,
+        // 32-row strips another 1 %
+        const long nblk32 = (long)B * ((OH + 31) / 32) * (OW >> 4) * (C >> 6);
+        if (OH >= 64 && nblk32 >= 2048) {
+            hipLaunchKernelGGL(blur_act_xp_kernel<32>, dim3((int)(nblk32 < 65536 ? nblk32 : 65536)), dim3(256), 0, (hipStream_t)stream,
+                               T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+            GX_CHECK_LAUNCH();
+            return GX_OK;
+        }
         const long nblk = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * (OW >> 4) * (C >> 6);
-        hipLaunchKernelGGL(blur_act_xp_kernel, dim3((int)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, (hipStream_t)stream, T, B,
+        hipLaunchKernelGGL(blur_act_xp_kernel<BLUR_ROWS>, dim3((int)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, (hipStream_t)stream, T, B,
                            TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
         GX_CHECK_LAUNCH();
         return GX_OK;
