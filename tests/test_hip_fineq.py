@@ -169,11 +169,11 @@ def test_tables_shifted_below_levels_without_taps(ops):
     assert rel(c_s, pooled) < 1e-5 and rel(gb_s, gb_f) < 1e-6
 
 
-@pytest.mark.parametrize("k,res,pool", [(8, 64, True), (16, 128, True), (5, 64, False), (1, 64, True)])
+@pytest.mark.parametrize("k,res,pool", [(8, 64, True), (16, 128, True), (5, 64, False), (1, 64, True), (12, 256, True)])
 def test_fused_finish_gemm_vs_fp64_and_the_two_kernel_route(ops, k, res, pool):
     """gx_gemm_f32_nt_planes_finish (the dense finish in the GEMM's epilogue, rows in 2 x 64-pixel tiles): G, its 2x2 sums
     and gWc against fp64, and against gx_gemm_f32_nt_planes + gx_proto_lowrank_finish(add_to) which it replaces"""
-    b, d, cf = 2, 512, 256
+    b, d, cf = (2, 512, 256) if res < 256 else (1, 256, 128)       # res 256: another D, CF and a single image
     rows = b * res * res
     torch.manual_seed(31 + k)
     tt = torch.randn(rows, cf).cuda()
