@@ -626,10 +626,18 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool)
     """G = a b^T with the low-rank path's dense finish in the GEMM's epilogue (gx_gemm_f32_nt_planes_finish):
     G += coeffs[:, :K] wc + coeffs[:, K] .* z, gwc = beta gwc + coeffs[:, :K]^T z, and the 2x2 sums of G.
     a (rows, K1) = pixels of res x res images, z (B, res, res, D); -> (G (B, res, res, D), Gpool (B, res/2, res/2, D) or None)"""
-    _chk(a, coeffs, z, wc, gwc)
+    _chk(coeffs, z, wc, gwc)
+    _chk2d(a)
     bsz, r, _, d = z.shape
     rows, k = bsz * r * r, wc.shape[0]
     L = lib()
+    if r != res or z.shape[2] != r or a.shape[0] != rows or tuple(wc.shape) != (k, d) or tuple(gwc.shape) != (k, d) or \
+            tuple(coeffs.shape) != (rows, L.gx_lowrank_stride(k)):
+        raise RuntimeError("gemm_nt_planes_finish: shape mismatch")
+    if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(d, a.shape[1]):
+        raise RuntimeError("gemm_nt_planes_finish: planes do not match (N, K)")
+    if not L.gx_gemm_finish_ok(d, a.shape[1], r, k):
+        raise RuntimeError("gemm_nt_planes_finish: not this shape / engine (gemm_finish_ok)")
     g = torch.empty_like(z)
     gp = torch.empty(bsz, r // 2, r // 2, d, dtype=torch.float32, device=z.device) if want_pool else None
     wsb = L.gx_gemm_finish_workspace_bytes(rows, d, k)
