@@ -86,6 +86,7 @@ SIGNATURES = {
     "gx_proto_lowrank_finish": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz, c_p]),
     "gx_upsample2_add_scores": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_pixel_norm": (c_i, [c_p, c_l, c_i, c_p, c_p]),
+    "gx_equal_linear_skinny": (c_i, [c_p, c_i, c_i, c_p, c_i, c_f, c_p, c_f, c_i, c_p, c_p]),
     "gx_bias_act": (c_i, [c_p, c_l, c_i, c_f, c_p, c_f, c_i, c_p]),
     "gx_lerp_rows": (c_i, [c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
     "gx_view_latents": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -1162,6 +1162,51 @@ __global__ void bias_act_kernel(float* __restrict__ y, long rows, int N, float a
     }
 }
 
+// EqualLinear + fused_leaky_relu for a FEW rows (the mapping network on a batch of latents, model.py:242-252, :420-435):
+//   out[r][n] = act(alpha * sum_k x[r][k] W[n][k] + bias[n] * bscale),  W given transposed (wt [K][N], made once per model).
+// 48 latents x 512 x 512 is 25 MFLOP: on the MFMA tiles that was 4 output tiles split 8 ways over k, a slab reduce and a
+// bias pass — three launches of 4-9 us per layer, eight layers in a row (0.24 ms of the bench step, all latency).  Here a
+// workgroup owns 64 columns x RG rows, its four waves a quarter of k each (weights: one coalesced 256-B row per k and
+// wave; activations: wave-uniform addresses, i.e. scalar loads), plain fp32 FMAs, fixed-order sum of the four quarters.
+template <int RG>
+__global__ __launch_bounds__(256) void equal_linear_skinny_kernel(const float* __restrict__ x, int rows, int K,
+                                                                  const float* __restrict__ wt, int N, float alpha,
+                                                                  const float* __restrict__ bias, float bscale, int act,
+                                                                  float* __restrict__ out) {
+    __shared__ float red[3][RG][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 64 + lane, nc = n < N ? n : N - 1;
+    const int r0 = blockIdx.y * RG, kq = K >> 2, k0 = w * kq;
+    float acc[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) acc[r] = 0.f;
+    for (int k = k0; k < k0 + kq; k += 4) {
+        float wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = wt[(long)(k + j) * N + nc];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)min(r0 + r, rows - 1) * K + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r] = fmaf(xv[j], wv[j], acc[r]);
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) red[w - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (w == 0 && n < N) {
+        const float b = bias ? bias[n] * bscale : 0.f;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (r0 + r >= rows) break;
+            const float v = ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane])) * alpha + b;
+            out[(long)(r0 + r) * N + n] = act ? lrelu_sqrt2(v) : v;
+        }
+    }
+}
+
 // out = base + psi * (w - base), base broadcast over rows of length D  (truncation, model.py:594-602)
 __global__ void lerp_rows_kernel(const float* __restrict__ w, const float* __restrict__ base, long n, int D, float psi,
                                  float* __restrict__ out) {
@@ -1664,6 +1709,18 @@ int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, floa
     long want = (rows * N + 255) / 256;
     const int nb = (int)(want < 2048 ? want : 2048);
     hipLaunchKernelGGL(bias_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, rows, N, alpha, bias, bscale, act);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// out (rows, N) = act(alpha * x (rows, K) wt (K, N) + bias * bscale): EqualLinear (+ fused_leaky_relu when act) for few rows,
+// wt = the layer's weight TRANSPOSED.  K % 16 == 0, every pointer 16-B aligned; x / out dense.
+int gx_equal_linear_skinny(const float* x, int rows, int K, const float* wt, int N, float alpha, const float* bias,
+                           float bscale, int act, float* out, void* stream) {
+    if (!x || !wt || !out || rows <= 0 || K <= 0 || N <= 0 || (K & 15) || (((uintptr_t)x | (uintptr_t)wt) & 15))
+        return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(equal_linear_skinny_kernel<8>, dim3(gx_cdiv(N, 64), gx_cdiv(rows, 8)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, K, wt, N, alpha, bias, bscale, act, out);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -34,7 +34,8 @@ def _equal_linear_params(in_dim, out_dim, bias_init=0.0, lr_mul=1.0):
     return m
 
 
-MAP_SPLIT_K = 8       # k split of the mapping-MLP GEMMs (tiny M: 15.1 -> 14.9 ms per step of views against unsplit)
+MAP_SPLIT_K = 8          # k split of the mapping-MLP GEMMs (tiny M: 15.1 -> 14.9 ms per step of views against unsplit)
+SKINNY_ROWS = 256        # up to this many latents the mapping layers run as ops.equal_linear_skinny (one launch per layer)
 
 
 def _fir(taps):
@@ -87,6 +88,15 @@ class MappingNetwork(nn.Module):
         for i in range(n_mlp):
             self.add_module(str(i + 1), _equal_linear_params(style_dim, style_dim, lr_mul=lr_mlp))
 
+    def _transposed(self, i, w):
+        """the layer's weight as (in, out), remade when the parameter changes (load_state_dict, .to(), an optimizer step)"""
+        cache = self.__dict__.setdefault("_wt_cache", {})
+        key = (w.data_ptr(), w._version, w.device)
+        hit = cache.get(i)
+        if hit is None or hit[0] != key:
+            cache[i] = hit = (key, w.t().contiguous())
+        return hit[1]
+
     def forward(self, z):
         if not z.is_cuda:
             raise RuntimeError("ganecdotes_amd.Generator runs on HIP devices only (no CPU fallback)")
@@ -95,6 +105,11 @@ class MappingNetwork(nn.Module):
         for i in range(self.n_mlp):
             lin = getattr(self, str(i + 1))
             w = lin.weight.detach()
+            if h.shape[0] <= SKINNY_ROWS and w.shape[1] % 16 == 0:
+                # a batch of latents: one latency-bound launch per layer instead of {GEMM split over k, slab reduce, bias + act}
+                h = ops.equal_linear_skinny(h, self._transposed(i, w), (1.0 / math.sqrt(w.shape[1])) * self.lr_mlp,
+                                            lin.bias.detach(), self.lr_mlp, act=True)
+                continue
             # few rows x 512 x 512: four output tiles of a 32-k-tile loop are latency-bound; split the k loop over 8 x 4 tiles
             y = ops.gemm(h, w, False, True, split_k=MAP_SPLIT_K if h.shape[0] <= 256 else 1)
             h = ops.bias_act_(y, alpha=(1.0 / math.sqrt(w.shape[1])) * self.lr_mlp, bias=lin.bias.detach(),
@@ -141,6 +156,7 @@ class Generator(nn.Module):
     def _invalidate(self):
         self._derived = None
         self._xplanes = {}
+        self.style.__dict__.pop("_wt_cache", None)
 
     def load_state_dict(self, *a, **k):
         self._invalidate()

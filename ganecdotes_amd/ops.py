@@ -540,6 +540,16 @@ def bias_act_(y, alpha=1.0, bias=None, bscale=1.0, act=True):
     return y
 
 
+def equal_linear_skinny(x, wt, alpha, bias, bscale, act=True):
+    """act(alpha * x @ wt + bias * bscale) for a few rows x (rows, K); wt (K, N) = the EqualLinear weight transposed"""
+    _chk(x, wt, bias)
+    rows, k = x.shape
+    out = torch.empty(rows, wt.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(lib().gx_equal_linear_skinny(_p(x), rows, k, _p(wt), wt.shape[1], alpha, _p(bias), bscale, int(act), _p(out),
+                                            _stream()), "gx_equal_linear_skinny")
+    return out
+
+
 def lerp_rows(w, base, psi):
     """base + psi * (w - base); base (1, D) or (D,) broadcast over the rows of w (..., D)."""
     _chk(w, base)

@@ -172,6 +172,10 @@ int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K
  * gx_nchw_to_nhwc    layout change at the API boundary */
 int gx_pixel_norm(const float* x, long rows, int D, float* y, void* stream);
 int gx_bias_act(float* y, long rows, int N, float alpha, const float* bias, float bscale, int act, void* stream);
+/* gx_equal_linear_skinny: EqualLinear (+ fused_leaky_relu) on a few rows in one launch — the mapping network's layers on a
+ * batch of latents (model.py:242-252, :420-435); wt = the layer's weight transposed, (K, N) */
+int gx_equal_linear_skinny(const float* x, int rows, int K, const float* wt, int N, float alpha, const float* bias,
+                           float bscale, int act, float* out, void* stream);
 int gx_lerp_rows(const float* w, const float* base, long n, int D, float psi, float* out, void* stream);
 /* the (B, n_latent, S) latents of one view: truncation (model.py:594-602) + the perturbation mix of
  * image_augmentor.py:42-53 / swav_clustering.py:599-640 in one pass */

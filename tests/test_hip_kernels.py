@@ -869,6 +869,50 @@ def test_mapping_pieces_golden_gv3(ops):
     assert rel_err(y, T(d["el_y"])) < 1e-5
 
 
+@pytest.mark.parametrize("rows,k,n,act", [(1, 512, 512, True), (5, 16, 16, True), (48, 512, 512, True), (200, 512, 100, False),
+                                          (13, 64, 70, True)])
+def test_equal_linear_skinny_vs_fp64_and_gv3(ops, rows, k, n, act):
+    """the one-launch EqualLinear (+ fused_leaky_relu) of the mapping network on a batch of latents: against fp64, against
+    the GEMM + bias_act route it replaces, and against the reference's own EqualLinear output (GV3)"""
+    torch.manual_seed(rows + n)
+    x = torch.randn(rows, k)
+    w = torch.randn(n, k)
+    b = torch.randn(n)
+    alpha, bscale = 0.01 / math.sqrt(k), 0.01
+    pre = (x.double() @ w.double().t()) * alpha + b.double() * bscale
+    want = torch.nn.functional.leaky_relu(pre, 0.2) * math.sqrt(2.0) if act else pre
+    got = ops.equal_linear_skinny(dev(x), dev(w.t().contiguous()), alpha, dev(b), bscale, act=act)
+    assert got.shape == (rows, n) and rel_err(got, want) < 2e-6
+    y = ops.gemm(dev(x), dev(w), False, True)
+    ops.bias_act_(y, alpha=alpha, bias=dev(b), bscale=bscale, act=act)
+    assert rel_err(got, y) < 1e-5
+    if (rows, k) == (5, 16):
+        d = load_golden("gv3_layers")
+        got = ops.equal_linear_skinny(dev(T(d["el_x"])), dev(T(d["el_weight"]).t().contiguous()), 0.01 / math.sqrt(16),
+                                      dev(d["el_bias"]), 0.01, act=True)
+        assert rel_err(got, T(d["el_y"])) < 1e-5
+
+
+def test_mapping_network_skinny_equals_gemm_route(ops):
+    """MappingNetwork.forward: 48 latents through the one-launch layers == through the split-K GEMM layers; the weight's
+    transposed copy follows the parameter (in-place update -> remade)"""
+    from ganecdotes_amd import generator as Gm
+    torch.manual_seed(3)
+    net = Gm.MappingNetwork(512, 8, 0.01).cuda()
+    z = torch.randn(48, 512, device="cuda")
+    a = net(z)
+    prev, Gm.SKINNY_ROWS = Gm.SKINNY_ROWS, 0
+    try:
+        b = net(z)
+        assert rel_err(a, b) < 2e-5
+        with torch.no_grad():
+            getattr(net, "1").weight.mul_(1.5)
+        b2 = net(z)
+    finally:
+        Gm.SKINNY_ROWS = prev
+    assert rel_err(net(z), b2) < 2e-5 and rel_err(b2, b) > 1e-3
+
+
 def test_modconv_ffhq_shapes(ops, engine):
     """A real-width layer (512->512 @ 16x16, batch 2) against the oracle."""
     from oracle import stylegan2_ref as G
