@@ -119,6 +119,7 @@ def test_ffhq256_batch2_two_patches_step_vs_oracle(gpu, engine, nproto):
     patches — BASELINE.json's 8 prototypes (quadratic-form finest level, batched gather / loss / scatter) and the
     reference's own 5000 (Sinkhorn first pass out of the score GEMM's epilogue)."""
     from oracle import swav_ref as S
+    from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
     from ganecdotes_amd.swav_clustering import SwAVClustering
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -136,8 +137,17 @@ def test_ffhq256_batch2_two_patches_step_vs_oracle(gpu, engine, nproto):
     params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
     images = [draw_image(512, 13, 6, 256 * 256, patches, transforms=True) for _ in range(2)]
     loss = sw.train_step(images)
+    # the oracle draws its OWN rotate / flip source maps here (oracle/swav_ref.py:rotflip_index_map), it is not handed the HIP
+    # ones as in the tests above: the two restatements of torchvision's rotation agree on every pixel of these four views
+    oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip) for v in im.views], im.picks)
+             for im in images]
+    for im in images:
+        for v in im.views:
+            assert v.angle is not None and abs(v.angle) > 0.05
+            same = ops.rotflip_map(v.angle, v.flip, 256, 256, "cuda").cpu().long() == S.rotflip_index_map(v.angle, v.flip, 256, 256)
+            assert float(same.float().mean()) > 0.9999
     ref_loss, grads, _ = S.swav_train_step(
-        sd, ml, 0.7, _oracle_images(images, 256), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
+        sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01,
         use_larc=True, hlen=5376, patch_size=20000, num_patches=patches, temperature=0.01, eps=0.005, niters=10,
         source_pdf="uniform", sinkhorn_scope="global")
     np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_TOL)

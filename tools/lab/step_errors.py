@@ -1,6 +1,6 @@
 """Measured error of one full-size optimizer step against the oracle (loss, the three gradients, the updated
 parameters) — the numbers behind the tolerances of tests/test_hip_fullsize.py.
-    python tools/lab/step_errors.py [batch] [patches] [prototypes] [engine 1|0]"""
+    python tools/lab/step_errors.py [batch] [patches] [prototypes] [engine 1|0] [own]"""
 import sys
 import numpy as np
 import torch
@@ -30,8 +30,15 @@ sw.build_heads()
 params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
 images = [draw_image(512, 13, 6, 256 * 256, patches, transforms=True) for _ in range(batch)]
 loss = sw.train_step(images)
+own = len(sys.argv) > 5 and sys.argv[5] == "own"       # the oracle's OWN rotate / flip source maps instead of the HIP ones
+oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip) for v in im.views], im.picks)
+         for im in images] if own else _oracle_images(images, 256)
+if own:
+    agree = [float((ops.rotflip_map(v.angle, v.flip, 256, 256, "cuda").cpu().long() ==
+                    S.rotflip_index_map(v.angle, v.flip, 256, 256)).float().mean()) for im in images for v in im.views]
+    print("source-map agreement per view:", " ".join(f"{a:.5f}" for a in agree))
 ref_loss, grads, _ = S.swav_train_step(
-    sd, ml, 0.7, _oracle_images(images, 256), params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True,
+    sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True,
     hlen=5376, patch_size=20000, num_patches=patches, temperature=0.01, eps=0.005, niters=10, source_pdf="uniform",
     sinkhorn_scope="global")
 print(f"B={batch} P={patches} K={nproto} engine={ops.get_gemm_mode()}: loss {loss.item():.6f} oracle {ref_loss:.6f} "
