@@ -862,7 +862,11 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
         const long per_tile = (long)K * 128 * 6;
         long gn = (2L << 20) / per_tile;
-        gn = gn < 1 ? 1 : (gn > g.tiles_n ? g.tiles_n : gn);
+        // ... but never a group of one: with N tiles of more than 2 MB of planes each (the dz GEMM at K = 5000: 3.85 MB) every N
+        // tile streamed the whole A matrix from HBM by itself — 26 GB per launch for 6.4 GB of dS (profiles/r03_traffic_k5000.json);
+        // pairs share it through L2 and the planes come from the Infinity Cache: 7.72 -> 7.46 ms, same-process A/B (dz_lab.py)
+        gn = gn < 2 ? 2 : gn;
+        gn = gn > g.tiles_n ? g.tiles_n : gn;
         g.n_group = (int)gn;
     }
     if (colmax_part && (beta != 0.f || ((uintptr_t)colmax_part & 15))) return GX_ERR_BAD_ARG;

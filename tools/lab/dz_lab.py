@@ -20,3 +20,4 @@ bp = ops.split_gemm_weights(wct)
 t1 = timeit(lambda: ops.gemm_nt_planes(buf, None, bp, out2))
 fl = 2.0 * m * n * k
 print(f"dz NN ws {t0:.3f} ms {fl/t0/1e9:.0f} TF/s | xw {t1:.3f} ms {fl/t1/1e9:.0f} TF/s  maxdiff {(out-out2).abs().max().item():g} ref {out.abs().max().item():g}")
+
