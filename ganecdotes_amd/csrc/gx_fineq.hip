@@ -99,7 +99,19 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     const bool isL = wid < 4;
     const int nkt1 = g.K1 >> 4;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int my_tiles = ((int)blockIdx.x < g.ntile) ? (g.ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // Tiles to workgroups: consecutive tiles share parents (the two image rows above one parent row are 2 x res / 128 tiles
+    // apart at most), and dispatch order deals consecutive workgroups to different XCDs — with tile = blockIdx.x + i gridDim.x
+    // every XCD's L2 fetched the parent table for itself (the table was read twice from HBM).  Each XCD takes a contiguous
+    // run of tiles instead, its workgroups walking it side by side.
+    int tile0 = (int)blockIdx.x, tstride = (int)gridDim.x, tend = g.ntile;
+    if ((gridDim.x & 7) == 0 && FQ_ABL != 31) {      // (FQ_ABL 31: the strided assignment, for the A/B)
+        const int xcd = blockIdx.x & 7, q = g.ntile >> 3, r = g.ntile & 7;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile0 = base + (int)(blockIdx.x >> 3);
+        tstride = (int)(gridDim.x >> 3);
+        tend = base + q + (xcd < r ? 1 : 0);
+    }
+    const int my_tiles = tile0 < tend ? (tend - 1 - tile0) / tstride + 1 : 0;
     if (my_tiles == 0) return;
 
     // ---- DMA sources.  A: unit p = tid holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3) (the layout of gemm_xw_kernel)
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     const float myb = (r32 < g.K && g.bias) ? g.bias[r32] : 0.f;
 
     // ---- prologue: what k-tiles -2 and -1 of a previous tile would have issued
-    int tm = (int)blockIdx.x;
+    int tm = tile0;
     int sb = 0;                                                          // B ring slot of the current k-tile (runtime: 16 % 3 != 0)
     issue_b(0, 0); issue_a(tm, 0, 0);
     issue_y(tm, 0, 0); issue_b(1, 1); issue_a(tm, 1, 1);
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     f32x16 acc[6];
     float sp[16];
     for (int it = 0; it < my_tiles; ++it) {
-        const int tn = (it + 1 < my_tiles) ? tm + (int)gridDim.x : tm;        // next tile (the last one prefetches itself: unused)
+        const int tn = (it + 1 < my_tiles) ? tm + tstride : tm;        // next tile (the last one prefetches itself: unused)
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
