@@ -342,6 +342,9 @@ def main():
                          "across ranks by all-reduce as BASELINE.json's north_star asks (default); 'image' = one problem per "
                          "image, view and patch (the reference's batch-1 semantics, no Sinkhorn collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ds-table", default="auto", choices=["auto", "on", "off"],
+                    help="many prototypes: d(scores) summed per pixel before the backward GEMMs (DESIGN 4.15); auto = when "
+                         "the patches draw more samples than the image has pixels")
     ap.add_argument("--reference-faithful", default="auto", choices=["auto", "on", "off"],
                     help="also time the reference's own nprototypes = 5000 (hfc_with_swav_ffhq_config.py:52) for a few steps and "
                          "nest the result in the JSON line; auto = on one GPU with the default 8 prototypes only")
@@ -401,6 +404,8 @@ def main():
 
     def make(nproto):
         wl = workload(args.batch, nproto, scope=args.scope)
+        if args.ds_table != "auto":
+            wl["swav_args"]["ds_table"] = args.ds_table == "on"
         sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
         torch.manual_seed(42 + rank)
         np.random.seed(42 + rank)

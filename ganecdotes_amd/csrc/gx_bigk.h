@@ -480,6 +480,158 @@ __global__ __launch_bounds__(256, 3) void ce_fused_bigk_kernel(const float* __re
     if (tid == 0) loss_part[blockIdx.x] = -0.5f * tot;
 }
 
+// The swapped CE of ALL patches of a step, pixel-major (DESIGN par. 4.15): a block owns a pixel of the (2 views x B images)
+// grid; for every patch that drew the pixel (inv[p][pixel] = its row in that patch's score matrices, -1 = not drawn) it
+// does what ce_fused_bigk_kernel does for one row pair — statistics, loss share, d(scores) — and ADDS the two d(scores)
+// rows up in registers; the pixel's rows of the per-view tables dSs / dSt [npix][ldd] are written ONCE (zeros for a
+// pixel no patch drew; columns up to kpad zeroed), so the backward GEMMs run over pixels instead of samples with no
+// read-modify-write of the tables (as a row-indexed accumulate the CE moved 2.3x the bytes and ran 3x longer).
+//   S_all [P][2][rows][ld]; la_all [(p * 2 + view) * ngroups + group][K], group = pixel / pix_per_group
+constexpr int CE_PMAX = 8;                  // patches per step the pixel-major CE takes
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
+                                                                const int* __restrict__ inv, long npix, int ngroups,
+                                                                long pix_per_group, const float* __restrict__ la_all,
+                                                                float inv_eps, float inv_T, float gscale,
+                                                                float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
+                                                                int kpad, float* __restrict__ loss_part,
+                                                                float* __restrict__ part_s, float* __restrict__ part_t) {
+    constexpr int NC = (NJ + 15) / 16;
+    __shared__ float red[2 * 16];
+    // the block's column sums of both tables (the bias gradient) live in LDS, every thread adding to its own columns: in
+    // registers (40 more) the kernel spilled 77 dwords at three workgroups per CU and ran at 1.8 TB/s
+    extern __shared__ __attribute__((aligned(16))) float csum[];         // [2][K]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float f = -0.5f * gscale * inv_T;
+    for (int k = tid; k < 2 * K; k += 256) csum[k] = 0.f;
+    float lacc = 0.f;
+    for (long pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+        f32x4 as[NC], at[NC];                                            // the pixel's accumulated d(scores), both views
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { as[c] = f32x4{0.f, 0.f, 0.f, 0.f}; at[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const long grp = ngroups > 1 ? pix / pix_per_group : 0;
+        int nrow[CE_PMAX];                                               // the pixel's row in every patch, fetched together
+#pragma unroll
+        for (int p = 0; p < CE_PMAX; ++p) nrow[p] = p < P ? __builtin_amdgcn_readfirstlane(inv[(long)p * npix + pix]) : -1;
+#pragma unroll
+        for (int p = 0; p < CE_PMAX; ++p) {
+            const int n = nrow[p];
+            if (n < 0) continue;                                         // block-uniform
+            const float* las = la_all + ((long)(p * 2) * ngroups + grp) * K;
+            const float* lat = la_all + ((long)(p * 2 + 1) * ngroups + grp) * K;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all + (long)(p * 2) * rows * ld, n, ld, K);
+            const __amdgpu_buffer_rsrc_t rt = bk_row_rsrc(S_all + (long)(p * 2 + 1) * rows * ld, n, ld, K);
+            f32x4 a[NC], b[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+            // the patch's la vectors (L2-resident: 10 x 20 KB; LDS has no room for all of them) are read ONCE per row pair into
+            // registers, not once per use: 10 instead of 30 loads per thread — at two workgroups per CU, where the registers
+            // for it exist (38.9 ms per step against 45.4 with three workgroups and the vectors re-read; same-box A/B)
+            f32x4 lsr[NC], ltr[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = min(4 * (tid + 256 * c), K - 4);
+                lsr[c] = *reinterpret_cast<const f32x4*>(las + k); ltr[c] = *reinterpret_cast<const f32x4*>(lat + k);
+            }
+#define CE_LS(c, k) lsr[c]
+#define CE_LT(c, k) ltr[c]
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = 4 * (tid + 256 * c);
+                if (k < K) {
+                    const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        mx[0] = fmaxf(mx[0], fmaf(a[c][q], inv_eps, ls[q]));
+                        mx[1] = fmaxf(mx[1], a[c][q]);
+                        mx[2] = fmaxf(mx[2], fmaf(b[c][q], inv_eps, lt[q]));
+                        mx[3] = fmaxf(mx[3], b[c][q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = gx_wave_max(mx[j]);
+                if (lane == 0) red[j * 4 + wid] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx[j] = fmaxf(fmaxf(red[j * 4], red[j * 4 + 1]), fmaxf(red[j * 4 + 2], red[j * 4 + 3]));
+            float sv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = 4 * (tid + 256 * c);
+                if (k < K) {
+                    const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sv[0] += bk_exp(fmaf(a[c][q], inv_eps, ls[q]) - mx[0]);
+                        sv[1] += bk_exp((a[c][q] - mx[1]) * inv_T);
+                        sv[2] += bk_exp(fmaf(b[c][q], inv_eps, lt[q]) - mx[2]);
+                        sv[3] += bk_exp((b[c][q] - mx[3]) * inv_T);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = gx_wave_sum(sv[j]);
+                if (lane == 0) red[16 + j * 4 + wid] = v;
+            }
+            __syncthreads();
+            float t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = (red[16 + j * 4] + red[16 + j * 4 + 1]) + (red[16 + j * 4 + 2] + red[16 + j * 4 + 3]);
+            const float wm_s = mx[0], m_s = mx[1], wm_t = mx[2], m_t = mx[3];
+            const float iv_s = 1.f / t4[0], z_s = t4[1], iv_t = 1.f / t4[2], z_t = t4[3];
+            const float iz_s = 1.f / z_s, iz_t = 1.f / z_t, lz_s = logf(z_s), lz_t = logf(z_t);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = 4 * (tid + 256 * c);
+                if (k < K) {
+                    const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float qs = bk_exp(fmaf(a[c][q], inv_eps, ls[q]) - wm_s) * iv_s;
+                        const float qt = bk_exp(fmaf(b[c][q], inv_eps, lt[q]) - wm_t) * iv_t;
+                        const float xs = (a[c][q] - m_s) * inv_T, xt = (b[c][q] - m_t) * inv_T;
+                        lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
+                        at[c][q] += f * (qs - bk_exp(xt) * iz_t);
+                        as[c][q] += f * (qt - bk_exp(xs) * iz_s);
+                    }
+                }
+            }
+            // (the next patch's first barrier orders these reads of red[16 ..] before its writes, its second those of red[0 ..])
+        }
+        const __amdgpu_buffer_rsrc_t ds = bk_row_rsrc(dSs, pix, ldd, kpad), dt = bk_row_rsrc(dSt, pix, ldd, kpad);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = 4 * (tid + 256 * c);
+            if (k < kpad) {                                              // columns K .. kpad - 1 hold zeros: the dz GEMM reads them
+                bk_store4(ds, k, as[c]); bk_store4(dt, k, at[c]);
+            }
+            if (k < K) {
+                *reinterpret_cast<f32x4*>(csum + k) += as[c];
+                *reinterpret_cast<f32x4*>(csum + K + k) += at[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = 4 * (tid + 256 * c);
+        if (k < K) {
+            *reinterpret_cast<f32x4*>(part_s + (long)blockIdx.x * K + k) = *reinterpret_cast<const f32x4*>(csum + k);
+            *reinterpret_cast<f32x4*>(part_t + (long)blockIdx.x * K + k) = *reinterpret_cast<const f32x4*>(csum + K + k);
+        }
+    }
+    __syncthreads();
+    __shared__ float red2[16];
+    const float tot = gx_block_sum(lacc, red2);
+    if (tid == 0) loss_part[blockIdx.x] = -0.5f * tot;
+}
+#undef CE_LS
+#undef CE_LT
+
 static inline int bigk_nj(int K) {          // registers per lane for a row of K scores; 0 = not supported
     const int need = (K + 63) / 64;
     const int opts[] = {16, 32, 48, 64, 80, 96};

@@ -1158,6 +1158,38 @@ int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
+// The swapped CE of every patch of a step with the d(scores) of a pixel added up over the patches that drew it
+// (ce_pixels_bigk_kernel): S_all [P][2 views][rows][ld] (SinkhornBatch order), inv [P][npix] int32 = the pixel's row in patch
+// p's matrices or -1, la_all [(p * 2 + view) * ngroups + group][K] with group = pixel / (npix / ngroups); dSs / dSt
+// [npix][ldd] are WRITTEN (not accumulated): sum over patches of what gx_swapped_ce_fused writes per row, columns K .. kpad - 1
+// zero.  loss_out / gb as there.  K as for gx_swapped_ce_fused; kpad in [K, ldd], a multiple of 4.
+int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, const int* inv, long npix, int ngroups,
+                         float eps, float temperature, const float* la_all, float grad_scale, float* dSs, float* dSt, long ldd,
+                         int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta,
+                         float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S_all || !inv || !la_all || !loss_out || !dSs || !dSt || !gb || P <= 0 || P > CE_PMAX || rows <= 0 || K <= 0 || ld < K || npix <= 0 ||
+        ngroups <= 0 || npix % ngroups || kpad < K || kpad > ldd || (kpad & 3))
+        return GX_ERR_BAD_ARG;
+    if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd) ||
+        (((uintptr_t)la_all) & 15) || 4 * 256 * ((bigk_nj(K) + 15) / 16) < kpad)
+        return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_swapped_ce_fused_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    const int nbk = (int)(npix < 2040 ? npix : 2040);
+    float* part_s = workspace + 2048;
+    float* part_t = part_s + (size_t)2048 * K;
+    GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((ce_pixels_bigk_kernel<NJ>), dim3(nbk), dim3(256), (size_t)2 * K * sizeof(float), (hipStream_t)stream,
+                                                    S_all, P, rows, K, ld, inv, npix, ngroups, npix / ngroups, la_all, 1.f / eps,
+                                                    1.f / temperature, grad_scale, dSs, dSt, ldd, kpad, workspace, part_s,
+                                                    part_t));
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(part_s, nbk, K, 1.f, gb_beta, gb, (hipStream_t)stream, part_s + (size_t)2040 * K);
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce(part_t, nbk, K, 1.f, 1.f, gb, (hipStream_t)stream, part_t + (size_t)2040 * K);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 // Every (patch, row group) pair of a step in one launch (K <= 64, contiguous rows: ld == K).  Scores S_all
 // [npatch][2 views][rows_per_patch][K] with row groups of `rows` rows (ngroups per patch: 1 for the global
 // Sinkhorn scope, B for the per-image one); la_all [(patch*2 + view)*ngroups + group][K] (SinkhornBatch order);

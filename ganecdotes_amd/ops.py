@@ -1195,6 +1195,29 @@ def swapped_ce_fused(sk_s, sk_t, temperature, grad_scale, loss_out, loss_scale, 
     return loss_out
 
 
+def swapped_ce_pixels(scores_all, skb, ngroups, inv, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, kpad,
+                      gb, gb_beta):
+    """The swapped CE of every patch of a step, pixel-major (gx_swapped_ce_pixels): scores_all (P, 2, rows, K) with skb its
+    solved SinkhornBatch ((p * 2 + view) * ngroups + group order), inv (P, npix) int32 = the pixel's row in patch p or -1;
+    d_s / d_t (npix, >= kpad) are written with the pixel's d(scores) summed over the patches that drew it."""
+    _chk(scores_all, loss_out, gb)
+    _chk2d(d_s, d_t)
+    npatch, two, rows, k = scores_all.shape
+    npix = d_s.shape[0]
+    if two != 2 or inv.dtype != torch.int32 or tuple(inv.shape) != (npatch, npix) or not inv.is_contiguous() or not inv.is_cuda or \
+            d_t.shape[0] != npix or d_s.stride(0) != d_t.stride(0) or skb.la.shape[0] != npatch * 2 * ngroups:
+        raise RuntimeError("swapped_ce_pixels: shape mismatch")
+    L = lib()
+    wsb = L.gx_swapped_ce_fused_workspace_bytes(k)
+    ws = workspace("ce_fused", wsb, scores_all.device)
+    with record("ce_fused_bigk_kernel", 0.0, 8.0 * npatch * rows * k + 8.0 * npix * kpad):     # scores once, tables once
+        _lib.check(L.gx_swapped_ce_pixels(_p(scores_all), npatch, rows, k, scores_all.stride(2), _p(inv), npix, ngroups, skb.eps,
+                                          temperature, _p(skb.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), kpad, loss_scale,
+                                          loss_beta, _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()),
+                   "gx_swapped_ce_pixels")
+    return loss_out
+
+
 # ------------------------------------------------------------------------------------- non-linear projection heads
 def gather_rows(z, picks, maps=None):
     """z (B, H, W, D) table; picks (B, N) int32 -> the sampled rows (B*N, D), zero where the rotation zero-filled"""

@@ -311,6 +311,17 @@ class SwAVClustering(ViewMixin):
         pad_ds = wc_planes is not None and K % 4 == 0 and K > 64
         Kp = (K + 15) // 16 * 16
         wct_planes = ops.split_gemm_weights(Wc.t().contiguous()) if pad_ds else None
+        # Many prototypes: d(scores) of every patch land on per-PIXEL rows (one table per view): a pixel drawn by
+        # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
+        # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
+        dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 6144 and P <= 8 and
+                 sa.get('ds_table', hw * hw < P * N) and
+                 8.0 * B * hw * hw * Kp + 8.0 * rows * K * P < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
+        if dstab:
+            pgroup = P             # every patch's scores stay until the one pixel-major CE pass of the step (8 B rows K P bytes)
+            npix = B * hw * hw
+            dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
+            pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
@@ -376,6 +387,21 @@ class SwAVClustering(ViewMixin):
                         sk_.cmax_preset = cm if ngroups == 1 else cm[g]
                         sk_.u_first_preset = uf if ngroups == 1 else uf[g]
                 skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+            if dstab:
+                # ONE pass over the scores of all patches: loss, bias gradient, and each pixel's d(scores) summed over the patches
+                # that drew it, written once (inv[p][pixel] = the pixel's row in patch p, -1 = not drawn)
+                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
+                nrow = torch.arange(rows, dtype=torch.int32, device=dev)
+                for gi, pno in enumerate(pnos):
+                    inv[gi].scatter_(0, (pb.picks[pno] + pix_base).reshape(-1).long(), nrow)
+                ops.swapped_ce_pixels(Sc_all, skb, ngroups, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp, gb,
+                                      0.0 if first_acc else 1.0)
+                first_acc = False
+                if return_aux:
+                    aux.update(scores_s=Sc_all[0, 0, :grows].clone(), scores_t=Sc_all[0, 1, :grows].clone(),
+                               q_s=skb[0].codes(), q_t=skb[ngroups].codes())
+                del inv, keep, Sc_all, skb
+                continue
             if batched:
                 dS_all = torch.empty_like(Sc_all)
                 ops.swapped_ce_batch(Sc_all, ngroups, skb, T, gscale, loss, gscale, 1.0, dS_all)
@@ -446,6 +472,22 @@ class SwAVClustering(ViewMixin):
                 keep[gi] = None
                 del X, Zh, Rn, Hc, Sc, dS
             del keep, Sc_all, skb
+        if dstab:
+            picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+            for v in range(2):
+                with self._timed("gather_rows"):
+                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
+                ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
+                         split_k=self._split_k(K, D, B * hw * hw))
+                dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
+                if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
+                    ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz)
+                else:
+                    ops.gemm(dS_tab[v][:, :K], Wc, False, False, out=dz)
+                with self._timed("scatter_rows"):
+                    ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
+                del zt, rnt, dz
+            del dS_tab
         pending = []
         if mode == 'pyramid':
             on_level = on_heads = None

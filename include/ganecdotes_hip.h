@@ -439,6 +439,10 @@ int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long
                         const float* la_s, const float* la_t, float grad_scale, float* dSs, float* dSt, long ldd,
                         float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta, float* workspace,
                         size_t workspace_bytes, void* stream);
+int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, const int* inv, long npix, int ngroups,
+                         float eps, float temperature, const float* la_all, float grad_scale, float* dSs, float* dSt, long ldd,
+                         int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta,
+                         float* workspace, size_t workspace_bytes, void* stream);
 int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
                         float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
                         float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream);

@@ -126,8 +126,11 @@ def test_ffhq256_batch2_two_patches_step_vs_oracle(gpu, engine, nproto):
     g, sd = full_generator(256)
     g = g.to(gpu)
     patches = 2 if nproto == 8 else 1
+    # K = 5000: through the per-pixel d(scores) tables and the pixel-major CE, which the bench step takes on its own
+    # (5 patches draw more samples than the image has pixels) and one patch would not
+    extra = dict(ds_table=True) if nproto > 64 else {}
     sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
-                        **ffhq_args(2, nproto, num_patches=patches, pick_source="host"))
+                        **ffhq_args(2, nproto, num_patches=patches, pick_source="host", **extra))
     torch.manual_seed(5)
     np.random.seed(5)
     with torch.no_grad():

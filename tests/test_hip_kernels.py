@@ -869,6 +869,43 @@ def test_mapping_pieces_golden_gv3(ops):
     assert rel_err(y, T(d["el_y"])) < 1e-5
 
 
+@pytest.mark.parametrize("k,ngroups", [(200, 1), (5000, 1), (132, 3)])
+def test_swapped_ce_pixels_equals_per_pair_ce_summed_per_pixel(ops, k, ngroups):
+    """gx_swapped_ce_pixels (every patch of a step in one pixel-major pass, a pixel's d(scores) summed over the patches that drew
+    it, tables written once) against gx_swapped_ce_fused per pair + an index_add per pixel: tables, loss and bias gradient"""
+    torch.manual_seed(k)
+    P, nimg, npp, n = 3, ngroups if ngroups > 1 else 2, 97, 60          # images, pixels per image, samples per image and patch
+    rows, npix, kp = nimg * n, nimg * npp, (k + 15) // 16 * 16
+    S = (torch.randn(P, 2, rows, k) * 0.1).cuda()
+    skb = ops.SinkhornBatch(S.reshape(P * 2 * ngroups, rows // ngroups, k), 0.05, 5)
+    skb.run()
+    inv = torch.full((P, npix), -1, dtype=torch.int32)
+    rows_to = []
+    for p in range(P):
+        idx = torch.cat([torch.randperm(npp)[:n] + b * npp for b in range(nimg)])
+        inv[p, idx] = torch.arange(rows, dtype=torch.int32)
+        rows_to.append(idx)
+    inv = inv.cuda()
+    ds, dt = torch.full((npix, kp), 7.0).cuda(), torch.full((npix, kp), 7.0).cuda()      # overwritten, padding zeroed
+    loss, gb = torch.zeros(1).cuda(), torch.zeros(k).cuda()
+    ops.swapped_ce_pixels(S, skb, ngroups, inv, 0.1, 1e-3, loss, 2.0, 0.0, ds, dt, kp, gb, 0.0)
+    want_s, want_t = torch.zeros(npix, k, dtype=torch.float64), torch.zeros(npix, k, dtype=torch.float64)
+    loss2, gb2 = torch.zeros(1).cuda(), torch.zeros(k).cuda()
+    grows = rows // ngroups
+    for p in range(P):
+        d_s, d_t = torch.empty(rows, k).cuda(), torch.empty(rows, k).cuda()
+        for g in range(ngroups):
+            r0, r1 = g * grows, (g + 1) * grows
+            ops.swapped_ce_fused(skb[(p * 2) * ngroups + g], skb[(p * 2 + 1) * ngroups + g], 0.1, 1e-3, loss2, 2.0, 1.0,
+                                 d_s[r0:r1], d_t[r0:r1], gb2, 1.0)
+        want_s.index_add_(0, rows_to[p], d_s.double().cpu())
+        want_t.index_add_(0, rows_to[p], d_t.double().cpu())
+    assert rel_err(ds[:, :k], want_s) < 2e-6 and rel_err(dt[:, :k], want_t) < 2e-6
+    assert torch.all(ds[:, k:] == 0) and torch.all(dt[:, k:] == 0)
+    assert abs(loss.item() - loss2.item()) < 1e-5 * abs(loss2.item())
+    assert rel_err(gb, gb2) < 1e-5
+
+
 @pytest.mark.parametrize("rows,k,n,act", [(1, 512, 512, True), (5, 16, 16, True), (48, 512, 512, True), (200, 512, 100, False),
                                           (13, 64, 70, True)])
 def test_equal_linear_skinny_vs_fp64_and_gv3(ops, rows, k, n, act):

@@ -258,6 +258,50 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
+@pytest.mark.parametrize("scope,batch,transforms", [("global", 3, True), ("image", 2, True), ("global", 2, False)])
+def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope, batch, transforms):
+    """Many prototypes with d(scores) accumulated on per-pixel rows (swav_args['ds_table']): 3 patches of 600
+    of the 1024 pixels, so most pixels are drawn by more than one patch; two steps against the oracle, and the same step
+    with the per-sample backward GEMMs"""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    kw = dict(sinkhorn_scope=scope, batch_size=batch, nprototypes=200, nclasses=16, num_patches=3, patch_size=600,
+              transforms=transforms)
+    sw = make_swav(g, gpu, tmp_path, ds_table=True, **kw)
+    sw2 = make_swav(g, gpu, tmp_path, ds_table=False, **kw)
+    torch.manual_seed(123)
+    np.random.seed(123)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sw.mean_latent = sw2.mean_latent = ml.cuda()
+    sw.build_heads()
+    sw2.build_heads()
+    for a, b in zip(sw2._params(), sw._params()):
+        a.copy_(b)
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    bufs = [None] * 3
+    for step in range(2):
+        images = [draw_image(16, 7, 3, 32 * 32, 3, transforms=transforms) for _ in range(batch)]
+        loss = sw.train_step(images)
+        loss2 = sw2.train_step(images)
+        oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                                 None if v.angle is None else
+                                                 ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
+                                     for v in im.views], im.picks) for im in images]
+        ref_loss, grads, bufs = S.swav_train_step(
+            sd, ml, 0.7, oimgs, params, bufs, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
+            patch_size=600, num_patches=3, temperature=0.1, eps=0.05, niters=10, source_pdf="uniform", sinkhorn_scope=scope)
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+        np.testing.assert_allclose(loss.item(), loss2.item(), rtol=1e-5)
+        for got, other, want in zip(sw._grads, sw2._grads, grads):
+            assert rel(got, want) < 2e-3 and rel(got, other) < 1e-4
+        for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+            assert rel(got, want) < 1e-4
+
+
 @pytest.mark.parametrize("nproto", [6148, 7001])
 def test_train_step_past_the_fused_ce_limit_vs_oracle(gpu, tmp_path, nproto):
     """More prototypes than the one-pass CE takes (K > 6144): the step falls back to gx_swapped_ce + gx_colsum.  With
