@@ -558,18 +558,23 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 4; ++j) mx[j] = fmaxf(fmaxf(red[j * 4], red[j * 4 + 1]), fmaxf(red[j * 4 + 2], red[j * 4 + 3]));
+            // the four exponentials of an element are evaluated ONCE: the sums pass leaves them in registers (the code ones
+            // over the la registers, dead by then) and the element-wise pass only scales them — v_exp_f32 is a quarter-rate
+            // instruction and the pass is VALU-bound
             float sv[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x4 es[NC], et[NC];                                        // exp((x - m) / T) of both views
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int k = 4 * (tid + 256 * c);
+                es[c] = f32x4{0.f, 0.f, 0.f, 0.f}; et[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < K) {
-                    const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        sv[0] += bk_exp(fmaf(a[c][q], inv_eps, ls[q]) - mx[0]);
-                        sv[1] += bk_exp((a[c][q] - mx[1]) * inv_T);
-                        sv[2] += bk_exp(fmaf(b[c][q], inv_eps, lt[q]) - mx[2]);
-                        sv[3] += bk_exp((b[c][q] - mx[3]) * inv_T);
+                        lsr[c][q] = bk_exp(fmaf(a[c][q], inv_eps, lsr[c][q]) - mx[0]);      // lsr / ltr now hold the code numerators
+                        es[c][q] = bk_exp((a[c][q] - mx[1]) * inv_T);
+                        ltr[c][q] = bk_exp(fmaf(b[c][q], inv_eps, ltr[c][q]) - mx[2]);
+                        et[c][q] = bk_exp((b[c][q] - mx[3]) * inv_T);
+                        sv[0] += lsr[c][q]; sv[1] += es[c][q]; sv[2] += ltr[c][q]; sv[3] += et[c][q];
                     }
                 }
             }
@@ -582,22 +587,20 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
             float t4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) t4[j] = (red[16 + j * 4] + red[16 + j * 4 + 1]) + (red[16 + j * 4 + 2] + red[16 + j * 4 + 3]);
-            const float wm_s = mx[0], m_s = mx[1], wm_t = mx[2], m_t = mx[3];
+            const float m_s = mx[1], m_t = mx[3];
             const float iv_s = 1.f / t4[0], z_s = t4[1], iv_t = 1.f / t4[2], z_t = t4[3];
             const float iz_s = 1.f / z_s, iz_t = 1.f / z_t, lz_s = logf(z_s), lz_t = logf(z_t);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int k = 4 * (tid + 256 * c);
                 if (k < K) {
-                    const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float qs = bk_exp(fmaf(a[c][q], inv_eps, ls[q]) - wm_s) * iv_s;
-                        const float qt = bk_exp(fmaf(b[c][q], inv_eps, lt[q]) - wm_t) * iv_t;
+                        const float qs = lsr[c][q] * iv_s, qt = ltr[c][q] * iv_t;
                         const float xs = (a[c][q] - m_s) * inv_T, xt = (b[c][q] - m_t) * inv_T;
                         lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
-                        at[c][q] += f * (qs - bk_exp(xt) * iz_t);
-                        as[c][q] += f * (qt - bk_exp(xs) * iz_s);
+                        at[c][q] += f * (qs - et[c][q] * iz_t);
+                        as[c][q] += f * (qt - es[c][q] * iz_s);
                     }
                 }
             }
