@@ -27,6 +27,8 @@ def _args(scope, pdf, nproto=12, projn="linear"):
                 temperature=0.1, nprototypes=nproto, nclasses=8 if nproto <= 16 else 16,   # D = 16: weight-plane GEMMs
                 hlen=56, add_local_loss=False, plot_test_images=False,
                 epoch_print_freq=1, max_masks=4, sinkhorn_scope=scope)
+    if projn == "linear+table":         # many prototypes with the per-pixel d(scores) tables under the sharded protocol
+        swav.update(projn_nw="linear", ds_table=True)
     return dict(perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None, perturb_std=[1.0] * 3),
                 swav_args=swav, sinkhorn_args=dict(source_pdf=pdf, niters=10, eps=0.05))
 
@@ -70,7 +72,8 @@ def _worker(rank, world, port, sd, scope, pdf, out, nproto=12, projn="linear"):
 @pytest.mark.parametrize("scope,pdf,nproto,projn", [
     ("global", "uniform", 12, "linear"), ("image", "uniform", 12, "linear"), ("global", "image", 12, "linear"),
     ("global", "uniform", 200, "linear"), ("image", "uniform", 200, "linear"),
-    ("global", "uniform", 12, "1-layer"), ("global", "uniform", 200, "2-layer"), ("image", "uniform", 12, "2-layer")])
+    ("global", "uniform", 12, "1-layer"), ("global", "uniform", 200, "2-layer"), ("image", "uniform", 12, "2-layer"),
+    ("global", "uniform", 200, "linear+table"), ("image", "uniform", 200, "linear+table")])
 def test_two_ranks_equal_one_rank(scope, pdf, nproto, projn):
     """nproto = 200: the many-prototype path (score GEMM on weight planes with the Sinkhorn column maxima from its
     epilogue, one-pass CE with the bias gradient) under the sharded protocol; projn '2-layer' with the global scope:
