@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                                                            const float* __restrict__ la, const float* __restrict__ c,
                                                            float c_uniform, float* __restrict__ lb_out,
                                                            float* __restrict__ part, unsigned* __restrict__ cmax_out,
-                                                           long s_stride = 0, long c_stride = 0) {
+                                                           long s_stride = 0, long c_stride = 0,
+                                                           const int* __restrict__ rowmap = nullptr) {
+    // rowmap (optional, [problem][rows] int32): row n of the problem is row rowmap[n] of S — a Sinkhorn problem over the
+    // SAMPLED rows of a per-pixel score table (DESIGN par. 4.15) without a gathered copy of them
     constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
     {   // blockIdx.y = problem of a batch of equally shaped ones: score matrices s_stride apart, K-vectors (cmax, la,
         // cmax_out) K apart, row marginals c_stride apart, partials [problem][block][K]  (gridDim.y == 1: one problem)
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         if (part) part += prob * gridDim.x * K;
         if (cmax_out) cmax_out += prob * K;
         if (lb_out) lb_out += prob * rows;
+        if (rowmap) rowmap += prob * rows;
     }
     extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | red[2][BK_R][4]
     float* vec = sm;
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         for (int r = 0; r < BK_R; ++r) {
             // rows past the end read as zeros through an EMPTY descriptor (their contributions are masked below)
             const bool live = r0 + r < rows;
-            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, live ? r0 + r : 0, ld, live ? K : 0);
+            const long srow = !live ? 0 : (rowmap ? (long)rowmap[r0 + r] : r0 + r);
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, srow, ld, live ? K : 0);
 #pragma unroll
             for (int cidx = 0; cidx < NC; ++cidx) w[r][cidx] = bk_load4(rs, 4 * (tid + 256 * cidx));
         }
@@ -495,7 +500,10 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
                                                                 float inv_eps, float inv_T, float gscale,
                                                                 float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
                                                                 int kpad, float* __restrict__ loss_part,
-                                                                float* __restrict__ part_s, float* __restrict__ part_t) {
+                                                                float* __restrict__ part_s, float* __restrict__ part_t,
+                                                                const float* __restrict__ St_tab = nullptr) {
+    // St_tab != NULL: the scores are per-pixel TABLES too (S_all = the first view's [npix][ld], St_tab the second's): a
+    // pixel's two score rows are read once for all the patches that drew it
     constexpr int NC = (NJ + 15) / 16;
     __shared__ float red[2 * 16];
     // the block's column sums of both tables (the bias gradient) live in LDS, every thread adding to its own columns: in
@@ -513,17 +521,27 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
         int nrow[CE_PMAX];                                               // the pixel's row in every patch, fetched together
 #pragma unroll
         for (int p = 0; p < CE_PMAX; ++p) nrow[p] = p < P ? __builtin_amdgcn_readfirstlane(inv[(long)p * npix + pix]) : -1;
+        f32x4 a[NC], b[NC];
+        if (St_tab) {
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < CE_PMAX; ++p) any = any || nrow[p] >= 0;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all, pix, ld, any ? K : 0), rt = bk_row_rsrc(St_tab, pix, ld, any ? K : 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+        }
 #pragma unroll
         for (int p = 0; p < CE_PMAX; ++p) {
             const int n = nrow[p];
             if (n < 0) continue;                                         // block-uniform
             const float* las = la_all + ((long)(p * 2) * ngroups + grp) * K;
             const float* lat = la_all + ((long)(p * 2 + 1) * ngroups + grp) * K;
-            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all + (long)(p * 2) * rows * ld, n, ld, K);
-            const __amdgpu_buffer_rsrc_t rt = bk_row_rsrc(S_all + (long)(p * 2 + 1) * rows * ld, n, ld, K);
-            f32x4 a[NC], b[NC];
+            if (!St_tab) {
+                const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all + (long)(p * 2) * rows * ld, n, ld, K);
+                const __amdgpu_buffer_rsrc_t rt = bk_row_rsrc(S_all + (long)(p * 2 + 1) * rows * ld, n, ld, K);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+                for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+            }
             // the patch's la vectors (L2-resident: 10 x 20 KB; LDS has no room for all of them) are read ONCE per row pair into
             // registers, not once per use: 10 instead of 30 loads per thread — at two workgroups per CU, where the registers
             // for it exist (38.9 ms per step against 45.4 with three workgroups and the vectors re-read; same-box A/B)

@@ -862,17 +862,18 @@ static int sk_blocks(long rows, int team) {
 }
 
 // cmax_k = max_n S_nk (kept in the workspace, ordered-uint encoded; reset here)
-int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspace, size_t workspace_bytes,
-                       void* stream) {
+static int sk_colmax_impl(const float* S, const int* rowmap, long rows, int K, long ld, float* workspace,
+                          size_t workspace_bytes, void* stream) {
     if (!S || !workspace || rows <= 0 || K <= 0 || ld < K) return GX_ERR_BAD_ARG;
     if (workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    if (rowmap && !(bigk_ok(K) && bigk_aligned(S, ld))) return GX_ERR_BAD_ARG;       // row maps: the many-prototype kernels only
     if (hipMemsetAsync(workspace, 0, (size_t)K * 4, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
     if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = bigk_pass_lds(K);
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, S, rows, K, ld, 0.f, nullptr, nullptr,
-                                                        nullptr, 0.f, nullptr, nullptr, (unsigned*)workspace));
+                                                        nullptr, 0.f, nullptr, nullptr, (unsigned*)workspace, 0L, 0L, rowmap));
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
@@ -881,6 +882,17 @@ int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspa
                        (unsigned*)workspace);
     GX_CHECK_LAUNCH();
     return GX_OK;
+}
+int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspace, size_t workspace_bytes,
+                       void* stream) {
+    return sk_colmax_impl(S, nullptr, rows, K, ld, workspace, workspace_bytes, stream);
+}
+// ... over the rows rowmap[0 .. rows) of a table S (int32 row indices; many prototypes only): the Sinkhorn problem of one
+// patch and view on the per-pixel score table of the view (DESIGN par. 4.15)
+int gx_sinkhorn_colmax_rows(const float* S, const int* rowmap, long rows, int K, long ld, float* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (!rowmap) return GX_ERR_BAD_ARG;
+    return sk_colmax_impl(S, rowmap, rows, K, ld, workspace, workspace_bytes, stream);
 }
 // Column-max exchange hooks for the sharded (multi-GPU) form: decode to / encode from floats.
 int gx_sinkhorn_cmax_get(const float* workspace, int K, float* out, void* stream) {
@@ -901,11 +913,12 @@ int gx_sinkhorn_cmax_set(float* workspace, int K, const float* in, void* stream)
 // One pass: first != 0 -> u_k = sum_n exp((S_nk - cmax_k)/eps); else the sweep with the log
 // scaling vector la (lb_out optional).  Result: local column sums u (K floats) at
 // gx_sinkhorn_u(workspace, K).
-int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,
-                     const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
-                     void* stream) {
+static int sk_pass_impl(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int first, const float* la,
+                        const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                        void* stream) {
     if (!S || rows <= 0 || K <= 0 || ld < K || eps <= 0.f || (!first && !la)) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_sinkhorn_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    if (rowmap && !(bigk_ok(K) && bigk_aligned(S, ld))) return GX_ERR_BAD_ARG;
     const int team = pick_team(K);
     const int nb = sk_blocks(rows, team);
     float* u = workspace + K;
@@ -919,12 +932,12 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
                                                             (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
                                                             (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
-                                                            nullptr));
+                                                            nullptr, 0L, 0L, rowmap));
         } else {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), dim3(nbk), dim3(256), lds,
                                                             (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
                                                             (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
-                                                            nullptr));
+                                                            nullptr, 0L, 0L, rowmap));
         }
         GX_CHECK_LAUNCH();
         launch_partial_reduce(part, nbk, K, 1.f, 0.f, u, (hipStream_t)stream, part + (size_t)2040 * K);   // rows 2040..2047 are spare
@@ -941,6 +954,17 @@ int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int f
     launch_partial_reduce(part, nb, K, 1.f, 0.f, u, (hipStream_t)stream);
     GX_CHECK_LAUNCH();
     return GX_OK;
+}
+int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,
+                     const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                     void* stream) {
+    return sk_pass_impl(S, nullptr, rows, K, ld, eps, first, la, c, c_uniform, lb_out, workspace, workspace_bytes, stream);
+}
+int gx_sinkhorn_pass_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int first, const float* la,
+                          const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (!rowmap) return GX_ERR_BAD_ARG;
+    return sk_pass_impl(S, rowmap, rows, K, ld, eps, first, la, c, c_uniform, lb_out, workspace, workspace_bytes, stream);
 }
 // (a group with many slices is merged in stages — chunks of 64 slices, then the chunks — so that the 10 000 slices of a
 // 320 000-row score matrix are not one thread's serial loop; workspace: gx_sinkhorn_first_from_parts_workspace_bytes)
@@ -1004,6 +1028,21 @@ int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters
     for (int it = 0; it < niters; ++it) {
         rc = gx_sinkhorn_pass(S, rows, K, ld, eps, it == 0, la, c, 1.f / (float)rows, nullptr, workspace,
                               workspace_bytes, stream);
+        if (rc) return rc;
+        rc = gx_sinkhorn_update(workspace + K, r, K, it == 0, workspace, eps, la, stream);
+        if (rc) return rc;
+    }
+    return GX_OK;
+}
+// gx_sinkhorn over the rows rowmap[0 .. rows) of a table (many prototypes only); c_uniform = the uniform row marginal
+// (1 / rows on one rank)
+int gx_sinkhorn_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int niters, const float* r,
+                     const float* c, float c_uniform, float* la, float* workspace, size_t workspace_bytes, void* stream) {
+    if (niters < 1 || !la || !rowmap) return GX_ERR_BAD_ARG;
+    int rc = sk_colmax_impl(S, rowmap, rows, K, ld, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    for (int it = 0; it < niters; ++it) {
+        rc = sk_pass_impl(S, rowmap, rows, K, ld, eps, it == 0, la, c, c_uniform, nullptr, workspace, workspace_bytes, stream);
         if (rc) return rc;
         rc = gx_sinkhorn_update(workspace + K, r, K, it == 0, workspace, eps, la, stream);
         if (rc) return rc;
@@ -1163,10 +1202,31 @@ int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long
 // p's matrices or -1, la_all [(p * 2 + view) * ngroups + group][K] with group = pixel / (npix / ngroups); dSs / dSt
 // [npix][ldd] are WRITTEN (not accumulated): sum over patches of what gx_swapped_ce_fused writes per row, columns K .. kpad - 1
 // zero.  loss_out / gb as there.  K as for gx_swapped_ce_fused; kpad in [K, ldd], a multiple of 4.
+static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long rows, int K, long ld, const int* inv, long npix,
+                          int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
+                          float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
+                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream);
 int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, const int* inv, long npix, int ngroups,
                          float eps, float temperature, const float* la_all, float grad_scale, float* dSs, float* dSt, long ldd,
                          int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta,
                          float* workspace, size_t workspace_bytes, void* stream) {
+    return ce_pixels_impl(S_all, nullptr, P, rows, K, ld, inv, npix, ngroups, eps, temperature, la_all, grad_scale, dSs, dSt, ldd,
+                          kpad, loss_scale, loss_beta, loss_out, gb, gb_beta, workspace, workspace_bytes, stream);
+}
+// ... with the scores as per-pixel tables as well (Ss_tab / St_tab [npix][ld], one per view): inv only says which patches
+// drew a pixel (>= 0), la_all as above
+int gx_swapped_ce_pixels_tab(const float* Ss_tab, const float* St_tab, int P, int K, long ld, const int* inv, long npix,
+                             int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
+                             float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
+                             float gb_beta, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!St_tab || !bigk_aligned(St_tab, ld)) return GX_ERR_BAD_ARG;
+    return ce_pixels_impl(Ss_tab, St_tab, P, 1, K, ld, inv, npix, ngroups, eps, temperature, la_all, grad_scale, dSs, dSt, ldd,
+                          kpad, loss_scale, loss_beta, loss_out, gb, gb_beta, workspace, workspace_bytes, stream);
+}
+static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long rows, int K, long ld, const int* inv, long npix,
+                          int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
+                          float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
+                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream) {
     if (!S_all || !inv || !la_all || !loss_out || !dSs || !dSt || !gb || P <= 0 || P > CE_PMAX || rows <= 0 || K <= 0 || ld < K || npix <= 0 ||
         ngroups <= 0 || npix % ngroups || kpad < K || kpad > ldd || (kpad & 3))
         return GX_ERR_BAD_ARG;
@@ -1180,7 +1240,7 @@ int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, c
     GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((ce_pixels_bigk_kernel<NJ>), dim3(nbk), dim3(256), (size_t)2 * K * sizeof(float), (hipStream_t)stream,
                                                     S_all, P, rows, K, ld, inv, npix, ngroups, npix / ngroups, la_all, 1.f / eps,
                                                     1.f / temperature, grad_scale, dSs, dSt, ldd, kpad, workspace, part_s,
-                                                    part_t));
+                                                    part_t, St_tab));
     GX_CHECK_LAUNCH();
     launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();

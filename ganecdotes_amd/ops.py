@@ -958,10 +958,17 @@ class Sinkhorn:
     Sharded: pass `reduce(tensor, op)` that all-reduces in place over the ranks ('max' for the K
     column maxima, 'sum' for the K column sums) and c_uniform = 1/rows_global."""
 
-    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="sk", la=None):
+    def __init__(self, scores, eps, niters, r=None, c=None, c_uniform=None, tag="sk", la=None, rowmap=None):
+        """rowmap (int32 (rows,), many prototypes only): the problem's rows are rows rowmap[n] of `scores`, a table with more
+        rows than the problem (the per-pixel score table of a view) — no gathered copy is made"""
         _chk(scores, r, c)
         self.S = scores
         self.rows, self.K = scores.shape
+        self.rowmap = rowmap
+        if rowmap is not None:
+            if rowmap.dtype != torch.int32 or not rowmap.is_cuda or not rowmap.is_contiguous() or rowmap.dim() != 1:
+                raise RuntimeError("Sinkhorn: rowmap must be a contiguous 1-D int32 HIP tensor")
+            self.rows = rowmap.numel()
         self.eps, self.niters = float(eps), int(niters)
         self.r, self.c = r, c
         self.c_uniform = 1.0 / self.rows if c_uniform is None else float(c_uniform)
@@ -980,7 +987,12 @@ class Sinkhorn:
 
     def run(self, reduce=None):
         L, S, K = lib(), self.S, self.K
-        if reduce is None and self.c_uniform == 1.0 / self.rows and self.cmax_preset is None:
+        if self.rowmap is not None and reduce is None and self.cmax_preset is None:
+            _lib.check(L.gx_sinkhorn_rows(_p(S), _p(self.rowmap), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r),
+                                          _p(self.c), self.c_uniform, _p(self.la), _p(self.ws), self.wsb, _stream()),
+                       "gx_sinkhorn_rows")
+            return self
+        if self.rowmap is None and reduce is None and self.c_uniform == 1.0 / self.rows and self.cmax_preset is None:
             if K <= 64 and self.rows >= 4096:
                 _lib.check(L.gx_sinkhorn_small(_p(S), self.rows, K, S.stride(0), self.eps, self.niters, _p(self.r),
                                                _p(self.c), _p(self.la), _p(self.ws), self.wsb, _stream()),
@@ -997,6 +1009,10 @@ class Sinkhorn:
         S = self.S
         if self.cmax_preset is not None:          # the pass over S is already paid for
             return self.cmax_set(self.cmax_preset)
+        if self.rowmap is not None:
+            _lib.check(lib().gx_sinkhorn_colmax_rows(_p(S), _p(self.rowmap), self.rows, self.K, S.stride(0), _p(self.ws),
+                                                     self.wsb, _stream()), "gx_sinkhorn_colmax_rows")
+            return
         _lib.check(lib().gx_sinkhorn_colmax(_p(S), self.rows, self.K, S.stride(0), _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_colmax")
 
@@ -1016,6 +1032,11 @@ class Sinkhorn:
             _lib.check(lib().gx_sinkhorn_first_preset(_p(self.u_first_preset), _p(self.cmax_preset), self.K, self.eps,
                                                       _p(self.ws), _stream()), "gx_sinkhorn_first_preset")
             return
+        if self.rowmap is not None:
+            _lib.check(lib().gx_sinkhorn_pass_rows(_p(S), _p(self.rowmap), self.rows, self.K, S.stride(0), self.eps, int(first),
+                                                   _p(self.la), _p(self.c), self.c_uniform, None, _p(self.ws), self.wsb,
+                                                   _stream()), "gx_sinkhorn_pass_rows")
+            return
         _lib.check(lib().gx_sinkhorn_pass(_p(S), self.rows, self.K, S.stride(0), self.eps, int(first), _p(self.la),
                                           _p(self.c), self.c_uniform, None, _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_pass")
@@ -1028,9 +1049,14 @@ class Sinkhorn:
         _lib.check(lib().gx_sinkhorn_update(_p(u), _p(self.r), self.K, int(first), _p(self.ws), self.eps,
                                             _p(self.la), _stream()), "gx_sinkhorn_update")
 
+    def scores(self):
+        """the problem's (rows, K) score matrix (a gathered copy when the problem lives on a table)"""
+        return self.S if self.rowmap is None else self.S[self.rowmap.long()]
+
     def codes(self):
-        q = torch.empty(self.rows, self.K, dtype=torch.float32, device=self.S.device)
-        _lib.check(lib().gx_sinkhorn_codes(_p(self.S), self.rows, self.K, self.S.stride(0), self.eps, _p(self.la),
+        S = self.scores()
+        q = torch.empty(self.rows, self.K, dtype=torch.float32, device=S.device)
+        _lib.check(lib().gx_sinkhorn_codes(_p(S), self.rows, self.K, S.stride(0), self.eps, _p(self.la),
                                            _p(q), q.stride(0), _stream()), "gx_sinkhorn_codes")
         return q
 
@@ -1059,6 +1085,20 @@ class SinkhornBatch:
                                c_uniform=self.c_uniform, tag=f"{tag}.{i}", la=self.la[i])
                       for i in range(self.nprob)]
 
+    @classmethod
+    def from_rows(cls, tables, rowmaps, eps, niters, c_uniform, tag="skb"):
+        """problems given as (score table, row map) pairs: problem i = rows rowmaps[i] of tables[i] (many prototypes)"""
+        self = cls.__new__(cls)
+        self.S = None
+        self.nprob, self.rows, self.K = len(tables), rowmaps[0].numel(), tables[0].shape[1]
+        self.eps, self.niters = float(eps), int(niters)
+        self.r = self.c = None
+        self.c_uniform, self.tag = float(c_uniform), tag
+        self.la = torch.empty(self.nprob, self.K, dtype=torch.float32, device=tables[0].device)
+        self.probs = [Sinkhorn(tables[i], eps, niters, c_uniform=self.c_uniform, tag=f"{tag}.{i}", la=self.la[i],
+                               rowmap=rowmaps[i]) for i in range(self.nprob)]
+        return self
+
     def __getitem__(self, i):
         return self.probs[i]
 
@@ -1072,6 +1112,14 @@ class SinkhornBatch:
             return self._run(None)
 
     def _run(self, reduce):
+        if self.S is None:                    # row-mapped problems on score tables: the per-problem many-prototype kernels
+            if reduce is None:
+                for p in self.probs:
+                    p.run()
+                return self
+            from .sharded import run_sinkhorn_group
+            run_sinkhorn_group(self.probs, self.niters, reduce)
+            return self
         if reduce is None and self.c_uniform == 1.0 / self.rows and self.K <= 64 and self.rows >= 4096:
             L = lib()
             wsb = self.nprob * L.gx_sinkhorn_workspace_bytes(self.K)
@@ -1215,6 +1263,29 @@ def swapped_ce_pixels(scores_all, skb, ngroups, inv, temperature, grad_scale, lo
                                           temperature, _p(skb.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), kpad, loss_scale,
                                           loss_beta, _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()),
                    "gx_swapped_ce_pixels")
+    return loss_out
+
+
+def swapped_ce_pixels_tab(s_tab, t_tab, skb, ngroups, inv, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, kpad,
+                          gb, gb_beta):
+    """swapped_ce_pixels with the scores as per-pixel tables too (s_tab / t_tab (npix, K), one per view): a pixel's score rows
+    are read once for all the patches that drew it; inv (P, npix) int32 only says which did (>= 0)"""
+    _chk(s_tab, t_tab, loss_out, gb)
+    _chk2d(d_s, d_t)
+    npix, k = s_tab.shape
+    npatch = inv.shape[0]
+    if inv.dtype != torch.int32 or tuple(inv.shape) != (npatch, npix) or not inv.is_contiguous() or not inv.is_cuda or \
+            tuple(t_tab.shape) != (npix, k) or d_s.shape[0] != npix or d_t.shape[0] != npix or d_s.stride(0) != d_t.stride(0) or \
+            skb.la.shape[0] != npatch * 2 * ngroups:
+        raise RuntimeError("swapped_ce_pixels_tab: shape mismatch")
+    L = lib()
+    wsb = L.gx_swapped_ce_fused_workspace_bytes(k)
+    ws = workspace("ce_fused", wsb, s_tab.device)
+    with record("ce_fused_bigk_kernel", 0.0, 8.0 * npix * k + 8.0 * npix * kpad):        # score tables once, d(scores) tables once
+        _lib.check(L.gx_swapped_ce_pixels_tab(_p(s_tab), _p(t_tab), npatch, k, s_tab.stride(0), _p(inv), npix, ngroups, skb.eps,
+                                              temperature, _p(skb.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), kpad,
+                                              loss_scale, loss_beta, _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()),
+                   "gx_swapped_ce_pixels_tab")
     return loss_out
 
 

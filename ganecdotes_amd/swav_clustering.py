@@ -317,14 +317,47 @@ class SwAVClustering(ViewMixin):
         dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 6144 and P <= 8 and
                  sa.get('ds_table', hw * hw < P * N) and
                  8.0 * B * hw * hw * Kp + 8.0 * rows * K * P < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
+        # ... and, with one Sinkhorn problem per patch and view (global scope, uniform marginals), the SCORES are a per-pixel table
+        # too: one score GEMM per view over the pixels, the Sinkhorn problems and the CE read their rows of it through the pick index
+        stab = dstab and ngroups == 1 and marg is None and sa.get('score_table', True)
         if dstab:
             pgroup = P             # every patch's scores stay until the one pixel-major CE pass of the step (8 B rows K P bytes)
             npix = B * hw * hw
             dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
             pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
+            picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+        if stab:
+            zt_tab, rn_tab, S_tab = [], [], []
+            for v in range(2):
+                with self._timed("gather_rows"):
+                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
+                st = torch.empty(npix, K, dtype=torch.float32, device=dev)
+                if not ops.gemm_planes_ok(zt, None, K, st):
+                    stab = False
+                    break
+                ops.gemm_nt_planes(zt, None, wc_planes, st, col_bias=bc)
+                zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
+            if stab:
+                rowmaps = [(pb.picks[pno] + pix_base).reshape(-1) for pno in pnos]          # a patch's samples -> table rows
+                with self._timed("sinkhorn"):
+                    skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
+                                                      [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
+                                                      1.0 / nglob)
+                    skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
+                nrow = torch.arange(rows, dtype=torch.int32, device=dev)
+                for gi in range(G):
+                    inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
+                ops.swapped_ce_pixels_tab(S_tab[0], S_tab[1], skb, 1, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
+                                          gb, 0.0 if first_acc else 1.0)
+                first_acc = False
+                if return_aux:
+                    aux.update(scores_s=skb[0].scores(), scores_t=skb[1].scores(), q_s=skb[0].codes(), q_t=skb[1].codes())
+                del inv, skb, rowmaps
+                continue
             Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)
             keep = []
             cmax_pre = {}
@@ -473,10 +506,12 @@ class SwAVClustering(ViewMixin):
                 del X, Zh, Rn, Hc, Sc, dS
             del keep, Sc_all, skb
         if dstab:
-            picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
             for v in range(2):
-                with self._timed("gather_rows"):
-                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
+                if stab:
+                    zt, rnt = zt_tab[v], rn_tab[v]
+                else:
+                    with self._timed("gather_rows"):
+                        zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])   # z_hat of every (output) pixel
                 ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
                          split_k=self._split_k(K, D, B * hw * hw))
                 dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
@@ -488,6 +523,8 @@ class SwAVClustering(ViewMixin):
                     ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
                 del zt, rnt, dz
             del dS_tab
+            if stab:
+                del zt_tab, rn_tab, S_tab
         pending = []
         if mode == 'pyramid':
             on_level = on_heads = None

@@ -372,6 +372,13 @@ int gx_sinkhorn_colmax(const float* S, long rows, int K, long ld, float* workspa
                        void* stream);
 int gx_sinkhorn_cmax_get(const float* workspace, int K, float* out, void* stream);
 int gx_sinkhorn_cmax_set(float* workspace, int K, const float* in, void* stream);
+int gx_sinkhorn_colmax_rows(const float* S, const int* rowmap, long rows, int K, long ld, float* workspace,
+                            size_t workspace_bytes, void* stream);
+int gx_sinkhorn_pass_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int first, const float* la,
+                          const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
+                          void* stream);
+int gx_sinkhorn_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int niters, const float* r,
+                     const float* c, float c_uniform, float* la, float* workspace, size_t workspace_bytes, void* stream);
 int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,
                      const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
                      void* stream);
@@ -443,6 +450,10 @@ int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, c
                          float eps, float temperature, const float* la_all, float grad_scale, float* dSs, float* dSt, long ldd,
                          int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta,
                          float* workspace, size_t workspace_bytes, void* stream);
+int gx_swapped_ce_pixels_tab(const float* Ss_tab, const float* St_tab, int P, int K, long ld, const int* inv, long npix,
+                             int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
+                             float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
+                             float gb_beta, float* workspace, size_t workspace_bytes, void* stream);
 int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
                         float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
                         float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream);
