@@ -459,13 +459,13 @@ def main():
         hb = (r5 or {}).get("hbm")
         out["reference_faithful"] = {
             "workload": f"ffhq-256 hfc_with_swav, 5000 prototypes (hfc_with_swav_ffhq_config.py:52), batch={args.batch}/GPU, "
-                        f"otherwise the configuration of this line; d(scores) summed per pixel before the two backward GEMMs "
-                        f"(5 x 20 000 samples are drawn from 65 536 pixels: --ds-table, DESIGN par. 4.15)",
+                        f"otherwise the configuration of this line; scores and d(scores) live on per-pixel tables, the three GEMMs run "
+                        f"over pixels (5 x 20 000 samples are drawn from 65 536 pixels: --ds-table, DESIGN par. 4.15)",
             "prototypes": 5000, "steps": rf_steps, "warmup": rf_warm,
             "ms_per_step": ms5, "value": rf_steps * args.batch * world / dt5, "unit": "images/s", "loss": loss5,
             "roofline": {
-                "kernel": "gx::gemm kernels (score NT GEMMs of the 10 view-patches, prototype-gradient TN and dz GEMMs over the "
-                          "pixels of both views, the pyramid); FLOPs = those the launches execute",
+                "kernel": "gx::gemm kernels (score NT, prototype-gradient TN and dz GEMMs over the pixels of both views, the "
+                          "pyramid); FLOPs = those the launches execute",
                 "mfma_tflops": None if not gemm else gemm["flops_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12,
                 "mfma_frac": None if not gemm else gemm["flops_per_step"] / (gemm["ms_per_step"] * 1e-3) / peak,
                 "gemm_ms_per_step": None if not gemm else gemm["ms_per_step"],

@@ -158,6 +158,8 @@ SIGNATURES = {
                                        c_p, c_p, c_f, c_p, c_sz, c_p]),
     "gx_sinkhorn_colmax_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_p, c_sz, c_p]),
     "gx_sinkhorn_pass_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_first_rows_workspace_bytes": (c_sz, [c_i]),
+    "gx_sinkhorn_first_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     "gx_swapped_ce_pixels": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_l, c_i, c_f, c_f, c_p, c_f, c_p, c_p, c_l, c_i, c_f, c_f, c_p,
                                    c_p, c_f, c_p, c_sz, c_p]),

@@ -19,7 +19,7 @@ __device__ __forceinline__ float bk_ord2f(unsigned o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-enum { BK_COLMAX = 0, BK_COLSUM = 1, BK_FIRST = 2, BK_SWEEP = 3 };
+enum { BK_COLMAX = 0, BK_COLSUM = 1, BK_FIRST = 2, BK_SWEEP = 3, BK_FIRSTLSE = 4 };
 
 // exp(x) for x <= ~0 (every call site subtracts a maximum first) as v_exp_f32(x * log2 e) with the product carried
 // in two floats: y = fl(x L) and its error fma(x, L, -y) + x (log2 e - L), folded back as exp2(y) (1 + r ln 2).
@@ -61,7 +61,10 @@ __device__ __forceinline__ void bk_store4(__amdgpu_buffer_rsrc_t r, int first_co
 // 275 VGPRs with the row itself, one wave per SIMD, 4.2 TB/s) and the block's partial row is written straight from
 // registers, no LDS atomics.  The row reductions of the sweep (max, then sum of exp, over all K columns) cross the four
 // waves through LDS; BK_R rows travel together (BK_R x NJ/16 float4 loads in flight per thread, two barriers per group).
-// MODE BK_COLMAX : cmax[k] = max_n S_nk                     (ordered-uint atomicMax into `cmax_out`)
+// MODE BK_FIRSTLSE: the column maxima AND the first pass in one sweep, with no reference known beforehand: per block and column
+//                   the running pair (m, s = sum exp((S_nk - m) / eps)) of an online log-sum-exp; part[b][k] = s and
+//                   lb_out reused as the float table [gridDim.x][K] of the m (merged exactly by sk_first_from_parts_kernel)
+//      BK_COLMAX : cmax[k] = max_n S_nk                     (ordered-uint atomicMax into `cmax_out`)
 //      BK_COLSUM : part[b][k] = sum_{rows of block} S_nk
 //      BK_FIRST  : part[b][k] = sum exp((S_nk - cmax_k)/eps)
 //      BK_SWEEP  : lb_n = log c_n - logsumexp_k(S_nk/eps + la_k); part[b][k] = sum exp(S_nk/eps + la_k + lb_n)
@@ -102,10 +105,12 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         __syncthreads();
     }
     f32x4 u[NC];
+    f32x4 um[MODE == BK_FIRSTLSE ? NC : 1];                              // BK_FIRSTLSE: the running column maxima
 #pragma unroll
     for (int cidx = 0; cidx < NC; ++cidx) {
         const float init = (MODE == BK_COLMAX) ? -INFINITY : 0.f;
         u[cidx] = f32x4{init, init, init, init};
+        if (MODE == BK_FIRSTLSE) um[cidx] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
     const long ngroups = (rows + BK_R - 1) / BK_R;
     for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -120,7 +125,21 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
 #pragma unroll
             for (int cidx = 0; cidx < NC; ++cidx) w[r][cidx] = bk_load4(rs, 4 * (tid + 256 * cidx));
         }
-        if (MODE == BK_COLMAX) {
+        if (MODE == BK_FIRSTLSE) {
+#pragma unroll
+            for (int r = 0; r < BK_R; ++r)
+                if (r0 + r < rows)
+#pragma unroll
+                    for (int cidx = 0; cidx < NC; ++cidx)
+                        if (4 * (tid + 256 * cidx) < K)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float x = w[r][cidx][q], d = (x - um[cidx][q]) * inv_eps;     // first row: d = +inf, e = 0
+                                const float e = bk_exp(-fabsf(d));
+                                u[cidx][q] = d > 0.f ? fmaf(u[cidx][q], e, 1.f) : u[cidx][q] + e;
+                                um[cidx][q] = fmaxf(um[cidx][q], x);
+                            }
+        } else if (MODE == BK_COLMAX) {
 #pragma unroll
             for (int r = 0; r < BK_R; ++r)
                 if (r0 + r < rows)
@@ -207,6 +226,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                 for (int q = 0; q < 4; ++q) atomicMax(cmax_out + k + q, bk_f2ord(u[cidx][q]));
             } else {
                 *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * K + k) = u[cidx];
+                if (MODE == BK_FIRSTLSE) *reinterpret_cast<f32x4*>(lb_out + (long)blockIdx.x * K + k) = um[cidx];
             }
         }
     }

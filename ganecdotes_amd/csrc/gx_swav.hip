@@ -1034,6 +1034,40 @@ int gx_sinkhorn(const float* S, long rows, int K, long ld, float eps, int niters
     }
     return GX_OK;
 }
+// The column maxima AND the first Sinkhorn pass of the problem "rows rowmap[0 .. rows) of table S" (rowmap NULL: rows 0 .. rows)
+// in ONE sweep: cmax[k] = max_n S_nk, u[k] = sum_n exp((S_nk - cmax[k]) / eps) (what gx_sinkhorn_colmax + gx_sinkhorn_pass(first)
+// leave in two) — every block keeps a running (max, sum) pair per column (online log-sum-exp, one exponential per score)
+// and the pairs are merged exactly.  Many prototypes only.  workspace >= gx_sinkhorn_first_rows_workspace_bytes(K).
+size_t gx_sinkhorn_first_rows_workspace_bytes(int K) { return (size_t)(2 * 2040 + 2 * 32 + 8) * K * sizeof(float); }
+int gx_sinkhorn_first_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, float* cmax, float* u,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+    if (!S || !cmax || !u || rows <= 0 || K <= 0 || ld < K || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    if (!(bigk_ok(K) && bigk_aligned(S, ld))) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_first_rows_workspace_bytes(K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbk = bigk_blocks(rows, 2040);
+    float* ps = workspace;                        // [nbk][K] sums
+    float* pm = ps + (size_t)2040 * K;            // [nbk][K] maxima
+    float* w = pm + (size_t)2040 * K;             // merge stage: 2 x 32 x K
+    const size_t lds = bigk_pass_lds(K);
+    GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRSTLSE>), dim3(nbk), dim3(256), lds, st, S, rows, K,
+                                                    ld, 1.f / eps, nullptr, nullptr, nullptr, 0.f, pm, ps, nullptr, 0L, 0L,
+                                                    rowmap));
+    GX_CHECK_LAUNCH();
+    const float* cin = pm;
+    const float* uin = ps;
+    int parts = nbk;
+    if (parts > 256) {                            // chunks of 64 blocks first (at most 32 of them)
+        const int nch = gx_cdiv(parts, 64);
+        hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(K, 64), nch), dim3(256), 0, st, cin, uin, 64, parts, K, 1.f / eps,
+                           w, w + (size_t)nch * K);
+        GX_CHECK_LAUNCH();
+        cin = w; uin = w + (size_t)nch * K; parts = nch;
+    }
+    hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(K, 64), 1), dim3(256), 0, st, cin, uin, parts, parts, K, 1.f / eps, cmax, u);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 // gx_sinkhorn over the rows rowmap[0 .. rows) of a table (many prototypes only); c_uniform = the uniform row marginal
 // (1 / rows on one rank)
 int gx_sinkhorn_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int niters, const float* r,

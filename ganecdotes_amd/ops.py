@@ -1061,6 +1061,24 @@ class Sinkhorn:
         return q
 
 
+def sinkhorn_first_rows(scores, eps, rowmap=None):
+    """(cmax (K,), u (K,)) of the Sinkhorn problem on `scores` (rows rowmap[n] of it when given): the column maxima and the
+    first pass u = exp((S - cmax) / eps).sum(0) in ONE sweep (online log-sum-exp per block, merged exactly) — what
+    Sinkhorn.cmax_preset / u_first_preset take"""
+    _chk(scores)
+    k = scores.shape[1]
+    rows = scores.shape[0] if rowmap is None else rowmap.numel()
+    L = lib()
+    cm = torch.empty(k, dtype=torch.float32, device=scores.device)
+    u = torch.empty(k, dtype=torch.float32, device=scores.device)
+    wsb = L.gx_sinkhorn_first_rows_workspace_bytes(k)
+    ws = workspace("sk_first_rows", wsb, scores.device)
+    with record("sinkhorn_pass_kernel", 0.0, 4.0 * rows * k):
+        _lib.check(L.gx_sinkhorn_first_rows(_p(scores), _p(rowmap), rows, k, scores.stride(0), eps, _p(cm), _p(u), _p(ws), wsb,
+                                            _stream()), "gx_sinkhorn_first_rows")
+    return cm, u
+
+
 class SinkhornBatch:
     """`nprob` independent, equally shaped Sinkhorn problems — the 2 views x patches (x images for
     the per-image scope) score matrices of one optimizer step — solved together.

@@ -346,6 +346,8 @@ class SwAVClustering(ViewMixin):
                     skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
                                                       [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
                                                       1.0 / nglob)
+                    for sk_ in skb.probs:      # column maxima + first pass of every problem in ONE sweep of its rows
+                        sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
                     skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
                 inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
                 nrow = torch.arange(rows, dtype=torch.int32, device=dev)

@@ -377,6 +377,9 @@ int gx_sinkhorn_colmax_rows(const float* S, const int* rowmap, long rows, int K,
 int gx_sinkhorn_pass_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int first, const float* la,
                           const float* c, float c_uniform, float* lb_out, float* workspace, size_t workspace_bytes,
                           void* stream);
+size_t gx_sinkhorn_first_rows_workspace_bytes(int K);
+int gx_sinkhorn_first_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, float* cmax, float* u,
+                           float* workspace, size_t workspace_bytes, void* stream);
 int gx_sinkhorn_rows(const float* S, const int* rowmap, long rows, int K, long ld, float eps, int niters, const float* r,
                      const float* c, float c_uniform, float* la, float* workspace, size_t workspace_bytes, void* stream);
 int gx_sinkhorn_pass(const float* S, long rows, int K, long ld, float eps, int first, const float* la,

@@ -869,6 +869,40 @@ def test_mapping_pieces_golden_gv3(ops):
     assert rel_err(y, T(d["el_y"])) < 1e-5
 
 
+@pytest.mark.parametrize("k,rows,eps,mapped", [(200, 1000, 0.05, True), (5000, 9001, 0.005, True), (132, 37, 0.005, False),
+                                               (1000, 40000, 0.05, True)])
+def test_sinkhorn_first_rows_one_sweep(ops, k, rows, eps, mapped):
+    """gx_sinkhorn_first_rows: column maxima + first Sinkhorn pass of a problem living on the rows rowmap[n] of a score table, in
+    one sweep (online log-sum-exp per block, merged exactly) — against fp64; rows outside the problem carry huge scores that
+    would underflow everything if they leaked into the reference; and a Sinkhorn problem started from it equals the
+    gathered-copy problem"""
+    torch.manual_seed(k + rows)
+    ntab = rows * 3 if mapped else rows
+    tab = (torch.randn(ntab, k) * 0.2)
+    rowmap = None
+    if mapped:
+        idx = torch.randperm(ntab)[:rows]
+        mask = torch.ones(ntab, dtype=torch.bool)
+        mask[idx] = False
+        tab[mask] += 50.0                               # not part of the problem
+        rowmap = idx.to(torch.int32).cuda()
+        sub = tab[idx]
+    else:
+        sub = tab
+    tabd = tab.cuda()
+    cm, u = ops.sinkhorn_first_rows(tabd, eps, rowmap)
+    want_cm = sub.double().max(0).values
+    want_u = torch.exp((sub.double() - want_cm) / eps).sum(0)
+    assert torch.equal(cm.cpu().double(), want_cm)
+    assert rel_err(u, want_u) < 2e-5
+    a = ops.Sinkhorn(tabd, eps, 5, rowmap=rowmap)
+    a.cmax_preset, a.u_first_preset = cm, u
+    a.run()
+    b = ops.Sinkhorn(sub.cuda().contiguous(), eps, 5).run()
+    assert rel_err(a.la, b.la) < 1e-5 or float((a.la - b.la).abs().max()) < 1e-4
+    assert rel_err(a.codes(), b.codes()) < 1e-4
+
+
 @pytest.mark.parametrize("k,ngroups", [(200, 1), (5000, 1), (132, 3)])
 def test_swapped_ce_pixels_equals_per_pair_ce_summed_per_pixel(ops, k, ngroups):
     """gx_swapped_ce_pixels (every patch of a step in one pixel-major pass, a pixel's d(scores) summed over the patches that drew
