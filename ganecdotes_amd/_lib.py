@@ -54,6 +54,9 @@ SIGNATURES = {
     "gx_sinkhorn_first_from_parts_workspace_bytes": (c_sz, [c_i, c_i]),
     "gx_sinkhorn_first_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_first_preset": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p]),
+    "gx_gemm_f32_nt_planes_mlive": (c_i, [c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
+    "gx_gemm_f32_klive": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
+                                c_p]),
     "gx_gemm_finish_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "gx_gemm_finish_workspace_bytes": (c_sz, [c_l, c_i, c_i]),
     "gx_gemm_f32_nt_planes_finish": (c_i, [c_l, c_i, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_sz,

@@ -50,6 +50,10 @@ struct GemmArgs {
     const float* fin_C; const float* fin_Z; const float* fin_Wc;
     float* fin_pool; float* fin_part;
     int fin_K, fin_ls, fin_rlog;
+    // optional device scalar: the rows of the LONG dimension that carry data — the M rows of gemm_xw_kernel (tiles at or past
+    // it return at once), the k rows of a TN contraction (its k range is cut there).  The many-prototype tables hold the drawn
+    // pixels first and their count is only known on the device: no host sync, the launch covers the capacity (DESIGN par. 4.15)
+    const int* live;
 };
 
 // (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
@@ -62,6 +66,20 @@ __device__ __forceinline__ void gemm_tile_of_block(int ntile, int& logical, int&
     const int L = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), ntile * (int)gridDim.y);
     split = L / ntile;
     logical = L - split * ntile;
+}
+
+// The k range of one split.  With a device-side bound (g.live: only the first *g.live of the K rows hold anything) the LIVE
+// range is what the launched splits share — cutting only the tail splits short left their workgroups idle while the others
+// ran as long as before (TN dWc over the score tables, 0.84 live: 31.2 -> 29.2 ms instead of -> 26).
+__device__ __forceinline__ void gemm_k_range(const GemmArgs& g, int split, int& kbeg, int& kend) {
+    int K = g.K, kps = g.k_per_split;
+    if (g.live) {
+        K = min(g.K, max(0, *g.live));
+        const int kt = (K + BK - 1) / BK, ns = (int)gridDim.y;
+        kps = (kt + ns - 1) / ns * BK;
+    }
+    kbeg = split * kps;
+    kend = min(K, kbeg + kps);
 }
 
 // Accumulators of a wave's (32 MT) x (32 NT) sub-tile whose first row / column in C is (row0, col0).
@@ -184,8 +202,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g) {
     const float* Bsrc = bsec ? g.B2 : g.B;
     const long ldbs = bsec ? g.ldb2 : g.ldb;
     const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
-    const int kbeg = split * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
+    int kbeg, kend;
+    gemm_k_range(g, split, kbeg, kend);
 
     f32x16 acc[2][2];
     zero_acc(acc);
@@ -241,8 +259,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (!TA && TB) ? 3 : 2) void gemm_x6_ker
     const float* Bsrc = bsec ? g.B2 : g.B;
     const long ldbs = bsec ? g.ldb2 : g.ldb;
     const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
-    const int kbeg = split * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
+    int kbeg, kend;
+    gemm_k_range(g, split, kbeg, kend);
 
     f32x16 acc[2][2];
     zero_acc(acc);
@@ -476,6 +494,13 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
     const int width = min(g.n_group, g.tiles_n - grp * g.n_group);      // the last group may be narrower
     tm = rem / width;
     tn = grp * g.n_group + (rem - tm * width);
+    if (g.live) {
+        // the rows past *g.live are the TAIL of the M tiles, and an XCD owns a contiguous run of logical tiles: the dead tail would
+        // sit on the last XCDs of a group and the others would carry a full load.  Deal the M tiles to eight interleaved
+        // sub-ranges instead (a bijection of [0, tiles_m)): every run then holds its share of the tail.
+        const int q = g.tiles_m >> 3, r = g.tiles_m & 7, j = tm & 7, i = tm >> 3;
+        tm = j * q + min(j, r) + i;
+    }
 }
 
 // NT contraction with the weight operand PRE-SPLIT (gx_split_gemm_weights: the projection / prototype weights change
@@ -503,6 +528,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     int tm, tn;
     xw_tile_of(g, logical, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    if (g.live && m0 >= *g.live) return;                             // rows past the live count: nothing reads the outputs
     const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;                      // K, K1 are multiples of 16
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -670,8 +696,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     const float* Bsrc = bsec ? g.B2 : g.B;
     const long ldbs = bsec ? g.ldb2 : g.ldb;
     const int nb0 = bsec ? n0 - g.N1 : n0, nbN = bsec ? g.N - g.N1 : g.N1;
-    const int kbeg = split * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
+    int kbeg, kend;
+    gemm_k_range(g, split, kbeg, kend);
     const int nkt = (kend - kbeg + XK - 1) / XK;
     char* slot0 = lds;
     char* slot1 = lds + WS_SLOT;
@@ -765,9 +791,10 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1) {
+                       int N1 = -1, const int* k_live = nullptr) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
+    g.live = k_live;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.usum_part = nullptr; g.sk_inv_eps = 0.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
@@ -836,7 +863,8 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
-                          float* usum_part = nullptr, float sk_eps = 0.f, const GemmArgs* fin = nullptr) {
+                          float* usum_part = nullptr, float sk_eps = 0.f, const GemmArgs* fin = nullptr,
+                          const int* m_live = nullptr) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -846,6 +874,8 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
         (((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)Bp | (uintptr_t)C | (uintptr_t)up_src) & 15))
         return GX_ERR_BAD_ARG;
     GemmArgs g;
+    g.live = m_live;
+    if (m_live && (colmax_part || fin)) return GX_ERR_BAD_ARG;        // per-slice outputs / the finish need every tile
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
         if (up_rf < 2 || (up_rf & (up_rf - 1)) || (long)M % ((long)up_rf * up_rf)) return GX_ERR_BAD_ARG;
@@ -913,6 +943,17 @@ int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lon
                            split_k, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// gx_gemm_f32 for a TN contraction whose k rows carry data only below *k_live (a device int; rows at or past it are not
+// read): transA must be 1.  The launch covers K; the count never visits the host.
+int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                      float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                      int split_k, float* workspace, size_t workspace_bytes, const int* k_live, void* stream) {
+    if (!transA || !k_live) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
+                           split_k, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1,
+                           k_live);
+}
+
 // C = alpha * [A1 | A2] opB + ... : A1 is [M][K1], A2 is [M][K2]; K1 must be a multiple of 32.
 // (two same-resolution feature taps contracted against adjacent column blocks of the
 // projection weight in one launch)
@@ -975,6 +1016,14 @@ int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long ld
     gx::launch_partial_reduce(workspace, tiles_m, K * N, 1.f, beta, gWc, (hipStream_t)stream, workspace + (size_t)tiles_m * K * N);
     GX_CHECK_LAUNCH();
     return GX_OK;
+}
+// gx_gemm_f32_nt_planes (one A source, no coarse table, no column maxima) for an A whose rows carry data only below *m_live
+// (a device int): 128-row tiles at or past it are skipped and their rows of C left untouched.
+int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* C,
+                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, void* stream) {
+    if (!m_live) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm_xw(M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, C, ldc, alpha, beta, nullptr, col_bias, nullptr, 0,
+                              nullptr, (hipStream_t)stream, nullptr, 0.f, nullptr, m_live);
 }
 // bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
 size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }

@@ -91,10 +91,12 @@ def _chk2d(*ts):
 
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
-         split_k=1):
+         split_k=1, live=None, live_frac=1.0):
     """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
     op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K).
-    a, b, out may be row-strided views (leading dimension = stride(0))."""
+    a, b, out may be row-strided views (leading dimension = stride(0)).
+    live (trans_a only): int32 device scalar, the k rows that carry data (the rest is not read; the launch covers K with no
+    host sync); live_frac = its expected share of K, for the FLOP accounting only."""
     _chk2d(a, b, out)
     _chk(row_scale, col_bias)
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -112,6 +114,14 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
     if split_k > 1:
         wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
         ws = workspace("gemm", wsb, a.device)
+    if live is not None:
+        if not trans_a or live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1:
+            raise RuntimeError("gemm: `live` is an int32 HIP scalar and needs trans_a")
+        with record("gemm_f32_kernel", 2.0 * m * n * k * live_frac):
+            _lib.check(L.gx_gemm_f32_klive(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
+                                           _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
+                                           wsb, _p(live), _stream()), "gx_gemm_f32_klive")
+        return out
     with record("gemm_f32_kernel", 2.0 * m * n * k):
         _lib.check(L.gx_gemm_f32(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
                                  _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
@@ -187,6 +197,25 @@ def gemm_planes_ok(a1, a2, n, out):
         if a is not None and (a.shape[1] % 16 or a.stride(0) % 4 or a.data_ptr() % 16 or a.stride(0) >= (1 << 22)):
             return False
     return True
+
+
+def gemm_nt_planes_live(a, b_planes, out, live, live_frac, col_bias=None, alpha=1.0, beta=0.0):
+    """gemm_nt_planes(a, None, b_planes, out, col_bias=...) for an `a` whose rows carry data only below the int32 device scalar
+    `live`: the 128-row tiles at or past it are skipped (their rows of `out` stay as they are); live_frac: expected share, for
+    the FLOP accounting"""
+    _chk2d(a, out)
+    _chk(col_bias)
+    m, k1 = a.shape
+    n = out.shape[1]
+    L = lib()
+    if out.shape[0] != m or b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(n, k1):
+        raise RuntimeError("gemm_nt_planes_live: shape mismatch")
+    if live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1:
+        raise RuntimeError("gemm_nt_planes_live: `live` is an int32 HIP scalar")
+    with record("gemm_f32_kernel", 2.0 * m * n * k1 * live_frac):
+        _lib.check(L.gx_gemm_f32_nt_planes_mlive(m, n, k1, _p(a), a.stride(0), _p(b_planes), _p(out), out.stride(0), alpha, beta,
+                                                 _p(col_bias), _p(live), _stream()), "gx_gemm_f32_nt_planes_mlive")
+    return out
 
 
 def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0,

@@ -327,21 +327,42 @@ class SwAVClustering(ViewMixin):
             pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
             picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
         if stab:
+            # Table rows = the pixels some patch drew, FIRST (84 % of them at 5 x 20 000 of 65 536), in pixel order; their count
+            # `live` stays on the device and bounds the three GEMMs there (no host sync: the launches cover all B * HW rows)
+            flat = [(pb.picks[pno] + pix_base).reshape(-1).long() for pno in range(P)]
+            drawn = torch.zeros(npix, dtype=torch.bool, device=dev)
+            for f_ in flat:
+                drawn[f_] = True
+            order = torch.argsort((~drawn).to(torch.int8), stable=True)                   # drawn pixel ids first
+            live = drawn.sum(dtype=torch.int32).reshape(1)
+            live_frac = 1.0 - (1.0 - N / float(hw * hw)) ** P                            # its expectation (FLOP accounting)
+            ar32 = torch.arange(npix, dtype=torch.int32, device=dev)
+            cid = torch.empty(npix, dtype=torch.int32, device=dev)
+            cid[order] = ar32                                                            # pixel id -> table row
+            rowmaps_all = [cid[f_] for f_ in flat]
+            order32 = order.to(torch.int32)
+            sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
+            scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
+            maps_flat = []
+            for v in range(2):
+                m_ = views[v][1]
+                mf = ar32 if m_ is None else torch.where(m_ >= 0, m_ + pix_base, m_).reshape(-1)
+                maps_flat.append(torch.cat([mf, sentinel]).view(1, npix + 1))
             zt_tab, rn_tab, S_tab = [], [], []
             for v in range(2):
-                with self._timed("gather_rows"):
-                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
+                with self._timed("gather_rows"):       # z_hat of the table's pixels (the image batch as ONE image of B * H rows)
+                    zt, rnt = ops.gather_rows_normalize(Zt[v].reshape(1, B * hw, hw, D), order32.view(1, npix), maps_flat[v])
                 st = torch.empty(npix, K, dtype=torch.float32, device=dev)
                 if not ops.gemm_planes_ok(zt, None, K, st):
                     stab = False
                     break
-                ops.gemm_nt_planes(zt, None, wc_planes, st, col_bias=bc)
+                ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
                 zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
             if stab:
-                rowmaps = [(pb.picks[pno] + pix_base).reshape(-1) for pno in pnos]          # a patch's samples -> table rows
+                rowmaps = [rowmaps_all[pno] for pno in pnos]                               # a patch's samples -> table rows
                 with self._timed("sinkhorn"):
                     skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
                                                       [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
@@ -509,14 +530,20 @@ class SwAVClustering(ViewMixin):
             del keep, Sc_all, skb
         if dstab:
             for v in range(2):
+                dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
                 if stab:
                     zt, rnt = zt_tab[v], rn_tab[v]
-                else:
-                    with self._timed("gather_rows"):
-                        zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])   # z_hat of every (output) pixel
+                    ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
+                             split_k=self._split_k(K, D, B * hw * hw), live=live, live_frac=live_frac)
+                    ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, live, live_frac)
+                    with self._timed("scatter_rows"):
+                        ops.normalize_bwd_scatter_(dz, zt, rnt, scat_picks, maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
+                    del zt, rnt, dz
+                    continue
+                with self._timed("gather_rows"):
+                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
                 ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
                          split_k=self._split_k(K, D, B * hw * hw))
-                dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
                 if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
                     ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz)
                 else:

@@ -104,6 +104,14 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
+/* ... with the long dimension's data rows counted on the device (the drawn pixels of the many-prototype tables come first,
+ * DESIGN.md par. 4.15): gx_gemm_f32_nt_planes_mlive skips the 128-row tiles at or past *m_live, gx_gemm_f32_klive (TN only)
+ * cuts the k range at *k_live */
+int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* C,
+                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, void* stream);
+int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                      float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                      int split_k, float* workspace, size_t workspace_bytes, const int* k_live, void* stream);
 /* gx_gemm_f32_nt_planes_finish: G = A1 B^T with the low-rank path's dense finish in the epilogue (autograd of
  * swav_clustering.py:171-175 through the pyramid, K <= 16): G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q], gWc = beta gWc +
  * coeffs[:, :K]^T Z, Gpool (may be NULL) = the 2x2 sums of G; rows = pixels of res x res images (DESIGN.md par. 4.14) */

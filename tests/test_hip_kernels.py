@@ -589,6 +589,49 @@ def test_gemm_upadd_fused_pyramid_level(ops, engine):
                        dev(torch.randn(18, 8)), 6)
 
 
+def test_gemm_live_bounds_on_the_device(ops):
+    """gx_gemm_f32_nt_planes_mlive / gx_gemm_f32_klive (DESIGN §4.15 d: the score tables hold the drawn pixels first and an
+    int32 DEVICE scalar says how many): the live rows are BITWISE those of the unbounded launch over the same rows, the rows
+    of whole dead 128-row tiles keep what they held, and the TN product equals the product over the live rows only —
+    whatever garbage (here NaN) sits past the bound."""
+    torch.manual_seed(61)
+    prev = ops.set_gemm_mode(1)
+    try:
+        for (m, n, k, live_n) in ((4096, 260, 64, 2500), (1300, 512, 5008, 1300), (1024, 132, 32, 0), (900, 68, 48, 129)):
+            a, w, cb = dev(torch.randn(m, k)), dev(torch.randn(n, k)), dev(torch.randn(n))
+            bp = ops.split_gemm_weights(w)
+            live = torch.tensor([live_n], dtype=torch.int32, device="cuda")
+            full = torch.empty(m, n, device="cuda")
+            ops.gemm_nt_planes(a, None, bp, full, col_bias=cb)
+            a_dead = a.clone()
+            a_dead[live_n:] = float("nan")                     # nothing past the bound may reach a live row
+            out = torch.full((m, n), -7.0, device="cuda")
+            ops.gemm_nt_planes_live(a_dead, bp, out, live, live_n / m, col_bias=cb)
+            assert torch.equal(out[:live_n], full[:live_n]), (m, n, k, live_n)
+            dead0 = -(-live_n // 128) * 128                    # rows of the tile the bound falls in are written (and unread)
+            assert torch.equal(out[dead0:], torch.full_like(out[dead0:], -7.0))
+            # TN: dS^T Z over the live rows, split-k over the LIVE range, accumulate form included
+            ds, z = dev(torch.randn(m, n)), dev(torch.randn(m, 40))
+            ds_dead, z_dead = ds.clone(), z.clone()
+            ds_dead[live_n:] = float("nan")
+            z_dead[live_n:] = float("nan")
+            want = ds[:live_n].double().t() @ z[:live_n].double()
+            for split in (1, 3, 8):
+                prior = torch.randn(n, 40, device="cuda")
+                got = prior.clone()
+                ops.gemm(ds_dead, z_dead, True, False, out=got, beta=0.5, split_k=split, live=live, live_frac=live_n / m)
+                assert rel_err(got, want + 0.5 * prior.double()) < 3e-6, (m, n, split, live_n)
+                again = prior.clone()
+                ops.gemm(ds_dead, z_dead, True, False, out=again, beta=0.5, split_k=split, live=live, live_frac=live_n / m)
+                assert torch.equal(got, again)
+        with pytest.raises(RuntimeError):                      # a host-side count is not what these entry points take
+            ops.gemm_nt_planes_live(a, bp, out, torch.tensor([3], dtype=torch.int32), 1.0)
+        with pytest.raises(RuntimeError):
+            ops.gemm(a, w, False, True, live=live)                 # the k bound is the TN form's
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 def test_gemm_nt_planes_bitwise_and_fp64(ops):
     """gx_gemm_f32_nt_planes (weights pre-split once per step, both operands by LDS-DMA): against fp64 and BITWISE
     against gx_gemm_f32 / _cat / _upadd on the bf16x6 engine, incl. ragged M / N tails, strided views, every epilogue

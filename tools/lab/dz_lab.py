@@ -21,3 +21,15 @@ t1 = timeit(lambda: ops.gemm_nt_planes(buf, None, bp, out2))
 fl = 2.0 * m * n * k
 print(f"dz NN ws {t0:.3f} ms {fl/t0/1e9:.0f} TF/s | xw {t1:.3f} ms {fl/t1/1e9:.0f} TF/s  maxdiff {(out-out2).abs().max().item():g} ref {out.abs().max().item():g}")
 
+
+# the same GEMMs with a device-side live-row bound: time against the share of live rows
+m2 = 1048576
+a2 = torch.zeros(m2, kp, device=dev); a2[:, :k] = torch.randn(m2, k, device=dev) * 1e-3
+o2 = torch.empty(m2, n, device=dev)
+zt = torch.randn(m2, n, device=dev)
+gw = torch.empty(k, n, device=dev)
+for frac in (1.0, 0.84, 0.5):
+    live = torch.tensor([int(m2 * frac)], dtype=torch.int32, device=dev)
+    t = timeit(lambda: ops.gemm_nt_planes_live(a2, bp, o2, live, frac))
+    t3 = timeit(lambda: ops.gemm(a2[:, :k], zt, True, False, out=gw, split_k=10, live=live, live_frac=frac))
+    print(f"  live {frac:4.2f}: dz xw {t:.2f} ms   dWc TN {t3:.2f} ms", flush=True)
