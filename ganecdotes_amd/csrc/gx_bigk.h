@@ -521,9 +521,12 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
                                                                 float* __restrict__ dSs, float* __restrict__ dSt, long ldd,
                                                                 int kpad, float* __restrict__ loss_part,
                                                                 float* __restrict__ part_s, float* __restrict__ part_t,
-                                                                const float* __restrict__ St_tab = nullptr) {
+                                                                const float* __restrict__ St_tab = nullptr,
+                                                                const int* __restrict__ live = nullptr) {
     // St_tab != NULL: the scores are per-pixel TABLES too (S_all = the first view's [npix][ld], St_tab the second's): a
-    // pixel's two score rows are read once for all the patches that drew it
+    // pixel's two score rows are read once for all the patches that drew it.  live != NULL: the drawn pixels are the first
+    // *live rows of the tables (DESIGN §4.15 d) — the d(scores) rows past them are neither read by the GEMMs nor written here
+    const long nlive = live ? min(npix, (long)max(0, *live)) : npix;      // (npix stays the row length of `inv`)
     constexpr int NC = (NJ + 15) / 16;
     __shared__ float red[2 * 16];
     // the block's column sums of both tables (the bias gradient) live in LDS, every thread adding to its own columns: in
@@ -532,8 +535,9 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float f = -0.5f * gscale * inv_T;
     for (int k = tid; k < 2 * K; k += 256) csum[k] = 0.f;
+    __syncthreads();          // a block without a pixel (or whose first pixel nobody drew) reaches its csum reads with no other barrier
     float lacc = 0.f;
-    for (long pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+    for (long pix = blockIdx.x; pix < nlive; pix += gridDim.x) {
         f32x4 as[NC], at[NC];                                            // the pixel's accumulated d(scores), both views
 #pragma unroll
         for (int c = 0; c < NC; ++c) { as[c] = f32x4{0.f, 0.f, 0.f, 0.f}; at[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }

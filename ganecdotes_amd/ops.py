@@ -1314,9 +1314,12 @@ def swapped_ce_pixels(scores_all, skb, ngroups, inv, temperature, grad_scale, lo
 
 
 def swapped_ce_pixels_tab(s_tab, t_tab, skb, ngroups, inv, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, kpad,
-                          gb, gb_beta):
+                          gb, gb_beta, live=None, live_frac=1.0):
     """swapped_ce_pixels with the scores as per-pixel tables too (s_tab / t_tab (npix, K), one per view): a pixel's score rows
-    are read once for all the patches that drew it; inv (P, npix) int32 only says which did (>= 0)"""
+    are read once for all the patches that drew it; inv (P, npix) int32 only says which did (>= 0).  live (int32 HIP scalar):
+    the drawn pixels are the first `live` rows of the tables — the d(scores) rows past them are left as they are (live_frac: its expected share, for the byte accounting)"""
+    if live is not None and (live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1):
+        raise RuntimeError("swapped_ce_pixels_tab: `live` is an int32 HIP scalar")
     _chk(s_tab, t_tab, loss_out, gb)
     _chk2d(d_s, d_t)
     npix, k = s_tab.shape
@@ -1328,10 +1331,11 @@ def swapped_ce_pixels_tab(s_tab, t_tab, skb, ngroups, inv, temperature, grad_sca
     L = lib()
     wsb = L.gx_swapped_ce_fused_workspace_bytes(k)
     ws = workspace("ce_fused", wsb, s_tab.device)
-    with record("ce_fused_bigk_kernel", 0.0, 8.0 * npix * k + 8.0 * npix * kpad):        # score tables once, d(scores) tables once
+    with record("ce_fused_bigk_kernel", 0.0, (8.0 * npix * k + 8.0 * npix * kpad) * live_frac):    # score tables once, d(scores) tables once
         _lib.check(L.gx_swapped_ce_pixels_tab(_p(s_tab), _p(t_tab), npatch, k, s_tab.stride(0), _p(inv), npix, ngroups, skb.eps,
                                               temperature, _p(skb.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), kpad,
-                                              loss_scale, loss_beta, _p(loss_out), _p(gb), gb_beta, _p(ws), wsb, _stream()),
+                                              loss_scale, loss_beta, _p(loss_out), _p(gb), gb_beta, _p(live), _p(ws), wsb,
+                                              _stream()),
                    "gx_swapped_ce_pixels_tab")
     return loss_out
 

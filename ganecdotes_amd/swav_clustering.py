@@ -375,7 +375,7 @@ class SwAVClustering(ViewMixin):
                 for gi in range(G):
                     inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
                 ops.swapped_ce_pixels_tab(S_tab[0], S_tab[1], skb, 1, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
-                                          gb, 0.0 if first_acc else 1.0)
+                                          gb, 0.0 if first_acc else 1.0, live=live, live_frac=live_frac)
                 first_acc = False
                 if return_aux:
                     aux.update(scores_s=skb[0].scores(), scores_t=skb[1].scores(), q_s=skb[0].codes(), q_t=skb[1].codes())

@@ -983,6 +983,40 @@ def test_swapped_ce_pixels_equals_per_pair_ce_summed_per_pixel(ops, k, ngroups):
     assert rel_err(gb, gb2) < 1e-5
 
 
+@pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None)])
+def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
+    """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
+    gx_swapped_ce_pixels on the gathered score rows with the same row potentials; with a device-side live bound the rows of
+    the d(scores) tables past it keep what they held and nothing of them reaches the loss or the bias gradient"""
+    torch.manual_seed(k + 1)
+    P, npix, rows, kp = 3, 233, 60, (k + 15) // 16 * 16
+    drawn = live_n if live_n is not None else npix
+    tabs = [(torch.randn(npix, k) * 0.1).cuda() for _ in range(2)]
+    rowmaps = [torch.randperm(drawn)[:rows].to(torch.int32).cuda() for _ in range(P)]
+    skb = ops.SinkhornBatch.from_rows([tabs[v] for _ in range(P) for v in range(2)], [rowmaps[p] for p in range(P) for _ in range(2)],
+                                      0.05, 5, 1.0 / k)
+    skb.run()
+    inv = torch.full((P, npix), -1, dtype=torch.int32, device="cuda")
+    for p in range(P):
+        inv[p].scatter_(0, rowmaps[p].long(), torch.arange(rows, dtype=torch.int32, device="cuda"))
+    live = None if live_n is None else torch.tensor([live_n], dtype=torch.int32, device="cuda")
+    ds, dt = torch.full((npix, kp), 7.0).cuda(), torch.full((npix, kp), 7.0).cuda()
+    loss, gb = torch.zeros(1).cuda(), torch.zeros(k).cuda()
+    ops.swapped_ce_pixels_tab(tabs[0], tabs[1], skb, 1, inv, 0.1, 1e-3, loss, 2.0, 0.0, ds, dt, kp, gb, 0.0, live=live)
+    S = torch.stack([torch.stack([tabs[v][rowmaps[p].long()] for v in range(2)]) for p in range(P)]).contiguous()
+    ds2, dt2 = torch.full((npix, kp), 7.0).cuda(), torch.full((npix, kp), 7.0).cuda()
+    loss2, gb2 = torch.zeros(1).cuda(), torch.zeros(k).cuda()
+    ops.swapped_ce_pixels(S, skb, 1, inv, 0.1, 1e-3, loss2, 2.0, 0.0, ds2, dt2, kp, gb2, 0.0)
+    assert rel_err(ds[:drawn], ds2[:drawn]) < 1e-6 and rel_err(dt[:drawn], dt2[:drawn]) < 1e-6
+    assert abs(loss.item() - loss2.item()) < 1e-6 * abs(loss2.item()) and rel_err(gb, gb2) < 1e-6
+    if live_n is not None:
+        assert torch.all(ds[live_n:] == 7.0) and torch.all(dt[live_n:] == 7.0)     # untouched: no GEMM reads them
+        assert torch.all(ds2[live_n:] == 0.0)                                      # (the unbounded form writes zeros there)
+    with pytest.raises(RuntimeError):
+        ops.swapped_ce_pixels_tab(tabs[0], tabs[1], skb, 1, inv, 0.1, 1e-3, loss, 2.0, 0.0, ds, dt, kp, gb, 0.0,
+                                  live=torch.tensor([3], dtype=torch.int32))
+
+
 @pytest.mark.parametrize("rows,k,n,act", [(1, 512, 512, True), (5, 16, 16, True), (48, 512, 512, True), (200, 512, 100, False),
                                           (13, 64, 70, True)])
 def test_equal_linear_skinny_vs_fp64_and_gv3(ops, rows, k, n, act):
