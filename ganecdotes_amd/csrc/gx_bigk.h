@@ -80,9 +80,19 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
     // rowmap (optional, [problem][rows] int32): row n of the problem is row rowmap[n] of S — a Sinkhorn problem over the
     // SAMPLED rows of a per-pixel score table (DESIGN par. 4.15) without a gathered copy of them
     constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
+    int bx = blockIdx.x;
     {   // blockIdx.y = problem of a batch of equally shaped ones: score matrices s_stride apart, K-vectors (cmax, la,
         // cmax_out) K apart, row marginals c_stride apart, partials [problem][block][K]  (gridDim.y == 1: one problem)
-        const long prob = blockIdx.y;
+        long prob = blockIdx.y;
+        if (rowmap && gridDim.y > 1) {
+            // problems that are row selections of ONE table (the patches of a view, DESIGN par. 4.15): their row maps are sorted,
+            // so block b of every problem walks the same stretch of the table — consecutive dispatch indices go to the SAME
+            // block of consecutive problems, all of them resident together, and a table row drawn by several patches is
+            // fetched from HBM once and found in the Infinity Cache by the others
+            const int L = blockIdx.y * gridDim.x + blockIdx.x;
+            prob = L % (int)gridDim.y;
+            bx = L / (int)gridDim.y;
+        }
         S += prob * s_stride;
         if (cmax) cmax += prob * K;
         if (la) la += prob * K;
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         if (MODE == BK_FIRSTLSE) um[cidx] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
     const long ngroups = (rows + BK_R - 1) / BK_R;
-    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    for (long grp = bx; grp < ngroups; grp += gridDim.x) {
         const long r0 = grp * BK_R;
         f32x4 w[BK_R][NC];
 #pragma unroll
@@ -225,8 +235,8 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
 #pragma unroll
                 for (int q = 0; q < 4; ++q) atomicMax(cmax_out + k + q, bk_f2ord(u[cidx][q]));
             } else {
-                *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * K + k) = u[cidx];
-                if (MODE == BK_FIRSTLSE) *reinterpret_cast<f32x4*>(lb_out + (long)blockIdx.x * K + k) = um[cidx];
+                *reinterpret_cast<f32x4*>(part + (long)bx * K + k) = u[cidx];
+                if (MODE == BK_FIRSTLSE) *reinterpret_cast<f32x4*>(lb_out + (long)bx * K + k) = um[cidx];
             }
         }
     }

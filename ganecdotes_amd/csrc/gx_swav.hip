@@ -1100,16 +1100,50 @@ static int bigk_batch_blocks(int nprob, long rows) {
 size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K) {
     return ((size_t)2 * nprob * K + (size_t)nprob * bigk_batch_blocks(nprob, rows) * K) * sizeof(float);
 }
+static int bigk_batch_impl(const float* S_all, const int* rowmap_all, int nprob, long prob_stride, long rows, int K, long ld,
+                           float eps, int niters, const float* r_all, long r_stride, const float* c_all, long c_stride,
+                           float c_uniform, const float* cmax_all, const float* u_first_all, float* la_all, float* workspace,
+                           size_t workspace_bytes, void* stream);
 int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
                            const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
                            const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream) {
+    if (rows <= 0) return GX_ERR_BAD_ARG;
+    return bigk_batch_impl(S_all, nullptr, nprob, prob_stride, rows, K, ld, eps, niters, r_all, r_stride, c_all, c_stride,
+                           1.f / (float)rows, cmax_all, u_first_all, la_all, workspace, workspace_bytes, stream);
+}
+// ... and several problems that are ROW SELECTIONS of one table (the patches of a view on its per-pixel score table, DESIGN
+// par. 4.15): rowmap_all [nprob][rows] int32, each SORTED ascending (a problem does not care about the order of its rows), so
+// that the problems' blocks — all resident together, dispatched interleaved — walk the table side by side and a row that
+// several patches drew comes from HBM once.  c_uniform = the uniform row marginal (1 / rows on one rank).
+static int rows_batch_blocks(int nprob, long rows) {
+    long nb = (3 * 256) / nprob;                  // every problem's blocks resident at once (3 workgroups per CU)
+    if (nb < 8) nb = 8;
+    const long groups = (rows + BK_R - 1) / BK_R;
+    return (int)(nb < groups ? nb : groups);
+}
+size_t gx_sinkhorn_rows_batch_workspace_bytes(int nprob, long rows, int K) {
+    return ((size_t)2 * nprob * K + (size_t)nprob * rows_batch_blocks(nprob, rows) * K) * sizeof(float);
+}
+int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, long rows, int K, long ld, float eps, int niters,
+                           float c_uniform, const float* cmax_all, const float* u_first_all, float* la_all, float* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!rowmap_all || !(c_uniform > 0.f) || nprob > 96) return GX_ERR_BAD_ARG;
+    return bigk_batch_impl(S, rowmap_all, nprob, 0, rows, K, ld, eps, niters, nullptr, 0, nullptr, 0, c_uniform, cmax_all,
+                           u_first_all, la_all, workspace, workspace_bytes, stream);
+}
+static int bigk_batch_impl(const float* S_all, const int* rowmap_all, int nprob, long prob_stride, long rows, int K, long ld,
+                           float eps, int niters, const float* r_all, long r_stride, const float* c_all, long c_stride,
+                           float c_uniform, const float* cmax_all, const float* u_first_all, float* la_all, float* workspace,
+                           size_t workspace_bytes, void* stream) {
     if (!S_all || !la_all || nprob <= 0 || nprob > 65535 || rows <= 0 || K <= 0 || ld < K || eps <= 0.f || niters < 1)
         return GX_ERR_BAD_ARG;
     if (u_first_all && !cmax_all) return GX_ERR_BAD_ARG;
     if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || (prob_stride & 3)) return GX_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < gx_sinkhorn_bigk_batch_workspace_bytes(nprob, rows, K)) return GX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < (rowmap_all ? gx_sinkhorn_rows_batch_workspace_bytes(nprob, rows, K)
+                                                    : gx_sinkhorn_bigk_batch_workspace_bytes(nprob, rows, K)))
+        return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = bigk_batch_blocks(nprob, rows);
+    const int nb = rowmap_all ? rows_batch_blocks(nprob, rows) : bigk_batch_blocks(nprob, rows);
     unsigned* cmax = (unsigned*)workspace;
     float* u = workspace + (size_t)nprob * K;
     float* part = u + (size_t)nprob * K;
@@ -1122,7 +1156,7 @@ int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long
         if (hipMemsetAsync(cmax, 0, (size_t)nprob * K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
         GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), grid, dim3(256), lds, st, S_all, rows, K,
                                                         ld, 0.f, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, cmax,
-                                                        prob_stride, 0L));
+                                                        prob_stride, 0L, rowmap_all));
     }
     GX_CHECK_LAUNCH();
     int kx = 1;
@@ -1136,12 +1170,12 @@ int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long
         }
         if (it == 0) {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), grid, dim3(256), lds, st, S_all, rows, K,
-                                                            ld, 1.f / eps, cmax, la_all, c_all, 1.f / (float)rows, nullptr, part,
-                                                            nullptr, prob_stride, c_stride));
+                                                            ld, 1.f / eps, cmax, la_all, c_all, c_uniform, nullptr, part,
+                                                            nullptr, prob_stride, c_stride, rowmap_all));
         } else {
             GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), grid, dim3(256), lds, st, S_all, rows, K,
-                                                            ld, 1.f / eps, cmax, la_all, c_all, 1.f / (float)rows, nullptr, part,
-                                                            nullptr, prob_stride, c_stride));
+                                                            ld, 1.f / eps, cmax, la_all, c_all, c_uniform, nullptr, part,
+                                                            nullptr, prob_stride, c_stride, rowmap_all));
         }
         GX_CHECK_LAUNCH();
         hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx, nprob), dim3(256), 0, st, part, nb, K, 1.f, 0.f, u, kx);

@@ -1133,10 +1133,13 @@ class SinkhornBatch:
                       for i in range(self.nprob)]
 
     @classmethod
-    def from_rows(cls, tables, rowmaps, eps, niters, c_uniform, tag="skb"):
-        """problems given as (score table, row map) pairs: problem i = rows rowmaps[i] of tables[i] (many prototypes)"""
+    def from_rows(cls, tables, rowmaps, eps, niters, c_uniform, tag="skb", sorted_rows=False):
+        """problems given as (score table, row map) pairs: problem i = rows rowmaps[i] of tables[i] (many prototypes).
+        sorted_rows: every row map ascends — the problems of one table are then solved side by side (gx_sinkhorn_rows_batch:
+        one launch per pass, a table row several problems hold is fetched from HBM once)"""
         self = cls.__new__(cls)
         self.S = None
+        self.sorted_rows = bool(sorted_rows)
         self.nprob, self.rows, self.K = len(tables), rowmaps[0].numel(), tables[0].shape[1]
         self.eps, self.niters = float(eps), int(niters)
         self.r = self.c = None
@@ -1161,8 +1164,26 @@ class SinkhornBatch:
     def _run(self, reduce):
         if self.S is None:                    # row-mapped problems on score tables: the per-problem many-prototype kernels
             if reduce is None:
-                for p in self.probs:
-                    p.run()
+                by_table = {}
+                for i, p in enumerate(self.probs):
+                    by_table.setdefault((p.S.data_ptr(), p.S.stride(0)), []).append(i)
+                for idx in by_table.values():
+                    grp = [self.probs[i] for i in idx]
+                    if not (self.sorted_rows and len(grp) > 1 and all(p.cmax_preset is not None for p in grp)):
+                        for p in grp:
+                            p.run()
+                        continue
+                    L, S = lib(), grp[0].S
+                    wsb = L.gx_sinkhorn_rows_batch_workspace_bytes(len(grp), self.rows, self.K)
+                    ws = workspace(self.tag + ".rows", wsb, S.device)
+                    maps = torch.stack([p.rowmap for p in grp])
+                    cm = torch.stack([p.cmax_preset for p in grp])
+                    uf = torch.stack([p.u_first_preset for p in grp]) if all(p.u_first_preset is not None for p in grp) else None
+                    la = torch.empty(len(grp), self.K, dtype=torch.float32, device=S.device)
+                    _lib.check(L.gx_sinkhorn_rows_batch(_p(S), _p(maps), len(grp), self.rows, self.K, S.stride(0), self.eps,
+                                                        self.niters, self.c_uniform, _p(cm), _p(uf), _p(la), _p(ws), wsb,
+                                                        _stream()), "gx_sinkhorn_rows_batch")
+                    self.la[idx] = la
                 return self
             from .sharded import run_sinkhorn_group
             run_sinkhorn_group(self.probs, self.niters, reduce)

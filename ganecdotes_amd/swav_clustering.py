@@ -339,7 +339,9 @@ class SwAVClustering(ViewMixin):
             ar32 = torch.arange(npix, dtype=torch.int32, device=dev)
             cid = torch.empty(npix, dtype=torch.int32, device=dev)
             cid[order] = ar32                                                            # pixel id -> table row
-            rowmaps_all = [cid[f_] for f_ in flat]
+            # a patch's samples as table rows, ASCENDING: a Sinkhorn problem does not care about the order of its rows, and sorted the
+            # patches of a view walk the table side by side (ops.SinkhornBatch.from_rows)
+            rowmaps_all = [torch.sort(cid[f_]).values for f_ in flat]
             order32 = order.to(torch.int32)
             sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
             scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
@@ -366,7 +368,7 @@ class SwAVClustering(ViewMixin):
                 with self._timed("sinkhorn"):
                     skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
                                                       [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
-                                                      1.0 / nglob)
+                                                      1.0 / nglob, sorted_rows=True)
                     for sk_ in skb.probs:      # column maxima + first pass of every problem in ONE sweep of its rows
                         sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
                     skb.run(self._reduce if (scope == 'global' and self.sharded) else None)

@@ -983,6 +983,31 @@ def test_swapped_ce_pixels_equals_per_pair_ce_summed_per_pixel(ops, k, ngroups):
     assert rel_err(gb, gb2) < 1e-5
 
 
+@pytest.mark.parametrize("k,rows,nprob", [(200, 1000, 5), (5000, 333, 3), (132, 4097, 2)])
+def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
+    """gx_sinkhorn_rows_batch (the patches of a view as sorted row selections of one score table, one launch per pass, blocks
+    of the problems interleaved) against the same problems solved one by one through gx_sinkhorn_pass_rows, and against the
+    plain solver on gathered copies of their rows"""
+    torch.manual_seed(k + rows)
+    npix = 2 * rows
+    tabs = [(torch.randn(npix, k) * 0.2).cuda() for _ in range(2)]
+    maps = [torch.sort(torch.randperm(npix)[:rows]).values.to(torch.int32).cuda() for _ in range(nprob)]
+    tl = [tabs[v] for _ in range(nprob) for v in range(2)]
+    ml = [maps[p] for p in range(nprob) for _ in range(2)]
+    for eps in (0.05, 0.005):
+        a = ops.SinkhornBatch.from_rows(tl, ml, eps, 6, 1.0 / rows, sorted_rows=True)
+        b = ops.SinkhornBatch.from_rows(tl, ml, eps, 6, 1.0 / rows)
+        for skb in (a, b):
+            for sk_ in skb.probs:
+                sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, eps, sk_.rowmap)
+            skb.run()
+        assert float((a.la - b.la).abs().max()) < 2e-4
+        for i in (0, 2 * nprob - 1):
+            ref = ops.Sinkhorn(tl[i][ml[i].long()].contiguous(), eps, 6).run()
+            assert float((a.la[i] - ref.la).abs().max()) < 2e-4
+            assert rel_err(a[i].codes(), ref.codes()) < 1e-4
+
+
 @pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None)])
 def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
     """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
