@@ -45,11 +45,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bk_row_rsrc(const float* base,
     const float* p = base + (long)(((unsigned long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, K * 4, 0x00020000);
 }
+#ifndef BK_LOAD_AUX
+#define BK_LOAD_AUX 0      // lab: cache-policy bits of the row loads / stores (2 = nt), tools/lab/bigk_aux.sh
+#endif
+#ifndef BK_STORE_AUX
+#define BK_STORE_AUX 0
+#endif
 __device__ __forceinline__ f32x4 bk_load4(__amdgpu_buffer_rsrc_t r, int first_col) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, first_col * 4, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, first_col * 4, 0, BK_LOAD_AUX));
 }
 __device__ __forceinline__ void bk_store4(__amdgpu_buffer_rsrc_t r, int first_col, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, first_col * 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, first_col * 4, 0, BK_STORE_AUX);
 }
 
 // Lane l owns columns 4*(l + 64*c) + q, q < 4, c < NJ/4 (one float4 per chunk: a wave-instruction
