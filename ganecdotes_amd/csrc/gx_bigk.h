@@ -1,4 +1,4 @@
-// Row kernels for MANY prototypes (64 < K <= 6144, e.g. the reference's K = 4000 / 5000): one
+// Row kernels for MANY prototypes (64 < K <= 6144, e.g. the reference's K = 4000 / 5000; the column passes up to 8192): one
 // wavefront owns a score row, lane l holds columns l + 64 j in registers (NJ = ceil(K/64) rounded
 // up), so a Sinkhorn sweep reads the row ONCE from HBM, evaluates ONE exp per score, reduces
 // with wavefront shuffles and accumulates the column sums in per-lane registers (no LDS atomics
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
     // rowmap (optional, [problem][rows] int32): row n of the problem is row rowmap[n] of S — a Sinkhorn problem over the
     // SAMPLED rows of a per-pixel score table (DESIGN par. 4.15) without a gathered copy of them
     constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
+    constexpr int R = NJ > 96 ? 2 : BK_R;                                // rows per group: two past 6144 columns (8 chunks per row)
     int bx = blockIdx.x;
     {   // blockIdx.y = problem of a batch of equally shaped ones: score matrices s_stride apart, K-vectors (cmax, la,
         // cmax_out) K apart, row marginals c_stride apart, partials [problem][block][K]  (gridDim.y == 1: one problem)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         if (lb_out) lb_out += prob * rows;
         if (rowmap) rowmap += prob * rows;
     }
-    extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | red[2][BK_R][4]
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // vec[K] | red[2][R][4]
     float* vec = sm;
     float* red = sm + K;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -128,12 +129,12 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         u[cidx] = f32x4{init, init, init, init};
         if (MODE == BK_FIRSTLSE) um[cidx] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
-    const long ngroups = (rows + BK_R - 1) / BK_R;
+    const long ngroups = (rows + R - 1) / R;
     for (long grp = bx; grp < ngroups; grp += gridDim.x) {
-        const long r0 = grp * BK_R;
-        f32x4 w[BK_R][NC];
+        const long r0 = grp * R;
+        f32x4 w[R][NC];
 #pragma unroll
-        for (int r = 0; r < BK_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             // rows past the end read as zeros through an EMPTY descriptor (their contributions are masked below)
             const bool live = r0 + r < rows;
             const long srow = !live ? 0 : (rowmap ? (long)rowmap[r0 + r] : r0 + r);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
         }
         if (MODE == BK_FIRSTLSE) {
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r)
+            for (int r = 0; r < R; ++r)
                 if (r0 + r < rows)
 #pragma unroll
                     for (int cidx = 0; cidx < NC; ++cidx)
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                             }
         } else if (MODE == BK_COLMAX) {
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r)
+            for (int r = 0; r < R; ++r)
                 if (r0 + r < rows)
 #pragma unroll
                     for (int cidx = 0; cidx < NC; ++cidx)
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                         for (int q = 0; q < 4; ++q) u[cidx][q] = fmaxf(u[cidx][q], w[r][cidx][q]);
         } else if (MODE == BK_COLSUM) {
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[r][cidx];          // dead rows / columns read 0
         } else if (MODE == BK_FIRST) {
@@ -175,23 +176,23 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                 if (k < K) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(vec + k);
 #pragma unroll
-                    for (int r = 0; r < BK_R; ++r)
+                    for (int r = 0; r < R; ++r)
                         if (r0 + r < rows)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) u[cidx][q] += bk_exp(fmaf(w[r][cidx][q], inv_eps, v[q]));
                 }
             }
         } else {
-            float mx[BK_R];
+            float mx[R];
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r) mx[r] = -INFINITY;
+            for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 #pragma unroll
             for (int cidx = 0; cidx < NC; ++cidx) {
                 const int k = 4 * (tid + 256 * cidx);
                 const bool ok = k < K;
                 const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(vec + k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < BK_R; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         w[r][cidx][q] = ok ? fmaf(w[r][cidx][q], inv_eps, v[q]) : -INFINITY;
@@ -199,14 +200,14 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
                     }
             }
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r) {
+            for (int r = 0; r < R; ++r) {
                 mx[r] = gx_wave_max(mx[r]);
                 if (lane == 0) red[r * 4 + wid] = mx[r];
             }
             __syncthreads();
-            float sum[BK_R];
+            float sum[R];
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r) {
+            for (int r = 0; r < R; ++r) {
                 mx[r] = fmaxf(fmaxf(red[r * 4], red[r * 4 + 1]), fmaxf(red[r * 4 + 2], red[r * 4 + 3]));
                 sum[r] = 0.f;
 #pragma unroll
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { w[r][cidx][q] = bk_exp(w[r][cidx][q] - mx[r]); sum[r] += w[r][cidx][q]; }
                 sum[r] = gx_wave_sum(sum[r]);
-                if (lane == 0) red[BK_R * 4 + r * 4 + wid] = sum[r];
+                if (lane == 0) red[R * 4 + r * 4 + wid] = sum[r];
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < BK_R; ++r) {
-                const float* rs = red + BK_R * 4 + r * 4;
+            for (int r = 0; r < R; ++r) {
+                const float* rs = red + R * 4 + r * 4;
                 const float tot = (rs[0] + rs[1]) + (rs[2] + rs[3]);
                 const bool live = r0 + r < rows;
                 const float cn = c ? (live ? c[r0 + r] : 0.f) : c_uniform;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
 //                 a handful of registers per lane, row statistics wave-uniform.
 // stats [rows][8] = {wm_s, 1/v_s, m_s, z_s, wm_t, 1/v_t, m_t, z_t}.
 template <int NJ>
-__global__ __launch_bounds__(256, 4) void ce_rowstats_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+__global__ __launch_bounds__(256, NJ > 96 ? 2 : 4) void ce_rowstats_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
                                                                   long rows, int K, long ld, float inv_eps, float inv_T,
                                                                   const float* __restrict__ la_s,
                                                                   const float* __restrict__ la_t,
@@ -695,12 +696,15 @@ __global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __r
 
 static inline int bigk_nj(int K) {          // registers per lane for a row of K scores; 0 = not supported
     const int need = (K + 63) / 64;
-    const int opts[] = {16, 32, 48, 64, 80, 96};
+    const int opts[] = {16, 32, 48, 64, 80, 96, 128};
     for (int o : opts)
         if (need <= o) return o;
     return 0;
 }
+// the column passes (Sinkhorn sweeps, column maxima / sums) take up to 8192 columns — the generic configuration's 8000 prototypes —,
+// the cross-entropy kernels, which hold several rows and their exponentials in registers, up to 6144
 static inline bool bigk_ok(int K) { return K > 64 && (K % 4) == 0 && bigk_nj(K) != 0; }
+static inline bool bigk_ce_ok(int K) { return bigk_ok(K) && bigk_nj(K) <= 96; }
 static inline bool bigk_aligned(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld % 4) == 0; }
 
 #define GX_BIGK_DISPATCH(NJV, CALL)            \
@@ -711,6 +715,16 @@ static inline bool bigk_aligned(const void* p, long ld) { return (((uintptr_t)p)
         case 64: { constexpr int NJ = 64; CALL; } break; \
         case 80: { constexpr int NJ = 80; CALL; } break; \
         default: { constexpr int NJ = 96; CALL; } break; \
+    }
+#define GX_BIGK_DISPATCH_PASS(NJV, CALL)       \
+    switch (NJV) {                             \
+        case 16: { constexpr int NJ = 16; CALL; } break; \
+        case 32: { constexpr int NJ = 32; CALL; } break; \
+        case 48: { constexpr int NJ = 48; CALL; } break; \
+        case 64: { constexpr int NJ = 64; CALL; } break; \
+        case 80: { constexpr int NJ = 80; CALL; } break; \
+        case 96: { constexpr int NJ = 96; CALL; } break; \
+        default: { constexpr int NJ = 128; CALL; } break; \
     }
 
 static inline int bigk_blocks(long rows, int cap) {

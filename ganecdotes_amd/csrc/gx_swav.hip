@@ -830,7 +830,7 @@ int gx_colsum(const float* x, long rows, int K, long ld, float alpha, float beta
     if (bigk_ok(K) && bigk_aligned(x, ld)) {   // many columns: wave-per-row streaming kernel
         const int nbk = bigk_blocks(rows, GX_COLSUM_BLOCKS);
         const size_t lds = bigk_pass_lds(K);
-        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLSUM>), dim3(nbk), dim3(256), lds,
+        GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLSUM>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, x, rows, K, ld, 0.f, nullptr, nullptr,
                                                         nullptr, 0.f, nullptr, workspace, nullptr));
         GX_CHECK_LAUNCH();
@@ -871,7 +871,7 @@ static int sk_colmax_impl(const float* S, const int* rowmap, long rows, int K, l
     if (bigk_ok(K) && bigk_aligned(S, ld)) {
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = bigk_pass_lds(K);
-        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
+        GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, S, rows, K, ld, 0.f, nullptr, nullptr,
                                                         nullptr, 0.f, nullptr, nullptr, (unsigned*)workspace, 0L, 0L, rowmap));
         GX_CHECK_LAUNCH();
@@ -929,12 +929,12 @@ static int sk_pass_impl(const float* S, const int* rowmap, long rows, int K, lon
         const int nbk = bigk_blocks(rows, 2040);           // partial area holds 2048*K floats
         const size_t lds = bigk_pass_lds(K);
         if (first) {
-            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
+            GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), dim3(nbk), dim3(256), lds,
                                                             (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
                                                             (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
                                                             nullptr, 0L, 0L, rowmap));
         } else {
-            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), dim3(nbk), dim3(256), lds,
+            GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), dim3(nbk), dim3(256), lds,
                                                             (hipStream_t)stream, S, rows, K, ld, 1.f / eps,
                                                             (const unsigned*)workspace, la, c, c_uniform, lb_out, part,
                                                             nullptr, 0L, 0L, rowmap));
@@ -1050,7 +1050,7 @@ int gx_sinkhorn_first_rows(const float* S, const int* rowmap, long rows, int K, 
     float* pm = ps + (size_t)2040 * K;            // [nbk][K] maxima
     float* w = pm + (size_t)2040 * K;             // merge stage: 2 x 32 x K
     const size_t lds = bigk_pass_lds(K);
-    GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRSTLSE>), dim3(nbk), dim3(256), lds, st, S, rows, K,
+    GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRSTLSE>), dim3(nbk), dim3(256), lds, st, S, rows, K,
                                                     ld, 1.f / eps, nullptr, nullptr, nullptr, 0.f, pm, ps, nullptr, 0L, 0L,
                                                     rowmap));
     GX_CHECK_LAUNCH();
@@ -1154,7 +1154,7 @@ static int bigk_batch_impl(const float* S_all, const int* rowmap_all, int nprob,
         hipLaunchKernelGGL(sk_ord_encode_kernel, dim3(gx_cdiv((long)nprob * K, 256)), dim3(256), 0, st, cmax_all, nprob * K, cmax);
     } else {
         if (hipMemsetAsync(cmax, 0, (size_t)nprob * K * 4, st) != hipSuccess) return GX_ERR_LAUNCH;
-        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), grid, dim3(256), lds, st, S_all, rows, K,
+        GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_COLMAX>), grid, dim3(256), lds, st, S_all, rows, K,
                                                         ld, 0.f, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, cmax,
                                                         prob_stride, 0L, rowmap_all));
     }
@@ -1169,11 +1169,11 @@ static int bigk_batch_impl(const float* S_all, const int* rowmap_all, int nprob,
             continue;
         }
         if (it == 0) {
-            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), grid, dim3(256), lds, st, S_all, rows, K,
+            GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_FIRST>), grid, dim3(256), lds, st, S_all, rows, K,
                                                             ld, 1.f / eps, cmax, la_all, c_all, c_uniform, nullptr, part,
                                                             nullptr, prob_stride, c_stride, rowmap_all));
         } else {
-            GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), grid, dim3(256), lds, st, S_all, rows, K,
+            GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((bigk_pass_kernel<NJ, BK_SWEEP>), grid, dim3(256), lds, st, S_all, rows, K,
                                                             ld, 1.f / eps, cmax, la_all, c_all, c_uniform, nullptr, part,
                                                             nullptr, prob_stride, c_stride, rowmap_all));
         }
@@ -1213,7 +1213,7 @@ int gx_swapped_ce(const float* Ss, const float* St, long rows, int K, long ld, f
         const int nbk = bigk_blocks(rows, 2040);
         const size_t lds = (size_t)2 * K * sizeof(float);
         float* stats = workspace + 2048;
-        GX_BIGK_DISPATCH(bigk_nj(K), hipLaunchKernelGGL((ce_rowstats_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
+        GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((ce_rowstats_bigk_kernel<NJ>), dim3(nbk), dim3(256), lds,
                                                         (hipStream_t)stream, Ss, St, rows, K, ld, 1.f / eps,
                                                         1.f / temperature, la_s, la_t, stats));
         GX_CHECK_LAUNCH();
@@ -1245,7 +1245,7 @@ int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long
                         size_t workspace_bytes, void* stream) {
     if (!Ss || !St || !la_s || !la_t || !loss_out || !dSs || !dSt || !gb || rows <= 0 || K <= 0 || ld < K || ldd < K)
         return GX_ERR_BAD_ARG;
-    if (!bigk_ok(K) || !bigk_aligned(Ss, ld) || !bigk_aligned(St, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd))
+    if (!bigk_ce_ok(K) || !bigk_aligned(Ss, ld) || !bigk_aligned(St, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd))
         return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_swapped_ce_fused_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     long nb = (rows + CE_R - 1) / CE_R;
@@ -1299,7 +1299,7 @@ static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long r
     if (!S_all || !inv || !la_all || !loss_out || !dSs || !dSt || !gb || P <= 0 || P > CE_PMAX || rows <= 0 || K <= 0 || ld < K || npix <= 0 ||
         ngroups <= 0 || npix % ngroups || kpad < K || kpad > ldd || (kpad & 3))
         return GX_ERR_BAD_ARG;
-    if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd) ||
+    if (!bigk_ce_ok(K) || !bigk_aligned(S_all, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd) ||
         (((uintptr_t)la_all) & 15) || 4 * 256 * ((bigk_nj(K) + 15) / 16) < kpad)
         return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_swapped_ce_fused_workspace_bytes(K)) return GX_ERR_WORKSPACE;

@@ -1201,7 +1201,7 @@ class SinkhornBatch:
         if reduce is None:
             S = self.S
             npre = sum(p.cmax_preset is not None for p in self.probs)
-            if (self.nprob >= 16 and 64 < self.K <= 6144 and self.K % 4 == 0 and self.c_uniform == 1.0 / self.rows and
+            if (self.nprob >= 16 and 64 < self.K <= 8192 and self.K % 4 == 0 and self.c_uniform == 1.0 / self.rows and
                     npre in (0, self.nprob) and S.stride(1) % 4 == 0 and S.stride(0) % 4 == 0 and S.data_ptr() % 16 == 0):
                 # many many-prototype problems (the per-image scope at K = 5000): one launch per pass for all of them
                 L = lib()

@@ -428,7 +428,7 @@ int gx_hist_range(const float* x, long n, unsigned* scratch, float* lohi, void* 
 int gx_hist_counts(const float* x, long n, const float* lohi, int bins, float* hist, unsigned* scratch, void* stream);
 int gx_hist_finish(float* hist, int bins, void* stream);
 
-/* nprob equally shaped many-prototype problems (64 < K <= 6144) in one launch per pass (blockIdx.y = problem): the
+/* nprob equally shaped many-prototype problems (64 < K <= 8192) in one launch per pass (blockIdx.y = problem): the
  * per-image Sinkhorn scope at the reference's own K = 5000 (swav_clustering.py:509-544 once per image, view and patch).
  * S_all + i * prob_stride = problem i, [rows][K]; r_all / c_all NULL = uniform marginals; cmax_all NULL or the column
  * maxima [nprob][K] (from gx_gemm_f32_nt_planes' colmax_part: no pass for them); la_all [nprob][K]. */

@@ -252,7 +252,8 @@ def test_hist_marginal_sharded_equals_single(ops):
     np.testing.assert_allclose(outs[0].numpy(), whole.numpy(), rtol=1e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("n,k,eps", [(2000, 8, 0.005), (777, 16, 0.003), (500, 1000, 0.01), (64, 5000, 0.005)])
+@pytest.mark.parametrize("n,k,eps", [(2000, 8, 0.005), (777, 16, 0.003), (500, 1000, 0.01), (64, 5000, 0.005), (67, 8000, 0.005),
+                                     (301, 6148, 0.01)])
 def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
     from oracle import swav_ref as S
     torch.manual_seed(n + k)
@@ -296,7 +297,8 @@ def test_sinkhorn_small_fused_path(ops, n, k, eps, pdf):
 
 @pytest.mark.parametrize("nprob,n,k,pdf", [(10, 20000, 8, "uniform"), (3, 4100, 16, "image"), (4, 5000, 40, "uniform"),
                                            (2, 300, 12, "uniform"), (2, 4200, 80, "uniform"),
-                                           (20, 703, 300, "uniform"), (17, 1030, 5000, "uniform"), (16, 400, 132, "image")])
+                                           (20, 703, 300, "uniform"), (17, 1030, 5000, "uniform"), (16, 400, 132, "image"),
+                                           (16, 333, 8000, "uniform")])
 def test_sinkhorn_batch_equals_per_problem(ops, nprob, n, k, pdf):
     """SinkhornBatch (one launch per iteration over all problems when K <= 64, rows >= 4096, and — many prototypes,
     >= 16 problems, the per-image scope at K = 5000 — gx_sinkhorn_bigk_batch; per-problem kernels otherwise) == each
@@ -447,7 +449,7 @@ def test_swapped_ce_golden_gv8(ops):
     assert rel_err(dt, t1.grad) < 1e-3
 
 
-@pytest.mark.parametrize("n,k", [(1000, 8), (300, 700)])
+@pytest.mark.parametrize("n,k", [(1000, 8), (300, 700), (131, 8000)])
 def test_swapped_ce_vs_oracle(ops, n, k):
     from oracle import swav_ref as S
     torch.manual_seed(n)
