@@ -85,6 +85,8 @@ def test_ffhq256_full_size_step_vs_oracle(gpu, engine, nproto):
     from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
     from ganecdotes_amd.swav_clustering import SwAVClustering
+    if nproto > 8 and ops.get_gemm_mode() == 0:
+        pytest.skip("the 8000-prototype case runs on the default engine only (suite time)")
     torch.set_num_threads(min(16, torch.get_num_threads()))
     g, sd = full_generator(256)
     g = g.to(gpu)
