@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void ce_fused_bigk_kernel(const float* __re
 //   S_all [P][2][rows][ld]; la_all [(p * 2 + view) * ngroups + group][K], group = pixel / pix_per_group
 constexpr int CE_PMAX = 8;                  // patches per step the pixel-major CE takes
 template <int NJ>
-__global__ __launch_bounds__(256, 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
+__global__ __launch_bounds__(256, NJ > 96 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
                                                                 const int* __restrict__ inv, long npix, int ngroups,
                                                                 long pix_per_group, const float* __restrict__ la_all,
                                                                 float inv_eps, float inv_T, float gscale,

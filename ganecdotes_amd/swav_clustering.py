@@ -314,12 +314,15 @@ class SwAVClustering(ViewMixin):
         # Many prototypes: d(scores) of every patch land on per-PIXEL rows (one table per view): a pixel drawn by
         # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
         # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
-        dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 6144 and P <= 8 and
+        # (memory: the two d(scores) tables + either the two score tables or every patch's per-sample scores, held to half the HBM)
+        want_stab = ngroups == 1 and marg is None and sa.get('score_table', True)
+        tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * K if want_stab else 8.0 * rows * K * P)
+        dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 8192 and P <= 8 and
                  sa.get('ds_table', hw * hw < P * N) and
-                 8.0 * B * hw * hw * Kp + 8.0 * rows * K * P < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
+                 tab_bytes < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
         # ... and, with one Sinkhorn problem per patch and view (global scope, uniform marginals), the SCORES are a per-pixel table
         # too: one score GEMM per view over the pixels, the Sinkhorn problems and the CE read their rows of it through the pick index
-        stab = dstab and ngroups == 1 and marg is None and sa.get('score_table', True)
+        stab = dstab and want_stab
         if dstab:
             pgroup = P             # every patch's scores stay until the one pixel-major CE pass of the step (8 B rows K P bytes)
             npix = B * hw * hw

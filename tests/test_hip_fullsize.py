@@ -80,7 +80,8 @@ def test_ffhq256_full_size_step_vs_oracle(gpu, engine, nproto):
     """ffhq-256, 13 taps / 5376 channels, 20 000 sampled pixels, D=512, K=8, T=0.01, eps=0.005
     (configs[1] at batch 1, one patch): loss, the three gradients and the LARC update against the
     oracle on identical draws — on either contraction engine.  K = 8000: the generic `hfc_with_swav` configuration's own
-    prototype count (configs/segmentors/hfc_with_swav_config.py), past the one-pass CE's 6144 columns."""
+    prototype count (configs/segmentors/hfc_with_swav_config.py), on the 8192-column forms of the row kernels and the per-pixel
+    tables like the bench step."""
     from oracle import swav_ref as S
     from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
@@ -91,7 +92,7 @@ def test_ffhq256_full_size_step_vs_oracle(gpu, engine, nproto):
     g, sd = full_generator(256)
     g = g.to(gpu)
     sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
-                        **ffhq_args(1, nproto, num_patches=1, pick_source="host"))
+                        **ffhq_args(1, nproto, num_patches=1, pick_source="host", **(dict(ds_table=True) if nproto > 64 else {})))
     torch.manual_seed(5)
     np.random.seed(5)
     with torch.no_grad():

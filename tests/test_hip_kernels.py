@@ -1010,7 +1010,7 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
             assert rel_err(a[i].codes(), ref.codes()) < 1e-4
 
 
-@pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None)])
+@pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190)])
 def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
     """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
     gx_swapped_ce_pixels on the gathered score rows with the same row potentials; with a device-side live bound the rows of

@@ -258,19 +258,21 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
-@pytest.mark.parametrize("scope,batch,transforms,score_table", [("global", 3, True, True), ("global", 3, True, False),
-                                                                ("image", 2, True, True), ("global", 2, False, True)])
-def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope, batch, transforms, score_table):
+@pytest.mark.parametrize("scope,batch,transforms,score_table,nproto", [
+    ("global", 3, True, True, 200), ("global", 3, True, False, 200), ("image", 2, True, True, 200), ("global", 2, False, True, 200),
+    ("global", 2, True, True, 6148), ("image", 2, True, True, 6148)])
+def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope, batch, transforms, score_table, nproto):
     """Many prototypes with d(scores) accumulated on per-pixel rows (swav_args['ds_table']): 3 patches of 600
     of the 1024 pixels, so most pixels are drawn by more than one patch; two steps against the oracle, and the same step
-    with the per-sample backward GEMMs"""
+    with the per-sample backward GEMMs.  6148 prototypes: the 8192-column forms of the row kernels (the generic configuration's
+    8000 prototypes take them), where the per-sample form is the two-kernel CE"""
     from oracle import swav_ref as S
     from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
     d = load_golden("gv10_pretrain")
     sd = golden_sd(d)
     g = mini_gen(sd, gpu)
-    kw = dict(sinkhorn_scope=scope, batch_size=batch, nprototypes=200, nclasses=16, num_patches=3, patch_size=600,
+    kw = dict(sinkhorn_scope=scope, batch_size=batch, nprototypes=nproto, nclasses=16, num_patches=3, patch_size=600,
               transforms=transforms)
     sw = make_swav(g, gpu, tmp_path, ds_table=True, score_table=score_table, **kw)       # score_table: the scores per pixel too
     sw2 = make_swav(g, gpu, tmp_path, ds_table=False, **kw)
