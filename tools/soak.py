@@ -24,9 +24,13 @@ sw = SwAVClustering(model=g, model_config=bench.ModelCfg, out_dir=None, device=d
 torch.manual_seed(42)
 np.random.seed(42)
 sw.build_heads()
+import time                                                     # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 losses = [sw.train_step(sw.draw_batch(batch)) for _ in range(steps)]
 l = torch.cat(losses).cpu().numpy()
+ms = (time.perf_counter() - t0) / steps * 1e3                   # includes the first (cold) step
 w = sw.projection[0].weight.data
 print(f"K={k} B={batch} scope={scope} pdf={pdf}: finite={bool(np.isfinite(l).all())} loss {l[0]:.4f} -> {l[-1]:.4f} "
       f"(min {l.min():.4f}); Wp finite={bool(torch.isfinite(w).all())}; "
-      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; {ms:.1f} ms/step")
