@@ -154,7 +154,7 @@ SIGNATURES = {
     "gx_sinkhorn_bigk_batch_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
     "gx_sinkhorn_bigk_batch": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_rows_batch_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
-    "gx_sinkhorn_rows_batch": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_f, c_i, c_f, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_rows_batch": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_swapped_ce_workspace_bytes": (c_sz, [c_l, c_i]),
     "gx_swapped_ce_fused_workspace_bytes": (c_sz, [c_i]),
     "gx_swapped_ce_fused": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_f,

@@ -1114,7 +1114,8 @@ int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long
 // ... and several problems that are ROW SELECTIONS of one table (the patches of a view on its per-pixel score table, DESIGN
 // par. 4.15): rowmap_all [nprob][rows] int32, each SORTED ascending (a problem does not care about the order of its rows), so
 // that the problems' blocks — all resident together, dispatched interleaved — walk the table side by side and a row that
-// several patches drew comes from HBM once.  c_uniform = the uniform row marginal (1 / rows on one rank).
+// several patches drew comes from HBM once.  r_all [nprob][K] / c_all [nprob][rows] (c in the order of the SORTED rows) or NULL:
+// uniform marginals, c_uniform = the row marginal (1 / rows on one rank).
 static int rows_batch_blocks(int nprob, long rows) {
     long nb = (3 * 256) / nprob;                  // every problem's blocks resident at once (3 workgroups per CU)
     if (nb < 8) nb = 8;
@@ -1125,10 +1126,10 @@ size_t gx_sinkhorn_rows_batch_workspace_bytes(int nprob, long rows, int K) {
     return ((size_t)2 * nprob * K + (size_t)nprob * rows_batch_blocks(nprob, rows) * K) * sizeof(float);
 }
 int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, long rows, int K, long ld, float eps, int niters,
-                           float c_uniform, const float* cmax_all, const float* u_first_all, float* la_all, float* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           const float* r_all, const float* c_all, float c_uniform, const float* cmax_all,
+                           const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream) {
     if (!rowmap_all || !(c_uniform > 0.f) || nprob > 96) return GX_ERR_BAD_ARG;
-    return bigk_batch_impl(S, rowmap_all, nprob, 0, rows, K, ld, eps, niters, nullptr, 0, nullptr, 0, c_uniform, cmax_all,
+    return bigk_batch_impl(S, rowmap_all, nprob, 0, rows, K, ld, eps, niters, r_all, K, c_all, rows, c_uniform, cmax_all,
                            u_first_all, la_all, workspace, workspace_bytes, stream);
 }
 static int bigk_batch_impl(const float* S_all, const int* rowmap_all, int nprob, long prob_stride, long rows, int K, long ld,

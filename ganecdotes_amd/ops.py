@@ -1133,20 +1133,24 @@ class SinkhornBatch:
                       for i in range(self.nprob)]
 
     @classmethod
-    def from_rows(cls, tables, rowmaps, eps, niters, c_uniform, tag="skb", sorted_rows=False):
+    def from_rows(cls, tables, rowmaps, eps, niters, c_uniform, tag="skb", sorted_rows=False, r=None, c=None):
         """problems given as (score table, row map) pairs: problem i = rows rowmaps[i] of tables[i] (many prototypes).
         sorted_rows: every row map ascends — the problems of one table are then solved side by side (gx_sinkhorn_rows_batch:
-        one launch per pass, a table row several problems hold is fetched from HBM once)"""
+        one launch per pass, a table row several problems hold is fetched from HBM once).  r / c: lists of the problems'
+        prototype (K,) and row (rows,) marginals, c in the order of rowmaps[i]; None = uniform"""
         self = cls.__new__(cls)
         self.S = None
         self.sorted_rows = bool(sorted_rows)
+        if (r is None) != (c is None):
+            raise RuntimeError("SinkhornBatch.from_rows: r and c come together")
         self.nprob, self.rows, self.K = len(tables), rowmaps[0].numel(), tables[0].shape[1]
         self.eps, self.niters = float(eps), int(niters)
         self.r = self.c = None
         self.c_uniform, self.tag = float(c_uniform), tag
         self.la = torch.empty(self.nprob, self.K, dtype=torch.float32, device=tables[0].device)
-        self.probs = [Sinkhorn(tables[i], eps, niters, c_uniform=self.c_uniform, tag=f"{tag}.{i}", la=self.la[i],
-                               rowmap=rowmaps[i]) for i in range(self.nprob)]
+        self.probs = [Sinkhorn(tables[i], eps, niters, r=None if r is None else r[i], c=None if c is None else c[i],
+                               c_uniform=self.c_uniform, tag=f"{tag}.{i}", la=self.la[i], rowmap=rowmaps[i])
+                      for i in range(self.nprob)]
         return self
 
     def __getitem__(self, i):
@@ -1180,9 +1184,12 @@ class SinkhornBatch:
                     cm = torch.stack([p.cmax_preset for p in grp])
                     uf = torch.stack([p.u_first_preset for p in grp]) if all(p.u_first_preset is not None for p in grp) else None
                     la = torch.empty(len(grp), self.K, dtype=torch.float32, device=S.device)
+                    r_all = c_all = None
+                    if grp[0].r is not None:
+                        r_all, c_all = torch.stack([p.r for p in grp]), torch.stack([p.c for p in grp])
                     _lib.check(L.gx_sinkhorn_rows_batch(_p(S), _p(maps), len(grp), self.rows, self.K, S.stride(0), self.eps,
-                                                        self.niters, self.c_uniform, _p(cm), _p(uf), _p(la), _p(ws), wsb,
-                                                        _stream()), "gx_sinkhorn_rows_batch")
+                                                        self.niters, _p(r_all), _p(c_all), self.c_uniform, _p(cm), _p(uf),
+                                                        _p(la), _p(ws), wsb, _stream()), "gx_sinkhorn_rows_batch")
                     self.la[idx] = la
                 return self
             from .sharded import run_sinkhorn_group

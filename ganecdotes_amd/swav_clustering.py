@@ -315,12 +315,12 @@ class SwAVClustering(ViewMixin):
         # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
         # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
         # (memory: the two d(scores) tables + either the two score tables or every patch's per-sample scores, held to half the HBM)
-        want_stab = ngroups == 1 and marg is None and sa.get('score_table', True)
+        want_stab = ngroups == 1 and sa.get('score_table', True)
         tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * K if want_stab else 8.0 * rows * K * P)
         dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 8192 and P <= 8 and
                  sa.get('ds_table', hw * hw < P * N) and
                  tab_bytes < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
-        # ... and, with one Sinkhorn problem per patch and view (global scope, uniform marginals), the SCORES are a per-pixel table
+        # ... and, with one Sinkhorn problem per patch and view (global scope), the SCORES are a per-pixel table
         # too: one score GEMM per view over the pixels, the Sinkhorn problems and the CE read their rows of it through the pick index
         stab = dstab and want_stab
         if dstab:
@@ -344,7 +344,11 @@ class SwAVClustering(ViewMixin):
             cid[order] = ar32                                                            # pixel id -> table row
             # a patch's samples as table rows, ASCENDING: a Sinkhorn problem does not care about the order of its rows, and sorted the
             # patches of a view walk the table side by side (ops.SinkhornBatch.from_rows)
-            rowmaps_all = [torch.sort(cid[f_]).values for f_ in flat]
+            # (with the 'image' source pdf the row marginal belongs to the sample's POSITION in its patch: it moves with the row)
+            sorted_all = [torch.sort(cid[f_]) for f_ in flat]
+            rowmaps_all = [s_.values for s_ in sorted_all]
+            c_sorted = None if marg is None else [[c_one[v][s_.indices] for v in range(2)] for s_ in sorted_all]
+            del sorted_all
             order32 = order.to(torch.int32)
             sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
             scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
@@ -371,7 +375,9 @@ class SwAVClustering(ViewMixin):
                 with self._timed("sinkhorn"):
                     skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
                                                       [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
-                                                      1.0 / nglob, sorted_rows=True)
+                                                      1.0 / nglob, sorted_rows=True,
+                                                      r=None if marg is None else [r_one[v] for _ in pnos for v in range(2)],
+                                                      c=None if marg is None else [c_sorted[pno][v] for pno in pnos for v in range(2)])
                     for sk_ in skb.probs:      # column maxima + first pass of every problem in ONE sweep of its rows
                         sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
                     skb.run(self._reduce if (scope == 'global' and self.sharded) else None)

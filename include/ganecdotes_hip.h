@@ -437,14 +437,15 @@ size_t gx_sinkhorn_bigk_batch_workspace_bytes(int nprob, long rows, int K);
 int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long rows, int K, long ld, float eps, int niters,
                            const float* r_all, long r_stride, const float* c_all, long c_stride, const float* cmax_all,
                            const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream);
-/* nprob problems that are row selections of ONE score table (the patches of a view, global scope, uniform marginals;
+/* nprob problems that are row selections of ONE score table (the patches of a view, global scope;
  * swav_clustering.py:509-544 once per view and patch): rowmap_all [nprob][rows] int32, each sorted ascending; one launch per
  * pass, the problems' blocks dispatched side by side so that a table row several patches drew is fetched from HBM once.
- * c_uniform = the uniform row marginal; cmax_all / u_first_all [nprob][K] as above (gx_sinkhorn_first_rows), or NULL. */
+ * r_all [nprob][K] / c_all [nprob][rows] (in the order of the sorted rows) = the 'image' source pdf's marginals, or NULL = uniform with
+ * c_uniform the row marginal; cmax_all / u_first_all [nprob][K] as above (gx_sinkhorn_first_rows), or NULL. */
 size_t gx_sinkhorn_rows_batch_workspace_bytes(int nprob, long rows, int K);
 int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, long rows, int K, long ld, float eps, int niters,
-                           float c_uniform, const float* cmax_all, const float* u_first_all, float* la_all, float* workspace,
-                           size_t workspace_bytes, void* stream);
+                           const float* r_all, const float* c_all, float c_uniform, const float* cmax_all,
+                           const float* u_first_all, float* la_all, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).

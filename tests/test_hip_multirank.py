@@ -73,7 +73,7 @@ def _worker(rank, world, port, sd, scope, pdf, out, nproto=12, projn="linear"):
     ("global", "uniform", 12, "linear"), ("image", "uniform", 12, "linear"), ("global", "image", 12, "linear"),
     ("global", "uniform", 200, "linear"), ("image", "uniform", 200, "linear"),
     ("global", "uniform", 12, "1-layer"), ("global", "uniform", 200, "2-layer"), ("image", "uniform", 12, "2-layer"),
-    ("global", "uniform", 200, "linear+table"), ("image", "uniform", 200, "linear+table")])
+    ("global", "uniform", 200, "linear+table"), ("image", "uniform", 200, "linear+table"), ("global", "image", 200, "linear+table")])
 def test_two_ranks_equal_one_rank(scope, pdf, nproto, projn):
     """nproto = 200: the many-prototype path (score GEMM on weight planes with the Sinkhorn column maxima from its
     epilogue, one-pass CE with the bias gradient) under the sharded protocol; projn '2-layer' with the global scope:

@@ -258,14 +258,16 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
-@pytest.mark.parametrize("scope,batch,transforms,score_table,nproto", [
-    ("global", 3, True, True, 200), ("global", 3, True, False, 200), ("image", 2, True, True, 200), ("global", 2, False, True, 200),
-    ("global", 2, True, True, 6148), ("image", 2, True, True, 6148)])
-def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope, batch, transforms, score_table, nproto):
+@pytest.mark.parametrize("scope,batch,transforms,score_table,nproto,pdf", [
+    ("global", 3, True, True, 200, "uniform"), ("global", 3, True, False, 200, "uniform"), ("image", 2, True, True, 200, "uniform"),
+    ("global", 2, False, True, 200, "uniform"), ("global", 2, True, True, 6148, "uniform"), ("image", 2, True, True, 6148, "uniform"),
+    ("global", 3, True, True, 200, "image"), ("global", 2, True, False, 200, "image"), ("image", 2, True, True, 200, "image")])
+def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope, batch, transforms, score_table, nproto, pdf):
     """Many prototypes with d(scores) accumulated on per-pixel rows (swav_args['ds_table']): 3 patches of 600
     of the 1024 pixels, so most pixels are drawn by more than one patch; two steps against the oracle, and the same step
     with the per-sample backward GEMMs.  6148 prototypes: the 8192-column forms of the row kernels (the generic configuration's
-    8000 prototypes take them), where the per-sample form is the two-kernel CE"""
+    8000 prototypes take them), where the per-sample form is the two-kernel CE; 'image' source pdf (the cat configuration): the row
+    marginals follow the samples through the sorted row maps of the score tables"""
     from oracle import swav_ref as S
     from ganecdotes_amd import ops
     from ganecdotes_amd.draws import draw_image
@@ -273,7 +275,7 @@ def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope,
     sd = golden_sd(d)
     g = mini_gen(sd, gpu)
     kw = dict(sinkhorn_scope=scope, batch_size=batch, nprototypes=nproto, nclasses=16, num_patches=3, patch_size=600,
-              transforms=transforms)
+              transforms=transforms, sinkhorn_args=dict(source_pdf=pdf))
     sw = make_swav(g, gpu, tmp_path, ds_table=True, score_table=score_table, **kw)       # score_table: the scores per pixel too
     sw2 = make_swav(g, gpu, tmp_path, ds_table=False, **kw)
     torch.manual_seed(123)
@@ -296,7 +298,7 @@ def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope,
                                      for v in im.views], im.picks) for im in images]
         ref_loss, grads, bufs = S.swav_train_step(
             sd, ml, 0.7, oimgs, params, bufs, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
-            patch_size=600, num_patches=3, temperature=0.1, eps=0.05, niters=10, source_pdf="uniform", sinkhorn_scope=scope)
+            patch_size=600, num_patches=3, temperature=0.1, eps=0.05, niters=10, source_pdf=pdf, sinkhorn_scope=scope)
         np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
         np.testing.assert_allclose(loss.item(), loss2.item(), rtol=1e-5)
         for got, other, want in zip(sw._grads, sw2._grads, grads):

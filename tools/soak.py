@@ -25,11 +25,13 @@ torch.manual_seed(42)
 np.random.seed(42)
 sw.build_heads()
 import time                                                     # noqa: E402
+warm = min(2, steps - 1)                                        # the first steps allocate; timed from the third on
+losses = [sw.train_step(sw.draw_batch(batch)) for _ in range(warm)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-losses = [sw.train_step(sw.draw_batch(batch)) for _ in range(steps)]
+losses += [sw.train_step(sw.draw_batch(batch)) for _ in range(steps - warm)]
 l = torch.cat(losses).cpu().numpy()
-ms = (time.perf_counter() - t0) / steps * 1e3                   # includes the first (cold) step
+ms = (time.perf_counter() - t0) / (steps - warm) * 1e3
 w = sw.projection[0].weight.data
 print(f"K={k} B={batch} scope={scope} pdf={pdf}: finite={bool(np.isfinite(l).all())} loss {l[0]:.4f} -> {l[-1]:.4f} "
       f"(min {l.min():.4f}); Wp finite={bool(torch.isfinite(w).all())}; "
