@@ -105,8 +105,8 @@ int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int 
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
 size_t gx_gemm_colmax_part_bytes(int M, int N);
 /* ... with the long dimension's data rows counted on the device (the drawn pixels of the many-prototype tables come first,
- * DESIGN.md par. 4.15): gx_gemm_f32_nt_planes_mlive skips the 128-row tiles at or past *m_live, gx_gemm_f32_klive (TN only)
- * cuts the k range at *k_live */
+ * DESIGN.md par. 4.15): gx_gemm_f32_nt_planes_mlive skips the 128-row tiles at or past *m_live (their rows of C keep what they
+ * held), gx_gemm_f32_klive (TN only) contracts over the first *k_live rows only, shared among its split_k splits */
 int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* C,
                                 long ldc, float alpha, float beta, const float* col_bias, const int* m_live, void* stream);
 int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
