@@ -38,6 +38,7 @@ import contextlib
 import math
 import os
 import time
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -214,6 +215,53 @@ class SwAVClustering(ViewMixin):
                 best, best_eff = s, eff
         return int(best if best_eff > 0 else max(1, min(want, cap)))
 
+    def _score_tables(self, pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, c_one):
+        """The per-pixel score tables of a many-prototype step (swav_clustering.py:171-182 once per view over the
+        pixels instead of once per patch over the samples): the drawn pixels first, their count on the device, each patch's samples
+        as sorted table rows, z_hat of the table's pixels and `S = z_hat Wc^T + b` per view.  c_one (2, rows): the 'image' source
+        pdf's row marginals (None = uniform).  Returns None when the weight-plane GEMM does not take the shape."""
+        dev = self.device
+        npix = B * hw * hw
+        pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
+        # Table rows = the pixels some patch drew, FIRST (84 % of them at 5 x 20 000 of 65 536), in pixel order; their count
+        # `live` stays on the device and bounds the three GEMMs there (no host sync: the launches cover all B * HW rows)
+        flat = [(pb.picks[pno] + pix_base).reshape(-1).long() for pno in range(P)]
+        drawn = torch.zeros(npix, dtype=torch.bool, device=dev)
+        for f_ in flat:
+            drawn[f_] = True
+        order = torch.argsort((~drawn).to(torch.int8), stable=True)                   # drawn pixel ids first
+        live = drawn.sum(dtype=torch.int32).reshape(1)
+        live_frac = 1.0 - (1.0 - N / float(hw * hw)) ** P                            # its expectation (FLOP accounting)
+        ar32 = torch.arange(npix, dtype=torch.int32, device=dev)
+        cid = torch.empty(npix, dtype=torch.int32, device=dev)
+        cid[order] = ar32                                                            # pixel id -> table row
+        # a patch's samples as table rows, ASCENDING: a Sinkhorn problem does not care about the order of its rows, and sorted the
+        # patches of a view walk the table side by side (ops.SinkhornBatch.from_rows)
+        # (with the 'image' source pdf the row marginal belongs to the sample's POSITION in its patch: it moves with the row)
+        sorted_all = [torch.sort(cid[f_]) for f_ in flat]
+        rowmaps_all = [s_.values for s_ in sorted_all]
+        c_sorted = None if c_one is None else [[c_one[v][s_.indices] for v in range(2)] for s_ in sorted_all]
+        del sorted_all
+        order32 = order.to(torch.int32)
+        sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
+        maps_flat = []
+        for v in range(2):
+            m_ = views[v][1]
+            mf = ar32 if m_ is None else torch.where(m_ >= 0, m_ + pix_base, m_).reshape(-1)
+            maps_flat.append(torch.cat([mf, sentinel]).view(1, npix + 1))
+        zt_tab, rn_tab, S_tab = [], [], []
+        for v in range(2):
+            with self._timed("gather_rows"):       # z_hat of the table's pixels (the image batch as ONE image of B * H rows)
+                zt, rnt = ops.gather_rows_normalize(Zt[v].reshape(1, B * hw, hw, D), order32.view(1, npix), maps_flat[v])
+            st = torch.empty(npix, K, dtype=torch.float32, device=dev)
+            if not ops.gemm_planes_ok(zt, None, K, st):
+                return None
+            ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
+            zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
+        return SimpleNamespace(live=live, live_frac=live_frac, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
+                               maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab)
+
     def train_step(self, images, return_aux=False):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
         as a 1-element HIP tensor (global mean; no host sync)."""
@@ -329,55 +377,21 @@ class SwAVClustering(ViewMixin):
             dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
             pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
             picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+        tb = None
         if stab:
-            # Table rows = the pixels some patch drew, FIRST (84 % of them at 5 x 20 000 of 65 536), in pixel order; their count
-            # `live` stays on the device and bounds the three GEMMs there (no host sync: the launches cover all B * HW rows)
-            flat = [(pb.picks[pno] + pix_base).reshape(-1).long() for pno in range(P)]
-            drawn = torch.zeros(npix, dtype=torch.bool, device=dev)
-            for f_ in flat:
-                drawn[f_] = True
-            order = torch.argsort((~drawn).to(torch.int8), stable=True)                   # drawn pixel ids first
-            live = drawn.sum(dtype=torch.int32).reshape(1)
-            live_frac = 1.0 - (1.0 - N / float(hw * hw)) ** P                            # its expectation (FLOP accounting)
-            ar32 = torch.arange(npix, dtype=torch.int32, device=dev)
-            cid = torch.empty(npix, dtype=torch.int32, device=dev)
-            cid[order] = ar32                                                            # pixel id -> table row
-            # a patch's samples as table rows, ASCENDING: a Sinkhorn problem does not care about the order of its rows, and sorted the
-            # patches of a view walk the table side by side (ops.SinkhornBatch.from_rows)
-            # (with the 'image' source pdf the row marginal belongs to the sample's POSITION in its patch: it moves with the row)
-            sorted_all = [torch.sort(cid[f_]) for f_ in flat]
-            rowmaps_all = [s_.values for s_ in sorted_all]
-            c_sorted = None if marg is None else [[c_one[v][s_.indices] for v in range(2)] for s_ in sorted_all]
-            del sorted_all
-            order32 = order.to(torch.int32)
-            sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
-            scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
-            maps_flat = []
-            for v in range(2):
-                m_ = views[v][1]
-                mf = ar32 if m_ is None else torch.where(m_ >= 0, m_ + pix_base, m_).reshape(-1)
-                maps_flat.append(torch.cat([mf, sentinel]).view(1, npix + 1))
-            zt_tab, rn_tab, S_tab = [], [], []
-            for v in range(2):
-                with self._timed("gather_rows"):       # z_hat of the table's pixels (the image batch as ONE image of B * H rows)
-                    zt, rnt = ops.gather_rows_normalize(Zt[v].reshape(1, B * hw, hw, D), order32.view(1, npix), maps_flat[v])
-                st = torch.empty(npix, K, dtype=torch.float32, device=dev)
-                if not ops.gemm_planes_ok(zt, None, K, st):
-                    stab = False
-                    break
-                ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
-                zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
+            tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one)
+            stab = tb is not None
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
             if stab:
-                rowmaps = [rowmaps_all[pno] for pno in pnos]                               # a patch's samples -> table rows
+                rowmaps = [tb.rowmaps[pno] for pno in pnos]                               # a patch's samples -> table rows
                 with self._timed("sinkhorn"):
-                    skb = ops.SinkhornBatch.from_rows([S_tab[v] for _ in pnos for v in range(2)],
+                    skb = ops.SinkhornBatch.from_rows([tb.S[v] for _ in pnos for v in range(2)],
                                                       [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
                                                       1.0 / nglob, sorted_rows=True,
                                                       r=None if marg is None else [r_one[v] for _ in pnos for v in range(2)],
-                                                      c=None if marg is None else [c_sorted[pno][v] for pno in pnos for v in range(2)])
+                                                      c=None if marg is None else [tb.c_sorted[pno][v] for pno in pnos for v in range(2)])
                     for sk_ in skb.probs:      # column maxima + first pass of every problem in ONE sweep of its rows
                         sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
                     skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
@@ -385,8 +399,8 @@ class SwAVClustering(ViewMixin):
                 nrow = torch.arange(rows, dtype=torch.int32, device=dev)
                 for gi in range(G):
                     inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
-                ops.swapped_ce_pixels_tab(S_tab[0], S_tab[1], skb, 1, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
-                                          gb, 0.0 if first_acc else 1.0, live=live, live_frac=live_frac)
+                ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, 1, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
+                                          gb, 0.0 if first_acc else 1.0, live=tb.live, live_frac=tb.live_frac)
                 first_acc = False
                 if return_aux:
                     aux.update(scores_s=skb[0].scores(), scores_t=skb[1].scores(), q_s=skb[0].codes(), q_t=skb[1].codes())
@@ -543,12 +557,12 @@ class SwAVClustering(ViewMixin):
             for v in range(2):
                 dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
                 if stab:
-                    zt, rnt = zt_tab[v], rn_tab[v]
+                    zt, rnt = tb.zt[v], tb.rn[v]
                     ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
-                             split_k=self._split_k(K, D, B * hw * hw), live=live, live_frac=live_frac)
-                    ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, live, live_frac)
+                             split_k=self._split_k(K, D, B * hw * hw), live=tb.live, live_frac=tb.live_frac)
+                    ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac)
                     with self._timed("scatter_rows"):
-                        ops.normalize_bwd_scatter_(dz, zt, rnt, scat_picks, maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
+                        ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
                     del zt, rnt, dz
                     continue
                 with self._timed("gather_rows"):
@@ -564,7 +578,7 @@ class SwAVClustering(ViewMixin):
                 del zt, rnt, dz
             del dS_tab
             if stab:
-                del zt_tab, rn_tab, S_tab
+                del tb
         pending = []
         if mode == 'pyramid':
             on_level = on_heads = None
