@@ -262,6 +262,36 @@ class SwAVClustering(ViewMixin):
         return SimpleNamespace(live=live, live_frac=live_frac, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
                                maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab)
 
+    def _tables_backward(self, dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw):
+        """Backward of the prototype layer from the per-pixel d(scores) tables (swav_clustering.py:459 through
+        :171-182), once per view over the pixels: gWc = dS^T z_hat, dz = dS Wc, normalise-backward + scatter into the projected
+        tables Gt through the rotate / flip maps.  tb: the score tables of _score_tables (their z_hat, pixel order and live
+        count are reused) or None (z_hat of every pixel gathered here)."""
+        dev = self.device
+        K, D = Wc.shape
+        npix = B * hw * hw
+        picks_all = None if tb is not None else torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+        for v in range(2):
+            dz = torch.empty(npix, D, dtype=torch.float32, device=dev)
+            if tb is not None:
+                zt, rnt = tb.zt[v], tb.rn[v]
+                ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
+                         split_k=self._split_k(K, D, npix), live=tb.live, live_frac=tb.live_frac)
+                ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac)
+                with self._timed("scatter_rows"):
+                    ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
+                continue
+            with self._timed("gather_rows"):
+                zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
+            ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0, split_k=self._split_k(K, D, npix))
+            if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
+                ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz)
+            else:
+                ops.gemm(dS_tab[v][:, :K], Wc, False, False, out=dz)
+            with self._timed("scatter_rows"):
+                ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
+            del zt, rnt, dz
+
     def train_step(self, images, return_aux=False):
         """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
         as a 1-element HIP tensor (global mean; no host sync)."""
@@ -376,7 +406,6 @@ class SwAVClustering(ViewMixin):
             npix = B * hw * hw
             dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
             pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
-            picks_all = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
         tb = None
         if stab:
             tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one)
@@ -554,31 +583,8 @@ class SwAVClustering(ViewMixin):
                 del X, Zh, Rn, Hc, Sc, dS
             del keep, Sc_all, skb
         if dstab:
-            for v in range(2):
-                dz = torch.empty(B * hw * hw, D, dtype=torch.float32, device=dev)
-                if stab:
-                    zt, rnt = tb.zt[v], tb.rn[v]
-                    ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
-                             split_k=self._split_k(K, D, B * hw * hw), live=tb.live, live_frac=tb.live_frac)
-                    ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac)
-                    with self._timed("scatter_rows"):
-                        ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
-                    del zt, rnt, dz
-                    continue
-                with self._timed("gather_rows"):
-                    zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
-                ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
-                         split_k=self._split_k(K, D, B * hw * hw))
-                if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
-                    ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz)
-                else:
-                    ops.gemm(dS_tab[v][:, :K], Wc, False, False, out=dz)
-                with self._timed("scatter_rows"):
-                    ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
-                del zt, rnt, dz
-            del dS_tab
-            if stab:
-                del tb
+            self._tables_backward(dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw)
+            del dS_tab, tb
         pending = []
         if mode == 'pyramid':
             on_level = on_heads = None
