@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restri
     // rowmap (optional, [problem][rows] int32): row n of the problem is row rowmap[n] of S — a Sinkhorn problem over the
     // SAMPLED rows of a per-pixel score table (DESIGN par. 4.15) without a gathered copy of them
     constexpr int NC = (NJ + 15) / 16;                                   // float4 chunks per thread and row
-    constexpr int R = NJ > 96 ? 2 : BK_R;                                // rows per group: two past 6144 columns (8 chunks per row)
+    constexpr int R = NJ > 80 ? 2 : BK_R;                                // rows per group: two past 5120 columns (four spilled 29 VGPRs at 6 chunks per row)
     int bx = blockIdx.x;
     {   // blockIdx.y = problem of a batch of equally shaped ones: score matrices s_stride apart, K-vectors (cmax, la,
         // cmax_out) K apart, row marginals c_stride apart, partials [problem][block][K]  (gridDim.y == 1: one problem)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 4) void ce_apply_bigk_kernel(const float* __re
 //   part_s / part_t [gridDim.x][K]: column sums of dSs / dSt over the block's rows
 constexpr int CE_R = 2;
 template <int NJ>
-__global__ __launch_bounds__(256, 3) void ce_fused_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
+__global__ __launch_bounds__(256, NJ > 80 ? 2 : 3) void ce_fused_bigk_kernel(const float* __restrict__ Ss, const float* __restrict__ St,
                                                                long rows, int K, long ld, float inv_eps, float inv_T,
                                                                const float* __restrict__ la_s, const float* __restrict__ la_t,
                                                                float gscale, float* __restrict__ dSs, float* __restrict__ dSt,
@@ -530,8 +530,10 @@ __global__ __launch_bounds__(256, 3) void ce_fused_bigk_kernel(const float* __re
 // read-modify-write of the tables (as a row-indexed accumulate the CE moved 2.3x the bytes and ran 3x longer).
 //   S_all [P][2][rows][ld]; la_all [(p * 2 + view) * ngroups + group][K], group = pixel / pix_per_group
 constexpr int CE_PMAX = 8;                  // patches per step the pixel-major CE takes
+// (two workgroups per CU up to 5120 columns; past that the rows and their exponentials need more than 256 registers — 188 spilled
+//  at 6144 columns — and the kernel runs at ONE workgroup per CU with the AGPRs as the second half of its register file)
 template <int NJ>
-__global__ __launch_bounds__(256, NJ > 96 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
+__global__ __launch_bounds__(256, NJ > 80 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
                                                                 const int* __restrict__ inv, long npix, int ngroups,
                                                                 long pix_per_group, const float* __restrict__ la_all,
                                                                 float inv_eps, float inv_T, float gscale,

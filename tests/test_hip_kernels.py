@@ -253,7 +253,7 @@ def test_hist_marginal_sharded_equals_single(ops):
 
 
 @pytest.mark.parametrize("n,k,eps", [(2000, 8, 0.005), (777, 16, 0.003), (500, 1000, 0.01), (64, 5000, 0.005), (67, 8000, 0.005),
-                                     (301, 6148, 0.01)])
+                                     (301, 6148, 0.01), (131, 6000, 0.005)])
 def test_sinkhorn_vs_oracle_shapes(ops, n, k, eps):
     from oracle import swav_ref as S
     torch.manual_seed(n + k)
@@ -470,7 +470,7 @@ def test_swapped_ce_vs_oracle(ops, n, k):
     assert rel_err(ds, s1.grad) < 1e-3 and rel_err(dt, t1.grad) < 1e-3
 
 
-@pytest.mark.parametrize("n,k", [(301, 700), (1030, 5000), (64, 68)])
+@pytest.mark.parametrize("n,k", [(301, 700), (1030, 5000), (64, 68), (130, 6000)])
 def test_swapped_ce_fused_many_prototypes(ops, n, k):
     """gx_swapped_ce_fused (one pass over both score matrices, bias gradient from the same pass): against the oracle's
     loss / autograd, and against the two-kernel gx_swapped_ce + gx_colsum on the same inputs; odd row counts, K not
@@ -1010,7 +1010,7 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
             assert rel_err(a[i].codes(), ref.codes()) < 1e-4
 
 
-@pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190)])
+@pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190), (6000, None)])
 def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
     """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
     gx_swapped_ce_pixels on the gathered score rows with the same row potentials; with a device-side live bound the rows of
