@@ -75,8 +75,11 @@ __device__ __forceinline__ void bk_store4(__amdgpu_buffer_rsrc_t r, int first_co
 //      BK_FIRST  : part[b][k] = sum exp((S_nk - cmax_k)/eps)
 //      BK_SWEEP  : lb_n = log c_n - logsumexp_k(S_nk/eps + la_k); part[b][k] = sum exp(S_nk/eps + la_k + lb_n)
 constexpr int BK_R = 4;
+#ifndef BK_PASS_MINB
+#define BK_PASS_MINB 3       // lab: workgroups per CU the column pass is compiled for (tools/lab/bigk_aux.sh)
+#endif
 template <int NJ, int MODE>
-__global__ __launch_bounds__(256, 3) void bigk_pass_kernel(const float* __restrict__ S, long rows, int K, long ld,
+__global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const float* __restrict__ S, long rows, int K, long ld,
                                                            float inv_eps, const unsigned* __restrict__ cmax,
                                                            const float* __restrict__ la, const float* __restrict__ c,
                                                            float c_uniform, float* __restrict__ lb_out,

@@ -1,0 +1,9 @@
+#!/bin/bash
+# the column pass compiled for 2 / 3 / 4 workgroups per CU (-DBK_PASS_MINB), built and timed on the GPU box: tools/lab/bigk_minb.sh 3 2 4
+root=$(pwd); pkg=$root/ganecdotes_amd
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -DBK_PASS_MINB=$n -I $pkg/csrc -I $root/include -c $pkg/csrc/gx_swav.hip -o $pkg/build/gx_swav.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $pkg/libganecdotes_hip.so $pkg/build/*.o || exit 1
+  echo "== BK_PASS_MINB=$n"
+  python3 tools/lab/sinkhorn_rows_lab.py 2>&1 | grep "sorted    side by side True"
+done
