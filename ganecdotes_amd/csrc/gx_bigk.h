@@ -533,10 +533,13 @@ __global__ __launch_bounds__(256, NJ > 80 ? 2 : 3) void ce_fused_bigk_kernel(con
 // read-modify-write of the tables (as a row-indexed accumulate the CE moved 2.3x the bytes and ran 3x longer).
 //   S_all [P][2][rows][ld]; la_all [(p * 2 + view) * ngroups + group][K], group = pixel / pix_per_group
 constexpr int CE_PMAX = 8;                  // patches per step the pixel-major CE takes
+#ifndef CE_PIX_NJ2
+#define CE_PIX_NJ2 80       // widest rows (64-column chunks per lane) compiled for two workgroups per CU (lab: tools/lab/bigk_minb.sh)
+#endif
 // (two workgroups per CU up to 5120 columns; past that the rows and their exponentials need more than 256 registers — 188 spilled
 //  at 6144 columns — and the kernel runs at ONE workgroup per CU with the AGPRs as the second half of its register file)
 template <int NJ>
-__global__ __launch_bounds__(256, NJ > 80 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
+__global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
                                                                 const int* __restrict__ inv, long npix, int ngroups,
                                                                 long pix_per_group, const float* __restrict__ la_all,
                                                                 float inv_eps, float inv_T, float gscale,
