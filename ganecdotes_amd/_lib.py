@@ -160,7 +160,7 @@ SIGNATURES = {
     "gx_swapped_ce_fused": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_f,
                                   c_p, c_sz, c_p]),
     "gx_swapped_ce_pixels_tab": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_l, c_i, c_f, c_f, c_p, c_f, c_p, c_p, c_l, c_i, c_f, c_f,
-                                       c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
+                                       c_p, c_p, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_colmax_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_p, c_sz, c_p]),
     "gx_sinkhorn_pass_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_first_rows_workspace_bytes": (c_sz, [c_i]),

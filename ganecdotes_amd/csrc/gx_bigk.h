@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
                                                                 int kpad, float* __restrict__ loss_part,
                                                                 float* __restrict__ part_s, float* __restrict__ part_t,
                                                                 const float* __restrict__ St_tab = nullptr,
-                                                                const int* __restrict__ live = nullptr) {
+                                                                const int* __restrict__ live = nullptr,
+                                                                const int* __restrict__ row_group = nullptr) {
     // St_tab != NULL: the scores are per-pixel TABLES too (S_all = the first view's [npix][ld], St_tab the second's): a
     // pixel's two score rows are read once for all the patches that drew it.  live != NULL: the drawn pixels are the first
     // *live rows of the tables (DESIGN §4.15 d) — the d(scores) rows past them are neither read by the GEMMs nor written here
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
         f32x4 as[NC], at[NC];                                            // the pixel's accumulated d(scores), both views
 #pragma unroll
         for (int c = 0; c < NC; ++c) { as[c] = f32x4{0.f, 0.f, 0.f, 0.f}; at[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const long grp = ngroups > 1 ? pix / pix_per_group : 0;
+        // the Sinkhorn problem (image) of the pixel: equal runs of pixels, or — tables with the drawn pixels first — looked up per row
+        const long grp = ngroups > 1 ? (row_group ? (long)__builtin_amdgcn_readfirstlane(row_group[pix]) : pix / pix_per_group) : 0;
         int nrow[CE_PMAX];                                               // the pixel's row in every patch, fetched together
 #pragma unroll
         for (int p = 0; p < CE_PMAX; ++p) nrow[p] = p < P ? __builtin_amdgcn_readfirstlane(inv[(long)p * npix + pix]) : -1;

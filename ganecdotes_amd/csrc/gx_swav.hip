@@ -1274,7 +1274,8 @@ int gx_swapped_ce_fused(const float* Ss, const float* St, long rows, int K, long
 static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long rows, int K, long ld, const int* inv, long npix,
                           int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
                           float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
-                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream, const int* live = nullptr);
+                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream, const int* live = nullptr,
+                          const int* row_group = nullptr);
 int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, const int* inv, long npix, int ngroups,
                          float eps, float temperature, const float* la_all, float grad_scale, float* dSs, float* dSt, long ldd,
                          int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb, float gb_beta,
@@ -1284,21 +1285,24 @@ int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, c
 }
 // ... with the scores as per-pixel tables as well (Ss_tab / St_tab [npix][ld], one per view): inv only says which patches
 // drew a pixel (>= 0), la_all as above.  live (device scalar, may be NULL): the tables hold the drawn pixels in their first
-// *live rows; the d(scores) rows past them are left untouched
+// *live rows; the d(scores) rows past them are left untouched.  row_group (int32 [npix], may be NULL; ngroups > 1): the Sinkhorn
+// problem (image) of every table row, where the rows of an image are no longer npix / ngroups apart
 int gx_swapped_ce_pixels_tab(const float* Ss_tab, const float* St_tab, int P, int K, long ld, const int* inv, long npix,
                              int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
                              float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
-                             float gb_beta, const int* live, float* workspace, size_t workspace_bytes, void* stream) {
+                             float gb_beta, const int* live, const int* row_group, float* workspace, size_t workspace_bytes,
+                             void* stream) {
     if (!St_tab || !bigk_aligned(St_tab, ld)) return GX_ERR_BAD_ARG;
     return ce_pixels_impl(Ss_tab, St_tab, P, 1, K, ld, inv, npix, ngroups, eps, temperature, la_all, grad_scale, dSs, dSt, ldd,
-                          kpad, loss_scale, loss_beta, loss_out, gb, gb_beta, workspace, workspace_bytes, stream, live);
+                          kpad, loss_scale, loss_beta, loss_out, gb, gb_beta, workspace, workspace_bytes, stream, live, row_group);
 }
 static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long rows, int K, long ld, const int* inv, long npix,
                           int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
                           float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
-                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream, const int* live) {
+                          float gb_beta, float* workspace, size_t workspace_bytes, void* stream, const int* live,
+                          const int* row_group) {
     if (!S_all || !inv || !la_all || !loss_out || !dSs || !dSt || !gb || P <= 0 || P > CE_PMAX || rows <= 0 || K <= 0 || ld < K || npix <= 0 ||
-        ngroups <= 0 || npix % ngroups || kpad < K || kpad > ldd || (kpad & 3))
+        ngroups <= 0 || (!row_group && npix % ngroups) || kpad < K || kpad > ldd || (kpad & 3))
         return GX_ERR_BAD_ARG;
     if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd) ||
         (((uintptr_t)la_all) & 15) || 4 * 256 * ((bigk_nj(K) + 15) / 16) < kpad)
@@ -1310,7 +1314,7 @@ static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long r
     GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((ce_pixels_bigk_kernel<NJ>), dim3(nbk), dim3(256), (size_t)2 * K * sizeof(float), (hipStream_t)stream,
                                                     S_all, P, rows, K, ld, inv, npix, ngroups, npix / ngroups, la_all, 1.f / eps,
                                                     1.f / temperature, grad_scale, dSs, dSt, ldd, kpad, workspace, part_s,
-                                                    part_t, St_tab, live));
+                                                    part_t, St_tab, live, row_group));
     GX_CHECK_LAUNCH();
     launch_partial_reduce(workspace, nbk, 1, loss_scale, loss_beta, loss_out, (hipStream_t)stream);
     GX_CHECK_LAUNCH();

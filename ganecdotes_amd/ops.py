@@ -1173,7 +1173,8 @@ class SinkhornBatch:
                     by_table.setdefault((p.S.data_ptr(), p.S.stride(0)), []).append(i)
                 for idx in by_table.values():
                     grp = [self.probs[i] for i in idx]
-                    if not (self.sorted_rows and len(grp) > 1 and all(p.cmax_preset is not None for p in grp)):
+                    npre = sum(p.cmax_preset is not None for p in grp)
+                    if not (self.sorted_rows and 1 < len(grp) <= 96 and npre in (0, len(grp))):
                         for p in grp:
                             p.run()
                         continue
@@ -1181,8 +1182,9 @@ class SinkhornBatch:
                     wsb = L.gx_sinkhorn_rows_batch_workspace_bytes(len(grp), self.rows, self.K)
                     ws = workspace(self.tag + ".rows", wsb, S.device)
                     maps = torch.stack([p.rowmap for p in grp])
-                    cm = torch.stack([p.cmax_preset for p in grp])
-                    uf = torch.stack([p.u_first_preset for p in grp]) if all(p.u_first_preset is not None for p in grp) else None
+                    # (no presets: the batch makes its own column maxima and first pass, one launch each over all problems)
+                    cm = torch.stack([p.cmax_preset for p in grp]) if npre else None
+                    uf = torch.stack([p.u_first_preset for p in grp]) if npre and all(p.u_first_preset is not None for p in grp) else None
                     la = torch.empty(len(grp), self.K, dtype=torch.float32, device=S.device)
                     r_all = c_all = None
                     if grp[0].r is not None:
@@ -1342,12 +1344,17 @@ def swapped_ce_pixels(scores_all, skb, ngroups, inv, temperature, grad_scale, lo
 
 
 def swapped_ce_pixels_tab(s_tab, t_tab, skb, ngroups, inv, temperature, grad_scale, loss_out, loss_scale, loss_beta, d_s, d_t, kpad,
-                          gb, gb_beta, live=None, live_frac=1.0):
+                          gb, gb_beta, live=None, live_frac=1.0, row_group=None):
     """swapped_ce_pixels with the scores as per-pixel tables too (s_tab / t_tab (npix, K), one per view): a pixel's score rows
     are read once for all the patches that drew it; inv (P, npix) int32 only says which did (>= 0).  live (int32 HIP scalar):
-    the drawn pixels are the first `live` rows of the tables — the d(scores) rows past them are left as they are (live_frac: its expected share, for the byte accounting)"""
+    the drawn pixels are the first `live` rows of the tables — the d(scores) rows past them are left as they are (live_frac: its expected share, for the byte accounting).  row_group (int32
+    (npix,), with ngroups > 1): the Sinkhorn problem (image) of every table row — the rows of an image are not npix / ngroups apart
+    once the drawn pixels come first"""
     if live is not None and (live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1):
         raise RuntimeError("swapped_ce_pixels_tab: `live` is an int32 HIP scalar")
+    if row_group is not None and (row_group.dtype != torch.int32 or not row_group.is_cuda or row_group.numel() != s_tab.shape[0]
+                                  or not row_group.is_contiguous()):
+        raise RuntimeError("swapped_ce_pixels_tab: `row_group` is an int32 HIP vector with one entry per table row")
     _chk(s_tab, t_tab, loss_out, gb)
     _chk2d(d_s, d_t)
     npix, k = s_tab.shape
@@ -1362,8 +1369,8 @@ def swapped_ce_pixels_tab(s_tab, t_tab, skb, ngroups, inv, temperature, grad_sca
     with record("ce_fused_bigk_kernel", 0.0, (8.0 * npix * k + 8.0 * npix * kpad) * live_frac):    # score tables once, d(scores) tables once
         _lib.check(L.gx_swapped_ce_pixels_tab(_p(s_tab), _p(t_tab), npatch, k, s_tab.stride(0), _p(inv), npix, ngroups, skb.eps,
                                               temperature, _p(skb.la), grad_scale, _p(d_s), _p(d_t), d_s.stride(0), kpad,
-                                              loss_scale, loss_beta, _p(loss_out), _p(gb), gb_beta, _p(live), _p(ws), wsb,
-                                              _stream()),
+                                              loss_scale, loss_beta, _p(loss_out), _p(gb), gb_beta, _p(live), _p(row_group), _p(ws),
+                                              wsb, _stream()),
                    "gx_swapped_ce_pixels_tab")
     return loss_out
 

@@ -240,8 +240,15 @@ class SwAVClustering(ViewMixin):
         # (with the 'image' source pdf the row marginal belongs to the sample's POSITION in its patch: it moves with the row)
         sorted_all = [torch.sort(cid[f_]) for f_ in flat]
         rowmaps_all = [s_.values for s_ in sorted_all]
-        c_sorted = None if c_one is None else [[c_one[v][s_.indices] for v in range(2)] for s_ in sorted_all]
+        if c_one is None:
+            c_sorted = None
+        elif c_one.dim() == 2:                 # global scope: (2, rows)
+            c_sorted = [[c_one[v][s_.indices] for v in range(2)] for s_ in sorted_all]
+        else:                                  # per-image scope: (2, B, N) — an image's samples stay together under the sort
+            c_sorted = [[torch.gather(c_one[v], 1, s_.indices.view(B, N) - (torch.arange(B, device=dev) * N).unsqueeze(1))
+                         for v in range(2)] for s_ in sorted_all]
         del sorted_all
+        row_group = (order // (hw * hw)).to(torch.int32)                             # table row -> image (per-image Sinkhorn scope)
         order32 = order.to(torch.int32)
         sentinel = torch.full((1,), -1, dtype=torch.int32, device=dev)
         scat_picks = torch.where(ar32 < live, order32, torch.full_like(order32, npix)).view(1, npix)   # rows past live: dropped
@@ -260,7 +267,7 @@ class SwAVClustering(ViewMixin):
             ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
             zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
         return SimpleNamespace(live=live, live_frac=live_frac, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
-                               maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab)
+                               maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab, row_group=row_group)
 
     def _tables_backward(self, dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw):
         """Backward of the prototype layer from the per-pixel d(scores) tables (swav_clustering.py:459 through
@@ -393,7 +400,7 @@ class SwAVClustering(ViewMixin):
         # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
         # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
         # (memory: the two d(scores) tables + either the two score tables or every patch's per-sample scores, held to half the HBM)
-        want_stab = ngroups == 1 and sa.get('score_table', True)
+        want_stab = sa.get('score_table', True) and (ngroups == 1 or P * 2 * ngroups <= 2 * 96)
         tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * K if want_stab else 8.0 * rows * K * P)
         dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 8192 and P <= 8 and
                  sa.get('ds_table', hw * hw < P * N) and
@@ -416,23 +423,36 @@ class SwAVClustering(ViewMixin):
             if stab:
                 rowmaps = [tb.rowmaps[pno] for pno in pnos]                               # a patch's samples -> table rows
                 with self._timed("sinkhorn"):
-                    skb = ops.SinkhornBatch.from_rows([tb.S[v] for _ in pnos for v in range(2)],
-                                                      [rowmaps[gi] for gi in range(G) for _ in range(2)], self.eps, self.niters,
-                                                      1.0 / nglob, sorted_rows=True,
-                                                      r=None if marg is None else [r_one[v] for _ in pnos for v in range(2)],
-                                                      c=None if marg is None else [tb.c_sorted[pno][v] for pno in pnos for v in range(2)])
-                    for sk_ in skb.probs:      # column maxima + first pass of every problem in ONE sweep of its rows
-                        sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
+                    # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
+                    # patch's sorted rows (its pixels are a contiguous run of the table)
+                    tabs, maps, rl, cl = [], [], [], []
+                    for gi, pno in enumerate(pnos):
+                        for v in range(2):
+                            for g in range(ngroups):
+                                tabs.append(tb.S[v])
+                                maps.append(rowmaps[gi] if ngroups == 1 else rowmaps[gi].view(B, N)[g])
+                                if marg is not None:
+                                    rl.append(r_one[v] if ngroups == 1 else r_one[v][g])
+                                    cl.append(tb.c_sorted[pno][v] if ngroups == 1 else tb.c_sorted[pno][v][g])
+                    skb = ops.SinkhornBatch.from_rows(tabs, maps, self.eps, self.niters, 1.0 / nglob, sorted_rows=True,
+                                                      r=rl or None, c=cl or None)
+                    if ngroups == 1:
+                        for sk_ in skb.probs:  # column maxima + first pass of every problem in ONE sweep of its rows
+                            sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
+                    # (per-image scope: 2 B P small problems — their maxima and first pass are two more launches of the batch)
                     skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+                    del tabs, maps, rl, cl
                 inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
                 nrow = torch.arange(rows, dtype=torch.int32, device=dev)
                 for gi in range(G):
                     inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
-                ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, 1, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
-                                          gb, 0.0 if first_acc else 1.0, live=tb.live, live_frac=tb.live_frac)
+                ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, ngroups, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
+                                          gb, 0.0 if first_acc else 1.0, live=tb.live, live_frac=tb.live_frac,
+                                          row_group=tb.row_group if ngroups > 1 else None)
                 first_acc = False
                 if return_aux:
-                    aux.update(scores_s=skb[0].scores(), scores_t=skb[1].scores(), q_s=skb[0].codes(), q_t=skb[1].codes())
+                    aux.update(scores_s=skb[0].scores(), scores_t=skb[ngroups].scores(), q_s=skb[0].codes(),
+                               q_t=skb[ngroups].codes())
                 del inv, skb, rowmaps
                 continue
             Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)

@@ -473,7 +473,8 @@ int gx_swapped_ce_pixels(const float* S_all, int P, long rows, int K, long ld, c
 int gx_swapped_ce_pixels_tab(const float* Ss_tab, const float* St_tab, int P, int K, long ld, const int* inv, long npix,
                              int ngroups, float eps, float temperature, const float* la_all, float grad_scale, float* dSs,
                              float* dSt, long ldd, int kpad, float loss_scale, float loss_beta, float* loss_out, float* gb,
-                             float gb_beta, const int* live, float* workspace, size_t workspace_bytes, void* stream);
+                             float gb_beta, const int* live, const int* row_group, float* workspace, size_t workspace_bytes,
+                             void* stream);
 int gx_swapped_ce_batch(const float* S_all, int npatch, int ngroups, long rows_per_patch, long rows, int K, float eps,
                         float temperature, const float* la_all, float grad_scale, float* dS_all, float loss_scale,
                         float loss_beta, float* loss_out, float* workspace, size_t workspace_bytes, void* stream);
