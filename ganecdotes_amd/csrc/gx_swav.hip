@@ -1117,7 +1117,9 @@ int gx_sinkhorn_bigk_batch(const float* S_all, int nprob, long prob_stride, long
 // several patches drew comes from HBM once.  r_all [nprob][K] / c_all [nprob][rows] (c in the order of the SORTED rows) or NULL:
 // uniform marginals, c_uniform = the row marginal (1 / rows on one rank).
 static int rows_batch_blocks(int nprob, long rows) {
-    long nb = (3 * 256) / nprob;                  // every problem's blocks resident at once (3 workgroups per CU)
+    // a view's few patches: every problem's blocks resident at once (3 workgroups per CU), walking the table side by side; the many
+    // small problems of the per-image scope: four rounds of blocks (nine blocks per problem left the sweeps 14 % short)
+    long nb = (nprob <= 8 ? 3 * 256 : 12 * 256) / nprob;
     if (nb < 8) nb = 8;
     const long groups = (rows + BK_R - 1) / BK_R;
     return (int)(nb < groups ? nb : groups);
