@@ -1171,10 +1171,11 @@ class SinkhornBatch:
                 by_table = {}
                 for i, p in enumerate(self.probs):
                     by_table.setdefault((p.S.data_ptr(), p.S.stride(0)), []).append(i)
-                for idx in by_table.values():
+                chunks = [ids[i:i + 96] for ids in by_table.values() for i in range(0, len(ids), 96)]     # <= 96 problems a launch
+                for idx in chunks:
                     grp = [self.probs[i] for i in idx]
                     npre = sum(p.cmax_preset is not None for p in grp)
-                    if not (self.sorted_rows and 1 < len(grp) <= 96 and npre in (0, len(grp))):
+                    if not (self.sorted_rows and len(grp) > 1 and npre in (0, len(grp))):
                         for p in grp:
                             p.run()
                         continue

@@ -400,7 +400,7 @@ class SwAVClustering(ViewMixin):
         # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
         # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
         # (memory: the two d(scores) tables + either the two score tables or every patch's per-sample scores, held to half the HBM)
-        want_stab = sa.get('score_table', True) and (ngroups == 1 or P * 2 * ngroups <= 2 * 96)
+        want_stab = sa.get('score_table', True)
         tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * K if want_stab else 8.0 * rows * K * P)
         dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 8192 and P <= 8 and
                  sa.get('ds_table', hw * hw < P * N) and

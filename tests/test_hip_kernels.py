@@ -985,11 +985,11 @@ def test_swapped_ce_pixels_equals_per_pair_ce_summed_per_pixel(ops, k, ngroups):
     assert rel_err(gb, gb2) < 1e-5
 
 
-@pytest.mark.parametrize("k,rows,nprob", [(200, 1000, 5), (5000, 333, 3), (132, 4097, 2)])
+@pytest.mark.parametrize("k,rows,nprob", [(200, 1000, 5), (5000, 333, 3), (132, 4097, 2), (132, 64, 100)])
 def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
     """gx_sinkhorn_rows_batch (the patches of a view as sorted row selections of one score table, one launch per pass, blocks
     of the problems interleaved) against the same problems solved one by one through gx_sinkhorn_pass_rows, and against the
-    plain solver on gathered copies of their rows"""
+    plain solver on gathered copies of their rows; 100 problems per table: two launches per pass"""
     torch.manual_seed(k + rows)
     npix = 2 * rows
     tabs = [(torch.randn(npix, k) * 0.2).cuda() for _ in range(2)]
@@ -1004,6 +1004,10 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
                 sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, eps, sk_.rowmap)
             skb.run()
         assert float((a.la - b.la).abs().max()) < 2e-4
+        # without presets the batch makes its own column maxima and first pass (the per-image scope's many small problems);
+        # more than 96 problems of a table go in several launches
+        c = ops.SinkhornBatch.from_rows(tl, ml, eps, 6, 1.0 / rows, sorted_rows=True).run()
+        assert float((c.la - b.la).abs().max()) < 2e-4
         for i in (0, 2 * nprob - 1):
             ref = ops.Sinkhorn(tl[i][ml[i].long()].contiguous(), eps, 6).run()
             assert float((a.la[i] - ref.la).abs().max()) < 2e-4
