@@ -25,6 +25,21 @@ def main():
     matplotlib.use("agg")
     import torch
     torch.set_num_threads(4)
+    # models/baggan/blocks.py:7 imports lib.gan.optim, whose two modules JIT-build their CUDA extensions at import
+    # (torch.utils.cpp_extension.load, upfirdn2d.py:11 / fused_act.py:21).  On CPU tensors — all this capture feeds — the
+    # reference never reaches them (upfirdn2d.py:156, fused_act.py:234 dispatch to its own torch-op twins), so the build is
+    # skipped: minutes of hipify + hipcc, and a lock file left in ~/.cache/torch_extensions by a killed build makes every
+    # later import wait forever (that is how this script hung in round 4).
+    import torch.utils.cpp_extension as _cpp
+
+    class _NotBuilt:
+        def __init__(self, name):
+            self._name = name
+
+        def __getattr__(self, attr):
+            raise RuntimeError(f"CUDA extension '{self._name}' is not built in a CPU capture (asked for .{attr})")
+
+    _cpp.load = lambda name, *a, **k: _NotBuilt(name)
     from models.baggan import models as BM
     BM.DEFAULT_RES_TO_CHANNEL_MAP = {4: 16, 8: 16, 16: 8, 32: 8}
     torch.manual_seed(1400)

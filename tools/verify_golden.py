@@ -62,7 +62,10 @@ def main():
     os.makedirs(tmp, exist_ok=True)
     for sc in SCRIPTS:
         print(f"== {sc}", flush=True)
-        r = subprocess.run([sys.executable, os.path.join(HERE, sc), "--out", tmp], capture_output=True, text=True)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(HERE, sc), "--out", tmp], capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            raise SystemExit(f"{sc} did not finish in 300 s (each capture takes seconds: something it imports is waiting)")
         if r.returncode != 0:
             print(r.stdout[-2000:], r.stderr[-4000:])
             raise SystemExit(f"{sc} failed with code {r.returncode}")
