@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libganecdotes_hip.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_conv.hip", "gx_fineq.hip", "gx_simclr.hip", "gx_projhead.hip", "gx_head.hip", "gx_kmeans.hip"]
+SOURCES = ["gx_gemm.hip", "gx_swav.hip", "gx_sktab.hip", "gx_conv.hip", "gx_fineq.hip", "gx_simclr.hip", "gx_projhead.hip", "gx_head.hip", "gx_kmeans.hip"]
 ARCH = "gfx950"
 
 

@@ -6,10 +6,9 @@
 // pay an LDS atomic per score; at K = 5000, 320 000 rows they ran at 0.4 TB/s.
 #pragma once
 #include "gx_common.h"
+#include "gx_bigk_io.h"
 
 namespace gx {
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bk_f2ord(float f) {
     const unsigned u = __float_as_uint(f);
@@ -19,6 +18,7 @@ __device__ __forceinline__ float bk_ord2f(unsigned o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+constexpr float BK_LOG2E = 1.44269504088896340736f, BK_LN2 = 0.693147180559945309417f;
 enum { BK_COLMAX = 0, BK_COLSUM = 1, BK_FIRST = 2, BK_SWEEP = 3, BK_FIRSTLSE = 4 };
 
 // exp(x) for x <= ~0 (every call site subtracts a maximum first) as v_exp_f32(x * log2 e) with the product carried
@@ -32,30 +32,6 @@ __device__ __forceinline__ float bk_exp(float x) {
     const float r = fmaf(x, L, -y) + x * L_LO;
     const float e = __builtin_amdgcn_exp2f(y);
     return fmaf(e * LN2, r, e);
-}
-
-// A score row through a buffer descriptor: columns past K read as 0 with no branch (hipcc turns
-// `k < K ? p[k] : x` into one branch + s_waitcnt vmcnt(0) PER LOAD, i.e. 80 serial round trips per
-// row).  `row` is wave-uniform by construction; readfirstlane makes that provable so the
-// descriptor stays in SGPRs.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bk_row_rsrc(const float* base, long row, long ld, int K) {
-    const long off = row * ld;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(off & 0xffffffffL));
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)off >> 32));
-    const float* p = base + (long)(((unsigned long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, K * 4, 0x00020000);
-}
-#ifndef BK_LOAD_AUX
-#define BK_LOAD_AUX 0      // lab: cache-policy bits of the row loads / stores (2 = nt), tools/lab/bigk_aux.sh
-#endif
-#ifndef BK_STORE_AUX
-#define BK_STORE_AUX 0
-#endif
-__device__ __forceinline__ f32x4 bk_load4(__amdgpu_buffer_rsrc_t r, int first_col) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, first_col * 4, 0, BK_LOAD_AUX));
-}
-__device__ __forceinline__ void bk_store4(__amdgpu_buffer_rsrc_t r, int first_col, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, first_col * 4, 0, BK_STORE_AUX);
 }
 
 // Lane l owns columns 4*(l + 64*c) + q, q < 4, c < NJ/4 (one float4 per chunk: a wave-instruction
@@ -121,9 +97,13 @@ __global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const floa
         for (int k = tid; k < K; k += 256) vec[k] = bk_ord2f(cmax[k]) * neg;      //  integer selects and lost: hipcc 7.2)
         __syncthreads();
     } else if (MODE == BK_SWEEP) {
-        for (int k = tid; k < K; k += 256) vec[k] = la[k];
+        // log2 units: exp(S/eps + la - max) = 2^(S (log2 e / eps) + la log2 e - max2), one v_exp_f32 per score on an argument
+        // <= 0 whose product with log2 e / eps is rounded once (a relative error of |arg| 2^-24 on a term <= 1: what the
+        // reference's own `scores / eps` carries into its exp, swav_clustering.py:519)
+        for (int k = tid; k < K; k += 256) vec[k] = la[k] * BK_LOG2E;
         __syncthreads();
     }
+    const float sc = MODE == BK_SWEEP ? inv_eps * BK_LOG2E : inv_eps;
     f32x4 u[NC];
     f32x4 um[MODE == BK_FIRSTLSE ? NC : 1];                              // BK_FIRSTLSE: the running column maxima
 #pragma unroll
@@ -140,6 +120,8 @@ __global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const floa
         for (int r = 0; r < R; ++r) {
             // rows past the end read as zeros through an EMPTY descriptor (their contributions are masked below)
             const bool live = r0 + r < rows;
+            // (rowmap: a row's index is read right in front of its loads — all R indices in one vector load up front, or a group
+            //  ahead, measured 9 % slower / spilled: profiles/r04_lab_sktab.txt)
             const long srow = !live ? 0 : (rowmap ? (long)rowmap[r0 + r] : r0 + r);
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, srow, ld, live ? K : 0);
 #pragma unroll
@@ -198,13 +180,13 @@ __global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const floa
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        w[r][cidx][q] = ok ? fmaf(w[r][cidx][q], inv_eps, v[q]) : -INFINITY;
+                        w[r][cidx][q] = ok ? fmaf(w[r][cidx][q], sc, v[q]) : -INFINITY;
                         mx[r] = fmaxf(mx[r], w[r][cidx][q]);
                     }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                mx[r] = gx_wave_max(mx[r]);
+                mx[r] = gx_wave_max_valu(mx[r]);
                 if (lane == 0) red[r * 4 + wid] = mx[r];
             }
             __syncthreads();
@@ -216,8 +198,8 @@ __global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const floa
 #pragma unroll
                 for (int cidx = 0; cidx < NC; ++cidx)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { w[r][cidx][q] = bk_exp(w[r][cidx][q] - mx[r]); sum[r] += w[r][cidx][q]; }
-                sum[r] = gx_wave_sum(sum[r]);
+                    for (int q = 0; q < 4; ++q) { w[r][cidx][q] = __builtin_amdgcn_exp2f(w[r][cidx][q] - mx[r]); sum[r] += w[r][cidx][q]; }
+                sum[r] = gx_wave_sum_valu(sum[r]);
                 if (lane == 0) red[R * 4 + r * 4 + wid] = sum[r];
             }
             __syncthreads();
@@ -230,7 +212,7 @@ __global__ __launch_bounds__(256, BK_PASS_MINB) void bigk_pass_kernel(const floa
                 const float f = live ? cn / tot : 0.f;                  // exp(lb + mx)
 #pragma unroll
                 for (int cidx = 0; cidx < NC; ++cidx) u[cidx] += w[r][cidx] * f;
-                if (lb_out && live && tid == 0) lb_out[r0 + r] = logf(cn) - mx[r] - logf(tot);
+                if (lb_out && live && tid == 0) lb_out[r0 + r] = logf(cn) - mx[r] * BK_LN2 - logf(tot);
             }
             // (the next group's first barrier orders this group's reads of `red` before its writes: every wave
             //  passes through it only after finishing here)

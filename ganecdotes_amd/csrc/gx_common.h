@@ -28,6 +28,11 @@ namespace gx {
 // (optional): >= 8 * K floats of scratch; with it many rows of many columns are reduced in two stages that fill the chip.
 void launch_partial_reduce(const float* part, int nblk, int K, float alpha, float beta, float* out, hipStream_t stream,
                            float* spare = nullptr);
+// the same for nprob problems at once: part [nprob][nblk][K] -> out [nprob][K]
+void launch_partial_reduce_batch(const float* part, int nblk, int K, int nprob, float* out, hipStream_t stream);
+// (max, sum) pairs of an online log-sum-exp merged exactly per problem: cmp / usp [nprob][per][K] -> cmax / u [nprob][K] (gx_swav.hip)
+void launch_first_from_parts(const float* cmp, const float* usp, int per, int nprob, int K, float inv_eps, float* cmax, float* u,
+                             hipStream_t stream);
 }  // namespace gx
 
 // Cross-lane exchange inside a row of 16 lanes by DPP (one VALU instruction, no LDS round trip, unlike
@@ -71,6 +76,32 @@ __device__ __forceinline__ float gx_xor16_sum(float x) {
     float a = x, b;
     asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
     return a + b;
+}
+__device__ __forceinline__ float gx_xor32_max(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float gx_xor16_max(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return fmaxf(a, b);
+}
+// wave-wide sum / max with no LDS crossbar step (four DPP steps inside the rows of 16 lanes, then the two permlane swaps);
+// all 64 lanes active
+__device__ __forceinline__ float gx_wave_sum_valu(float v) {
+    v += gx_dpp<GX_DPP_XOR1>(v);
+    v += gx_dpp<GX_DPP_XOR2>(v);
+    v += gx_dpp<GX_DPP_HALF_MIRROR>(v);
+    v += gx_dpp<GX_DPP_MIRROR>(v);
+    return gx_xor32_sum(gx_xor16_sum(v));
+}
+__device__ __forceinline__ float gx_wave_max_valu(float v) {
+    v = fmaxf(v, gx_dpp<GX_DPP_XOR1>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_XOR2>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, gx_dpp<GX_DPP_MIRROR>(v));
+    return gx_xor32_max(gx_xor16_max(v));
 }
 // reductions over a power-of-two team of consecutive lanes (team <= 64); every lane gets the result
 __device__ __forceinline__ float gx_team_sum(float v, int team) {

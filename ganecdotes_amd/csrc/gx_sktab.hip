@@ -1,0 +1,487 @@
+// Sinkhorn-Knopp on the per-pixel score TABLES of a many-prototype step (DESIGN par. 4.15 / 4.16; swav_clustering.py:509-544
+// once per view and patch).  A step's problems are row selections of two tables (one per view): problem (p, v) = the rows
+// of table v that patch p drew.  The per-problem kernels (gx_bigk.h, gx_sinkhorn_rows_batch) sweep every problem's rows on
+// their own — a table row that several patches drew (1.8 draws per drawn pixel at 5 x 20 000 of 65 536) is read once per
+// draw.  Here ONE pass over the live rows of a table serves all its patches: a row is loaded once, and for every patch that
+// drew it (inv[p][row] >= 0) the pass does what bigk_pass_kernel<., BK_SWEEP> does for a row of that problem.
+//
+// Work split: a workgroup of T = 64 ceil(K / 512) threads (640 at K = 5000) owns groups of 4 consecutive table rows; thread t
+// holds columns 4 (t + T c) + q, c < 2, of every row it visits, so a problem's column accumulators are 8 registers per
+// thread (P problems: 8 P) and leave as the block's partial row; the patches' log scaling vectors sit in LDS (P x 8T
+// floats, in log2 units: one workgroup per CU).  The row reductions (max, then sum of exp, over all K columns) cross the
+// waves through LDS.  The patches of a group are software-pipelined: step s computes the maxima of patch s (A), the
+// exponentials and sums of patch s - 1 (B) and accumulates patch s - 2 (C) — ONE barrier per step, P + 2 per group — and the
+// next group's rows are in flight (registers) while the current one is worked on.
+// exp: 2^(t log2 e / eps ...) by v_exp_f32 on arguments <= 0 whose product with log2 e / eps is rounded once: a relative
+// error of |arg| 2^-24 on a term e^arg <= 1, i.e. at most 0.37 x 2^-24 of the row's largest term — the error the reference's
+// own `scores / eps` carries into its exp (swav_clustering.py:519).
+#include "gx_bigk_io.h"
+
+namespace gx {
+
+constexpr int SKT_R = 4;            // table rows per group
+constexpr int SKT_MAXT = 768;       // threads per workgroup at most (K <= 6144)
+constexpr int SKT_MAXW = SKT_MAXT / 64;
+constexpr int SKT_LA_CAP = 32768;   // floats of LDS for the patches' scaling vectors (P x 8T)
+constexpr float SKT_LOG2E = 1.44269504088896340736f;
+
+struct SkTabArgs {
+    const float* S[2];       // score tables of the two views, [npix][ld]
+    long ld;
+    int K;
+    const float* wt;         // [nv][P][npix] row weights: the row marginal c_n of table row q in patch p's problem, 0 = not in it
+    long wt_view;            // stride between the views' weights (0: both views share them — uniform marginals)
+    long npix;
+    const int* live;         // device scalar: the drawn pixels are table rows [0, *live) (NULL: npix)
+    float sc;                // log2(e) / eps
+    const float* la;         // [(p * 2 + view)][K] log scaling vectors (sweep)
+    float* part;             // [(p * 2 + view)][nb][K] column sums of the block (first pass: relative to partm)
+    float* partm;            // first pass: [(p * 2 + view)][nb][K] running column maxima of the block
+    int nb;
+};
+
+__device__ __forceinline__ float skt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// workgroup barrier that retires this wave's LDS writes but leaves its vector-memory loads in flight (__syncthreads() may
+// drain them: csrc/gx_fineq.hip)
+__device__ __forceinline__ void skt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the column maxima AND the first pass of all problems in one sweep of the tables (online log-sum-exp per block and
+//      column, as bigk_pass_kernel<., BK_FIRSTLSE>; the (max, sum) pairs are merged exactly by sk_first_from_parts_kernel)
+// Row weights of a pass, made once per call from the index tables (a few tens of microseconds): wt[v][p][q] = the row marginal
+// of table row q in problem (p, v) — c_uniform, or c[(p * 2 + v)][inv[p][q]] — and 0 when patch p did not draw it or q >= live.
+// The sweeps then learn everything about a group of rows from ONE vector load (lane p * R + r), issued with the rows.
+__global__ void sk_table_weights_kernel(const int* __restrict__ inv, long npix, int P, const int* __restrict__ live,
+                                        const float* __restrict__ c, long rows, float c_uniform, float* __restrict__ wt) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y, v = blockIdx.z;
+    if (q >= npix) return;
+    const long lv = live ? (long)*live : npix;
+    const int iv = q < lv ? inv[(long)p * npix + q] : -1;
+    float w = 0.f;
+    if (iv >= 0) w = c ? c[(long)(p * 2 + v) * rows + iv] : c_uniform;
+    wt[((long)v * P + p) * npix + q] = w;
+}
+
+// the weights of the R rows of group g under the P patches: lane p * R + r of every wave holds wt[p][g R + r]
+template <int P>
+__device__ __forceinline__ float skt_group_weights(const float* __restrict__ wt, long npix, long g, long ngroups, int lane) {
+    const int p = lane / SKT_R, r = lane % SKT_R;
+    const long row = g * SKT_R + r;
+    float w = 0.f;
+    if (lane < P * SKT_R && g < ngroups && row < npix) w = wt[(long)p * npix + row];
+    return w;
+}
+__device__ __forceinline__ float skt_lane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+template <int P>
+__global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
+    constexpr bool PF = P <= 3;                  // the next group's rows in flight under this one's (registers permitting)
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int view = blockIdx.y, K = a.K;
+    const float* S = a.S[view];
+    const long live = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
+    const long ngroups = (live + SKT_R - 1) / SKT_R;
+    const float inv_eps2 = a.sc;                                       // log2(e) / eps
+    const float* wt = a.wt + view * a.wt_view;
+    const int lane = tid & 63;
+    f32x4 m[P][2], s[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            m[p][c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            s[p][c] = zero4();
+        }
+    f32x4 w[SKT_R][2];
+    float gw;
+    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd) {
+        gwd = skt_group_weights<P>(wt, a.npix, g, ngroups, lane);
+#pragma unroll
+        for (int r = 0; r < SKT_R; ++r) {
+            const long row = g * SKT_R + r;
+            const bool ok = g < ngroups && row < live;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
+        }
+    };
+    if (PF) load(blockIdx.x, w, gw);
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        f32x4 wn[PF ? SKT_R : 1][2];
+        float gwn = 0.f;
+        if constexpr (PF) load(g + gridDim.x, wn, gwn);
+        else load(g, w, gw);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r)
+                if (skt_lane(gw, p * SKT_R + r) > 0.f) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = w[r][c][q], d = (x - m[p][c][q]) * inv_eps2;     // first row: d = +inf, e = 0
+                            const float e = skt_exp2(-fabsf(d));
+                            s[p][c][q] = d > 0.f ? fmaf(s[p][c][q], e, 1.f) : s[p][c][q] + e;
+                            m[p][c][q] = fmaxf(m[p][c][q], x);
+                        }
+                }
+        if constexpr (PF) {
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
+            }
+            gw = gwn;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const long o = ((long)(p * 2 + view) * a.nb + blockIdx.x) * K;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = 4 * (tid + T * c);
+            if (k < K) {
+                *reinterpret_cast<f32x4*>(a.part + o + k) = s[p][c];
+                *reinterpret_cast<f32x4*>(a.partm + o + k) = m[p][c];
+            }
+        }
+    }
+}
+
+// ---- one Sinkhorn sweep of all problems: part[(p, v)][b][k] = sum over the block's rows n of problem (p, v) of
+//      c_n exp(S_nk / eps + la_k) / sum_j exp(S_nj / eps + la_j)
+// A group's R rows go through a patch TOGETHER (four independent reduction chains, no branch per row): maxima -> barrier ->
+// exponentials and sums -> barrier -> accumulate, and a patch none of them belongs to costs nothing, not even a barrier.  The
+// table rows are ordered by their membership mask (ganecdotes_amd/swav_clustering.py _score_tables), so the rows of a group
+// almost always belong to the same patches — 1.8 of 5 on average; a row of a mixed group that is not in the patch rides along
+// with weight 0.
+// Four values per lane (the group's four rows) reduced over the wave TOGETHER: two butterfly steps hand half of the values to
+// the partner lane each (lane ^ 1 keeps rows {0, 1} or {2, 3}, lane ^ 2 one of its two), after which a lane holds ONE row's
+// sum over its quad — row 2 (lane & 1) + ((lane >> 1) & 1) — and the quads are joined by two rotations inside the row of 16
+// lanes and the two permlane swaps: 7 cross-lane steps instead of 4 x 6.  Inline asm: one instruction per step (fmaxf behind a
+// DPP move costs hipcc a v_mov_dpp and two canonicalising v_max), the s_nop in front of every DPP step is the wait its
+// freshly written source needs.
+#define SKT_DPP_OP(name, op, ctrl)                                                                  \
+    __device__ __forceinline__ float name(float give, float keep) {                                 \
+        float r;                                                                                    \
+        asm volatile("s_nop 1\n\t" op "_dpp %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf"         \
+                     : "=v"(r) : "v"(give), "v"(keep));                                           \
+        return r;                                                                                   \
+    }
+SKT_DPP_OP(skt_add_x1, "v_add_f32", "quad_perm:[1,0,3,2]")
+SKT_DPP_OP(skt_add_x2, "v_add_f32", "quad_perm:[2,3,0,1]")
+SKT_DPP_OP(skt_add_r4, "v_add_f32", "row_ror:4")
+SKT_DPP_OP(skt_add_r8, "v_add_f32", "row_ror:8")
+SKT_DPP_OP(skt_max_x1, "v_max_f32", "quad_perm:[1,0,3,2]")
+SKT_DPP_OP(skt_max_x2, "v_max_f32", "quad_perm:[2,3,0,1]")
+SKT_DPP_OP(skt_max_r4, "v_max_f32", "row_ror:4")
+SKT_DPP_OP(skt_max_r8, "v_max_f32", "row_ror:8")
+#undef SKT_DPP_OP
+__device__ __forceinline__ float skt_vmax(float a, float b) {        // v_max_f32 with no canonicalising twin (no NaN can reach it)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float skt_swap16(float x, bool is_max) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return is_max ? skt_vmax(a, b) : a + b;
+}
+__device__ __forceinline__ float skt_swap32(float x, bool is_max) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return is_max ? skt_vmax(a, b) : a + b;
+}
+// row held by `lane` after the butterfly, and the lane (0 .. 3) that holds row r
+__device__ __forceinline__ int skt_row_of_lane(int lane) { return 2 * (lane & 1) + ((lane >> 1) & 1); }
+__device__ __forceinline__ int skt_lane_of_row(int r) { return 2 * (r & 1) + (r >> 1); }
+// WIDE: over all 64 lanes (a wave's partial of each row); otherwise over each row of 16 lanes (the waves' partials, one per lane)
+template <bool MAX, bool WIDE>
+__device__ __forceinline__ float skt_reduce4(f32x4 v, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float k0 = b0 ? v[2] : v[0], k1 = b0 ? v[3] : v[1], g0 = b0 ? v[0] : v[2], g1 = b0 ? v[1] : v[3];
+    const float s0 = MAX ? skt_max_x1(g0, k0) : skt_add_x1(g0, k0);
+    const float s1 = MAX ? skt_max_x1(g1, k1) : skt_add_x1(g1, k1);
+    const float kk = b1 ? s1 : s0, gg = b1 ? s0 : s1;
+    float s = MAX ? skt_max_x2(gg, kk) : skt_add_x2(gg, kk);
+    s = MAX ? skt_max_r4(s, s) : skt_add_r4(s, s);
+    s = MAX ? skt_max_r8(s, s) : skt_add_r8(s, s);
+    if (WIDE) s = skt_swap32(skt_swap16(s, MAX), MAX);
+    return s;                                            // the total of row skt_row_of_lane(lane)
+}
+static_assert(SKT_R == 4, "a wave's partials of a group are one float4");
+
+template <int P>
+__global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
+    __shared__ __attribute__((aligned(16))) float la2[SKT_LA_CAP];                   // [P][8T], log2 units, -inf past K
+    __shared__ __attribute__((aligned(16))) float redm[16][SKT_R], reds[16][SKT_R];  // [wave][row]: the waves' partials
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int myrow = skt_row_of_lane(lane);
+    if (tid < 16 * SKT_R) {
+        (&redm[0][0])[tid] = -INFINITY;
+        (&reds[0][0])[tid] = 0.f;
+    }
+    const int view = blockIdx.y, K = a.K, W8 = 8 * T;
+    const float* S = a.S[view];
+    for (int p = 0; p < P; ++p)
+        for (int k = tid; k < W8; k += T) la2[p * W8 + k] = k < K ? a.la[(long)(p * 2 + view) * K + k] * SKT_LOG2E : -INFINITY;
+    __syncthreads();
+    const long live = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
+    const long ngroups = (live + SKT_R - 1) / SKT_R;
+    const float sc = a.sc;
+    const float* wt = a.wt + view * a.wt_view;
+    f32x4 u[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p) u[p][0] = u[p][1] = zero4();
+    f32x4 w[SKT_R][2];
+    float gw;
+    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd) {
+        gwd = skt_group_weights<P>(wt, a.npix, g, ngroups, lane);
+#pragma unroll
+        for (int r = 0; r < SKT_R; ++r) {
+            const long row = g * SKT_R + r;
+            const bool ok = g < ngroups && row < live;
+            const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
+        }
+    };
+    load(blockIdx.x, w, gw);
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        f32x4 wn[SKT_R][2];                                 // the next group's rows fly under this group's arithmetic
+        float gwn;
+        load(g + gridDim.x, wn, gwn);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float cw[SKT_R];
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r) {
+                cw[r] = skt_lane(gw, p * SKT_R + r);
+                any = any || cw[r] > 0.f;
+            }
+            if (!any) continue;                             // (uniform over the workgroup: every wave holds the same weights)
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * tid);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * (tid + T));
+            f32x4 e[SKT_R][2];
+            f32x4 mx4;
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e[r][0][q] = fmaf(w[r][0][q], sc, l0[q]);
+                    e[r][1][q] = fmaf(w[r][1][q], sc, l1[q]);
+                    mx = skt_vmax(mx, skt_vmax(e[r][0][q], e[r][1][q]));
+                }
+                mx4[r] = mx;
+            }
+            {   // the wave's maximum of each row -> its slot (lanes 0 .. 3 hold one row each) ; all waves' -> every lane
+                const float m = skt_reduce4<true, true>(mx4, lane);
+                if (lane < SKT_R) redm[wid][myrow] = m;
+                skt_barrier();
+                const float ma = skt_reduce4<true, false>(*reinterpret_cast<const f32x4*>(&redm[lane & 15][0]), lane);
+#pragma unroll
+                for (int r = 0; r < SKT_R; ++r) mx4[r] = skt_lane(ma, skt_lane_of_row(r));
+            }
+            f32x4 sm4;
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e[r][0][q] = skt_exp2(e[r][0][q] - mx4[r]);
+                    e[r][1][q] = skt_exp2(e[r][1][q] - mx4[r]);
+                    sum += e[r][0][q] + e[r][1][q];
+                }
+                sm4[r] = sum;
+            }
+            {
+                const float t = skt_reduce4<false, true>(sm4, lane);
+                if (lane < SKT_R) reds[wid][myrow] = t;
+                skt_barrier();
+                const float ta = skt_reduce4<false, false>(*reinterpret_cast<const f32x4*>(&reds[lane & 15][0]), lane);
+#pragma unroll
+                for (int r = 0; r < SKT_R; ++r) sm4[r] = skt_lane(ta, skt_lane_of_row(r));
+            }
+#pragma unroll
+            for (int r = 0; r < SKT_R; ++r) {
+                const float f = cw[r] * __builtin_amdgcn_rcpf(sm4[r]);          // (1 ulp: the sums it scales carry more)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) u[p][c] += e[r][c] * f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SKT_R; ++r) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
+        }
+        gw = gwn;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const long o = ((long)(p * 2 + view) * a.nb + blockIdx.x) * K;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = 4 * (tid + T * c);
+            if (k < K) *reinterpret_cast<f32x4*>(a.part + o + k) = u[p][c];
+        }
+    }
+}
+
+// la_k = (first ? -cmax_k / eps : la_k) + log r_k - log u_k for all problems (cmax as plain floats); blockIdx.y = problem
+__global__ void sk_table_update_kernel(const float* __restrict__ u, const float* __restrict__ r, int K, int first,
+                                       const float* __restrict__ cmax, float inv_eps, float* __restrict__ la) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long o = (long)blockIdx.y * K + k;
+    const float base = first ? -cmax[o] * inv_eps : la[o];
+    la[o] = base + logf(r ? r[o] : 1.f / (float)K) - logf(u[o]);
+}
+// u *= exp((cmax_local - cmax_global) / eps): a rank's first-pass sums re-based on the maxima over all ranks
+__global__ void sk_table_rebase_kernel(float* __restrict__ u, const float* __restrict__ cm_local, const float* __restrict__ cm_global,
+                                       long n, float inv_eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[i] *= expf((cm_local[i] - cm_global[i]) * inv_eps);
+}
+
+static inline int skt_threads(int K) {
+    int t = 64 * ((K + 511) / 512);
+    return t < 256 ? 256 : t;
+}
+static inline int skt_blocks(long npix) {
+    const long groups = (npix + SKT_R - 1) / SKT_R;
+    return (int)(groups < 256 ? groups : 256);                 // one workgroup per CU (the scaling vectors fill its LDS)
+}
+
+#define SKT_DISPATCH(PV, CALL)                      \
+    switch (PV) {                                   \
+        case 1: { constexpr int P = 1; CALL; } break; \
+        case 2: { constexpr int P = 2; CALL; } break; \
+        case 3: { constexpr int P = 3; CALL; } break; \
+        case 4: { constexpr int P = 4; CALL; } break; \
+        default: { constexpr int P = 5; CALL; } break; \
+    }
+
+}  // namespace gx
+
+using namespace gx;
+
+extern "C" {
+
+int gx_sinkhorn_table_ok(int npatch, int K) {
+    return npatch >= 1 && npatch <= 5 && K > 64 && K % 4 == 0 && K <= 8 * SKT_MAXT && (long)npatch * 8 * skt_threads(K) <= SKT_LA_CAP;
+}
+// workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix]
+static inline size_t skt_parts_floats(int npatch, long npix, int K) { return (size_t)2 * 2 * npatch * skt_blocks(npix) * K; }
+size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K) {
+    return (skt_parts_floats(npatch, npix, K) + (size_t)2 * npatch * npix) * sizeof(float);
+}
+// the row weights of this call into the workspace; returns their view stride (0 = both views share them)
+static long skt_weights(const int* inv, long npix, int npatch, const int* live, const float* c_all, long rows, float c_uniform,
+                        float* wt, hipStream_t st) {
+    const int nv = c_all ? 2 : 1;
+    hipLaunchKernelGGL(sk_table_weights_kernel, dim3(gx_cdiv(npix, 256), npatch, nv), dim3(256), 0, st, inv, npix, npatch, live,
+                       c_all, rows, c_uniform, wt);
+    return c_all ? (long)npatch * npix : 0L;
+}
+
+static int skt_check(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, float eps) {
+    if (!S0 || !S1 || !inv || npix <= 0 || ld < K || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    if (!gx_sinkhorn_table_ok(npatch, K)) return GX_ERR_BAD_ARG;
+    if ((((uintptr_t)S0 | (uintptr_t)S1) & 15) != 0 || (ld % 4) != 0) return GX_ERR_ALIGN;
+    return GX_OK;
+}
+
+// cmax [2 P][K], u [2 P][K] (problem index p * 2 + view): column maxima over the problem's rows and
+// u_k = sum_n exp((S_nk - cmax_k) / eps) — ONE sweep of the live rows of the two tables
+int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
+                            const int* live, float eps, float* cmax, float* u, float* workspace, size_t workspace_bytes,
+                            void* stream) {
+    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps);
+    if (rc) return rc;
+    if (!cmax || !u) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = skt_blocks(npix), nprob = 2 * npatch;
+    SkTabArgs a{};
+    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live;
+    a.sc = SKT_LOG2E / eps; a.part = workspace; a.partm = workspace + (size_t)nprob * nb * K; a.nb = nb;
+    float* wt = workspace + skt_parts_floats(npatch, npix, K);
+    a.wt = wt;
+    a.wt_view = skt_weights(inv, npix, npatch, live, nullptr, 0, 1.f, wt, st);          // membership only
+    GX_CHECK_LAUNCH();
+    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+    GX_CHECK_LAUNCH();
+    // a block that met no row of a problem leaves (-inf, 0): sk_first_from_parts_kernel skips such parts
+    launch_first_from_parts(a.partm, a.part, nb, nprob, K, 1.f / eps, cmax, u, st);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// u [2 P][K]: this rank's column sums of one sweep under the scaling vectors la [2 P][K]
+int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
+                            const int* live, float eps, const float* la, const float* c_all, long rows, float c_uniform,
+                            float* u, float* workspace, size_t workspace_bytes, void* stream) {
+    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps);
+    if (rc) return rc;
+    if (!la || !u || (c_all && rows <= 0) || (!c_all && !(c_uniform > 0.f))) return GX_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K)) return GX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = skt_blocks(npix), nprob = 2 * npatch;
+    SkTabArgs a{};
+    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live;
+    a.sc = SKT_LOG2E / eps; a.la = la; a.part = workspace; a.nb = nb;
+    float* wt = workspace + skt_parts_floats(npatch, npix, K);
+    a.wt = wt;
+    a.wt_view = skt_weights(inv, npix, npatch, live, c_all, rows, c_uniform, wt, st);
+    GX_CHECK_LAUNCH();
+    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+    GX_CHECK_LAUNCH();
+    launch_partial_reduce_batch(workspace, nb, K, nprob, u, st);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// la = (first ? -cmax / eps : la) + log r - log u for the 2 P problems (r_all [2 P][K] or NULL = uniform 1 / K)
+int gx_sinkhorn_table_update(const float* u, const float* r_all, int nprob, int K, int first, const float* cmax, float eps,
+                             float* la, void* stream) {
+    if (!u || !la || nprob <= 0 || K <= 0 || (first && !cmax) || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_table_update_kernel, dim3(gx_cdiv(K, 256), nprob), dim3(256), 0, (hipStream_t)stream, u, r_all, K, first,
+                       cmax, 1.f / eps, la);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// sharded first pass: u (relative to this rank's maxima cm_local) re-based on the all-reduced maxima cm_global
+int gx_sinkhorn_table_rebase(float* u, const float* cm_local, const float* cm_global, long n, float eps, void* stream) {
+    if (!u || !cm_local || !cm_global || n <= 0 || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sk_table_rebase_kernel, dim3(gx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, u, cm_local, cm_global, n,
+                       1.f / eps);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// The whole single-rank solve: la [2 P][K] (problem p * 2 + view).  cmax / u: scratch [2 P][K] each.
+int gx_sinkhorn_table(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, const int* live,
+                      float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
+                      float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream) {
+    if (niters < 1 || !la) return GX_ERR_BAD_ARG;
+    int rc = gx_sinkhorn_table_first(S0, S1, ld, K, inv, npix, npatch, live, eps, cmax, u, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 1, cmax, eps, la, stream);
+    if (rc) return rc;
+    for (int it = 1; it < niters; ++it) {
+        rc = gx_sinkhorn_table_sweep(S0, S1, ld, K, inv, npix, npatch, live, eps, la, c_all, rows, c_uniform, u, workspace,
+                                     workspace_bytes, stream);
+        if (rc) return rc;
+        rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 0, nullptr, eps, la, stream);
+        if (rc) return rc;
+    }
+    return GX_OK;
+}
+
+}  // extern "C"

@@ -706,6 +706,16 @@ __global__ __launch_bounds__(256) void sk_first_from_parts_kernel(const float* _
         u[(long)gi * N + col] = a;
     }
 }
+void launch_partial_reduce_batch(const float* part, int nblk, int K, int nprob, float* out, hipStream_t stream) {
+    int kx = 1;
+    while (kx < 64 && kx < K) kx <<= 1;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((K + kx - 1) / kx, nprob), dim3(256), 0, stream, part, nblk, K, 1.f, 0.f, out, kx);
+}
+void launch_first_from_parts(const float* cmp, const float* usp, int per, int nprob, int K, float inv_eps, float* cmax, float* u,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(sk_first_from_parts_kernel, dim3(gx_cdiv(K, 64), nprob), dim3(256), 0, stream, cmp, usp, per, nprob * per, K,
+                       inv_eps, cmax, u);
+}
 __global__ void sk_first_preset_kernel(const float* __restrict__ u_local, const float* __restrict__ cmax_local, int K, float inv_eps,
                                        const unsigned* __restrict__ cmax, float* __restrict__ u) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1260,6 +1260,96 @@ class SinkhornBatch:
         return self
 
 
+def sinkhorn_table_ok(npatch, k):
+    """the table solver takes this many patches and prototypes (their scaling vectors must fit one CU's LDS)"""
+    return bool(lib().gx_sinkhorn_table_ok(int(npatch), int(k)))
+
+
+class SinkhornTable:
+    """All Sinkhorn problems of a many-prototype step solved ON the two per-pixel score tables (csrc/gx_sktab.hip): problem
+    (p, v) = the rows of view v's table that patch p drew; every pass reads a table row ONCE for all the patches that drew it.
+
+    s_tab / t_tab (npix, K); inv (P, npix) int32: row of table row q in patch p's problem, -1 = not drawn; live: int32 HIP
+    scalar (the drawn pixels are table rows [0, live)) or None.  Problem index = p * 2 + view: `la` (2P, K) is what
+    swapped_ce_pixels_tab reads; r (2P, K) / c (2P, rows) = the 'image' source pdf's marginals (c in the order inv numbers a
+    problem's rows) or None = uniform with c_uniform the row marginal.  rowmaps (optional, list of P int32 vectors): lets
+    self[i] hand out problem i's scores / codes (tests)."""
+
+    def __init__(self, s_tab, t_tab, inv, live, eps, niters, c_uniform, rows, r=None, c=None, rowmaps=None, tag="sktab"):
+        _chk(s_tab, t_tab, r, c)
+        npix, k = s_tab.shape
+        if tuple(t_tab.shape) != (npix, k) or t_tab.stride(0) != s_tab.stride(0) or inv.dtype != torch.int32 or \
+                inv.dim() != 2 or inv.shape[1] != npix or not inv.is_contiguous() or not inv.is_cuda:
+            raise RuntimeError("SinkhornTable: shape mismatch")
+        if live is not None and (live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1):
+            raise RuntimeError("SinkhornTable: `live` is an int32 HIP scalar")
+        if (r is None) != (c is None):
+            raise RuntimeError("SinkhornTable: r and c come together")
+        self.P = inv.shape[0]
+        self.nprob = 2 * self.P
+        if not sinkhorn_table_ok(self.P, k):
+            raise RuntimeError(f"SinkhornTable: {self.P} patches x {k} prototypes do not fit (ops.sinkhorn_table_ok)")
+        if r is not None and (tuple(r.shape) != (self.nprob, k) or tuple(c.shape) != (self.nprob, rows)):
+            raise RuntimeError("SinkhornTable: r is (2P, K), c is (2P, rows)")
+        self.S = (s_tab, t_tab)
+        self.inv, self.live, self.K, self.npix, self.rows = inv, live, k, npix, int(rows)
+        self.eps, self.niters, self.c_uniform = float(eps), int(niters), float(c_uniform)
+        self.r, self.c, self.rowmaps, self.tag = r, c, rowmaps, tag
+        dev = s_tab.device
+        self.la = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
+        self.cmax = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
+        self.u = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
+        self.wsb = lib().gx_sinkhorn_table_workspace_bytes(self.P, npix, k)
+        self.ws = workspace(tag, self.wsb, dev)
+
+    def _args(self):
+        s, t = self.S
+        return (_p(s), _p(t), s.stride(0), self.K, _p(self.inv), self.npix, self.P, _p(self.live), self.eps)
+
+    def first(self):
+        _lib.check(lib().gx_sinkhorn_table_first(*self._args(), _p(self.cmax), _p(self.u), _p(self.ws), self.wsb, _stream()),
+                   "gx_sinkhorn_table_first")
+
+    def sweep(self):
+        _lib.check(lib().gx_sinkhorn_table_sweep(*self._args(), _p(self.la), _p(self.c), self.rows, self.c_uniform, _p(self.u),
+                                                 _p(self.ws), self.wsb, _stream()), "gx_sinkhorn_table_sweep")
+
+    def update(self, first, cmax=None):
+        _lib.check(lib().gx_sinkhorn_table_update(_p(self.u), _p(self.r), self.nprob, self.K, int(first),
+                                                  _p(self.cmax if cmax is None else cmax), self.eps, _p(self.la), _stream()),
+                   "gx_sinkhorn_table_update")
+
+    def run(self, reduce=None):
+        """reduce(tensor, 'max' | 'sum') all-reduces in place over the ranks (rows sharded, c_uniform = 1 / global rows):
+        one MAX exchange of the 2P K column maxima and `niters` SUM exchanges of the 2P K column sums"""
+        # bytes: the live rows of both tables once per pass (the byte accounting of the caller's live_frac is not known here:
+        # the whole tables are charged by the caller through `record`)
+        if reduce is None:
+            _lib.check(lib().gx_sinkhorn_table(*self._args(), self.niters, _p(self.r), _p(self.c), self.rows, self.c_uniform,
+                                               _p(self.la), _p(self.cmax), _p(self.u), _p(self.ws), self.wsb, _stream()),
+                       "gx_sinkhorn_table")
+            return self
+        self.first()
+        cm = self.cmax.clone()
+        reduce(cm, "max")
+        _lib.check(lib().gx_sinkhorn_table_rebase(_p(self.u), _p(self.cmax), _p(cm), self.u.numel(), self.eps, _stream()),
+                   "gx_sinkhorn_table_rebase")
+        reduce(self.u, "sum")
+        self.update(True, cmax=cm)
+        for _ in range(1, self.niters):
+            self.sweep()
+            reduce(self.u, "sum")
+            self.update(False)
+        return self
+
+    def __getitem__(self, i):
+        """problem i = p * 2 + view as a Sinkhorn state (scores(), codes()); needs `rowmaps`"""
+        if self.rowmaps is None:
+            raise RuntimeError("SinkhornTable: built without rowmaps")
+        return Sinkhorn(self.S[i % 2], self.eps, self.niters, c_uniform=self.c_uniform, tag=f"{self.tag}.{i}", la=self.la[i],
+                        rowmap=self.rowmaps[i // 2])
+
+
 def hist_marginal(x, bins, reduce=None):
     """normalised torch.histc(x, bins)+1e-9 with h[0]=h[1]; with `reduce` the data range and the
     bin counts are all-reduced over the ranks (x = this rank's part of the norm maps)."""

@@ -215,7 +215,7 @@ class SwAVClustering(ViewMixin):
                 best, best_eff = s, eff
         return int(best if best_eff > 0 else max(1, min(want, cap)))
 
-    def _score_tables(self, pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, c_one):
+    def _score_tables(self, pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, c_one, by_mask=False):
         """The per-pixel score tables of a many-prototype step (swav_clustering.py:171-182 once per view over the
         pixels instead of once per patch over the samples): the drawn pixels first, their count on the device, each patch's samples
         as sorted table rows, z_hat of the table's pixels and `S = z_hat Wc^T + b` per view.  c_one (2, rows): the 'image' source
@@ -229,7 +229,15 @@ class SwAVClustering(ViewMixin):
         drawn = torch.zeros(npix, dtype=torch.bool, device=dev)
         for f_ in flat:
             drawn[f_] = True
-        order = torch.argsort((~drawn).to(torch.int8), stable=True)                   # drawn pixel ids first
+        if by_mask and P <= 14:
+            # ... and, for the table Sinkhorn (csrc/gx_sktab.hip), the drawn pixels grouped by WHICH patches drew them: the rows of
+            # a 4-row group then go through the same patches together
+            mkey = torch.zeros(npix, dtype=torch.int16, device=dev)
+            for p_, f_ in enumerate(flat):
+                mkey[f_] += 1 << p_
+            order = torch.argsort(torch.where(mkey > 0, mkey, torch.full_like(mkey, 1 << 14)), stable=True)
+        else:
+            order = torch.argsort((~drawn).to(torch.int8), stable=True)               # drawn pixel ids first
         live = drawn.sum(dtype=torch.int32).reshape(1)
         live_frac = 1.0 - (1.0 - N / float(hw * hw)) ** P                            # its expectation (FLOP accounting)
         ar32 = torch.arange(npix, dtype=torch.int32, device=dev)
@@ -415,37 +423,50 @@ class SwAVClustering(ViewMixin):
             pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
         tb = None
         if stab:
-            tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one)
+            tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one,
+                                    by_mask=ngroups == 1 and sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(P, K))
             stab = tb is not None
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
             G = len(pnos)
             if stab:
                 rowmaps = [tb.rowmaps[pno] for pno in pnos]                               # a patch's samples -> table rows
-                with self._timed("sinkhorn"):
-                    # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
-                    # patch's sorted rows (its pixels are a contiguous run of the table)
-                    tabs, maps, rl, cl = [], [], [], []
-                    for gi, pno in enumerate(pnos):
-                        for v in range(2):
-                            for g in range(ngroups):
-                                tabs.append(tb.S[v])
-                                maps.append(rowmaps[gi] if ngroups == 1 else rowmaps[gi].view(B, N)[g])
-                                if marg is not None:
-                                    rl.append(r_one[v] if ngroups == 1 else r_one[v][g])
-                                    cl.append(tb.c_sorted[pno][v] if ngroups == 1 else tb.c_sorted[pno][v][g])
-                    skb = ops.SinkhornBatch.from_rows(tabs, maps, self.eps, self.niters, 1.0 / nglob, sorted_rows=True,
-                                                      r=rl or None, c=cl or None)
-                    if ngroups == 1:
-                        for sk_ in skb.probs:  # column maxima + first pass of every problem in ONE sweep of its rows
-                            sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
-                    # (per-image scope: 2 B P small problems — their maxima and first pass are two more launches of the batch)
-                    skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
-                    del tabs, maps, rl, cl
-                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
+                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)           # table row -> its row in patch gi's problem
                 nrow = torch.arange(rows, dtype=torch.int32, device=dev)
                 for gi in range(G):
                     inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
+                with self._timed("sinkhorn"):
+                    if ngroups == 1 and sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(G, K):
+                        # one problem per patch and view: ALL of them in one pass over the live rows of the two tables per
+                        # iteration — a row several patches drew is read once (csrc/gx_sktab.hip)
+                        r_tab = c_tab = None
+                        if marg is not None:              # problem index = patch * 2 + view
+                            r_tab = torch.stack([r_one[v] for _ in pnos for v in range(2)])
+                            c_tab = torch.stack([tb.c_sorted[pno][v] for pno in pnos for v in range(2)])
+                        skb = ops.SinkhornTable(tb.S[0], tb.S[1], inv, tb.live, self.eps, self.niters, 1.0 / nglob, rows,
+                                                r=r_tab, c=c_tab, rowmaps=rowmaps if return_aux else None)
+                        with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
+                            skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+                    else:
+                        # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
+                        # patch's sorted rows (its pixels are a contiguous run of the table)
+                        tabs, maps, rl, cl = [], [], [], []
+                        for gi, pno in enumerate(pnos):
+                            for v in range(2):
+                                for g in range(ngroups):
+                                    tabs.append(tb.S[v])
+                                    maps.append(rowmaps[gi] if ngroups == 1 else rowmaps[gi].view(B, N)[g])
+                                    if marg is not None:
+                                        rl.append(r_one[v] if ngroups == 1 else r_one[v][g])
+                                        cl.append(tb.c_sorted[pno][v] if ngroups == 1 else tb.c_sorted[pno][v][g])
+                        skb = ops.SinkhornBatch.from_rows(tabs, maps, self.eps, self.niters, 1.0 / nglob, sorted_rows=True,
+                                                          r=rl or None, c=cl or None)
+                        if ngroups == 1:
+                            for sk_ in skb.probs:  # column maxima + first pass of every problem in ONE sweep of its rows
+                                sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
+                        # (per-image scope: 2 B P small problems — their maxima and first pass are two more launches of the batch)
+                        skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+                        del tabs, maps, rl, cl
                 ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, ngroups, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
                                           gb, 0.0 if first_acc else 1.0, live=tb.live, live_frac=tb.live_frac,
                                           row_group=tb.row_group if ngroups > 1 else None)

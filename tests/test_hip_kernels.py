@@ -1014,6 +1014,88 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
             assert rel_err(a[i].codes(), ref.codes()) < 1e-4
 
 
+@pytest.mark.parametrize("k,npix,rows,P,live_n,pdf", [(200, 1500, 600, 5, 1300, False), (5000, 700, 333, 3, None, False),
+                                                     (132, 9000, 4097, 2, 8000, True), (4000, 2600, 900, 5, 2401, True),
+                                                     (6144, 300, 120, 5, 290, False), (1024, 500, 77, 1, None, False)])
+def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, pdf):
+    """gx_sinkhorn_table (every problem of a step — patches x views — solved on the two per-pixel score tables, a table row
+    read once per pass for all the patches that drew it) against the same problems solved one by one on gathered copies of
+    their rows, and its first pass against fp64; rows past `live` and rows no patch drew carry scores that would swamp
+    everything if they leaked in; with the 'image' pdf's row / prototype marginals; and split over two faked ranks (rows of
+    every problem in two halves, the exchanges as sums / maxima of the two) = the single-rank solve"""
+    torch.manual_seed(k + npix)
+    drawn = live_n if live_n is not None else npix
+    eps, niters = 0.005 if k >= 1000 else 0.05, 6
+    tabs = [(torch.randn(npix, k) * 0.2) for _ in range(2)]
+    rowmaps = [torch.sort(torch.randperm(drawn)[:rows]).values for _ in range(P)]
+    used = torch.zeros(npix, dtype=torch.bool)
+    for m in rowmaps:
+        used[m] = True
+    for t in tabs:
+        t[~used] += 40.0                                   # rows of no problem (drawn by no patch, or past the live bound)
+    tabd = [t.cuda() for t in tabs]
+    inv = torch.full((P, npix), -1, dtype=torch.int32)
+    for p in range(P):
+        inv[p, rowmaps[p]] = torch.arange(rows, dtype=torch.int32)
+    inv = inv.cuda()
+    live = None if live_n is None else torch.tensor([live_n], dtype=torch.int32, device="cuda")
+    r = c = None
+    if pdf:
+        r = torch.rand(2 * P, k) + 0.1
+        r = (r / r.sum(1, keepdim=True)).cuda()
+        c = torch.rand(2 * P, rows) + 0.1
+        c = (c / c.sum(1, keepdim=True)).cuda()
+    assert ops.sinkhorn_table_ok(P, k)
+    st = ops.SinkhornTable(tabd[0], tabd[1], inv, live, eps, niters, 1.0 / rows, rows, r=r, c=c,
+                           rowmaps=[m.to(torch.int32).cuda() for m in rowmaps])
+    st.first()
+    for i in (0, 2 * P - 1):
+        sub = tabs[i % 2][rowmaps[i // 2]].double()
+        want_cm = sub.max(0).values
+        assert torch.equal(st.cmax[i].cpu().double(), want_cm)
+        assert rel_err(st.u[i], torch.exp((sub - want_cm) / eps).sum(0)) < 2e-5
+    st.run()
+    for i in range(2 * P):
+        sub = tabd[i % 2][rowmaps[i // 2].cuda()].contiguous()
+        ref = ops.Sinkhorn(sub, eps, niters, r=None if r is None else r[i].contiguous(), c=None if c is None else c[i].contiguous()).run()
+        assert float((st.la[i] - ref.la).abs().max()) < 2e-4, i
+        if i in (0, 2 * P - 1):
+            assert rel_err(st[i].codes(), ref.codes()) < 1e-4
+    # two faked ranks: each holds half of the table rows (its own tables, inv numbering its own half of every problem)
+    half = [torch.arange(npix) % 2 == h for h in range(2)]
+    parts = []
+    for h in range(2):
+        rows_h = torch.nonzero(half[h]).squeeze(1)
+        invh = torch.full((P, rows_h.numel()), -1, dtype=torch.int32)
+        ch = None if c is None else torch.zeros(2 * P, rows, device="cuda")
+        for p in range(P):
+            sel = inv[p].cpu()[rows_h]
+            pos = torch.nonzero(sel >= 0).squeeze(1)
+            invh[p, pos] = torch.arange(pos.numel(), dtype=torch.int32)
+            if c is not None:
+                for v in range(2):
+                    ch[p * 2 + v, :pos.numel()] = c[p * 2 + v][sel[pos].long()]
+        parts.append(ops.SinkhornTable(tabd[0][rows_h.cuda()].contiguous(), tabd[1][rows_h.cuda()].contiguous(), invh.cuda(), None, eps,
+                                       niters, 1.0 / rows, rows, r=r, c=ch, tag=f"skt_half{h}"))
+    for q in parts:
+        q.first()
+    cm = torch.maximum(parts[0].cmax, parts[1].cmax)
+    for q in parts:
+        ops._lib.check(ops.lib().gx_sinkhorn_table_rebase(ops._p(q.u), ops._p(q.cmax), ops._p(cm), q.u.numel(), eps, ops._stream()), "rebase")
+    usum = parts[0].u + parts[1].u
+    for q in parts:
+        q.u.copy_(usum)
+        q.update(True, cmax=cm)
+    for _ in range(1, niters):
+        for q in parts:
+            q.sweep()
+        usum = parts[0].u + parts[1].u
+        for q in parts:
+            q.u.copy_(usum)
+            q.update(False)
+    assert float((parts[0].la - st.la).abs().max()) < 2e-4 and torch.equal(parts[0].la, parts[1].la)
+
+
 @pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190), (6000, None)])
 def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
     """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
