@@ -35,6 +35,9 @@ struct SkTabArgs {
     const int* live;         // device scalar: the drawn pixels are table rows [0, *live) (NULL: npix)
     float sc;                // log2(e) / eps
     const float* la;         // [(p * 2 + view)][K] log scaling vectors (sweep)
+    const float* stats;      // [(p * 2 + view)][2] = {largest step of la since the last sweep (log2 units), 1 if the shifted form is safe}
+                             // from the update before this sweep, or NULL: every row's maximum is taken exactly
+    float* ltab;             // [2][P][npix] log2-sum-exp of every (view, patch, table row) under the la of the sweep that wrote it
     float* part;             // [(p * 2 + view)][nb][K] column sums of the block (first pass: relative to partm)
     float* partm;            // first pass: [(p * 2 + view)][nb][K] running column maxima of the block
     int nb;
@@ -63,12 +66,12 @@ __global__ void sk_table_weights_kernel(const int* __restrict__ inv, long npix, 
 }
 
 // the weights of the R rows of group g under the P patches: lane p * R + r of every wave holds wt[p][g R + r]
-template <int P>
+template <int P, int R = SKT_R>
 __device__ __forceinline__ float skt_group_weights(const float* __restrict__ wt, long npix, long g, long ngroups, int lane) {
-    const int p = lane / SKT_R, r = lane % SKT_R;
-    const long row = g * SKT_R + r;
+    const int p = lane / R, r = lane % R;
+    const long row = g * R + r;
     float w = 0.f;
-    if (lane < P * SKT_R && g < ngroups && row < npix) w = wt[(long)p * npix + row];
+    if (lane < P * R && g < ngroups && row < npix) w = wt[(long)p * npix + row];
     return w;
 }
 __device__ __forceinline__ float skt_lane(float v, int l) {
@@ -77,12 +80,15 @@ __device__ __forceinline__ float skt_lane(float v, int l) {
 
 template <int P>
 __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
-    constexpr bool PF = P <= 3;                  // the next group's rows in flight under this one's (registers permitting)
+    // the next group's rows are in flight under this one's arithmetic; four rows per group while the registers last (the
+    // running (max, sum) pairs are 16 P of them), two past three patches
+    constexpr bool PF = true;
+    constexpr int R = P <= 3 ? SKT_R : 2;
     const int T = blockDim.x, tid = threadIdx.x;
     const int view = blockIdx.y, K = a.K;
     const float* S = a.S[view];
     const long live = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
-    const long ngroups = (live + SKT_R - 1) / SKT_R;
+    const long ngroups = (live + R - 1) / R;
     const float inv_eps2 = a.sc;                                       // log2(e) / eps
     const float* wt = a.wt + view * a.wt_view;
     const int lane = tid & 63;
@@ -94,13 +100,13 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
             m[p][c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             s[p][c] = zero4();
         }
-    f32x4 w[SKT_R][2];
+    f32x4 w[R][2];
     float gw;
-    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd) {
-        gwd = skt_group_weights<P>(wt, a.npix, g, ngroups, lane);
+    auto load = [&](long g, f32x4 (&dst)[R][2], float& gwd) {
+        gwd = skt_group_weights<P, R>(wt, a.npix, g, ngroups, lane);
 #pragma unroll
-        for (int r = 0; r < SKT_R; ++r) {
-            const long row = g * SKT_R + r;
+        for (int r = 0; r < R; ++r) {
+            const long row = g * R + r;
             const bool ok = g < ngroups && row < live;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
 #pragma unroll
@@ -109,15 +115,15 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     };
     if (PF) load(blockIdx.x, w, gw);
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        f32x4 wn[PF ? SKT_R : 1][2];
+        f32x4 wn[PF ? R : 1][2];
         float gwn = 0.f;
         if constexpr (PF) load(g + gridDim.x, wn, gwn);
         else load(g, w, gw);
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r)
-                if (skt_lane(gw, p * SKT_R + r) > 0.f) {
+            for (int r = 0; r < R; ++r)
+                if (skt_lane(gw, p * R + r) > 0.f) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
                 }
         if constexpr (PF) {
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r) {
+            for (int r = 0; r < R; ++r) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
             }
@@ -214,16 +220,20 @@ __device__ __forceinline__ float skt_reduce4(f32x4 v, int lane) {
 }
 static_assert(SKT_R == 4, "a wave's partials of a group are one float4");
 
-template <int P>
+template <int P, bool SHIFT>
 __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     __shared__ __attribute__((aligned(16))) float la2[SKT_LA_CAP];                   // [P][8T], log2 units, -inf past K
-    __shared__ __attribute__((aligned(16))) float redm[16][SKT_R], reds[16][SKT_R];  // [wave][row]: the waves' partials
+    // the waves' partials, [wave][row]; the sums alternate between two buffers from one patch block to the next (a shifted
+    // block has ONE barrier: a fast wave's next sums must not land in the slots a slow wave is still reading)
+    __shared__ __attribute__((aligned(16))) float redm[16][SKT_R], reds[2][16][SKT_R];
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int myrow = skt_row_of_lane(lane);
     if (tid < 16 * SKT_R) {
         (&redm[0][0])[tid] = -INFINITY;
-        (&reds[0][0])[tid] = 0.f;
+        (&reds[0][0][0])[tid] = 0.f;
+        (&reds[1][0][0])[tid] = 0.f;
     }
+    int par = 0;
     const int view = blockIdx.y, K = a.K, W8 = 8 * T;
     const float* S = a.S[view];
     for (int p = 0; p < P; ++p)
@@ -233,13 +243,33 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     const long ngroups = (live + SKT_R - 1) / SKT_R;
     const float sc = a.sc;
     const float* wt = a.wt + view * a.wt_view;
+    float* ltab = a.ltab + (long)view * P * a.npix;
+    // Two forms, two instantiations.  SHIFT (every sweep after the first): a row's scores are exponentiated relative to
+    // sigma = its log2-sum-exp under the PREVIOUS sweep's scaling vector + the largest step any la_k took since — an upper
+    // bound of its new maximum that is known before the row is touched, so the maxima pass, its barrier and its LDS round
+    // trip drop out.  Nothing overflows (every term <= 1); the largest term is >= 2^-(log2 K + spread of the steps), and the
+    // update that made la vouches for a spread below 64 (stats[1]).  The problems it does not vouch for — and all of them in
+    // the first sweep, stats == NULL — go through the exact form, which takes the row maxima first; a launch works on its own
+    // problems only and returns at once when it has none.
+    float dmx[P];
+    bool sel[P];
+    bool some = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int flag = a.stats ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(a.stats)[(p * 2 + view) * 2 + 1]) : 0;
+        dmx[p] = SHIFT ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.stats[(p * 2 + view) * 2]))) : 0.f;
+        sel[p] = SHIFT ? flag != 0 : flag == 0;
+        some = some || sel[p];
+    }
+    if (!some) return;
     f32x4 u[P][2];
 #pragma unroll
     for (int p = 0; p < P; ++p) u[p][0] = u[p][1] = zero4();
     f32x4 w[SKT_R][2];
-    float gw;
-    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd) {
+    float gw, gl;
+    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd, float& gld) {
         gwd = skt_group_weights<P>(wt, a.npix, g, ngroups, lane);
+        gld = SHIFT ? skt_group_weights<P>(ltab, a.npix, g, ngroups, lane) : 0.f;
 #pragma unroll
         for (int r = 0; r < SKT_R; ++r) {
             const long row = g * SKT_R + r;
@@ -249,11 +279,11 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
             for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
         }
     };
-    load(blockIdx.x, w, gw);
+    load(blockIdx.x, w, gw, gl);
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         f32x4 wn[SKT_R][2];                                 // the next group's rows fly under this group's arithmetic
-        float gwn;
-        load(g + gridDim.x, wn, gwn);
+        float gwn, gln;
+        load(g + gridDim.x, wn, gwn, gln);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             float cw[SKT_R];
@@ -263,23 +293,27 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                 cw[r] = skt_lane(gw, p * SKT_R + r);
                 any = any || cw[r] > 0.f;
             }
-            if (!any) continue;                             // (uniform over the workgroup: every wave holds the same weights)
+            if (!any || !sel[p]) continue;                  // (uniform over the workgroup: every wave holds the same weights)
             const f32x4 l0 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * tid);
             const f32x4 l1 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * (tid + T));
             f32x4 e[SKT_R][2];
             f32x4 mx4;
+            if constexpr (SHIFT) {
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r) {
-                float mx = -INFINITY;
+                for (int r = 0; r < SKT_R; ++r) mx4[r] = cw[r] > 0.f ? skt_lane(gl, p * SKT_R + r) + dmx[p] : 0.f;
+            } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e[r][0][q] = fmaf(w[r][0][q], sc, l0[q]);
-                    e[r][1][q] = fmaf(w[r][1][q], sc, l1[q]);
-                    mx = skt_vmax(mx, skt_vmax(e[r][0][q], e[r][1][q]));
+                for (int r = 0; r < SKT_R; ++r) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e[r][0][q] = fmaf(w[r][0][q], sc, l0[q]);
+                        e[r][1][q] = fmaf(w[r][1][q], sc, l1[q]);
+                        mx = skt_vmax(mx, skt_vmax(e[r][0][q], e[r][1][q]));
+                    }
+                    mx4[r] = mx;
                 }
-                mx4[r] = mx;
-            }
-            {   // the wave's maximum of each row -> its slot (lanes 0 .. 3 hold one row each) ; all waves' -> every lane
+                // the wave's maximum of each row -> its slot (lanes 0 .. 3 hold one row each) ; all waves' -> every lane
                 const float m = skt_reduce4<true, true>(mx4, lane);
                 if (lane < SKT_R) redm[wid][myrow] = m;
                 skt_barrier();
@@ -293,26 +327,29 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                 float sum = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    e[r][0][q] = skt_exp2(e[r][0][q] - mx4[r]);
-                    e[r][1][q] = skt_exp2(e[r][1][q] - mx4[r]);
+                    e[r][0][q] = skt_exp2((SHIFT ? fmaf(w[r][0][q], sc, l0[q]) : e[r][0][q]) - mx4[r]);
+                    e[r][1][q] = skt_exp2((SHIFT ? fmaf(w[r][1][q], sc, l1[q]) : e[r][1][q]) - mx4[r]);
                     sum += e[r][0][q] + e[r][1][q];
                 }
                 sm4[r] = sum;
             }
             {
                 const float t = skt_reduce4<false, true>(sm4, lane);
-                if (lane < SKT_R) reds[wid][myrow] = t;
+                if (lane < SKT_R) reds[par][wid][myrow] = t;
                 skt_barrier();
-                const float ta = skt_reduce4<false, false>(*reinterpret_cast<const f32x4*>(&reds[lane & 15][0]), lane);
+                const float ta = skt_reduce4<false, false>(*reinterpret_cast<const f32x4*>(&reds[par][lane & 15][0]), lane);
+                par ^= 1;
 #pragma unroll
                 for (int r = 0; r < SKT_R; ++r) sm4[r] = skt_lane(ta, skt_lane_of_row(r));
             }
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r) {
-                const float f = cw[r] * __builtin_amdgcn_rcpf(sm4[r]);          // (1 ulp: the sums it scales carry more)
+            for (int r = 0; r < SKT_R; ++r)
+                if (cw[r] > 0.f) {                          // (a row of a mixed group that is not in this patch: nothing of it counts)
+                    const float f = cw[r] * __builtin_amdgcn_rcpf(sm4[r]);          // (1 ulp: the sums it scales carry more)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) u[p][c] += e[r][c] * f;
-            }
+                    for (int c = 0; c < 2; ++c) u[p][c] += e[r][c] * f;
+                    if (tid == 0) ltab[(long)p * a.npix + g * SKT_R + r] = mx4[r] + __builtin_amdgcn_logf(sm4[r]);
+                }
         }
 #pragma unroll
         for (int r = 0; r < SKT_R; ++r) {
@@ -320,9 +357,11 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
             for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
         }
         gw = gwn;
+        gl = gln;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+        if (!sel[p]) continue;
         const long o = ((long)(p * 2 + view) * a.nb + blockIdx.x) * K;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -332,14 +371,30 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     }
 }
 
-// la_k = (first ? -cmax_k / eps : la_k) + log r_k - log u_k for all problems (cmax as plain floats); blockIdx.y = problem
-__global__ void sk_table_update_kernel(const float* __restrict__ u, const float* __restrict__ r, int K, int first,
-                                       const float* __restrict__ cmax, float inv_eps, float* __restrict__ la) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    const long o = (long)blockIdx.y * K + k;
-    const float base = first ? -cmax[o] * inv_eps : la[o];
-    la[o] = base + logf(r ? r[o] : 1.f / (float)K) - logf(u[o]);
+// la_k = (first ? -cmax_k / eps : la_k) + log r_k - log u_k for all problems (cmax as plain floats); blockIdx.x = problem.
+// stats (optional) [problem][2]: the largest step any la_k took, in log2 units, and 1 (as an int) if the steps of the problem
+// lie within 64 log2 units of each other and are finite — what lets the next sweep run in its shifted form
+__global__ __launch_bounds__(256) void sk_table_update_kernel(const float* __restrict__ u, const float* __restrict__ r, int K, int first,
+                                                              const float* __restrict__ cmax, float inv_eps, float* __restrict__ la,
+                                                              float* __restrict__ stats) {
+    __shared__ float red[16];
+    const long o0 = (long)blockIdx.x * K;
+    float dmax = -INFINITY, dmin = INFINITY;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const long o = o0 + k;
+        const float d = logf(r ? r[o] : 1.f / (float)K) - logf(u[o]);
+        la[o] = (first ? -cmax[o] * inv_eps : la[o]) + d;
+        dmax = fmaxf(dmax, d);                  // (a NaN step is dropped by fmaxf / fminf and caught by the spread test below
+        dmin = fminf(dmin, d == d ? d : INFINITY);            //  only if every step is one; an infinite one fails the test)
+        if (!(d == d)) dmax = INFINITY;
+    }
+    dmax = gx_block_max(dmax, red);
+    dmin = -gx_block_max(-dmin, red);
+    if (stats && threadIdx.x == 0) {
+        const float spread = (dmax - dmin) * SKT_LOG2E;
+        stats[blockIdx.x * 2] = dmax * SKT_LOG2E;
+        reinterpret_cast<int*>(stats)[blockIdx.x * 2 + 1] = (!first && spread < 64.f && fabsf(dmax) < 1e30f) ? 1 : 0;
+    }
 }
 // u *= exp((cmax_local - cmax_global) / eps): a rank's first-pass sums re-based on the maxima over all ranks
 __global__ void sk_table_rebase_kernel(float* __restrict__ u, const float* __restrict__ cm_local, const float* __restrict__ cm_global,
@@ -375,10 +430,11 @@ extern "C" {
 int gx_sinkhorn_table_ok(int npatch, int K) {
     return npatch >= 1 && npatch <= 5 && K > 64 && K % 4 == 0 && K <= 8 * SKT_MAXT && (long)npatch * 8 * skt_threads(K) <= SKT_LA_CAP;
 }
-// workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix]
+// workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix] | log2-sum-exp of the rows [2][P][npix]
+// (the last part carries a sweep's row normalisers to the next one: the calls of one solve share their workspace)
 static inline size_t skt_parts_floats(int npatch, long npix, int K) { return (size_t)2 * 2 * npatch * skt_blocks(npix) * K; }
 size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K) {
-    return (skt_parts_floats(npatch, npix, K) + (size_t)2 * npatch * npix) * sizeof(float);
+    return (skt_parts_floats(npatch, npix, K) + (size_t)4 * npatch * npix) * sizeof(float);
 }
 // the row weights of this call into the workspace; returns their view stride (0 = both views share them)
 static long skt_weights(const int* inv, long npix, int npatch, const int* live, const float* c_all, long rows, float c_uniform,
@@ -424,8 +480,8 @@ int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, co
 
 // u [2 P][K]: this rank's column sums of one sweep under the scaling vectors la [2 P][K]
 int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, const float* la, const float* c_all, long rows, float c_uniform,
-                            float* u, float* workspace, size_t workspace_bytes, void* stream) {
+                            const int* live, float eps, const float* la, const float* stats, const float* c_all, long rows,
+                            float c_uniform, float* u, float* workspace, size_t workspace_bytes, void* stream) {
     int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps);
     if (rc) return rc;
     if (!la || !u || (c_all && rows <= 0) || (!c_all && !(c_uniform > 0.f))) return GX_ERR_BAD_ARG;
@@ -434,13 +490,19 @@ int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, co
     const int nb = skt_blocks(npix), nprob = 2 * npatch;
     SkTabArgs a{};
     a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live;
-    a.sc = SKT_LOG2E / eps; a.la = la; a.part = workspace; a.nb = nb;
+    a.sc = SKT_LOG2E / eps; a.la = la; a.stats = stats; a.part = workspace; a.nb = nb;
     float* wt = workspace + skt_parts_floats(npatch, npix, K);
     a.wt = wt;
+    a.ltab = wt + (size_t)2 * npatch * npix;
     a.wt_view = skt_weights(inv, npix, npatch, live, c_all, rows, c_uniform, wt, st);
     GX_CHECK_LAUNCH();
-    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+    // the exact form for the problems the update does not vouch for (all of them without stats), the shifted form for the others
+    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
     GX_CHECK_LAUNCH();
+    if (stats) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+        GX_CHECK_LAUNCH();
+    }
     launch_partial_reduce_batch(workspace, nb, K, nprob, u, st);
     GX_CHECK_LAUNCH();
     return GX_OK;
@@ -448,10 +510,10 @@ int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, co
 
 // la = (first ? -cmax / eps : la) + log r - log u for the 2 P problems (r_all [2 P][K] or NULL = uniform 1 / K)
 int gx_sinkhorn_table_update(const float* u, const float* r_all, int nprob, int K, int first, const float* cmax, float eps,
-                             float* la, void* stream) {
+                             float* la, float* stats, void* stream) {
     if (!u || !la || nprob <= 0 || K <= 0 || (first && !cmax) || !(eps > 0.f)) return GX_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sk_table_update_kernel, dim3(gx_cdiv(K, 256), nprob), dim3(256), 0, (hipStream_t)stream, u, r_all, K, first,
-                       cmax, 1.f / eps, la);
+    hipLaunchKernelGGL(sk_table_update_kernel, dim3(nprob), dim3(256), 0, (hipStream_t)stream, u, r_all, K, first, cmax, 1.f / eps, la,
+                       stats);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -468,17 +530,17 @@ int gx_sinkhorn_table_rebase(float* u, const float* cm_local, const float* cm_gl
 // The whole single-rank solve: la [2 P][K] (problem p * 2 + view).  cmax / u: scratch [2 P][K] each.
 int gx_sinkhorn_table(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, const int* live,
                       float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
-                      float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream) {
-    if (niters < 1 || !la) return GX_ERR_BAD_ARG;
+                      float* cmax, float* u, float* stats, float* workspace, size_t workspace_bytes, void* stream) {
+    if (niters < 1 || !la || !stats) return GX_ERR_BAD_ARG;
     int rc = gx_sinkhorn_table_first(S0, S1, ld, K, inv, npix, npatch, live, eps, cmax, u, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 1, cmax, eps, la, stream);
+    rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 1, cmax, eps, la, nullptr, stream);
     if (rc) return rc;
-    for (int it = 1; it < niters; ++it) {
-        rc = gx_sinkhorn_table_sweep(S0, S1, ld, K, inv, npix, npatch, live, eps, la, c_all, rows, c_uniform, u, workspace,
-                                     workspace_bytes, stream);
+    for (int it = 1; it < niters; ++it) {      // the first sweep takes the row maxima exactly and leaves the row normalisers behind
+        rc = gx_sinkhorn_table_sweep(S0, S1, ld, K, inv, npix, npatch, live, eps, la, it == 1 ? nullptr : stats, c_all, rows,
+                                     c_uniform, u, workspace, workspace_bytes, stream);
         if (rc) return rc;
-        rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 0, nullptr, eps, la, stream);
+        rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 0, nullptr, eps, la, stats, stream);
         if (rc) return rc;
     }
     return GX_OK;

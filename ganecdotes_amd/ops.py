@@ -1299,6 +1299,7 @@ class SinkhornTable:
         self.la = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
         self.cmax = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
         self.u = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(self.nprob, 2, dtype=torch.float32, device=dev)      # what an update tells the next sweep
         self.wsb = lib().gx_sinkhorn_table_workspace_bytes(self.P, npix, k)
         self.ws = workspace(tag, self.wsb, dev)
 
@@ -1310,13 +1311,17 @@ class SinkhornTable:
         _lib.check(lib().gx_sinkhorn_table_first(*self._args(), _p(self.cmax), _p(self.u), _p(self.ws), self.wsb, _stream()),
                    "gx_sinkhorn_table_first")
 
-    def sweep(self):
-        _lib.check(lib().gx_sinkhorn_table_sweep(*self._args(), _p(self.la), _p(self.c), self.rows, self.c_uniform, _p(self.u),
-                                                 _p(self.ws), self.wsb, _stream()), "gx_sinkhorn_table_sweep")
+    def sweep(self, shifted=False):
+        """shifted: the sweep before this one ran on this workspace and `update` has been called since — the rows are
+        exponentiated relative to a bound known beforehand where the update vouched for it (no maxima pass)"""
+        _lib.check(lib().gx_sinkhorn_table_sweep(*self._args(), _p(self.la), _p(self.stats) if shifted else None, _p(self.c),
+                                                 self.rows, self.c_uniform, _p(self.u), _p(self.ws), self.wsb, _stream()),
+                   "gx_sinkhorn_table_sweep")
 
     def update(self, first, cmax=None):
         _lib.check(lib().gx_sinkhorn_table_update(_p(self.u), _p(self.r), self.nprob, self.K, int(first),
-                                                  _p(self.cmax if cmax is None else cmax), self.eps, _p(self.la), _stream()),
+                                                  _p(self.cmax if cmax is None else cmax), self.eps, _p(self.la),
+                                                  None if first else _p(self.stats), _stream()),
                    "gx_sinkhorn_table_update")
 
     def run(self, reduce=None):
@@ -1326,8 +1331,8 @@ class SinkhornTable:
         # the whole tables are charged by the caller through `record`)
         if reduce is None:
             _lib.check(lib().gx_sinkhorn_table(*self._args(), self.niters, _p(self.r), _p(self.c), self.rows, self.c_uniform,
-                                               _p(self.la), _p(self.cmax), _p(self.u), _p(self.ws), self.wsb, _stream()),
-                       "gx_sinkhorn_table")
+                                               _p(self.la), _p(self.cmax), _p(self.u), _p(self.stats), _p(self.ws), self.wsb,
+                                               _stream()), "gx_sinkhorn_table")
             return self
         self.first()
         cm = self.cmax.clone()
@@ -1336,8 +1341,8 @@ class SinkhornTable:
                    "gx_sinkhorn_table_rebase")
         reduce(self.u, "sum")
         self.update(True, cmax=cm)
-        for _ in range(1, self.niters):
-            self.sweep()
+        for it in range(1, self.niters):
+            self.sweep(shifted=it > 1)
             reduce(self.u, "sum")
             self.update(False)
         return self

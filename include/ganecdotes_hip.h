@@ -454,24 +454,28 @@ int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, lon
  * every [2 npatch][K] array.  c_all [2 npatch][rows] (row marginals in the order inv numbers a problem's rows) or NULL =
  * c_uniform; r_all [2 npatch][K] or NULL = uniform.
  *   _first : cmax = column maxima, u = sum_n exp((S_nk - cmax_k) / eps) over each problem's rows, one sweep
- *   _sweep : u = this rank's column sums of one iteration under la
- *   _update: la = (first ? -cmax / eps : la) + log r - log u
+ *   _sweep : u = this rank's column sums of one iteration under la.  stats = NULL: every row's maximum is taken exactly, and
+ *            the rows' log2-sum-exp are left in the workspace; stats = what the _update that made `la` wrote, after a sweep on
+ *            the SAME workspace: the problems it vouches for are exponentiated relative to (previous log2-sum-exp + largest
+ *            step of la), a bound known before the row is touched — no maxima pass
+ *   _update: la = (first ? -cmax / eps : la) + log r - log u; stats (optional) [2 npatch][2] = {largest step in log2 units,
+ *            int 1 if the steps lie within 64 log2 units of each other}
  *   _rebase: u *= exp((cm_local - cm_global) / eps) (sharded first pass, after the MAX all-reduce of cmax)
- *   gx_sinkhorn_table: the whole single-rank solve (niters iterations), cmax / u = scratch [2 npatch][K]. */
+ *   gx_sinkhorn_table: the whole single-rank solve (niters iterations), cmax / u = scratch [2 npatch][K], stats [2 npatch][2]. */
 int gx_sinkhorn_table_ok(int npatch, int K);
 size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K);
 int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
                             const int* live, float eps, float* cmax, float* u, float* workspace, size_t workspace_bytes,
                             void* stream);
 int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, const float* la, const float* c_all, long rows, float c_uniform,
-                            float* u, float* workspace, size_t workspace_bytes, void* stream);
+                            const int* live, float eps, const float* la, const float* stats, const float* c_all, long rows,
+                            float c_uniform, float* u, float* workspace, size_t workspace_bytes, void* stream);
 int gx_sinkhorn_table_update(const float* u, const float* r_all, int nprob, int K, int first, const float* cmax, float eps,
-                             float* la, void* stream);
+                             float* la, float* stats, void* stream);
 int gx_sinkhorn_table_rebase(float* u, const float* cm_local, const float* cm_global, long n, float eps, void* stream);
 int gx_sinkhorn_table(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, const int* live,
                       float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
-                      float* cmax, float* u, float* workspace, size_t workspace_bytes, void* stream);
+                      float* cmax, float* u, float* stats, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).

@@ -1086,14 +1086,33 @@ def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, p
     for q in parts:
         q.u.copy_(usum)
         q.update(True, cmax=cm)
-    for _ in range(1, niters):
+    for it in range(1, niters):
         for q in parts:
-            q.sweep()
+            q.sweep(shifted=it > 1)
         usum = parts[0].u + parts[1].u
         for q in parts:
             q.u.copy_(usum)
             q.update(False)
     assert float((parts[0].la - st.la).abs().max()) < 2e-4 and torch.equal(parts[0].la, parts[1].la)
+    # every sweep in its exact form (row maxima first) = the solve above, whose later sweeps ran in the shifted form wherever
+    # the update vouched for it; and a problem the update does NOT vouch for (its steps spread over more than 64 log2 units)
+    # falls back to the exact form inside the same call
+    ex = ops.SinkhornTable(tabd[0], tabd[1], inv, live, eps, niters, 1.0 / rows, rows, r=r, c=c, tag="skt_exact")
+    ex.first()
+    ex.update(True)
+    for _ in range(1, niters):
+        ex.sweep(shifted=False)
+        ex.update(False)
+    assert float((ex.la - st.la).abs().max()) < 2e-4
+    assert st.stats[:, 1].view(torch.int32).min().item() == 1          # (this data: every problem ran shifted)
+    ex.stats.copy_(st.stats)
+    ex.stats[0, 1] = 0.0                                               # problem 0 not vouched for
+    la_before = ex.la.clone()
+    ex.sweep(shifted=True)
+    u_mixed = ex.u.clone()
+    ex.la.copy_(la_before)
+    ex.sweep(shifted=False)
+    assert rel_err(u_mixed, ex.u) < 1e-5
 
 
 @pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190), (6000, None)])

@@ -61,9 +61,12 @@ def main():
     gb_prob = 2.0 * P * rows * K * 4 / 1e9
     t_first = timeit(st.first)
     t_sweep = timeit(st.sweep)
+    st.update(False)
+    t_shift = timeit(lambda: st.sweep(shifted=True))
     t_all = timeit(lambda: st.run(), n=2, warm=1)
     print(f"table first : {t_first:7.2f} ms  ({gb_tab / t_first * 1e3:6.0f} GB/s of live table rows; {gb_prob / t_first * 1e3:6.0f} GB/s of problem rows)")
     print(f"table sweep : {t_sweep:7.2f} ms  ({gb_tab / t_sweep * 1e3:6.0f} GB/s of live table rows; {gb_prob / t_sweep * 1e3:6.0f} GB/s of problem rows)")
+    print(f"shifted     : {t_shift:7.2f} ms  ({gb_tab / t_shift * 1e3:6.0f} GB/s of live table rows; {gb_prob / t_shift * 1e3:6.0f} GB/s of problem rows)   vouched for: {st.stats[:, 1].view(torch.int32).tolist()}")
     print(f"table solve : {t_all:7.2f} ms (10 iterations, both views, {2 * P} problems)")
     # the per-problem path it replaces: the patches of a view side by side, one view after the other
     def old():
