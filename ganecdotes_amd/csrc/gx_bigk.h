@@ -34,6 +34,12 @@ __device__ __forceinline__ float bk_exp(float x) {
     return fmaf(e * LN2, r, e);
 }
 
+// ... and with the product x log2 e rounded ONCE: a relative error of |x| 2^-24 on a term e^x <= 1, i.e. at most 0.37 x 2^-24 of
+// the largest term of the sum it enters — the error the reference's own `scores / eps` and `scores / T` carry into their exp
+// (swav_clustering.py:519, :553).  Two VALU instructions; what the cross-entropy kernels — VALU-bound next to their row
+// traffic — evaluate four times per score.
+__device__ __forceinline__ float bk_exp1(float x) { return __builtin_amdgcn_exp2f(x * BK_LOG2E); }
+
 // Lane l owns columns 4*(l + 64*c) + q, q < 4, c < NJ/4 (one float4 per chunk: a wave-instruction
 // covers 1 KiB of the row).  Needs K % 4 == 0, ld % 4 == 0, 16-B aligned base.
 #define BK_COL(lane, c) (4 * ((lane) + 64 * (c)))
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(256, NJ > 96 ? 2 : 4) void ce_rowstats_bigk_kernel(
                     const f32x4 v = *reinterpret_cast<const f32x4*>(la + k);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        vs += bk_exp(fmaf(w[cidx][q], inv_eps, v[q]) - wm);
-                        z += bk_exp((w[cidx][q] - m) * inv_T);
+                        vs += bk_exp1(fmaf(w[cidx][q], inv_eps, v[q]) - wm);
+                        z += bk_exp1((w[cidx][q] - m) * inv_T);
                     }
                 }
             }
@@ -336,12 +342,12 @@ __global__ __launch_bounds__(256, 4) void ce_apply_bigk_kernel(const float* __re
             f32x4 d_s, d_t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float qs = bk_exp(fmaf(a[q], inv_eps, ls[q]) - wm_s) * iv_s;
-                const float qt = bk_exp(fmaf(b[q], inv_eps, lt[q]) - wm_t) * iv_t;
+                const float qs = bk_exp1(fmaf(a[q], inv_eps, ls[q]) - wm_s) * iv_s;
+                const float qt = bk_exp1(fmaf(b[q], inv_eps, lt[q]) - wm_t) * iv_t;
                 const float xs = (a[q] - m_s) * inv_T, xt = (b[q] - m_t) * inv_T;
                 lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
-                d_t[q] = f * (qs - bk_exp(xt) * iz_t);
-                d_s[q] = f * (qt - bk_exp(xs) * iz_s);
+                d_t[q] = f * (qs - bk_exp1(xt) * iz_t);
+                d_s[q] = f * (qt - bk_exp1(xs) * iz_s);
             }
             if (write) { bk_store4(dt, k, d_t); bk_store4(ds, k, d_s); }
         }
@@ -442,10 +448,10 @@ __global__ __launch_bounds__(256, NJ > 80 ? 2 : 3) void ce_fused_bigk_kernel(con
                 for (int r = 0; r < CE_R; ++r)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        sv[r][0] += bk_exp(fmaf(a[r][c][q], inv_eps, ls[q]) - mx[r][0]);
-                        sv[r][1] += bk_exp((a[r][c][q] - mx[r][1]) * inv_T);
-                        sv[r][2] += bk_exp(fmaf(b[r][c][q], inv_eps, lt[q]) - mx[r][2]);
-                        sv[r][3] += bk_exp((b[r][c][q] - mx[r][3]) * inv_T);
+                        sv[r][0] += bk_exp1(fmaf(a[r][c][q], inv_eps, ls[q]) - mx[r][0]);
+                        sv[r][1] += bk_exp1((a[r][c][q] - mx[r][1]) * inv_T);
+                        sv[r][2] += bk_exp1(fmaf(b[r][c][q], inv_eps, lt[q]) - mx[r][2]);
+                        sv[r][3] += bk_exp1((b[r][c][q] - mx[r][3]) * inv_T);
                     }
             }
         }
@@ -479,12 +485,12 @@ __global__ __launch_bounds__(256, NJ > 80 ? 2 : 3) void ce_fused_bigk_kernel(con
                     f32x4 d_s, d_t;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float qs = bk_exp(fmaf(a[r][c][q], inv_eps, ls[q]) - wm_s) * iv_s;
-                        const float qt = bk_exp(fmaf(b[r][c][q], inv_eps, lt[q]) - wm_t) * iv_t;
+                        const float qs = bk_exp1(fmaf(a[r][c][q], inv_eps, ls[q]) - wm_s) * iv_s;
+                        const float qt = bk_exp1(fmaf(b[r][c][q], inv_eps, lt[q]) - wm_t) * iv_t;
                         const float xs = (a[r][c][q] - m_s) * inv_T, xt = (b[r][c][q] - m_t) * inv_T;
                         lacc += qs * (xt - lz_t) + qt * (xs - lz_s);
-                        d_t[q] = f * (qs - bk_exp(xt) * iz_t);
-                        d_s[q] = f * (qt - bk_exp(xs) * iz_s);
+                        d_t[q] = f * (qs - bk_exp1(xt) * iz_t);
+                        d_s[q] = f * (qt - bk_exp1(xs) * iz_s);
                     }
                     bk_store4(dt, k, d_t); bk_store4(ds, k, d_s);
                     cs[c] += d_s; ct[c] += d_t;
@@ -621,10 +627,10 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
                 if (k < K) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        lsr[c][q] = bk_exp(fmaf(a[c][q], inv_eps, lsr[c][q]) - mx[0]);      // lsr / ltr now hold the code numerators
-                        es[c][q] = bk_exp((a[c][q] - mx[1]) * inv_T);
-                        ltr[c][q] = bk_exp(fmaf(b[c][q], inv_eps, ltr[c][q]) - mx[2]);
-                        et[c][q] = bk_exp((b[c][q] - mx[3]) * inv_T);
+                        lsr[c][q] = bk_exp1(fmaf(a[c][q], inv_eps, lsr[c][q]) - mx[0]);      // lsr / ltr now hold the code numerators
+                        es[c][q] = bk_exp1((a[c][q] - mx[1]) * inv_T);
+                        ltr[c][q] = bk_exp1(fmaf(b[c][q], inv_eps, ltr[c][q]) - mx[2]);
+                        et[c][q] = bk_exp1((b[c][q] - mx[3]) * inv_T);
                         sv[0] += lsr[c][q]; sv[1] += es[c][q]; sv[2] += ltr[c][q]; sv[3] += et[c][q];
                     }
                 }
