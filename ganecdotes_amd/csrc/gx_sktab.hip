@@ -8,10 +8,21 @@
 // Work split: a workgroup of T = 64 ceil(K / 512) threads (640 at K = 5000) owns groups of 4 consecutive table rows; thread t
 // holds columns 4 (t + T c) + q, c < 2, of every row it visits, so a problem's column accumulators are 8 registers per
 // thread (P problems: 8 P) and leave as the block's partial row; the patches' log scaling vectors sit in LDS (P x 8T
-// floats, in log2 units: one workgroup per CU).  The row reductions (max, then sum of exp, over all K columns) cross the
-// waves through LDS.  The patches of a group are software-pipelined: step s computes the maxima of patch s (A), the
-// exponentials and sums of patch s - 1 (B) and accumulates patch s - 2 (C) — ONE barrier per step, P + 2 per group — and the
-// next group's rows are in flight (registers) while the current one is worked on.
+// floats, in log2 units: one workgroup per CU), the next group's rows fly into a second set of row registers meanwhile.
+// The table rows are ordered by WHICH patches drew them (swav_clustering.py _score_tables), so the four rows of a group go
+// through a patch together — four independent reduction chains, no branch per row — and a patch none of them belongs to
+// costs nothing.  The row reductions cross the waves through LDS: a wave's four partials are reduced together (7 cross-lane
+// steps, skt_reduce4), lane i < 16 of every wave then reads wave i's and the same butterfly joins them.
+// History (bench shape, both views, ms per pass; tools/lab/sktab_lab.py, profiles/r04_lab_sktab.txt): 22.9 with the membership
+// read row by row through scalar-looking loads that hipcc made vector loads + vmcnt(0) — each also waiting for the row loads
+// before it; 20.0 without the compiler's NW-long reduction loops; 13.6 with the patches software-pipelined (one barrier per
+// patch, a branch per row and patch: the rows of a group rarely share their patches in pixel order); 10.9 with the rows
+// grouped by membership and a group's rows going through a patch together; 8.5 with the four-value butterfly and one
+// v_max_f32 per step (fmaxf behind a DPP move costs three instructions); 7.3 in the shifted form (below).  The per-problem
+// sweeps it replaces: 10.0 (gx_sinkhorn_rows_batch with the same one-instruction exp), bound by the 12.6 B/clk a CU can load —
+// 7.1 TB/s of row bytes whether they come from HBM or the Infinity Cache — so the way on was fewer bytes INTO the CU.
+// Tried and dropped: pulling the next group towards L2 with one 4-byte load (or LDS-DMA) per thread and 128-byte line: a touch
+// moves its whole line to the CU — twice the line requests and fabric bytes per row, sweeps 1.7x slower.
 // exp: 2^(t log2 e / eps ...) by v_exp_f32 on arguments <= 0 whose product with log2 e / eps is rounded once: a relative
 // error of |arg| 2^-24 on a term e^arg <= 1, i.e. at most 0.37 x 2^-24 of the row's largest term — the error the reference's
 // own `scores / eps` carries into its exp (swav_clustering.py:519).
@@ -48,8 +59,6 @@ __device__ __forceinline__ float skt_exp2(float x) { return __builtin_amdgcn_exp
 // drain them: csrc/gx_fineq.hip)
 __device__ __forceinline__ void skt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- the column maxima AND the first pass of all problems in one sweep of the tables (online log-sum-exp per block and
-//      column, as bigk_pass_kernel<., BK_FIRSTLSE>; the (max, sum) pairs are merged exactly by sk_first_from_parts_kernel)
 // Row weights of a pass, made once per call from the index tables (a few tens of microseconds): wt[v][p][q] = the row marginal
 // of table row q in problem (p, v) — c_uniform, or c[(p * 2 + v)][inv[p][q]] — and 0 when patch p did not draw it or q >= live.
 // The sweeps then learn everything about a group of rows from ONE vector load (lane p * R + r), issued with the rows.
@@ -78,6 +87,8 @@ __device__ __forceinline__ float skt_lane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// ---- the column maxima AND the first pass of all problems in one sweep of the tables (online log-sum-exp per block and
+//      column, as bigk_pass_kernel<., BK_FIRSTLSE>; the (max, sum) pairs are merged exactly by sk_first_from_parts_kernel)
 template <int P>
 __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     // the next group's rows are in flight under this one's arithmetic; four rows per group while the registers last (the
