@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, dense v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA = 2500e12          # same guide: dense v_mfma_f32_32x32x16_bf16 (no sparsity)
 PEAK_HBM = 8.0e12
+TRAFFIC_FILE = "r04_traffic.json"   # PMC passes of this round (tools/profile_bench.sh): HBM bytes per launch of the dominant kernel
 
 
 class ModelCfg:
@@ -425,7 +426,7 @@ def main():
             print(f"# {k:24s} {v['ms_per_step']:9.2f} ms/step  {v['launches_per_step']:7.1f} launches  "
                   f"{v['flops_per_step'] / max(v['ms_per_step'], 1e-9) / 1e9:8.1f} TFLOP/s  "
                   f"{v['bytes_per_step'] / max(v['ms_per_step'], 1e-9) / 1e6:8.1f} GB/s", file=sys.stderr)
-    roof = roofline_of(stats, ms_step, os.path.join(ROOT, "profiles", "r03_traffic.json"))
+    roof = roofline_of(stats, ms_step, os.path.join(ROOT, "profiles", TRAFFIC_FILE))
     x6 = ops.get_gemm_mode() == 1
     out = {
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
@@ -460,7 +461,8 @@ def main():
         out["reference_faithful"] = {
             "workload": f"ffhq-256 hfc_with_swav, 5000 prototypes (hfc_with_swav_ffhq_config.py:52), batch={args.batch}/GPU, "
                         f"otherwise the configuration of this line; scores and d(scores) live on per-pixel tables, the three GEMMs run "
-                        f"over pixels (5 x 20 000 samples are drawn from 65 536 pixels: --ds-table, DESIGN par. 4.15)",
+                        f"over pixels (5 x 20 000 samples are drawn from 65 536 pixels: --ds-table, DESIGN par. 4.15) and the "
+                        f"step's Sinkhorn problems are solved on the tables, every row read once per pass (DESIGN par. 4.16)",
             "prototypes": 5000, "steps": rf_steps, "warmup": rf_warm,
             "ms_per_step": ms5, "value": rf_steps * args.batch * world / dt5, "unit": "images/s", "loss": loss5,
             "roofline": {
