@@ -154,12 +154,14 @@ SIGNATURES = {
     "gx_sinkhorn_bigk_batch_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
     "gx_sinkhorn_bigk_batch": (c_i, [c_p, c_i, c_l, c_l, c_i, c_l, c_f, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_table_ok": (c_i, [c_i, c_i]),
-    "gx_sinkhorn_table_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
-    "gx_sinkhorn_table_first": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_f, c_p, c_p, c_p, c_sz, c_p]),
-    "gx_sinkhorn_table_sweep": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_f, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_table_workspace_bytes": (c_sz, [c_i, c_l, c_i, c_i]),
+    "gx_sinkhorn_table_first": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_table_sweep": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_sz,
+                                      c_p]),
     "gx_sinkhorn_table_update": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p]),
     "gx_sinkhorn_table_rebase": (c_i, [c_p, c_p, c_p, c_l, c_f, c_p]),
-    "gx_sinkhorn_table": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_f, c_i, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_sinkhorn_table": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_i, c_f, c_i, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p, c_p,
+                                c_sz, c_p]),
     "gx_sinkhorn_rows_batch_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
     "gx_sinkhorn_rows_batch": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_f, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_swapped_ce_workspace_bytes": (c_sz, [c_l, c_i]),

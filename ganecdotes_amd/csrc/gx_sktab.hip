@@ -44,6 +44,9 @@ struct SkTabArgs {
     long wt_view;            // stride between the views' weights (0: both views share them — uniform marginals)
     long npix;
     const int* live;         // device scalar: the drawn pixels are table rows [0, *live) (NULL: npix)
+    const int* seg;          // per-image scope: [ngrp + 1] device ints, image b's live rows are table rows [seg[b], seg[b + 1])
+    int ngrp;                // Sinkhorn problems per (patch, view): 1, or the images (blockIdx.z = image); problem index
+                             // = (p * 2 + view) * ngrp + image in every per-problem array
     float sc;                // log2(e) / eps
     const float* la;         // [(p * 2 + view)][K] log scaling vectors (sweep)
     const float* stats;      // [(p * 2 + view)][2] = {largest step of la since the last sweep (log2 units), 1 if the shifted form is safe}
@@ -76,12 +79,21 @@ __global__ void sk_table_weights_kernel(const int* __restrict__ inv, long npix, 
 
 // the weights of the R rows of group g under the P patches: lane p * R + r of every wave holds wt[p][g R + r]
 template <int P, int R = SKT_R>
-__device__ __forceinline__ float skt_group_weights(const float* __restrict__ wt, long npix, long g, long ngroups, int lane) {
+__device__ __forceinline__ float skt_group_weights(const float* __restrict__ wt, long npix, long lo, long hi, long g, int lane) {
     const int p = lane / R, r = lane % R;
-    const long row = g * R + r;
+    const long row = lo + g * R + r;
     float w = 0.f;
-    if (lane < P * R && g < ngroups && row < npix) w = wt[(long)p * npix + row];
+    if (lane < P * R && row < hi) w = wt[(long)p * npix + row];
     return w;
+}
+// the rows [lo, hi) this workgroup's problems live on: all live rows, or those of image blockIdx.z
+__device__ __forceinline__ void skt_window(const SkTabArgs& a, long& lo, long& hi) {
+    lo = 0;
+    hi = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
+    if (a.seg) {
+        lo = (long)__builtin_amdgcn_readfirstlane(a.seg[blockIdx.z]);
+        hi = (long)__builtin_amdgcn_readfirstlane(a.seg[blockIdx.z + 1]);
+    }
 }
 __device__ __forceinline__ float skt_lane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -98,8 +110,10 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     const int T = blockDim.x, tid = threadIdx.x;
     const int view = blockIdx.y, K = a.K;
     const float* S = a.S[view];
-    const long live = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
-    const long ngroups = (live + R - 1) / R;
+    long lo, live;
+    skt_window(a, lo, live);
+    const long ngroups = (live - lo + R - 1) / R;
+    const int img = blockIdx.z;
     const float inv_eps2 = a.sc;                                       // log2(e) / eps
     const float* wt = a.wt + view * a.wt_view;
     const int lane = tid & 63;
@@ -114,11 +128,11 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     f32x4 w[R][2];
     float gw;
     auto load = [&](long g, f32x4 (&dst)[R][2], float& gwd) {
-        gwd = skt_group_weights<P, R>(wt, a.npix, g, ngroups, lane);
+        gwd = skt_group_weights<P, R>(wt, a.npix, lo, live, g, lane);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const long row = g * R + r;
-            const bool ok = g < ngroups && row < live;
+            const long row = lo + g * R + r;
+            const bool ok = row < live;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
 #pragma unroll
             for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const long o = ((long)(p * 2 + view) * a.nb + blockIdx.x) * K;
+        const long o = (((long)(p * 2 + view) * a.ngrp + img) * a.nb + blockIdx.x) * K;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int k = 4 * (tid + T * c);
@@ -245,13 +259,15 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
         (&reds[1][0][0])[tid] = 0.f;
     }
     int par = 0;
-    const int view = blockIdx.y, K = a.K, W8 = 8 * T;
+    const int view = blockIdx.y, img = blockIdx.z, K = a.K, W8 = 8 * T;
     const float* S = a.S[view];
     for (int p = 0; p < P; ++p)
-        for (int k = tid; k < W8; k += T) la2[p * W8 + k] = k < K ? a.la[(long)(p * 2 + view) * K + k] * SKT_LOG2E : -INFINITY;
+        for (int k = tid; k < W8; k += T)
+            la2[p * W8 + k] = k < K ? a.la[((long)(p * 2 + view) * a.ngrp + img) * K + k] * SKT_LOG2E : -INFINITY;
     __syncthreads();
-    const long live = a.live ? (long)__builtin_amdgcn_readfirstlane(*a.live) : a.npix;
-    const long ngroups = (live + SKT_R - 1) / SKT_R;
+    long lo, live;
+    skt_window(a, lo, live);
+    const long ngroups = (live - lo + SKT_R - 1) / SKT_R;
     const float sc = a.sc;
     const float* wt = a.wt + view * a.wt_view;
     float* ltab = a.ltab + (long)view * P * a.npix;
@@ -267,8 +283,9 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     bool some = false;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int flag = a.stats ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(a.stats)[(p * 2 + view) * 2 + 1]) : 0;
-        dmx[p] = SHIFT ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.stats[(p * 2 + view) * 2]))) : 0.f;
+        const long pr = (long)(p * 2 + view) * a.ngrp + img;
+        const int flag = a.stats ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(a.stats)[pr * 2 + 1]) : 0;
+        dmx[p] = SHIFT ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.stats[pr * 2]))) : 0.f;
         sel[p] = SHIFT ? flag != 0 : flag == 0;
         some = some || sel[p];
     }
@@ -279,12 +296,12 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     f32x4 w[SKT_R][2];
     float gw, gl;
     auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd, float& gld) {
-        gwd = skt_group_weights<P>(wt, a.npix, g, ngroups, lane);
-        gld = SHIFT ? skt_group_weights<P>(ltab, a.npix, g, ngroups, lane) : 0.f;
+        gwd = skt_group_weights<P>(wt, a.npix, lo, live, g, lane);
+        gld = SHIFT ? skt_group_weights<P>(ltab, a.npix, lo, live, g, lane) : 0.f;
 #pragma unroll
         for (int r = 0; r < SKT_R; ++r) {
-            const long row = g * SKT_R + r;
-            const bool ok = g < ngroups && row < live;
+            const long row = lo + g * SKT_R + r;
+            const bool ok = row < live;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
 #pragma unroll
             for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                     const float f = cw[r] * __builtin_amdgcn_rcpf(sm4[r]);          // (1 ulp: the sums it scales carry more)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) u[p][c] += e[r][c] * f;
-                    if (tid == 0) ltab[(long)p * a.npix + g * SKT_R + r] = mx4[r] + __builtin_amdgcn_logf(sm4[r]);
+                    if (tid == 0) ltab[(long)p * a.npix + lo + g * SKT_R + r] = mx4[r] + __builtin_amdgcn_logf(sm4[r]);
                 }
         }
 #pragma unroll
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (!sel[p]) continue;
-        const long o = ((long)(p * 2 + view) * a.nb + blockIdx.x) * K;
+        const long o = (((long)(p * 2 + view) * a.ngrp + img) * a.nb + blockIdx.x) * K;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int k = 4 * (tid + T * c);
@@ -418,9 +435,10 @@ static inline int skt_threads(int K) {
     int t = 64 * ((K + 511) / 512);
     return t < 256 ? 256 : t;
 }
-static inline int skt_blocks(long npix) {
-    const long groups = (npix + SKT_R - 1) / SKT_R;
-    return (int)(groups < 256 ? groups : 256);                 // one workgroup per CU (the scaling vectors fill its LDS)
+static inline int skt_blocks(long npix, int ngrp) {             // workgroups per view and image: one per CU in all (LDS)
+    const long groups = (npix / ngrp + SKT_R - 1) / SKT_R;
+    const long nb = (256 + ngrp - 1) / ngrp;
+    return (int)(groups < nb ? (groups < 1 ? 1 : groups) : nb);
 }
 
 #define SKT_DISPATCH(PV, CALL)                      \
@@ -443,9 +461,12 @@ int gx_sinkhorn_table_ok(int npatch, int K) {
 }
 // workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix] | log2-sum-exp of the rows [2][P][npix]
 // (the last part carries a sweep's row normalisers to the next one: the calls of one solve share their workspace)
-static inline size_t skt_parts_floats(int npatch, long npix, int K) { return (size_t)2 * 2 * npatch * skt_blocks(npix) * K; }
-size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K) {
-    return (skt_parts_floats(npatch, npix, K) + (size_t)4 * npatch * npix) * sizeof(float);
+static inline size_t skt_parts_floats(int npatch, long npix, int K, int ngrp) {
+    return (size_t)2 * 2 * npatch * ngrp * skt_blocks(npix, ngrp) * K;
+}
+size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K, int ngroups) {
+    if (ngroups < 1) ngroups = 1;
+    return (skt_parts_floats(npatch, npix, K, ngroups) + (size_t)4 * npatch * npix) * sizeof(float);
 }
 // the row weights of this call into the workspace; returns their view stride (0 = both views share them)
 static long skt_weights(const int* inv, long npix, int npatch, const int* live, const float* c_all, long rows, float c_uniform,
@@ -456,8 +477,10 @@ static long skt_weights(const int* inv, long npix, int npatch, const int* live, 
     return c_all ? (long)npatch * npix : 0L;
 }
 
-static int skt_check(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, float eps) {
-    if (!S0 || !S1 || !inv || npix <= 0 || ld < K || !(eps > 0.f)) return GX_ERR_BAD_ARG;
+static int skt_check(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, float eps,
+                     const int* seg, int ngroups) {
+    if (!S0 || !S1 || !inv || npix <= 0 || ld < K || !(eps > 0.f) || ngroups < 1 || ngroups > 65535 || (ngroups > 1 && !seg))
+        return GX_ERR_BAD_ARG;
     if (!gx_sinkhorn_table_ok(npatch, K)) return GX_ERR_BAD_ARG;
     if ((((uintptr_t)S0 | (uintptr_t)S1) & 15) != 0 || (ld % 4) != 0) return GX_ERR_ALIGN;
     return GX_OK;
@@ -466,22 +489,22 @@ static int skt_check(const float* S0, const float* S1, long ld, int K, const int
 // cmax [2 P][K], u [2 P][K] (problem index p * 2 + view): column maxima over the problem's rows and
 // u_k = sum_n exp((S_nk - cmax_k) / eps) — ONE sweep of the live rows of the two tables
 int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, float* cmax, float* u, float* workspace, size_t workspace_bytes,
-                            void* stream) {
-    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps);
+                            const int* live, const int* seg, int ngroups, float eps, float* cmax, float* u, float* workspace,
+                            size_t workspace_bytes, void* stream) {
+    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps, seg, ngroups);
     if (rc) return rc;
     if (!cmax || !u) return GX_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K)) return GX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K, ngroups)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = skt_blocks(npix), nprob = 2 * npatch;
+    const int nb = skt_blocks(npix, ngroups), nprob = 2 * npatch * ngroups;
     SkTabArgs a{};
-    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live;
+    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live; a.seg = ngroups > 1 ? seg : nullptr; a.ngrp = ngroups;
     a.sc = SKT_LOG2E / eps; a.part = workspace; a.partm = workspace + (size_t)nprob * nb * K; a.nb = nb;
-    float* wt = workspace + skt_parts_floats(npatch, npix, K);
+    float* wt = workspace + skt_parts_floats(npatch, npix, K, ngroups);
     a.wt = wt;
     a.wt_view = skt_weights(inv, npix, npatch, live, nullptr, 0, 1.f, wt, st);          // membership only
     GX_CHECK_LAUNCH();
-    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
     GX_CHECK_LAUNCH();
     // a block that met no row of a problem leaves (-inf, 0): sk_first_from_parts_kernel skips such parts
     launch_first_from_parts(a.partm, a.part, nb, nprob, K, 1.f / eps, cmax, u, st);
@@ -491,27 +514,28 @@ int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, co
 
 // u [2 P][K]: this rank's column sums of one sweep under the scaling vectors la [2 P][K]
 int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, const float* la, const float* stats, const float* c_all, long rows,
-                            float c_uniform, float* u, float* workspace, size_t workspace_bytes, void* stream) {
-    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps);
+                            const int* live, const int* seg, int ngroups, float eps, const float* la, const float* stats,
+                            const float* c_all, long rows, float c_uniform, float* u, float* workspace, size_t workspace_bytes,
+                            void* stream) {
+    int rc = skt_check(S0, S1, ld, K, inv, npix, npatch, eps, seg, ngroups);
     if (rc) return rc;
     if (!la || !u || (c_all && rows <= 0) || (!c_all && !(c_uniform > 0.f))) return GX_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K)) return GX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K, ngroups)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = skt_blocks(npix), nprob = 2 * npatch;
+    const int nb = skt_blocks(npix, ngroups), nprob = 2 * npatch * ngroups;
     SkTabArgs a{};
-    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live;
+    a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live; a.seg = ngroups > 1 ? seg : nullptr; a.ngrp = ngroups;
     a.sc = SKT_LOG2E / eps; a.la = la; a.stats = stats; a.part = workspace; a.nb = nb;
-    float* wt = workspace + skt_parts_floats(npatch, npix, K);
+    float* wt = workspace + skt_parts_floats(npatch, npix, K, ngroups);
     a.wt = wt;
     a.ltab = wt + (size_t)2 * npatch * npix;
     a.wt_view = skt_weights(inv, npix, npatch, live, c_all, rows, c_uniform, wt, st);
     GX_CHECK_LAUNCH();
     // the exact form for the problems the update does not vouch for (all of them without stats), the shifted form for the others
-    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
     GX_CHECK_LAUNCH();
     if (stats) {
-        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2), dim3(skt_threads(K)), 0, st, a));
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
         GX_CHECK_LAUNCH();
     }
     launch_partial_reduce_batch(workspace, nb, K, nprob, u, st);
@@ -540,18 +564,20 @@ int gx_sinkhorn_table_rebase(float* u, const float* cm_local, const float* cm_gl
 
 // The whole single-rank solve: la [2 P][K] (problem p * 2 + view).  cmax / u: scratch [2 P][K] each.
 int gx_sinkhorn_table(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, const int* live,
-                      float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
+                      const int* seg, int ngroups, float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
                       float* cmax, float* u, float* stats, float* workspace, size_t workspace_bytes, void* stream) {
     if (niters < 1 || !la || !stats) return GX_ERR_BAD_ARG;
-    int rc = gx_sinkhorn_table_first(S0, S1, ld, K, inv, npix, npatch, live, eps, cmax, u, workspace, workspace_bytes, stream);
+    const int nprob = 2 * npatch * (ngroups < 1 ? 1 : ngroups);
+    int rc = gx_sinkhorn_table_first(S0, S1, ld, K, inv, npix, npatch, live, seg, ngroups, eps, cmax, u, workspace, workspace_bytes,
+                                     stream);
     if (rc) return rc;
-    rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 1, cmax, eps, la, nullptr, stream);
+    rc = gx_sinkhorn_table_update(u, r_all, nprob, K, 1, cmax, eps, la, nullptr, stream);
     if (rc) return rc;
     for (int it = 1; it < niters; ++it) {      // the first sweep takes the row maxima exactly and leaves the row normalisers behind
-        rc = gx_sinkhorn_table_sweep(S0, S1, ld, K, inv, npix, npatch, live, eps, la, it == 1 ? nullptr : stats, c_all, rows,
-                                     c_uniform, u, workspace, workspace_bytes, stream);
+        rc = gx_sinkhorn_table_sweep(S0, S1, ld, K, inv, npix, npatch, live, seg, ngroups, eps, la, it == 1 ? nullptr : stats, c_all,
+                                     rows, c_uniform, u, workspace, workspace_bytes, stream);
         if (rc) return rc;
-        rc = gx_sinkhorn_table_update(u, r_all, 2 * npatch, K, 0, nullptr, eps, la, stats, stream);
+        rc = gx_sinkhorn_table_update(u, r_all, nprob, K, 0, nullptr, eps, la, stats, stream);
         if (rc) return rc;
     }
     return GX_OK;

@@ -1267,15 +1267,19 @@ def sinkhorn_table_ok(npatch, k):
 
 class SinkhornTable:
     """All Sinkhorn problems of a many-prototype step solved ON the two per-pixel score tables (csrc/gx_sktab.hip): problem
-    (p, v) = the rows of view v's table that patch p drew; every pass reads a table row ONCE for all the patches that drew it.
+    (p, v[, b]) = the rows of view v's table that patch p drew [in image b]; every pass reads a table row ONCE for all the
+    patches that drew it.
 
-    s_tab / t_tab (npix, K); inv (P, npix) int32: row of table row q in patch p's problem, -1 = not drawn; live: int32 HIP
-    scalar (the drawn pixels are table rows [0, live)) or None.  Problem index = p * 2 + view: `la` (2P, K) is what
-    swapped_ce_pixels_tab reads; r (2P, K) / c (2P, rows) = the 'image' source pdf's marginals (c in the order inv numbers a
-    problem's rows) or None = uniform with c_uniform the row marginal.  rowmaps (optional, list of P int32 vectors): lets
-    self[i] hand out problem i's scores / codes (tests)."""
+    s_tab / t_tab (npix, K); inv (P, npix) int32: row of table row q in patch p's problem(s), -1 = not drawn; live: int32 HIP
+    scalar (the drawn pixels are table rows [0, live)) or None.  ngroups = 1: one problem per patch and view; ngroups = B with
+    seg (B + 1,) int32 on the device: one per image too — image b's live rows are table rows [seg[b], seg[b + 1]) and inv
+    numbers a patch's samples image by image (rows / ngroups each).  Problem index = (p * 2 + view) * ngroups + image: `la`
+    (2P ngroups, K) is what swapped_ce_pixels_tab reads; r (2P ngroups, K) / c (2P, rows) = the 'image' source pdf's marginals
+    (c in the order inv numbers the rows) or None = uniform with c_uniform the row marginal.  rowmaps (optional, list of P int32
+    vectors): lets self[i] hand out problem i's scores / codes (tests)."""
 
-    def __init__(self, s_tab, t_tab, inv, live, eps, niters, c_uniform, rows, r=None, c=None, rowmaps=None, tag="sktab"):
+    def __init__(self, s_tab, t_tab, inv, live, eps, niters, c_uniform, rows, r=None, c=None, rowmaps=None, tag="sktab",
+                 ngroups=1, seg=None):
         _chk(s_tab, t_tab, r, c)
         npix, k = s_tab.shape
         if tuple(t_tab.shape) != (npix, k) or t_tab.stride(0) != s_tab.stride(0) or inv.dtype != torch.int32 or \
@@ -1285,14 +1289,18 @@ class SinkhornTable:
             raise RuntimeError("SinkhornTable: `live` is an int32 HIP scalar")
         if (r is None) != (c is None):
             raise RuntimeError("SinkhornTable: r and c come together")
+        self.ngroups = int(ngroups)
+        if self.ngroups > 1 and (seg is None or seg.dtype != torch.int32 or not seg.is_cuda or seg.numel() != self.ngroups + 1
+                                 or not seg.is_contiguous() or rows % self.ngroups):
+            raise RuntimeError("SinkhornTable: per-image problems need seg = (ngroups + 1) int32 row offsets on the device")
         self.P = inv.shape[0]
-        self.nprob = 2 * self.P
+        self.nprob = 2 * self.P * self.ngroups
         if not sinkhorn_table_ok(self.P, k):
             raise RuntimeError(f"SinkhornTable: {self.P} patches x {k} prototypes do not fit (ops.sinkhorn_table_ok)")
-        if r is not None and (tuple(r.shape) != (self.nprob, k) or tuple(c.shape) != (self.nprob, rows)):
-            raise RuntimeError("SinkhornTable: r is (2P, K), c is (2P, rows)")
+        if r is not None and (tuple(r.shape) != (self.nprob, k) or tuple(c.shape) != (2 * self.P, rows)):
+            raise RuntimeError("SinkhornTable: r is (2P ngroups, K), c is (2P, rows)")
         self.S = (s_tab, t_tab)
-        self.inv, self.live, self.K, self.npix, self.rows = inv, live, k, npix, int(rows)
+        self.inv, self.live, self.seg, self.K, self.npix, self.rows = inv, live, seg, k, npix, int(rows)
         self.eps, self.niters, self.c_uniform = float(eps), int(niters), float(c_uniform)
         self.r, self.c, self.rowmaps, self.tag = r, c, rowmaps, tag
         dev = s_tab.device
@@ -1300,12 +1308,13 @@ class SinkhornTable:
         self.cmax = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
         self.u = torch.empty(self.nprob, k, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(self.nprob, 2, dtype=torch.float32, device=dev)      # what an update tells the next sweep
-        self.wsb = lib().gx_sinkhorn_table_workspace_bytes(self.P, npix, k)
+        self.wsb = lib().gx_sinkhorn_table_workspace_bytes(self.P, npix, k, self.ngroups)
         self.ws = workspace(tag, self.wsb, dev)
 
     def _args(self):
         s, t = self.S
-        return (_p(s), _p(t), s.stride(0), self.K, _p(self.inv), self.npix, self.P, _p(self.live), self.eps)
+        return (_p(s), _p(t), s.stride(0), self.K, _p(self.inv), self.npix, self.P, _p(self.live), _p(self.seg), self.ngroups,
+                self.eps)
 
     def first(self):
         _lib.check(lib().gx_sinkhorn_table_first(*self._args(), _p(self.cmax), _p(self.u), _p(self.ws), self.wsb, _stream()),
@@ -1326,9 +1335,7 @@ class SinkhornTable:
 
     def run(self, reduce=None):
         """reduce(tensor, 'max' | 'sum') all-reduces in place over the ranks (rows sharded, c_uniform = 1 / global rows):
-        one MAX exchange of the 2P K column maxima and `niters` SUM exchanges of the 2P K column sums"""
-        # bytes: the live rows of both tables once per pass (the byte accounting of the caller's live_frac is not known here:
-        # the whole tables are charged by the caller through `record`)
+        one MAX exchange of the problems' K column maxima and `niters` SUM exchanges of their K column sums"""
         if reduce is None:
             _lib.check(lib().gx_sinkhorn_table(*self._args(), self.niters, _p(self.r), _p(self.c), self.rows, self.c_uniform,
                                                _p(self.la), _p(self.cmax), _p(self.u), _p(self.stats), _p(self.ws), self.wsb,
@@ -1348,11 +1355,15 @@ class SinkhornTable:
         return self
 
     def __getitem__(self, i):
-        """problem i = p * 2 + view as a Sinkhorn state (scores(), codes()); needs `rowmaps`"""
+        """problem i = (p * 2 + view) * ngroups + image as a Sinkhorn state (scores(), codes()); needs `rowmaps`"""
         if self.rowmaps is None:
             raise RuntimeError("SinkhornTable: built without rowmaps")
-        return Sinkhorn(self.S[i % 2], self.eps, self.niters, c_uniform=self.c_uniform, tag=f"{self.tag}.{i}", la=self.la[i],
-                        rowmap=self.rowmaps[i // 2])
+        pv, g = divmod(i, self.ngroups)
+        rm = self.rowmaps[pv // 2]
+        if self.ngroups > 1:
+            rm = rm.view(self.ngroups, -1)[g].contiguous()
+        return Sinkhorn(self.S[pv % 2], self.eps, self.niters, c_uniform=self.c_uniform, tag=f"{self.tag}.{i}", la=self.la[i],
+                        rowmap=rm)
 
 
 def hist_marginal(x, bins, reduce=None):

@@ -215,7 +215,7 @@ class SwAVClustering(ViewMixin):
                 best, best_eff = s, eff
         return int(best if best_eff > 0 else max(1, min(want, cap)))
 
-    def _score_tables(self, pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, c_one, by_mask=False):
+    def _score_tables(self, pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, c_one, by_mask=False, by_image=False):
         """The per-pixel score tables of a many-prototype step (swav_clustering.py:171-182 once per view over the
         pixels instead of once per patch over the samples): the drawn pixels first, their count on the device, each patch's samples
         as sorted table rows, z_hat of the table's pixels and `S = z_hat Wc^T + b` per view.  c_one (2, rows): the 'image' source
@@ -229,13 +229,22 @@ class SwAVClustering(ViewMixin):
         drawn = torch.zeros(npix, dtype=torch.bool, device=dev)
         for f_ in flat:
             drawn[f_] = True
+        seg = None
         if by_mask and P <= 14:
             # ... and, for the table Sinkhorn (csrc/gx_sktab.hip), the drawn pixels grouped by WHICH patches drew them: the rows of
-            # a 4-row group then go through the same patches together
-            mkey = torch.zeros(npix, dtype=torch.int16, device=dev)
+            # a 4-row group then go through the same patches together.  Per-image scope: image by image (an image's problems live
+            # on ITS run of the table, `seg`), by membership inside an image.
+            mkey = torch.zeros(npix, dtype=torch.int32, device=dev)
             for p_, f_ in enumerate(flat):
                 mkey[f_] += 1 << p_
-            order = torch.argsort(torch.where(mkey > 0, mkey, torch.full_like(mkey, 1 << 14)), stable=True)
+            if by_image:
+                img = torch.arange(npix, dtype=torch.int32, device=dev) // (hw * hw)
+                key = torch.where(mkey > 0, (img << 14) + mkey, torch.full_like(mkey, 1 << 30))
+                seg = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+                seg[1:] = torch.cumsum(drawn.view(B, hw * hw).sum(1, dtype=torch.int32), 0, dtype=torch.int32)
+            else:
+                key = torch.where(mkey > 0, mkey, torch.full_like(mkey, 1 << 30))
+            order = torch.argsort(key, stable=True)
         else:
             order = torch.argsort((~drawn).to(torch.int8), stable=True)               # drawn pixel ids first
         live = drawn.sum(dtype=torch.int32).reshape(1)
@@ -274,7 +283,7 @@ class SwAVClustering(ViewMixin):
                 return None
             ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
             zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
-        return SimpleNamespace(live=live, live_frac=live_frac, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
+        return SimpleNamespace(live=live, live_frac=live_frac, seg=seg, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
                                maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab, row_group=row_group)
 
     def _tables_backward(self, dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw):
@@ -424,7 +433,7 @@ class SwAVClustering(ViewMixin):
         tb = None
         if stab:
             tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one,
-                                    by_mask=ngroups == 1 and sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(P, K))
+                                    by_mask=sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(P, K), by_image=ngroups > 1)
             stab = tb is not None
         for p0 in range(0, P, pgroup):
             pnos = list(range(p0, min(P, p0 + pgroup)))
@@ -436,15 +445,20 @@ class SwAVClustering(ViewMixin):
                 for gi in range(G):
                     inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
                 with self._timed("sinkhorn"):
-                    if ngroups == 1 and sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(G, K):
-                        # one problem per patch and view: ALL of them in one pass over the live rows of the two tables per
-                        # iteration — a row several patches drew is read once (csrc/gx_sktab.hip)
+                    if sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(G, K) and (ngroups == 1 or tb.seg is not None):
+                        # ALL problems of the step in one pass over the live rows of the two tables per iteration — a row several
+                        # patches drew is read once (csrc/gx_sktab.hip); per-image scope: a workgroup stays inside
+                        # one image's run of the table
                         r_tab = c_tab = None
-                        if marg is not None:              # problem index = patch * 2 + view
-                            r_tab = torch.stack([r_one[v] for _ in pnos for v in range(2)])
-                            c_tab = torch.stack([tb.c_sorted[pno][v] for pno in pnos for v in range(2)])
+                        if marg is not None:              # problem index = (patch * 2 + view) * ngroups + image
+                            if ngroups == 1:
+                                r_tab = torch.stack([r_one[v] for _ in pnos for v in range(2)])
+                            else:
+                                r_tab = torch.stack([r_one[v][g] for _ in pnos for v in range(2) for g in range(ngroups)])
+                            c_tab = torch.stack([tb.c_sorted[pno][v].reshape(-1) for pno in pnos for v in range(2)])
                         skb = ops.SinkhornTable(tb.S[0], tb.S[1], inv, tb.live, self.eps, self.niters, 1.0 / nglob, rows,
-                                                r=r_tab, c=c_tab, rowmaps=rowmaps if return_aux else None)
+                                                r=r_tab, c=c_tab, rowmaps=rowmaps if return_aux else None, ngroups=ngroups,
+                                                seg=tb.seg)
                         with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
                             skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
                     else:

@@ -450,8 +450,10 @@ int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, lon
 /* All Sinkhorn problems of a many-prototype step ON the two per-pixel score tables (one per view; global scope:
  * swav_clustering.py:509-544 once per view and patch), every table row read ONCE per pass for all the patches that drew it
  * (csrc/gx_sktab.hip).  S0 / S1 [npix][ld]; inv [npatch][npix] int32: the row of table row q in patch p's problem, -1 = not
- * drawn; live (device int32 scalar or NULL): the drawn pixels are table rows [0, *live).  Problem index = p * 2 + view in
- * every [2 npatch][K] array.  c_all [2 npatch][rows] (row marginals in the order inv numbers a problem's rows) or NULL =
+ * drawn; live (device int32 scalar or NULL): the drawn pixels are table rows [0, *live).  ngroups = 1: one problem per patch
+ * and view (the global scope); ngroups = B with seg [B + 1] device int32: one per image too (the reference's batch-1
+ * semantics), image b's live rows being table rows [seg[b], seg[b + 1]) and inv numbering a patch's samples image by image.
+ * Problem index = (p * 2 + view) * ngroups + image in every per-problem array ([2 npatch ngroups][K] below).  c_all [2 npatch][rows] (row marginals in the order inv numbers a problem's rows) or NULL =
  * c_uniform; r_all [2 npatch][K] or NULL = uniform.
  *   _first : cmax = column maxima, u = sum_n exp((S_nk - cmax_k) / eps) over each problem's rows, one sweep
  *   _sweep : u = this rank's column sums of one iteration under la.  stats = NULL: every row's maximum is taken exactly, and
@@ -463,19 +465,21 @@ int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, lon
  *   _rebase: u *= exp((cm_local - cm_global) / eps) (sharded first pass, after the MAX all-reduce of cmax)
  *   gx_sinkhorn_table: the whole single-rank solve (niters iterations), cmax / u = scratch [2 npatch][K], stats [2 npatch][2]. */
 int gx_sinkhorn_table_ok(int npatch, int K);
-size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K);
+size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K, int ngroups);
 int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, float* cmax, float* u, float* workspace, size_t workspace_bytes,
-                            void* stream);
+                            const int* live, const int* seg, int ngroups, float eps, float* cmax, float* u, float* workspace,
+                            size_t workspace_bytes, void* stream);
 int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
-                            const int* live, float eps, const float* la, const float* stats, const float* c_all, long rows,
-                            float c_uniform, float* u, float* workspace, size_t workspace_bytes, void* stream);
+                            const int* live, const int* seg, int ngroups, float eps, const float* la, const float* stats,
+                            const float* c_all, long rows, float c_uniform, float* u, float* workspace, size_t workspace_bytes,
+                            void* stream);
 int gx_sinkhorn_table_update(const float* u, const float* r_all, int nprob, int K, int first, const float* cmax, float eps,
                              float* la, float* stats, void* stream);
 int gx_sinkhorn_table_rebase(float* u, const float* cm_local, const float* cm_global, long n, float eps, void* stream);
 int gx_sinkhorn_table(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch, const int* live,
-                      float eps, int niters, const float* r_all, const float* c_all, long rows, float c_uniform, float* la,
-                      float* cmax, float* u, float* stats, float* workspace, size_t workspace_bytes, void* stream);
+                      const int* seg, int ngroups, float eps, int niters, const float* r_all, const float* c_all, long rows,
+                      float c_uniform, float* la, float* cmax, float* u, float* stats, float* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ---- swapped-prediction cross-entropy forward + d(scores)   swav_clustering.py:547-570 -------
  * q_s/q_t come from the Sinkhorn log-scaling vectors la_s / la_t (never materialised).

@@ -1115,6 +1115,51 @@ def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, p
     assert rel_err(u_mixed, ex.u) < 1e-5
 
 
+@pytest.mark.parametrize("k,B,nl,N,P,pdf", [(200, 3, 500, 200, 5, False), (5000, 2, 150, 64, 3, True), (132, 5, 1000, 999, 2, False)])
+def test_sinkhorn_table_per_image_problems(ops, k, B, nl, N, P, pdf):
+    """gx_sinkhorn_table with one problem per image too (the per-image Sinkhorn scope: the reference's batch-1 semantics): image
+    b's live rows are the run [seg[b], seg[b + 1]) of the table, a workgroup stays inside one image; against every problem
+    solved on a gathered copy of its rows"""
+    torch.manual_seed(k + B)
+    npix = B * nl + 37                                      # the tail: pixels no patch drew
+    eps, niters = 0.005 if k >= 1000 else 0.05, 6
+    tabs = [(torch.randn(npix, k) * 0.2) for _ in range(2)]
+    for t in tabs:
+        t[B * nl:] += 40.0
+    rowmaps = [torch.cat([torch.sort(torch.randperm(nl)[:N]).values + b * nl for b in range(B)]) for _ in range(P)]
+    used = torch.zeros(npix, dtype=torch.bool)
+    for m in rowmaps:
+        used[m] = True
+    for t in tabs:
+        t[~used] += 40.0
+    tabd = [t.cuda() for t in tabs]
+    rows = B * N
+    inv = torch.full((P, npix), -1, dtype=torch.int32)
+    for p in range(P):
+        inv[p, rowmaps[p]] = torch.arange(rows, dtype=torch.int32)
+    seg = (torch.arange(B + 1, dtype=torch.int32) * nl).cuda()
+    live = torch.tensor([B * nl], dtype=torch.int32, device="cuda")
+    r = c = None
+    if pdf:
+        r = torch.rand(2 * P * B, k) + 0.1
+        r = (r / r.sum(1, keepdim=True)).cuda()
+        c = torch.rand(2 * P, B, N) + 0.1
+        c = (c / c.sum(2, keepdim=True)).reshape(2 * P, rows).cuda()
+    st = ops.SinkhornTable(tabd[0], tabd[1], inv.cuda(), live, eps, niters, 1.0 / N, rows, r=r, c=c,
+                           rowmaps=[m.to(torch.int32).cuda() for m in rowmaps], ngroups=B, seg=seg)
+    st.run()
+    assert st.la.shape == (2 * P * B, k)
+    for i in range(2 * P * B):
+        pv, b = divmod(i, B)
+        sub = tabd[pv % 2][rowmaps[pv // 2][b * N:(b + 1) * N].cuda()].contiguous()
+        ref = ops.Sinkhorn(sub, eps, niters, r=None if r is None else r[i].contiguous(),
+                           c=None if c is None else c[pv][b * N:(b + 1) * N].contiguous()).run()
+        assert float((st.la[i] - ref.la).abs().max()) < 2e-4, i
+    assert rel_err(st[2 * P * B - 1].codes(), ref.codes()) < 1e-4
+    with pytest.raises(RuntimeError):
+        ops.SinkhornTable(tabd[0], tabd[1], inv.cuda(), live, eps, niters, 1.0 / N, rows, ngroups=B)          # no seg
+
+
 @pytest.mark.parametrize("k,live_n", [(200, 150), (5000, 233), (132, None), (8000, 190), (6000, None)])
 def test_swapped_ce_pixels_on_score_tables_equals_the_gathered_form(ops, k, live_n):
     """gx_swapped_ce_pixels_tab (scores as per-pixel tables, Sinkhorn problems row-mapped onto them) against
