@@ -30,6 +30,9 @@
 
 namespace gx {
 
+#ifndef SKT_ABL
+#define SKT_ABL 0                   // lab ablation: 1 = the sweeps load their rows and do nothing with them
+#endif
 constexpr int SKT_R = 4;            // table rows per group
 constexpr int SKT_MAXT = 768;       // threads per workgroup at most (K <= 6144)
 constexpr int SKT_MAXW = SKT_MAXT / 64;
@@ -322,6 +325,10 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                 any = any || cw[r] > 0.f;
             }
             if (!any || !sel[p]) continue;                  // (uniform over the workgroup: every wave holds the same weights)
+#if SKT_ABL == 1
+            asm volatile("" ::"v"(w[0][0][0]), "v"(w[1][0][0]), "v"(w[2][0][0]), "v"(w[3][0][0]), "v"(w[0][1][0]), "v"(w[1][1][0]), "v"(w[2][1][0]), "v"(w[3][1][0]));
+            continue;                                       // lab: the loads alone
+#endif
             const f32x4 l0 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * tid);
             const f32x4 l1 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * (tid + T));
             f32x4 e[SKT_R][2];
