@@ -461,6 +461,8 @@ class SwAVClustering(ViewMixin):
                                                 seg=tb.seg)
                         with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
                             skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
+                        if getattr(self, '_sk_probe', None) is not None:          # tools/soak.py: what the last update vouched for
+                            self._sk_probe.append(skb.stats.clone())
                     else:
                         # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
                         # patch's sorted rows (its pixels are a contiguous run of the table)

@@ -24,6 +24,7 @@ sw = SwAVClustering(model=g, model_config=bench.ModelCfg, out_dir=None, device=d
 torch.manual_seed(42)
 np.random.seed(42)
 sw.build_heads()
+sw._sk_probe = [] if k > 64 else None            # many prototypes: the table Sinkhorn's per-problem step statistics of every step
 import time                                                     # noqa: E402
 warm = min(2, steps - 1)                                        # the first steps allocate; timed from the third on
 losses = [sw.train_step(sw.draw_batch(batch)) for _ in range(warm)]
@@ -36,3 +37,8 @@ w = sw.projection[0].weight.data
 print(f"K={k} B={batch} scope={scope} pdf={pdf}: finite={bool(np.isfinite(l).all())} loss {l[0]:.4f} -> {l[-1]:.4f} "
       f"(min {l.min():.4f}); Wp finite={bool(torch.isfinite(w).all())}; "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; {ms:.1f} ms/step")
+if sw._sk_probe:
+    st = torch.stack(sw._sk_probe).cpu()
+    ok = st[..., 1].contiguous().view(torch.int32)
+    print(f"  table Sinkhorn: {st.shape[0]} steps x {st.shape[1]} problems; last update vouched for the shifted form in "
+          f"{100.0 * ok.float().mean():.1f} % of them; largest last step of la {st[..., 0].abs().max():.3f} log2 units")
