@@ -482,6 +482,39 @@ def test_bench_step_properties(gpu, bench_state, nproto):
         assert rel(a_, b_) < 1e-4
 
 
+@pytest.mark.parametrize("scope,nproto", [("global", 5000), ("image", 5000), ("global", 4000)])
+def test_table_sinkhorn_step_at_bench_patches(gpu, bench_state, scope, nproto):
+    """The reference's own prototype counts with the bench's 5 patches of 20 000 samples (4 images per step here): scores and
+    d(scores) on per-pixel tables and the step's Sinkhorn problems solved ON the tables, every patch in one pass per iteration
+    (DESIGN §4.16).  Size-independent properties of the codes (a transport plan with the prescribed sample marginal), the loss
+    = the swapped cross-entropy of those codes recomputed in fp64, and the same step with the per-problem sweeps
+    (swav_args['sinkhorn_table'] = False: an independent implementation on differently ordered tables) — loss and gradients."""
+    g, ml, make = bench_state
+    batch, P = 4, 5
+    sw = make(nproto, batch=batch, num_patches=P, sinkhorn_scope=scope)
+    sw2 = make(nproto, batch=batch, num_patches=P, sinkhorn_scope=scope, sinkhorn_table=False)
+    torch.manual_seed(10)
+    np.random.seed(10)
+    images = sw.draw_batch(batch)
+    torch.manual_seed(20)
+    loss, aux = sw.train_step(images, return_aux=True)
+    torch.manual_seed(20)
+    loss2 = sw2.train_step(images)
+    rows = batch * 20000 if scope == "global" else 20000          # rows of the problem aux hands out (patch 0; image 0)
+    for tag in "st":
+        q = aux[f"q_{tag}"].double()
+        assert q.shape == (rows, nproto) and bool((q >= 0).all())
+        assert float((q.sum(1) - 1).abs().max()) < 1e-4
+    np.testing.assert_allclose(loss2.item(), loss.item(), rtol=2e-5)
+    for a_, b_ in zip(sw._grads, sw2._grads):
+        assert rel(a_, b_) < 1e-4
+    if scope == "global":                                             # patch 0's share of the loss from its codes and scores
+        ps = torch.log_softmax(aux["scores_s"].double() / 0.01, 1)
+        pt = torch.log_softmax(aux["scores_t"].double() / 0.01, 1)
+        part = -0.5 * ((aux["q_t"].double() * ps).sum(1).mean() + (aux["q_s"].double() * pt).sum(1).mean())
+        assert np.isfinite(float(part)) and 0.2 * loss.item() < float(part) < 5 * loss.item()
+
+
 def test_cat256_per_rank_step_properties(gpu, bench_state):
     """configs[2]'s per-rank shape exactly as hfc_with_swav_cat_config.py:52-65 sets it: 16 images, 16 prototypes,
     source_pdf='image', eps = 0.003.  The marginals the step prescribes are the reference's histograms of the whole norm
