@@ -110,6 +110,7 @@ class SwAVClustering(ViewMixin):
         self.layer_hf_dim = layer_hf_dim
         self._bufs = None
         self._step_no = 0
+        self._sk_probe = None                        # a list: train_step appends the table Sinkhorn's last step statistics (tools/soak.py)
 
     def _patch_mode(self):
         """'patch' sampling (swav_clustering.py:150-158, :383-385): a square crop of patch_size x patch_size
@@ -219,7 +220,9 @@ class SwAVClustering(ViewMixin):
         """The per-pixel score tables of a many-prototype step (swav_clustering.py:171-182 once per view over the
         pixels instead of once per patch over the samples): the drawn pixels first, their count on the device, each patch's samples
         as sorted table rows, z_hat of the table's pixels and `S = z_hat Wc^T + b` per view.  c_one (2, rows): the 'image' source
-        pdf's row marginals (None = uniform).  Returns None when the weight-plane GEMM does not take the shape."""
+        pdf's row marginals (None = uniform).  by_mask: the drawn pixels grouped by which patches drew them (what the table
+        Sinkhorn wants), by_image: image by image first (`seg`: an image's run of the table; the per-image scope).
+        Returns None when the weight-plane GEMM does not take the shape."""
         dev = self.device
         npix = B * hw * hw
         pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
@@ -461,7 +464,7 @@ class SwAVClustering(ViewMixin):
                                                 seg=tb.seg)
                         with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
                             skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
-                        if getattr(self, '_sk_probe', None) is not None:          # tools/soak.py: what the last update vouched for
+                        if self._sk_probe is not None:                            # tools/soak.py: what the last update vouched for
                             self._sk_probe.append(skb.stats.clone())
                     else:
                         # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
