@@ -1341,18 +1341,13 @@ class SinkhornTable:
                                                _p(self.la), _p(self.cmax), _p(self.u), _p(self.stats), _p(self.ws), self.wsb,
                                                _stream()), "gx_sinkhorn_table")
             return self
-        self.first()
-        cm = self.cmax.clone()
-        reduce(cm, "max")
+        from .sharded import run_sinkhorn_table
+        return run_sinkhorn_table(self, self.niters, reduce)
+
+    def rebase(self, cm):
+        """self.u (first-pass sums relative to this rank's maxima self.cmax) re-based on the maxima cm over all ranks"""
         _lib.check(lib().gx_sinkhorn_table_rebase(_p(self.u), _p(self.cmax), _p(cm), self.u.numel(), self.eps, _stream()),
                    "gx_sinkhorn_table_rebase")
-        reduce(self.u, "sum")
-        self.update(True, cmax=cm)
-        for it in range(1, self.niters):
-            self.sweep(shifted=it > 1)
-            reduce(self.u, "sum")
-            self.update(False)
-        return self
 
     def __getitem__(self, i):
         """problem i = (p * 2 + view) * ngroups + image as a Sinkhorn state (scores(), codes()); needs `rowmaps`"""

@@ -7,7 +7,8 @@ stand-in), so the N>1 control flow is exercised by world_size-2 tests without a 
 
 Exchange steps (everything else is rank-local):
   Sinkhorn, per call :  all_reduce(MAX) of the K column maxima, then per iteration one
-                        all_reduce(SUM) of the K column sums (20 KB at K=5000; latency-bound)
+                        all_reduce(SUM) of the K column sums (20 KB at K=5000; latency-bound); the problems of a step
+                        exchange together (run_sinkhorn_group; on score tables run_sinkhorn_table)
   optimizer step     :  all_reduce(SUM) of {dWc, db, loss} (issued before the pyramid backward) and of
                         every pyramid level's column block of dWp as soon as it is produced, all
                         asynchronous: only the coarsest levels' message is not hidden behind GEMMs
@@ -73,6 +74,31 @@ def run_sinkhorn_group(ks, niters, reduce=None):
         for i, k in enumerate(ks):
             k.update(it == 0, u=u[i])
     return ks
+
+
+def run_sinkhorn_table(k, niters, reduce=None):
+    """Drive the table solver (every problem of a step on the per-pixel score tables, ops.SinkhornTable) over row-sharded
+    tables: the problems' exchanges travel together — ONE max all-reduce of their column maxima, then `niters` sum all-reduces of
+    their column sums (the first pass's sums are re-based on the all-reduced maxima first).
+
+    `k` provides: first() (leaves k.cmax, k.u relative to it) ; rebase(cm) (k.u re-based on the maxima cm) ; update(first, cmax=)
+    (new scaling vectors from k.u, and — first=False — the step statistics the next sweep may rely on) ; sweep(shifted) (k.u =
+    this rank's column sums; shifted: the sweep before it ran on the same state).  The statistics come from all-reduced sums,
+    so every rank takes the same form of every sweep.  With reduce=None it is the single-rank algorithm."""
+    k.first()
+    cm = k.cmax
+    if reduce is not None:
+        cm = k.cmax.clone()
+        reduce(cm, "max")
+        k.rebase(cm)
+        reduce(k.u, "sum")
+    k.update(True, cmax=cm)
+    for it in range(1, niters):
+        k.sweep(shifted=it > 1)
+        if reduce is not None:
+            reduce(k.u, "sum")
+        k.update(False)
+    return k
 
 
 def allreduce_flat(tensors, group):

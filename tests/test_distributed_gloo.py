@@ -119,6 +119,86 @@ def test_grouped_sharded_sinkhorn_shares_the_exchanges():
         assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
 
 
+class TorchTableKernels:
+    """CPU stand-in with the interface sharded.run_sinkhorn_table expects (the maths of csrc/gx_sktab.hip): `nprob` problems
+    over this rank's rows; scores (nprob, rows, K).  The shifted sweeps exponentiate relative to the previous sweep's
+    log-sum-exp + the largest step of la, exactly like the kernel, and check what the kernel relies on."""
+
+    def __init__(self, scores, eps, n_global):
+        self.S, self.eps = scores, eps
+        self.nprob, _, self.K = scores.shape
+        self.c = 1.0 / n_global
+        self.cmax = self.u = self.la = self.lse = self.dmax = None
+        self.shifted_sweeps = 0
+
+    def first(self):
+        self.cmax = self.S.max(1)[0]
+        self.u = torch.exp((self.S - self.cmax[:, None]) / self.eps).sum(1)
+
+    def rebase(self, cm):
+        self.u *= torch.exp((self.cmax - cm) / self.eps)
+
+    def update(self, first, cmax=None):
+        d = float(np.log(1.0 / self.K)) - torch.log(self.u)
+        self.la = (-(self.cmax if cmax is None else cmax) / self.eps if first else self.la) + d
+        self.dmax = None if first else d.max(1)[0]                       # the step statistics (all-reduced sums: same on every rank)
+        self.spread = None if first else (d.max(1)[0] - d.min(1)[0])
+
+    def sweep(self, shifted=False):
+        w = self.S / self.eps + self.la[:, None]
+        if shifted:
+            assert self.lse is not None and bool((self.spread < 64 * np.log(2.0)).all())
+            sigma = self.lse + self.dmax[:, None]                        # known before the row is touched
+            assert bool((w.max(2)[0] <= sigma + 1e-4).all())             # an upper bound of every row's new maximum
+            e = torch.exp(w - sigma[..., None])
+            tot = e.sum(2)
+            self.shifted_sweeps += 1
+        else:
+            sigma = w.max(2)[0]
+            e = torch.exp(w - sigma[..., None])
+            tot = e.sum(2)
+        self.lse = sigma + torch.log(tot)
+        self.u = (e * (self.c / tot)[..., None]).sum(1)
+
+    def codes(self):
+        return torch.softmax(self.S / self.eps + self.la[:, None], dim=2)
+
+
+def _table_worker(rank, world, port, problems, eps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharded.shard_range(problems.shape[1], rank, world)
+    k = TorchTableKernels(problems[:, lo:hi].clone(), eps, problems.shape[1])
+    red = CountingReduce(dist.group.WORLD)
+    sharded.run_sinkhorn_table(k, 10, red)
+    out[rank] = (lo, hi, k.codes().numpy(), red.calls, k.shifted_sweeps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_table_sinkhorn_two_ranks_equals_oracle():
+    """The table solver's exchange protocol (sharded.run_sinkhorn_table: first pass -> MAX -> re-base -> SUM -> update, then
+    sweep -> SUM -> update, the later sweeps in the shifted form) under two gloo ranks: every problem's codes equal the
+    reference's sinkhorn_knopp on all rows, with 1 + niters collectives for all problems together."""
+    from oracle import swav_ref as S
+    torch.manual_seed(9)
+    n, kk, eps, nprob = 301, 12, 0.02, 4
+    problems = 0.3 * torch.randn(nprob, n, kk)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_table_worker, args=(2, _free_port(), problems, eps, out), nprocs=2, join=True)
+    for r in range(2):
+        lo, hi, q, calls, nshift = out[r]
+        assert calls == 11 and nshift == 8
+        for i in range(nprob):
+            ref = S.sinkhorn_knopp(problems[i], eps, 10, fp64=True).numpy()
+            assert np.all(np.abs(q[i] - ref[lo:hi]) <= 1e-3 * ref[lo:hi].max(axis=1, keepdims=True))
+    one = TorchTableKernels(problems.clone(), eps, n)
+    sharded.run_sinkhorn_table(one, 10, None)
+    np.testing.assert_allclose(np.concatenate([out[0][2], out[1][2]], 1), one.codes().numpy(), rtol=1e-4, atol=1e-7)
+
+
 def test_shard_range_covers_everything():
     for n in (1, 7, 16, 33):
         for w in (1, 2, 3, 8):
