@@ -161,13 +161,20 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     const int r32 = lane & 31, hh = lane >> 5;
     const int afr = rg * 32 + r32, af = (afr >> 2) & 3;                     // A fragment: row r32 of the row group, k = 8 hh ..
     const int au0 = (afr * 4 + ((2 * hh) ^ af)) * 16, au1 = (afr * 4 + ((2 * hh + 1) ^ af)) * 16;
-    // t[row_r][column r32 of block nb] in the A ring: k-tile 2 nb + (r32 >> 4), k = r32 & 15 (see gemm_xw_kernel's unit map)
-    const int tk = r32 & 15;
-    const int tbase = rg * 2048 + hh * 256 + (tk & 3) * 4;
-    const int tb_e = tbase + (((tk >> 2) ^ hh) << 4), tb_o = tbase + (((tk >> 2) ^ (2 + hh)) << 4);
-    const int ybase = rg * 2048 + (2 * hh) * 128 + r32 * 4;                 // Y[parent ((r & 3) >> 1) + 4 (r >> 2) + 2 hh][r32]
+    // the fold of a finished block reads, for the lane's row, the 16 columns its accumulator registers hold: quads hh and
+    // 2 + hh of the row in the two k-tiles of the block (A ring, 16-B units swizzled like the fragment reads) and the same
+    // columns of the parent's Y2 row
+    const int tq0 = afr * 64 + ((hh ^ af) << 4), tq1 = afr * 64 + (((2 + hh) ^ af) << 4);
+    const int ybase = rg * 2048 + (r32 >> 1) * 128 + hh * 16;               // Y[parent r32 / 2][4 hh ..] (+ 32 B per group of 8 columns)
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
-    const float myb = (r32 < g.K && g.bias) ? g.bias[r32] : 0.f;
+    f32x4 myb[2];                                                         // bias of the prototypes 4 hh + 8 g2 .. + 3 this lane writes
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * hh + 8 * g2 + q;
+            myb[g2][q] = (k < g.K && g.bias) ? g.bias[k] : 0.f;
+        }
 
     // ---- prologue: what k-tiles -2 and -1 of a previous tile would have issued
     int tm = tile0;
@@ -176,15 +183,14 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     issue_y(tm, 0, 0); issue_b(1, 1); issue_a(tm, 1, 1);
 
     f32x16 acc[6];
-    float sp[16];
+    float sp;                                                            // this lane's share of its row's t^T M t + t . Y2
     for (int it = 0; it < my_tiles; ++it) {
         const int tn = (it + 1 < my_tiles) ? tm + tstride : tm;        // next tile (the last one prefetches itself: unused)
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sp[r] = 0.f;
+        sp = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             if (FQ_ABL >= 3 && FQ_ABL <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -225,8 +231,10 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                             const int nb = gb + j;
                             if (nb > hi || nb < nb0) continue;
 #pragma unroll
-                            for (int q = 0; q < 3; ++q)
+                            for (int q = 0; q < 3; ++q) {
+                                if (FQ_ABL == 8 && (gb != lo || j != 0)) { b[j][q] = b[0][q]; continue; }   // lab: one block's fragments for all
                                 b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * FQ_PST + x_kc_off(nb * 32 + r32, hh));
+                            }
                         }
 #pragma unroll
                         for (int u = 0; u < 6; ++u)
@@ -234,7 +242,9 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                             for (int j = 0; j < 2; ++j) {
                                 const int nb = gb + j;
                                 if (nb > hi || nb < nb0 || FQ_ABL == 2) continue;
-                                acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[j][TB[u]], acc[nb - lo], 0, 0, 0);
+                                // operands swapped: the accumulator is the block of U TRANSPOSED — lane = the row of t (r32),
+                                // register r = column (r & 3) + 8 (r >> 2) + 4 hh of the block — so that a row's fold is lane-local
+                                acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][TB[u]], a[TA[u]], acc[nb - lo], 0, 0, 0);
                             }
                     }
                 };
@@ -242,24 +252,26 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                 else run(std::integral_constant<bool, false>{});
             }
             if ((t & 1) && FQ_ABL != 6 && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
-                const char* tsrc = lds + (((t - 1) + (r32 >> 4)) & 3) * FQ_A;
+                // sp += sum over the lane's 16 columns j of t[row][j] (U[row][j] + Y2[parent][j]): four 16-byte reads of t
+                // (k-tiles t - 1 and t, both still in the A ring) and four of Y2 — the accumulator being U^T, everything
+                // else is in this lane's registers.  (Round 3 held U with lane = column: 32 ds_read_b32 per fold and
+                // sixteen 32-lane reductions per tile: 0.57 of the kernel's 1.41 ms, tools/lab/fineq_abl.sh 6)
+                const char* ta = lds + ((t - 1) & 3) * FQ_A;
+                const char* tb = lds + (t & 3) * FQ_A;
                 const char* ysrc = ldsY + (nb0 & 1) * FQ_Y + ybase;
+                const f32x4 tv[4] = {*reinterpret_cast<const f32x4*>(ta + tq0), *reinterpret_cast<const f32x4*>(ta + tq1),
+                                     *reinterpret_cast<const f32x4*>(tb + tq0), *reinterpret_cast<const f32x4*>(tb + tq1)};
+                const f32x4 yv[4] = {*reinterpret_cast<const f32x4*>(ysrc), *reinterpret_cast<const f32x4*>(ysrc + 32),
+                                     *reinterpret_cast<const f32x4*>(ysrc + 64), *reinterpret_cast<const f32x4*>(ysrc + 96)};
                 auto fold = [&](const f32x16& u) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float tv = *reinterpret_cast<const float*>(tsrc + (((r >> 2) & 1) ? tb_o : tb_e) + (r & 3) * 64 + (r >> 2) * 512);
-                        const float yv = *reinterpret_cast<const float*>(ysrc + (((r & 3) >> 1) + 4 * (r >> 2)) * 128);
-                        sp[r] = fmaf(tv, u[r] + yv, sp[r]);
-                    }
+                    for (int r = 0; r < 16; ++r) sp = fmaf(tv[r >> 2][r & 3], u[r] + yv[r >> 2][r & 3], sp);
                 };
                 if (isL) fold(acc[nb0 <= 5 ? nb0 : 5]);
                 else fold(acc[nb0 >= 6 ? nb0 - 6 : 0]);
                 if (isL && nb0 == 5) {                                      // L's share of the row sums is complete
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = gx_team_sum(sp[r], 32);
-                        if (r32 == 0) xs[rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = v;
-                    }
+                    const float v = gx_xor32_sum(sp);
+                    if (hh == 0) xs[rg * 32 + r32] = v;
                 }
             }
             sb = sb + 1 >= FQ_NSB ? 0 : sb + 1;
@@ -267,18 +279,27 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
         if (!isL) {
             // ---- rows: |z|^2 = L's share + R's + nc[parent]; scores from the score block + Ac[parent]
             // (the score block of Y arrived at k-tile 12 + 2; xs was written at k-tile 11: four barriers ago)
-            const char* ysc = ldsY + 2 * FQ_Y + rg * 2048 + (2 * hh) * 128;
-            const int row0 = tm * 128 + rg * 32;
+            // lane = row r32 (both halves of the wave): the half hh holds prototypes 4 hh + 8 g2 .. + 3 in registers 4 g2 .. + 3
+            const char* yp = ldsY + 2 * FQ_Y + rg * 2048 + (r32 >> 1) * 128;
+            const long row = (long)tm * 128 + rg * 32 + r32;
+            const float nsq = gx_xor32_sum(sp) + xs[rg * 32 + r32] + *reinterpret_cast<const float*>(yp + 16 * 4);
+            const float rn = 1.f / fmaxf(sqrtf(fmaxf(nsq, 0.f)), 1e-12f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const char* yp = ysc + (((r & 3) >> 1) + 4 * (r >> 2)) * 128;
-                const float nsq = gx_team_sum(sp[r], 32) + xs[rg * 32 + rr] + *reinterpret_cast<const float*>(yp + 16 * 4);
-                const float rn = 1.f / fmaxf(sqrtf(fmaxf(nsq, 0.f)), 1e-12f);
-                const int row = row0 + rr;
-                if (r32 < g.K) g.sc_table[(long)row * g.K + r32] = fmaf(acc[2][r] + *reinterpret_cast<const float*>(yp + r32 * 4), rn, myb);
-                if (r32 == 0) g.rn_table[row] = rn;
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int k0 = 4 * hh + 8 * g2;
+                if (k0 >= g.K) continue;
+                const f32x4 ac = *reinterpret_cast<const f32x4*>(yp + k0 * 4);
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = fmaf(acc[2][4 * g2 + q] + ac[q], rn, myb[g2][q]);
+                float* dst = g.sc_table + row * g.K + k0;
+                if (k0 + 3 < g.K && (g.K & 3) == 0) *reinterpret_cast<f32x4*>(dst) = o;
+                else
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k0 + q < g.K) dst[q] = o[q];
             }
+            if (hh == 0) g.rn_table[row] = rn;
         }
         tm = tn;
     }
