@@ -254,8 +254,11 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
             if ((t & 1) && FQ_ABL != 6 && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
                 // sp += sum over the lane's 16 columns j of t[row][j] (U[row][j] + Y2[parent][j]): four 16-byte reads of t
                 // (k-tiles t - 1 and t, both still in the A ring) and four of Y2 — the accumulator being U^T, everything
-                // else is in this lane's registers.  (Round 3 held U with lane = column: 32 ds_read_b32 per fold and
-                // sixteen 32-lane reductions per tile: 0.57 of the kernel's 1.41 ms, tools/lab/fineq_abl.sh 6)
+                // else is in this lane's registers.  (Round 3 held U with lane = column: 32 ds_read_b32 per fold and sixteen
+                // 32-lane reductions per tile; 1.41 -> 1.22 ms.  FQ_ABL 6 — no fold — is NOT what the fold costs: without it
+                // the products of eight of the nine column blocks are dead code and hipcc drops them: 0.70 ms = the kernel
+                // without its MFMAs, 0.63.  What is left is that sum itself: 0.63 ms of waits, fragment reads and split +
+                // 0.59 ms of MFMAs that one barrier domain per CU runs one after the other.)
                 const char* ta = lds + ((t - 1) & 3) * FQ_A;
                 const char* tb = lds + (t & 3) * FQ_A;
                 const char* ysrc = ldsY + (nb0 & 1) * FQ_Y + ybase;
