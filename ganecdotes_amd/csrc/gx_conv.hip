@@ -517,16 +517,24 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
     const char* xp = reinterpret_cast<const char*>(g.xp);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-    auto issue = [&](int cc, int to, unsigned wb, char* dst) {       // 6 LDS-DMA instructions per thread
+    // 6 LDS-DMA instructions per thread.  with_a: lab only (tools/lab/conv_abl.sh: -DXP_ABL_A2 / -DXP_ABL_B2 fetch the x planes /
+    // the weight planes for 4 of the 9 taps — what sharing a halo tile among the taps would save: 3 % / 4 %)
+    auto issue = [&](int cc, int to, unsigned wb, char* dst, bool with_a = true) {
         const unsigned va = pixbyte + (unsigned)to;                  // signed add: the padded pixel is never negative
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
+#ifdef XP_ABL_A2
+            if (!with_a) break;
+#endif
             const char* base = xp + (long)(cc * 3 + p) * (long)g.xp_plane_bytes;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)g.xp_plane_bytes, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)va, 0, 0, 0);
         }
         const unsigned blk = wb + (unsigned)cc * 3u * 4096u;
+#ifdef XP_ABL_B2
+        if (!with_a) return;
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + 12288 + p * 4096 + wid * 1024), 16,
@@ -550,7 +558,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             const bool wrap = (tap + 1 == NT);
             if (!(wrap && last_cc))
                 issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
-                      lds + (buf ^ 1) * XP_STAGE_BYTES);
+                      lds + (buf ^ 1) * XP_STAGE_BYTES, NT < 9 || wrap || tap < 1 || (tap + 1) % 3 == 0);
             if constexpr (M16) xp16_mfma_ktile(As, As + 12288, acc, wr, wc, lane);
             else x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
             buf ^= 1;
