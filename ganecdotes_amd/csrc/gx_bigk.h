@@ -38,7 +38,14 @@ __device__ __forceinline__ float bk_exp(float x) {
 // the largest term of the sum it enters — the error the reference's own `scores / eps` and `scores / T` carry into their exp
 // (swav_clustering.py:519, :553).  Two VALU instructions; what the cross-entropy kernels — VALU-bound next to their row
 // traffic — evaluate four times per score.
+#ifndef CE_PIX_ABL
+#define CE_PIX_ABL 0        // lab (tools/lab/ce_tab_abl.sh): 1 no scaling-vector loads, 2 no d(scores) stores, 3 a multiply for every exponential
+#endif
+#if CE_PIX_ABL == 3
+__device__ __forceinline__ float bk_exp1(float x) { return x * BK_LOG2E; }
+#else
 __device__ __forceinline__ float bk_exp1(float x) { return __builtin_amdgcn_exp2f(x * BK_LOG2E); }
+#endif
 
 // Lane l owns columns 4*(l + 64*c) + q, q < 4, c < NJ/4 (one float4 per chunk: a wave-instruction
 // covers 1 KiB of the row).  Needs K % 4 == 0, ld % 4 == 0, 16-B aligned base.
@@ -589,6 +596,9 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
             for (int c = 0; c < NC; ++c) {
                 const int k = min(4 * (tid + 256 * c), K - 4);
                 lsr[c] = *reinterpret_cast<const f32x4*>(las + k); ltr[c] = *reinterpret_cast<const f32x4*>(lat + k);
+#if CE_PIX_ABL == 1
+                lsr[c] = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; ltr[c] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};      // lab: no scaling-vector loads
+#endif
             }
 #define CE_LS(c, k) lsr[c]
 #define CE_LT(c, k) ltr[c]
@@ -667,7 +677,11 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int k = 4 * (tid + 256 * c);
+#if CE_PIX_ABL == 2
+            if (k < kpad && as[c][0] == 123.f) {                         // lab: no d(scores) stores
+#else
             if (k < kpad) {                                              // columns K .. kpad - 1 hold zeros: the dz GEMM reads them
+#endif
                 bk_store4(ds, k, as[c]); bk_store4(dt, k, at[c]);
             }
             if (k < K) {
