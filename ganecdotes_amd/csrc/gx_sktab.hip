@@ -37,6 +37,8 @@ constexpr int SKT_R = 4;            // table rows per group
 constexpr int SKT_MAXT = 768;       // threads per workgroup at most (K <= 6144)
 constexpr int SKT_MAXW = SKT_MAXT / 64;
 constexpr int SKT_LA_CAP = 32768;   // floats of LDS for the patches' scaling vectors (P x 8T)
+constexpr int SKT_LA_CAP4 = 40000;  // ... of the wide form (16 columns per thread, K <= 8192: P x K floats)
+constexpr int SKT_T4 = 512;         // threads per workgroup at most in the wide form
 constexpr float SKT_LOG2E = 1.44269504088896340736f;
 
 struct SkTabArgs {
@@ -104,12 +106,12 @@ __device__ __forceinline__ float skt_lane(float v, int l) {
 
 // ---- the column maxima AND the first pass of all problems in one sweep of the tables (online log-sum-exp per block and
 //      column, as bigk_pass_kernel<., BK_FIRSTLSE>; the (max, sum) pairs are merged exactly by sk_first_from_parts_kernel)
-template <int P>
-__global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
+template <int P, int NC = 2>       // NC: 16-byte column chunks per thread (2; 4 = the wide form for 6144 < K <= 8192, 512 threads)
+__global__ __launch_bounds__(NC == 2 ? SKT_MAXT : SKT_T4) void sk_table_first_kernel(SkTabArgs a) {
     // the next group's rows are in flight under this one's arithmetic; four rows per group while the registers last (the
-    // running (max, sum) pairs are 16 P of them), two past three patches
+    // running (max, sum) pairs are 8 NC P of them), two past three patches, one in the wide form
     constexpr bool PF = true;
-    constexpr int R = P <= 3 ? SKT_R : 2;
+    constexpr int R = NC == 2 ? (P <= 3 ? SKT_R : 2) : 1;
     const int T = blockDim.x, tid = threadIdx.x;
     const int view = blockIdx.y, K = a.K;
     const float* S = a.S[view];
@@ -120,17 +122,17 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     const float inv_eps2 = a.sc;                                       // log2(e) / eps
     const float* wt = a.wt + view * a.wt_view;
     const int lane = tid & 63;
-    f32x4 m[P][2], s[P][2];
+    f32x4 m[P][NC], s[P][NC];
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             m[p][c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             s[p][c] = zero4();
         }
-    f32x4 w[R][2];
+    f32x4 w[R][NC];
     float gw;
-    auto load = [&](long g, f32x4 (&dst)[R][2], float& gwd) {
+    auto load = [&](long g, f32x4 (&dst)[R][NC], float& gwd) {
         gwd = skt_group_weights<P, R>(wt, a.npix, lo, live, g, lane);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -138,12 +140,12 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
             const bool ok = row < live;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
+            for (int c = 0; c < NC; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
         }
     };
     if (PF) load(blockIdx.x, w, gw);
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        f32x4 wn[PF ? R : 1][2];
+        f32x4 wn[PF ? R : 1][NC];
         float gwn = 0.f;
         if constexpr (PF) load(g + gridDim.x, wn, gwn);
         else load(g, w, gw);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
             for (int r = 0; r < R; ++r)
                 if (skt_lane(gw, p * R + r) > 0.f) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < NC; ++c)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float x = w[r][c][q], d = (x - m[p][c][q]) * inv_eps2;     // first row: d = +inf, e = 0
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
+                for (int c = 0; c < NC; ++c) w[r][c] = wn[r][c];
             }
             gw = gwn;
         }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_first_kernel(SkTabArgs a) {
     for (int p = 0; p < P; ++p) {
         const long o = (((long)(p * 2 + view) * a.ngrp + img) * a.nb + blockIdx.x) * K;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int k = 4 * (tid + T * c);
             if (k < K) {
                 *reinterpret_cast<f32x4*>(a.part + o + k) = s[p][c];
@@ -248,9 +250,12 @@ __device__ __forceinline__ float skt_reduce4(f32x4 v, int lane) {
 }
 static_assert(SKT_R == 4, "a wave's partials of a group are one float4");
 
-template <int P, bool SHIFT>
-__global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
-    __shared__ __attribute__((aligned(16))) float la2[SKT_LA_CAP];                   // [P][8T], log2 units, -inf past K
+template <int P, bool SHIFT, int NC = 2>
+__global__ __launch_bounds__(NC == 2 ? SKT_MAXT : SKT_T4) void sk_table_sweep_kernel(SkTabArgs a) {
+    // NC = 4, the wide form (6144 < K <= 8192: the generic configuration's 8000 prototypes): 16 columns per thread, 512 threads,
+    // two rows per group (the reductions still carry four values, two of them idle), the scaling vectors K apart in LDS
+    constexpr int R = NC == 2 ? SKT_R : 2;
+    __shared__ __attribute__((aligned(16))) float la2[NC == 2 ? SKT_LA_CAP : SKT_LA_CAP4];      // [P][8T] (wide: [P][K]), log2 units, -inf past K
     // the waves' partials, [wave][row]; the sums alternate between two buffers from one patch block to the next (a shifted
     // block has ONE barrier: a fast wave's next sums must not land in the slots a slow wave is still reading)
     __shared__ __attribute__((aligned(16))) float redm[16][SKT_R], reds[2][16][SKT_R];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
         (&reds[1][0][0])[tid] = 0.f;
     }
     int par = 0;
-    const int view = blockIdx.y, img = blockIdx.z, K = a.K, W8 = 8 * T;
+    const int view = blockIdx.y, img = blockIdx.z, K = a.K, W8 = NC == 2 ? 8 * T : K;
     const float* S = a.S[view];
     for (int p = 0; p < P; ++p)
         for (int k = tid; k < W8; k += T)
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
     __syncthreads();
     long lo, live;
     skt_window(a, lo, live);
-    const long ngroups = (live - lo + SKT_R - 1) / SKT_R;
+    const long ngroups = (live - lo + R - 1) / R;
     const float sc = a.sc;
     const float* wt = a.wt + view * a.wt_view;
     float* ltab = a.ltab + (long)view * P * a.npix;
@@ -293,59 +298,70 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
         some = some || sel[p];
     }
     if (!some) return;
-    f32x4 u[P][2];
+    f32x4 u[P][NC];
 #pragma unroll
-    for (int p = 0; p < P; ++p) u[p][0] = u[p][1] = zero4();
-    f32x4 w[SKT_R][2];
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) u[p][c] = zero4();
+    f32x4 w[R][NC];
     float gw, gl;
-    auto load = [&](long g, f32x4 (&dst)[SKT_R][2], float& gwd, float& gld) {
-        gwd = skt_group_weights<P>(wt, a.npix, lo, live, g, lane);
-        gld = SHIFT ? skt_group_weights<P>(ltab, a.npix, lo, live, g, lane) : 0.f;
+    auto load = [&](long g, f32x4 (&dst)[R][NC], float& gwd, float& gld) {
+        gwd = skt_group_weights<P, R>(wt, a.npix, lo, live, g, lane);
+        gld = SHIFT ? skt_group_weights<P, R>(ltab, a.npix, lo, live, g, lane) : 0.f;
 #pragma unroll
-        for (int r = 0; r < SKT_R; ++r) {
-            const long row = lo + g * SKT_R + r;
+        for (int r = 0; r < R; ++r) {
+            const long row = lo + g * R + r;
             const bool ok = row < live;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S, ok ? row : 0, a.ld, ok ? K : 0);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
+            for (int c = 0; c < NC; ++c) dst[r][c] = bk_load4(rs, 4 * (tid + T * c));
         }
     };
     load(blockIdx.x, w, gw, gl);
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        f32x4 wn[SKT_R][2];                                 // the next group's rows fly under this group's arithmetic
+        f32x4 wn[R][NC];                                 // the next group's rows fly under this group's arithmetic
         float gwn, gln;
         load(g + gridDim.x, wn, gwn, gln);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float cw[SKT_R];
+            float cw[R];
             bool any = false;
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r) {
-                cw[r] = skt_lane(gw, p * SKT_R + r);
+            for (int r = 0; r < R; ++r) {
+                cw[r] = skt_lane(gw, p * R + r);
                 any = any || cw[r] > 0.f;
             }
             if (!any || !sel[p]) continue;                  // (uniform over the workgroup: every wave holds the same weights)
 #if SKT_ABL == 1
-            asm volatile("" ::"v"(w[0][0][0]), "v"(w[1][0][0]), "v"(w[2][0][0]), "v"(w[3][0][0]), "v"(w[0][1][0]), "v"(w[1][1][0]), "v"(w[2][1][0]), "v"(w[3][1][0]));
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) asm volatile("" ::"v"(w[r][c][0]));
             continue;                                       // lab: the loads alone
 #endif
-            const f32x4 l0 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * tid);
-            const f32x4 l1 = *reinterpret_cast<const f32x4*>(la2 + p * W8 + 4 * (tid + T));
-            f32x4 e[SKT_R][2];
-            f32x4 mx4;
+            f32x4 l[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int kc = 4 * (tid + T * c);
+                l[c] = (NC == 2 || kc < K) ? *reinterpret_cast<const f32x4*>(la2 + p * W8 + kc)
+                                           : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+            f32x4 e[R][NC];
+            f32x4 mx4 = SHIFT ? zero4() : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if constexpr (SHIFT) {
 #pragma unroll
-                for (int r = 0; r < SKT_R; ++r) mx4[r] = cw[r] > 0.f ? skt_lane(gl, p * SKT_R + r) + dmx[p] : 0.f;
+                for (int r = 0; r < R; ++r) mx4[r] = cw[r] > 0.f ? skt_lane(gl, p * R + r) + dmx[p] : 0.f;
             } else {
 #pragma unroll
-                for (int r = 0; r < SKT_R; ++r) {
+                for (int r = 0; r < R; ++r) {
                     float mx = -INFINITY;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        e[r][0][q] = fmaf(w[r][0][q], sc, l0[q]);
-                        e[r][1][q] = fmaf(w[r][1][q], sc, l1[q]);
-                        mx = skt_vmax(mx, skt_vmax(e[r][0][q], e[r][1][q]));
-                    }
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            e[r][c][q] = fmaf(w[r][c][q], sc, l[c][q]);
+                            mx = skt_vmax(mx, e[r][c][q]);
+                        }
                     mx4[r] = mx;
                 }
                 // the wave's maximum of each row -> its slot (lanes 0 .. 3 hold one row each) ; all waves' -> every lane
@@ -354,17 +370,27 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                 skt_barrier();
                 const float ma = skt_reduce4<true, false>(*reinterpret_cast<const f32x4*>(&redm[lane & 15][0]), lane);
 #pragma unroll
-                for (int r = 0; r < SKT_R; ++r) mx4[r] = skt_lane(ma, skt_lane_of_row(r));
+                for (int r = 0; r < R; ++r) mx4[r] = skt_lane(ma, skt_lane_of_row(r));
             }
-            f32x4 sm4;
+            f32x4 sm4 = zero4();
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r) {
+            for (int r = 0; r < R; ++r) {
                 float sum = 0.f;
+                if constexpr (NC == 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e[r][0][q] = skt_exp2((SHIFT ? fmaf(w[r][0][q], sc, l0[q]) : e[r][0][q]) - mx4[r]);
-                    e[r][1][q] = skt_exp2((SHIFT ? fmaf(w[r][1][q], sc, l1[q]) : e[r][1][q]) - mx4[r]);
-                    sum += e[r][0][q] + e[r][1][q];
+                    for (int q = 0; q < 4; ++q) {
+                        e[r][0][q] = skt_exp2((SHIFT ? fmaf(w[r][0][q], sc, l[0][q]) : e[r][0][q]) - mx4[r]);
+                        e[r][1][q] = skt_exp2((SHIFT ? fmaf(w[r][1][q], sc, l[1][q]) : e[r][1][q]) - mx4[r]);
+                        sum += e[r][0][q] + e[r][1][q];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            e[r][c][q] = skt_exp2((SHIFT ? fmaf(w[r][c][q], sc, l[c][q]) : e[r][c][q]) - mx4[r]);
+                            sum += e[r][c][q];
+                        }
                 }
                 sm4[r] = sum;
             }
@@ -375,21 +401,21 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
                 const float ta = skt_reduce4<false, false>(*reinterpret_cast<const f32x4*>(&reds[par][lane & 15][0]), lane);
                 par ^= 1;
 #pragma unroll
-                for (int r = 0; r < SKT_R; ++r) sm4[r] = skt_lane(ta, skt_lane_of_row(r));
+                for (int r = 0; r < R; ++r) sm4[r] = skt_lane(ta, skt_lane_of_row(r));
             }
 #pragma unroll
-            for (int r = 0; r < SKT_R; ++r)
+            for (int r = 0; r < R; ++r)
                 if (cw[r] > 0.f) {                          // (a row of a mixed group that is not in this patch: nothing of it counts)
                     const float f = cw[r] * __builtin_amdgcn_rcpf(sm4[r]);          // (1 ulp: the sums it scales carry more)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) u[p][c] += e[r][c] * f;
-                    if (tid == 0) ltab[(long)p * a.npix + lo + g * SKT_R + r] = mx4[r] + __builtin_amdgcn_logf(sm4[r]);
+                    for (int c = 0; c < NC; ++c) u[p][c] += e[r][c] * f;
+                    if (tid == 0) ltab[(long)p * a.npix + lo + g * R + r] = mx4[r] + __builtin_amdgcn_logf(sm4[r]);
                 }
         }
 #pragma unroll
-        for (int r = 0; r < SKT_R; ++r) {
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) w[r][c] = wn[r][c];
+            for (int c = 0; c < NC; ++c) w[r][c] = wn[r][c];
         }
         gw = gwn;
         gl = gln;
@@ -399,7 +425,7 @@ __global__ __launch_bounds__(SKT_MAXT) void sk_table_sweep_kernel(SkTabArgs a) {
         if (!sel[p]) continue;
         const long o = (((long)(p * 2 + view) * a.ngrp + img) * a.nb + blockIdx.x) * K;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int k = 4 * (tid + T * c);
             if (k < K) *reinterpret_cast<f32x4*>(a.part + o + k) = u[p][c];
         }
@@ -438,8 +464,13 @@ __global__ void sk_table_rebase_kernel(float* __restrict__ u, const float* __res
     if (i < n) u[i] *= expf((cm_local[i] - cm_global[i]) * inv_eps);
 }
 
-static inline int skt_threads(int K) {
-    int t = 64 * ((K + 511) / 512);
+// chunks of 4 columns per thread: 2 while the scaling vectors of all patches fit LDS 8 T apart at T <= 768, else the wide form
+static inline int skt_nc(int npatch, int K) {
+    const int t = 64 * ((K + 511) / 512);
+    return (t <= SKT_MAXT && (long)npatch * 8 * (t < 256 ? 256 : t) <= SKT_LA_CAP) ? 2 : 4;
+}
+static inline int skt_threads(int K, int nc = 2) {
+    int t = 64 * ((K + 256 * nc - 1) / (256 * nc));
     return t < 256 ? 256 : t;
 }
 static inline int skt_blocks(long npix, int ngrp) {             // workgroups per view and image: one per CU in all (LDS)
@@ -464,7 +495,9 @@ using namespace gx;
 extern "C" {
 
 int gx_sinkhorn_table_ok(int npatch, int K) {
-    return npatch >= 1 && npatch <= 5 && K > 64 && K % 4 == 0 && K <= 8 * SKT_MAXT && (long)npatch * 8 * skt_threads(K) <= SKT_LA_CAP;
+    if (npatch < 1 || npatch > 5 || K <= 64 || K % 4 != 0) return 0;
+    if (skt_nc(npatch, K) == 2) return 1;
+    return K <= 16 * SKT_T4 && (long)npatch * K <= SKT_LA_CAP4;                 // the wide form: 16 columns per thread
 }
 // workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix] | log2-sum-exp of the rows [2][P][npix]
 // (the last part carries a sweep's row normalisers to the next one: the calls of one solve share their workspace)
@@ -511,7 +544,11 @@ int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, co
     a.wt = wt;
     a.wt_view = skt_weights(inv, npix, npatch, live, nullptr, 0, 1.f, wt, st);          // membership only
     GX_CHECK_LAUNCH();
-    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+    if (skt_nc(npatch, K) == 2) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+    } else {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_first_kernel<P, 4>), dim3(nb, 2, ngroups), dim3(skt_threads(K, 4)), 0, st, a));
+    }
     GX_CHECK_LAUNCH();
     // a block that met no row of a problem leaves (-inf, 0): sk_first_from_parts_kernel skips such parts
     launch_first_from_parts(a.partm, a.part, nb, nprob, K, 1.f / eps, cmax, u, st);
@@ -539,10 +576,19 @@ int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, co
     a.wt_view = skt_weights(inv, npix, npatch, live, c_all, rows, c_uniform, wt, st);
     GX_CHECK_LAUNCH();
     // the exact form for the problems the update does not vouch for (all of them without stats), the shifted form for the others
-    SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+    const bool wide = skt_nc(npatch, K) == 4;
+    if (!wide) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+    } else {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false, 4>), dim3(nb, 2, ngroups), dim3(skt_threads(K, 4)), 0, st, a));
+    }
     GX_CHECK_LAUNCH();
     if (stats) {
-        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+        if (!wide) {
+            SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
+        } else {
+            SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true, 4>), dim3(nb, 2, ngroups), dim3(skt_threads(K, 4)), 0, st, a));
+        }
         GX_CHECK_LAUNCH();
     }
     launch_partial_reduce_batch(workspace, nb, K, nprob, u, st);

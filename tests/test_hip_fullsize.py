@@ -482,7 +482,7 @@ def test_bench_step_properties(gpu, bench_state, nproto):
         assert rel(a_, b_) < 1e-4
 
 
-@pytest.mark.parametrize("scope,nproto", [("global", 5000), ("image", 5000), ("global", 4000)])
+@pytest.mark.parametrize("scope,nproto", [("global", 5000), ("image", 5000), ("global", 4000), ("global", 8000), ("image", 8000)])
 def test_table_sinkhorn_step_at_bench_patches(gpu, bench_state, scope, nproto):
     """The reference's own prototype counts with the bench's 5 patches of 20 000 samples (4 images per step here): scores and
     d(scores) on per-pixel tables and the step's Sinkhorn problems solved ON the tables, every patch in one pass per iteration

@@ -1016,7 +1016,10 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
 
 @pytest.mark.parametrize("k,npix,rows,P,live_n,pdf", [(200, 1500, 600, 5, 1300, False), (5000, 700, 333, 3, None, False),
                                                      (132, 9000, 4097, 2, 8000, True), (4000, 2600, 900, 5, 2401, True),
-                                                     (6144, 300, 120, 5, 290, False), (1024, 500, 77, 1, None, False)])
+                                                     (6144, 300, 120, 5, 290, False), (1024, 500, 77, 1, None, False),
+                                                     # the wide form (16 columns per thread): the generic configuration's 8000 prototypes
+                                                     (8000, 403, 150, 5, 390, False), (6400, 350, 100, 3, None, True),
+                                                     (8192, 200, 64, 4, 190, False)])
 def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, pdf):
     """gx_sinkhorn_table (every problem of a step — patches x views — solved on the two per-pixel score tables, a table row
     read once per pass for all the patches that drew it) against the same problems solved one by one on gathered copies of
@@ -1115,7 +1118,8 @@ def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, p
     assert rel_err(u_mixed, ex.u) < 1e-5
 
 
-@pytest.mark.parametrize("k,B,nl,N,P,pdf", [(200, 3, 500, 200, 5, False), (5000, 2, 150, 64, 3, True), (132, 5, 1000, 999, 2, False)])
+@pytest.mark.parametrize("k,B,nl,N,P,pdf", [(200, 3, 500, 200, 5, False), (5000, 2, 150, 64, 3, True), (132, 5, 1000, 999, 2, False),
+                                            (8000, 2, 120, 50, 5, False)])
 def test_sinkhorn_table_per_image_problems(ops, k, B, nl, N, P, pdf):
     """gx_sinkhorn_table with one problem per image too (the per-image Sinkhorn scope: the reference's batch-1 semantics): image
     b's live rows are the run [seg[b], seg[b + 1]) of the table, a workgroup stays inside one image; against every problem
