@@ -467,6 +467,9 @@ __global__ void sk_table_rebase_kernel(float* __restrict__ u, const float* __res
 // chunks of 4 columns per thread: 2 while the scaling vectors of all patches fit LDS 8 T apart at T <= 768, else the wide form
 static inline int skt_nc(int npatch, int K) {
     const int t = 64 * ((K + 511) / 512);
+#ifdef SKT_FORCE_WIDE
+    if ((long)npatch * K <= SKT_LA_CAP4 && K <= 16 * SKT_T4) return 4;          // lab: the wide form wherever it fits
+#endif
     return (t <= SKT_MAXT && (long)npatch * 8 * (t < 256 ? 256 : t) <= SKT_LA_CAP) ? 2 : 4;
 }
 static inline int skt_threads(int K, int nc = 2) {
