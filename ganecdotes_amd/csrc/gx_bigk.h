@@ -531,10 +531,14 @@ constexpr int CE_PMAX = 8;                  // patches per step the pixel-major 
 #ifndef CE_PIX_NJ2
 #define CE_PIX_NJ2 80       // widest rows (64-column chunks per lane) compiled for two workgroups per CU (lab: tools/lab/bigk_minb.sh)
 #endif
-// (two workgroups per CU up to 5120 columns; past that the rows and their exponentials need more than 256 registers — 188 spilled
-//  at 6144 columns — and the kernel runs at ONE workgroup per CU with the AGPRs as the second half of its register file)
-template <int NJ>
-__global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
+// (two workgroups of 256 threads per CU up to 5120 columns; past that the rows and their exponentials need more than 256 registers per
+//  thread — 188 spilled at 6144 columns —: ONE workgroup of 512 threads per CU, half the columns per thread; round 3 ran 256
+//  threads there with the AGPRs as the second half of the register file: four waves per CU, 43.6 ms at K = 8000)
+#ifndef CE_PIX_BT_WIDE
+#define CE_PIX_BT_WIDE 512     // threads per workgroup past CE_PIX_NJ2 (lab: 512 / 1024)
+#endif
+template <int NJ, int BT = (NJ > CE_PIX_NJ2 ? CE_PIX_BT_WIDE : 256)>
+__global__ __launch_bounds__(BT, BT == 256 ? 2 : 1) void ce_pixels_bigk_kernel(const float* __restrict__ S_all, int P, long rows, int K, long ld,
                                                                 const int* __restrict__ inv, long npix, int ngroups,
                                                                 long pix_per_group, const float* __restrict__ la_all,
                                                                 float inv_eps, float inv_T, float gscale,
@@ -548,14 +552,14 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
     // pixel's two score rows are read once for all the patches that drew it.  live != NULL: the drawn pixels are the first
     // *live rows of the tables (DESIGN §4.15 d) — the d(scores) rows past them are neither read by the GEMMs nor written here
     const long nlive = live ? min(npix, (long)max(0, *live)) : npix;      // (npix stays the row length of `inv`)
-    constexpr int NC = (NJ + 15) / 16;
-    __shared__ float red[2 * 16];
+    constexpr int NC = (NJ * 64 + 4 * BT - 1) / (4 * BT), NW = BT / 64;      // 16-byte chunks per thread; waves
+    __shared__ __attribute__((aligned(16))) float red[2 * 4 * NW];
     // the block's column sums of both tables (the bias gradient) live in LDS, every thread adding to its own columns: in
     // registers (40 more) the kernel spilled 77 dwords at three workgroups per CU and ran at 1.8 TB/s
     extern __shared__ __attribute__((aligned(16))) float csum[];         // [2][K]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float f = -0.5f * gscale * inv_T;
-    for (int k = tid; k < 2 * K; k += 256) csum[k] = 0.f;
+    for (int k = tid; k < 2 * K; k += BT) csum[k] = 0.f;
     __syncthreads();          // a block without a pixel (or whose first pixel nobody drew) reaches its csum reads with no other barrier
     float lacc = 0.f;
     for (long pix = blockIdx.x; pix < nlive; pix += gridDim.x) {
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
             for (int p = 0; p < CE_PMAX; ++p) any = any || nrow[p] >= 0;
             const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all, pix, ld, any ? K : 0), rt = bk_row_rsrc(St_tab, pix, ld, any ? K : 0);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+            for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + BT * c)); b[c] = bk_load4(rt, 4 * (tid + BT * c)); }
         }
 #pragma unroll
         for (int p = 0; p < CE_PMAX; ++p) {
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
                 const __amdgpu_buffer_rsrc_t rs = bk_row_rsrc(S_all + (long)(p * 2) * rows * ld, n, ld, K);
                 const __amdgpu_buffer_rsrc_t rt = bk_row_rsrc(S_all + (long)(p * 2 + 1) * rows * ld, n, ld, K);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + 256 * c)); b[c] = bk_load4(rt, 4 * (tid + 256 * c)); }
+                for (int c = 0; c < NC; ++c) { a[c] = bk_load4(rs, 4 * (tid + BT * c)); b[c] = bk_load4(rt, 4 * (tid + BT * c)); }
             }
             // the patch's la vectors (L2-resident: 10 x 20 KB; LDS has no room for all of them) are read ONCE per row pair into
             // registers, not once per use: 10 instead of 30 loads per thread — at two workgroups per CU, where the registers
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
             f32x4 lsr[NC], ltr[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int k = min(4 * (tid + 256 * c), K - 4);
+                const int k = min(4 * (tid + BT * c), K - 4);
                 lsr[c] = *reinterpret_cast<const f32x4*>(las + k); ltr[c] = *reinterpret_cast<const f32x4*>(lat + k);
 #if CE_PIX_ABL == 1
                 lsr[c] = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; ltr[c] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};      // lab: no scaling-vector loads
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
             float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int k = 4 * (tid + 256 * c);
+                const int k = 4 * (tid + BT * c);
                 if (k < K) {
                     const f32x4 ls = CE_LS(c, k), lt = CE_LT(c, k);
 #pragma unroll
@@ -620,11 +624,19 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = gx_wave_max(mx[j]);
-                if (lane == 0) red[j * 4 + wid] = v;
+                if (lane == 0) red[j * NW + wid] = v;
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mx[j] = fmaxf(fmaxf(red[j * 4], red[j * 4 + 1]), fmaxf(red[j * 4 + 2], red[j * 4 + 3]));
+            for (int j = 0; j < 4; ++j) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < NW; i += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + j * NW + i);
+                    m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                }
+                mx[j] = m;
+            }
             // the four exponentials of an element are evaluated ONCE: the sums pass leaves them in registers (the code ones
             // over the la registers, dead by then) and the element-wise pass only scales them — v_exp_f32 is a quarter-rate
             // instruction and the pass is VALU-bound
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
             f32x4 es[NC], et[NC];                                        // exp((x - m) / T) of both views
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int k = 4 * (tid + 256 * c);
+                const int k = 4 * (tid + BT * c);
                 es[c] = f32x4{0.f, 0.f, 0.f, 0.f}; et[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < K) {
 #pragma unroll
@@ -648,18 +660,26 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = gx_wave_sum(sv[j]);
-                if (lane == 0) red[16 + j * 4 + wid] = v;
+                if (lane == 0) red[4 * NW + j * NW + wid] = v;
             }
             __syncthreads();
             float t4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t4[j] = (red[16 + j * 4] + red[16 + j * 4 + 1]) + (red[16 + j * 4 + 2] + red[16 + j * 4 + 3]);
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; i += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + 4 * NW + j * NW + i);
+                    t += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                t4[j] = t;
+            }
             const float m_s = mx[1], m_t = mx[3];
             const float iv_s = 1.f / t4[0], z_s = t4[1], iv_t = 1.f / t4[2], z_t = t4[3];
             const float iz_s = 1.f / z_s, iz_t = 1.f / z_t, lz_s = logf(z_s), lz_t = logf(z_t);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int k = 4 * (tid + 256 * c);
+                const int k = 4 * (tid + BT * c);
                 if (k < K) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -671,12 +691,12 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
                     }
                 }
             }
-            // (the next patch's first barrier orders these reads of red[16 ..] before its writes, its second those of red[0 ..])
+            // (the next patch's first barrier orders these reads of the sums' half of `red` before its writes, its second those of the maxima's)
         }
         const __amdgpu_buffer_rsrc_t ds = bk_row_rsrc(dSs, pix, ldd, kpad), dt = bk_row_rsrc(dSt, pix, ldd, kpad);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int k = 4 * (tid + 256 * c);
+            const int k = 4 * (tid + BT * c);
 #if CE_PIX_ABL == 2
             if (k < kpad && as[c][0] == 123.f) {                         // lab: no d(scores) stores
 #else
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(256, NJ > CE_PIX_NJ2 ? 1 : 2) void ce_pixels_bigk_k
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int k = 4 * (tid + 256 * c);
+        const int k = 4 * (tid + BT * c);
         if (k < K) {
             *reinterpret_cast<f32x4*>(part_s + (long)blockIdx.x * K + k) = *reinterpret_cast<const f32x4*>(csum + k);
             *reinterpret_cast<f32x4*>(part_t + (long)blockIdx.x * K + k) = *reinterpret_cast<const f32x4*>(csum + K + k);

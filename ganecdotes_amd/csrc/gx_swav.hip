@@ -1316,14 +1316,15 @@ static int ce_pixels_impl(const float* S_all, const float* St_tab, int P, long r
     if (!S_all || !inv || !la_all || !loss_out || !dSs || !dSt || !gb || P <= 0 || P > CE_PMAX || rows <= 0 || K <= 0 || ld < K || npix <= 0 ||
         ngroups <= 0 || (!row_group && npix % ngroups) || kpad < K || kpad > ldd || (kpad & 3))
         return GX_ERR_BAD_ARG;
+    const int cebt = bigk_nj(K) > CE_PIX_NJ2 ? CE_PIX_BT_WIDE : 256;              // ce_pixels_bigk_kernel's block
     if (!bigk_ok(K) || !bigk_aligned(S_all, ld) || !bigk_aligned(dSs, ldd) || !bigk_aligned(dSt, ldd) ||
-        (((uintptr_t)la_all) & 15) || 4 * 256 * ((bigk_nj(K) + 15) / 16) < kpad)
+        (((uintptr_t)la_all) & 15) || 4 * cebt * ((bigk_nj(K) * 64 + 4 * cebt - 1) / (4 * cebt)) < kpad)
         return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_swapped_ce_fused_workspace_bytes(K)) return GX_ERR_WORKSPACE;
     const int nbk = (int)(npix < 2040 ? npix : 2040);
     float* part_s = workspace + 2048;
     float* part_t = part_s + (size_t)2048 * K;
-    GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((ce_pixels_bigk_kernel<NJ>), dim3(nbk), dim3(256), (size_t)2 * K * sizeof(float), (hipStream_t)stream,
+    GX_BIGK_DISPATCH_PASS(bigk_nj(K), hipLaunchKernelGGL((ce_pixels_bigk_kernel<NJ>), dim3(nbk), dim3(cebt), (size_t)2 * K * sizeof(float), (hipStream_t)stream,
                                                     S_all, P, rows, K, ld, inv, npix, ngroups, npix / ngroups, la_all, 1.f / eps,
                                                     1.f / temperature, grad_scale, dSs, dSt, ldd, kpad, workspace, part_s,
                                                     part_t, St_tab, live, row_group));
