@@ -464,6 +464,8 @@ int gx_sinkhorn_rows_batch(const float* S, const int* rowmap_all, int nprob, lon
  *            int 1 if the steps lie within 64 log2 units of each other}
  *   _rebase: u *= exp((cm_local - cm_global) / eps) (sharded first pass, after the MAX all-reduce of cmax)
  *   gx_sinkhorn_table: the whole single-rank solve (niters iterations), cmax / u = scratch [2 npatch][K], stats [2 npatch][2]. */
+/* shapes the table solver takes: npatch <= 5, K % 4 == 0, K > 64, and the patches' scaling vectors fit one CU's LDS — 8 columns per
+ * thread (K <= 6144, npatch * 8 * 64 * ceil(K / 512) <= 32768 floats) or the wide form, 16 columns per thread (K <= 8192, npatch * K <= 40000) */
 int gx_sinkhorn_table_ok(int npatch, int K);
 size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K, int ngroups);
 int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, const int* inv, long npix, int npatch,
