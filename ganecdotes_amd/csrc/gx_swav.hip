@@ -1497,7 +1497,9 @@ __global__ void sumpool2_kernel(const float* __restrict__ fine, float* __restric
 }
 
 // zhat[row] = normalize(Z[b][src(pick[row])]) (zero row where the rotation zero-filled), rnorm[row].
-// One wave per row.
+// One wave per row.  NV > 0: D = 256 NV and 16-byte aligned rows — the row is read ONCE, 16 bytes per lane and load (NV = 0: any
+// D, dword loads, the row read twice: 2.6 TB/s of rows at D = 512 against 4+ for the vector form)
+template <int NV>
 __global__ void gather_rows_normalize_kernel(const float* __restrict__ Z, int HW, int D, const int* __restrict__ picks,
                                              const int* __restrict__ maps, int rows_per_img, long rows,
                                              float* __restrict__ zhat, float* __restrict__ rnorm) {
@@ -1514,16 +1516,33 @@ __global__ void gather_rows_normalize_kernel(const float* __restrict__ Z, int HW
         return;
     }
     const float* src = Z + ((long)b * HW + pix) * D;
-    float s = 0.f;
-    for (int c = lane; c < D; c += 64) { const float v = src[c]; s = fmaf(v, v, s); }
-    s = gx_wave_sum(s);
-    const float rn = 1.f / fmaxf(sqrtf(s), 1e-12f);
-    for (int c = lane; c < D; c += 64) out[c] = src[c] * rn;
-    if (lane == 0) rnorm[row] = rn;
+    if constexpr (NV > 0) {
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(src + 4 * (lane + 64 * i));
+            s = fmaf(v[i][0], v[i][0], fmaf(v[i][1], v[i][1], fmaf(v[i][2], v[i][2], fmaf(v[i][3], v[i][3], s))));
+        }
+        s = gx_wave_sum(s);
+        const float rn = 1.f / fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(out + 4 * (lane + 64 * i)) = v[i] * rn;
+        if (lane == 0) rnorm[row] = rn;
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) { const float v = src[c]; s = fmaf(v, v, s); }
+        s = gx_wave_sum(s);
+        const float rn = 1.f / fmaxf(sqrtf(s), 1e-12f);
+        for (int c = lane; c < D; c += 64) out[c] = src[c] * rn;
+        if (lane == 0) rnorm[row] = rn;
+    }
 }
 
 // G[b][src(pick[row])][:] += rnorm * (dzh - zh <zh, dzh>)   (normalise-backward fused with the
-// adjoint of the row gather; float atomics, 256 contiguous bytes per wave-instruction)
+// adjoint of the row gather; float atomics — two output pixels of a rotated view can sample the same source pixel —, 256
+// contiguous bytes per wave-instruction.  The 16-bytes-per-lane form of the gather above is NOT for this kernel: an atomic
+// instruction whose lanes are 16 bytes apart touches eight times the cache lines — 3.3 -> 11.2 ms at the K = 5000 bench shape)
 __global__ void normalize_bwd_scatter_kernel(const float* __restrict__ dzh, const float* __restrict__ zh,
                                              const float* __restrict__ rnorm, int HW, int D,
                                              const int* __restrict__ picks, const int* __restrict__ maps,
@@ -1572,8 +1591,17 @@ int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* pi
                              float* zhat, float* rnorm, void* stream) {
     if (!Z || !picks || !zhat || !rnorm || B <= 0 || HW <= 0 || D <= 0 || rows_per_img <= 0) return GX_ERR_BAD_ARG;
     const long rows = (long)B * rows_per_img;
-    hipLaunchKernelGGL(gx::gather_rows_normalize_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, Z,
-                       HW, D, picks, maps, rows_per_img, rows, zhat, rnorm);
+    const bool vec = (D % 256) == 0 && D <= 1024 && ((((uintptr_t)Z | (uintptr_t)zhat) & 15) == 0);
+#define GX_GRN(NV_) hipLaunchKernelGGL(gx::gather_rows_normalize_kernel<NV_>, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, Z, \
+                                       HW, D, picks, maps, rows_per_img, rows, zhat, rnorm)
+    switch (vec ? D / 256 : 0) {
+        case 1: GX_GRN(1); break;
+        case 2: GX_GRN(2); break;
+        case 3: GX_GRN(3); break;
+        case 4: GX_GRN(4); break;
+        default: GX_GRN(0); break;
+    }
+#undef GX_GRN
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -781,6 +781,34 @@ def test_pyramid_pieces(ops):
     assert rel_err(gfull.reshape(b, hw * hw, d), want) < 1e-5
 
 
+@pytest.mark.parametrize("d", [256, 512, 768, 1024, 260])
+def test_gather_normalize_and_its_scatter_vector_rows(ops, d):
+    """gx_gather_rows_normalize on rows of 256 NV floats (read once, 16 bytes per lane and load; 260: the dword form) and
+    gx_normalize_bwd_scatter against torch: rotated / flipped views (zero-filled picks, source pixels drawn twice), autograd's gradient"""
+    torch.manual_seed(d)
+    b, hw, n = 2, 12, 120
+    zc = torch.randn(b, hw, hw, d)
+    z = dev(zc)
+    picks = torch.stack([torch.randperm(hw * hw)[:n] for _ in range(b)]).int().cuda()
+    maps = torch.stack([ops.rotflip_map(10.0, True, hw, hw, "cuda"), ops.rotflip_map(-7.0, False, hw, hw, "cuda")])
+    zh, rn = ops.gather_rows_normalize(z, picks, maps)
+    src = torch.gather(maps.cpu().long(), 1, picks.cpu().long())
+    flat = zc.reshape(b, hw * hw, d)
+    rows = torch.stack([flat[i][src[i].clamp(min=0)] * (src[i] >= 0).float()[:, None] for i in range(b)])
+    assert rel_err(zh, torch.nn.functional.normalize(rows.reshape(-1, d), dim=1)) < 1e-6
+    assert int((src < 0).sum()) > 0 and any(len(set(src[i][src[i] >= 0].tolist())) < int((src[i] >= 0).sum()) for i in range(b))
+    gin = torch.randn(b * n, d)
+    x1 = rows.reshape(-1, d).clone().requires_grad_(True)
+    torch.nn.functional.normalize(x1, dim=1).backward(gin)
+    gfull = torch.zeros(b, hw, hw, d, device="cuda")
+    ops.normalize_bwd_scatter_(dev(gin), zh, rn, picks, maps, gfull)
+    want = torch.zeros(b, hw * hw, d)
+    for i in range(b):
+        ok = src[i] >= 0
+        want[i].index_add_(0, src[i][ok], x1.grad.reshape(b, n, d)[i][ok])
+    assert rel_err(gfull.reshape(b, hw * hw, d), want) < 1e-5
+
+
 @pytest.mark.parametrize("d,k", [(256, 8), (512, 12), (512, 16), (256, 3)])
 def test_small_prototype_fused_kernels(ops, d, k):
     """fused K<=16 kernels == the unfused gather/normalise/GEMM/colsum/scatter chain"""
