@@ -342,6 +342,11 @@ def main():
                     help="Sinkhorn scope: 'global' = one problem per view and patch over the whole (sharded) batch, normalised "
                          "across ranks by all-reduce as BASELINE.json's north_star asks (default); 'image' = one problem per "
                          "image, view and patch (the reference's batch-1 semantics, no Sinkhorn collective)")
+    ap.add_argument("--pdf", default="uniform", choices=["uniform", "image"],
+                    help="Sinkhorn marginals: 'uniform' (BASELINE.json's config, hfc_with_swav_ffhq_config.py) or 'image' = the "
+                         "histograms of the norm maps (hfc_with_swav_cat_config.py:63-65; eps defaults to that file's 0.003); "
+                         "not the headline configuration: a line with it says so in config.workload")
+    ap.add_argument("--eps", type=float, default=0.0, help="Sinkhorn eps (default: 0.005, or 0.003 with --pdf image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ds-table", default="auto", choices=["auto", "on", "off"],
                     help="many prototypes: d(scores) summed per pixel before the backward GEMMs (DESIGN 4.15); auto = when "
@@ -405,6 +410,10 @@ def main():
 
     def make(nproto):
         wl = workload(args.batch, nproto, scope=args.scope)
+        if args.pdf != "uniform":
+            wl["sinkhorn_args"].update(source_pdf=args.pdf, eps=args.eps if args.eps else 0.003)
+        elif args.eps:
+            wl["sinkhorn_args"]["eps"] = args.eps
         if args.ds_table != "auto":
             wl["swav_args"]["ds_table"] = args.ds_table == "on"
         sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
@@ -436,7 +445,9 @@ def main():
                        "error, tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
                        if x6 else "fp32 MFMA (exact fmaf chains)"),
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
-                               f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, eps=0.005, "
+                               f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, "
+                               f"eps={args.eps if args.eps else (0.005 if args.pdf == 'uniform' else 0.003)}, "
+                               + ("" if args.pdf == "uniform" else f"source_pdf={args.pdf} (NOT the headline configuration), ") +
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
                                f"the device generator (= the set randperm[:N] selects); views = the 13 feature taps of both "
                                f"perturbed latents (the RGB image, which enters no loss term, is not rendered)",
