@@ -334,6 +334,24 @@ __device__ __forceinline__ void xw_epilogue(const GemmArgs& g, f32x16 (&acc)[1][
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) rs[ps] = row_scale[min(row0 + ps * 4 + rl, g.M - 1)];
     }
+#ifdef XW_ABL_DIRECT
+    // lab (WRONG values, the right store pattern): what an epilogue that stores the accumulators straight from registers — lane =
+    // row, four consecutive columns per register quad, no LDS staging — would cost; tools/lab/sc_lab.py
+    if (!up_src && !row_scale && !q.colmax_part) {
+        const int row = row0 + (lane & 31);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cc = col0 + nt * 32 + 8 * g4 + 4 * (lane >> 5);
+                f32x4 v = {acc[0][nt][4 * g4], acc[0][nt][4 * g4 + 1], acc[0][nt][4 * g4 + 2], acc[0][nt][4 * g4 + 3]};
+                v *= alpha;
+                v += cb;
+                if (row < g.M && cc < g.N) *reinterpret_cast<f32x4*>(g.C + (long)row * g.ldc + cc) = v;
+            }
+        return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
