@@ -41,3 +41,5 @@ wt = ops.split_gemm_weights(torch.nn.functional.pad(w, (0, 0, 0, kp - K)).t().co
 dz = torch.empty(rows, 512, device=dev)
 t = timeit(lambda: ops.gemm_nt_planes(ds, None, wt, dz))
 print(f"dz     {rows} x 512 x {kp}: {t:7.3f} ms  {2.0 * rows * kp * 512 / t / 1e9:6.1f} TFLOP/s")
+t = timeit(lambda: ops.gemm_nt_planes(a, None, wp, out, col_bias=bias, want_colmax=True, sk_eps=0.005))
+print(f"scores + per-slice column maxima and first-pass sums (and their merge over all rows): {t:7.3f} ms")
