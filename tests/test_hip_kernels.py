@@ -227,6 +227,21 @@ def test_sinkhorn_image_pdf(ops, tag):
     assert np.all(np.abs(q - ref) <= 1e-3 * ref.max(axis=1, keepdims=True))
 
 
+@pytest.mark.parametrize("bins", [16, 4096, 4097])
+def test_hist_marginal_counts_at_norm_map_size(ops, bins):
+    """gx_hist_marginal on a norm map of the bench's size (a million values) against torch.histc + the reference's fix-ups
+    (swav_clustering.py:524-530): few bins (counted per block in LDS: the cat configuration's 16) and many (global atomics)"""
+    torch.manual_seed(bins)
+    x = torch.rand(1_000_003) * 3.0 + torch.randn(1_000_003).abs()
+    h = torch.histc(x, bins) + 1e-9
+    h[0] = h[1]
+    want = (h / h.sum()).numpy()
+    got = ops.hist_marginal(dev(x), bins).cpu().numpy()
+    # a value within an ulp of a bin edge may fall on either side (the kernel divides where torch multiplies by a reciprocal):
+    # about n * bins * 2^-23 such values, each moving 1 / n between two neighbouring bins
+    assert np.abs(got - want).sum() < 2e-5 + 1e-6 * bins and np.abs(got - want).max() < 6e-6
+
+
 def test_hist_marginal_sharded_equals_single(ops):
     torch.manual_seed(14)
     x = torch.rand(4, 32, 32) * 5 + 0.3
