@@ -874,6 +874,11 @@ def test_row_ops(ops):
     out = torch.zeros(512, device="cuda")
     ops.colsum(dev(z), out)
     assert rel_err(out, z.double().sum(0)) < 1e-5
+    # row sums of squares over the first `cused` columns: every lane-team width of the 16-byte form, and the dword form (odd widths)
+    for c, cused in ((24, 24), (32, 20), (64, 64), (128, 128), (256, 100), (512, 512), (512, 448), (77, 77), (64, 30), (1024, 1024)):
+        x = torch.randn(1037, c)
+        got = ops.row_sumsq(dev(x), cused)
+        assert rel_err(got, (x[:, :cused].double() ** 2).sum(1)) < 1e-6
 
 
 def test_larc_sgd(ops):
