@@ -18,6 +18,7 @@ from torch import nn
 
 from . import ops
 from .draws import ImageDraws, ViewDraws, draw_image
+from .hostcfg import limit_host_threads
 from .pyramid import Pyramid
 from .swav_clustering import _NullLogger
 from .views import ViewMixin
@@ -59,6 +60,7 @@ class SimCLRClustering(ViewMixin):
         if self.device.type != 'cuda':
             raise RuntimeError("SimCLRClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
         ops.lib()
+        limit_host_threads()
         self.writer = tb
         self.nclasses = simclr_args['nclasses']
         self._hlen = simclr_args['hlen']

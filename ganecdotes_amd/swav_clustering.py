@@ -46,6 +46,7 @@ from torch import nn
 
 from . import ops, sharded
 from .draws import ImageDraws, draw_image
+from .hostcfg import limit_host_threads
 from .views import PreparedBatch, ViewMixin
 from .pyramid import Pyramid
 from .projection_head import ProjectionHead, build_projection
@@ -69,6 +70,7 @@ class SwAVClustering(ViewMixin):
         if self.device.type != 'cuda':
             raise RuntimeError("SwAVClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
         ops.lib()                                   # fail loudly if the HIP extension is missing
+        limit_host_threads()                        # the host only feeds the GPU: no more threads than CPUs it may use (hostcfg.py)
         self.writer = tb
         self._hlen = swav_args['hlen']
         self.nclasses = swav_args['nclasses']

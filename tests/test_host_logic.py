@@ -236,3 +236,19 @@ def test_baggan_generator_speaks_the_reference_keys():
     m = load_config(mapper.models['pidray-256'], 'model_config')
     assert m.is_baggan and m.truncation == 0.9 and m.gen_args['img_resolution'] == 256
     assert load_config(mapper.models['pidray-hammer-256'], 'model_config').truncation == 0.95
+
+
+def test_host_thread_cap_only_lowers():
+    """hostcfg.limit_host_threads: torch's intra-op pool is capped at the CPUs the process may use (affinity, cgroup quota) and
+    at 16; it never raises the count and acts once per process"""
+    import torch
+    from ganecdotes_amd import hostcfg
+    before = torch.get_num_threads()
+    n = hostcfg.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    got = hostcfg.limit_host_threads()
+    assert got == torch.get_num_threads() and got <= before and got <= max(16, 1)
+    torch.set_num_threads(max(1, got - 1) if got > 1 else 1)
+    again = hostcfg.limit_host_threads()                 # once per process: a later call leaves the caller's own setting alone
+    assert again == torch.get_num_threads()
+    torch.set_num_threads(before)
