@@ -751,9 +751,16 @@ class SwAVClustering(ViewMixin):
         batch = sa.get('batch_size', 1)
         t0 = time.time()
         self.loss_history = []
+        # the next batch is drawn (host RNG, same order) and staged BEFORE a step's loss is read back for the log: the read-back
+        # waits for the GPU, and the host-side draws (80 randperms of 65 536 per ffhq batch) would otherwise start only after it
+        total = sa['num_epochs'] * sa['num_samples']
+        nxt = self.draw_batch(batch) if total > 0 else None
+        done = 0
         for e in range(sa['num_epochs']):
             for _ in range(sa['num_samples']):
-                loss = self.train_step(self.draw_batch(batch))
+                loss = self.train_step(nxt)
+                done += 1
+                nxt = self.draw_batch(batch) if done < total else None
                 self.loss_history.append(loss)
                 if self.writer is not None:
                     self.writer.add_scalar('swav/loss', loss.item(), e)
