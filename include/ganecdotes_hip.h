@@ -421,6 +421,7 @@ int gx_sinkhorn_small_batch_finish(int nprob, int K, float eps, int niters, cons
                                    const float* u_last, const float* workspace, float* la, void* stream);
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
+/* scratch: 258 words (the data range as two ordered ints + 256 block partials of the normalising sum) */
 int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);
 /* the same in three stages for the sharded form: range (all_reduce MIN/MAX of lohi) -> counts
  * (all_reduce SUM of hist) -> finish */

@@ -242,6 +242,19 @@ def test_hist_marginal_counts_at_norm_map_size(ops, bins):
     assert np.abs(got - want).sum() < 2e-5 + 1e-6 * bins and np.abs(got - want).max() < 6e-6
 
 
+def test_hist_marginal_many_bins_two_launch_normalisation(ops):
+    """one bin per sample (320 000 at the bench batch): gx_hist_marginal normalises in two launches over all CUs; the staged form
+    (gx_hist_range / _counts / _finish: one block) on the same data gives the same marginal, and it sums to one"""
+    torch.manual_seed(5)
+    x = dev(torch.rand(1_048_576) * 2.0 + torch.randn(1_048_576).abs())
+    for bins in (16384, 320000):
+        a = ops.hist_marginal(x, bins)
+        b = ops.hist_marginal(x, bins, reduce=lambda t, op: None)
+        assert abs(float(a.double().sum()) - 1.0) < 1e-5
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.max())
+        assert float(a[0]) == float(a[1])
+
+
 def test_hist_marginal_sharded_equals_single(ops):
     torch.manual_seed(14)
     x = torch.rand(4, 32, 32) * 5 + 0.3
