@@ -242,6 +242,23 @@ def test_hist_marginal_counts_at_norm_map_size(ops, bins):
     assert np.abs(got - want).sum() < 2e-5 + 1e-6 * bins and np.abs(got - want).max() < 6e-6
 
 
+@pytest.mark.parametrize("bins", [4097, 8192, 8193, 320000])
+def test_hist_counts_many_bins_exact(ops, bins):
+    """the range-owning histogram (a block counts a range of 8192 bins in LDS while it scans all values, plain stores) against
+    torch.bincount of the same fp32 bin arithmetic, int((x - lo) / (hi - lo) * bins): exact counts, odd lengths, unaligned views"""
+    torch.manual_seed(bins)
+    for n, off in ((1_048_576, 0), (100_003, 1)):
+        xb = dev(torch.rand(n + off) * 2.0 + torch.randn(n + off).abs())
+        x = xb[off:]
+        lo, hi = x.min(), x.max()
+        pos = ((x - lo) / (hi - lo) * float(bins)).to(torch.int64).clamp_(0, bins - 1)
+        want = torch.bincount(pos, minlength=bins).double() + 1e-9
+        want[0] = want[1]
+        want = want / want.sum()
+        got = ops.hist_marginal(x.contiguous() if off == 0 else x, bins).double()
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.max())
+
+
 def test_hist_marginal_many_bins_two_launch_normalisation(ops):
     """one bin per sample (320 000 at the bench batch): gx_hist_marginal normalises in two launches over all CUs; the staged form
     (gx_hist_range / _counts / _finish: one block) on the same data gives the same marginal, and it sums to one"""
