@@ -81,10 +81,11 @@ __device__ __forceinline__ void rs_find_bin(const unsigned* hist, int nbins, uns
 __global__ __launch_bounds__(1024) void random_subset_kernel(const unsigned* __restrict__ keys, int HW, int N,
                                                              int* __restrict__ picks) {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned s_bin, s_below, s_scan[2][16], s_tot[2];
+    __shared__ unsigned s_bin, s_below, s_w[2][16];
     const unsigned* k = keys + (long)blockIdx.x * HW;
     int* out = picks + (long)blockIdx.x * N;
     const int tid = threadIdx.x;
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)k) & 15) == 0);     // 16-byte key loads
     unsigned prefix = 0, need = (unsigned)N, below = 0;
     // three radix levels: shifts 21, 10, 0 with 11, 11, 10 bits
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
@@ -94,9 +95,16 @@ __global__ __launch_bounds__(1024) void random_subset_kernel(const unsigned* __r
         for (int i = tid; i < 2048; i += 1024) hist[i] = 0u;
         __syncthreads();
         const int hs = shifts[lv] + bits[lv];                    // bits above this level
-        for (int i = tid; i < HW; i += 1024) {
-            const unsigned v = k[i];
+        auto count = [&](unsigned v) {
             if (lv == 0 || (v >> hs) == prefix) atomicAdd(&hist[(v >> shifts[lv]) & (nb - 1)], 1u);
+        };
+        if (vec) {
+            for (int i = tid; i < (HW >> 2); i += 1024) {
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(k)[i];
+                count(v[0]); count(v[1]); count(v[2]); count(v[3]);
+            }
+        } else {
+            for (int i = tid; i < HW; i += 1024) count(k[i]);
         }
         __syncthreads();
         rs_find_bin(hist, nb, need, &s_bin, &s_below);
@@ -107,31 +115,33 @@ __global__ __launch_bounds__(1024) void random_subset_kernel(const unsigned* __r
         __syncthreads();
     }
     const unsigned T = prefix;                                    // the N-th smallest key; `need` of the keys == T are taken
-    // order-preserving compaction: thread t owns the contiguous index range [t*per, (t+1)*per)
-    const int per = (HW + 1023) / 1024, i0 = tid * per, i1 = min(HW, i0 + per);
-    unsigned nless = 0, ntie = 0;
-    for (int i = i0; i < i1; ++i) { const unsigned v = k[i]; nless += v < T; ntie += v == T; }
-    // block exclusive scans of (nless, ntie)
-    unsigned incl[2] = {nless, ntie};
+    // Order-preserving compaction, a tile of 1024 consecutive keys at a time (coalesced reads; a thread owning a contiguous
+    // range of the row instead read 64 cache lines per wave instruction, twice: 1.8 of the 2.0 ms the kernel took on the car
+    // configuration's 262 144-pixel rows): positions from wave ballots + the 16 waves' counts; the keys < T come out ascending
+    // at out[0 .. below), the first `need` of the keys == T behind them.
     const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    unsigned base_less = 0, base_tie = 0;
+    for (int t0 = 0; t0 < HW; t0 += 1024) {
+        const int i = t0 + tid;
+        const unsigned v = i < HW ? k[i] : 0xFFFFFFFFu;           // (keys are fp32 in [0, 1): never 0xFFFFFFFF)
+        const bool less = v < T, tie = v == T && i < HW;
+        const unsigned long long bl = __ballot(less), bt = __ballot(tie);
+        if (lane == 0) { s_w[0][wv] = (unsigned)__popcll(bl); s_w[1][wv] = (unsigned)__popcll(bt); }
+        __syncthreads();
+        unsigned ol = base_less + (unsigned)__popcll(bl & lt_mask), ot = base_tie + (unsigned)__popcll(bt & lt_mask);
+        unsigned tl = 0, tt = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl[q], o, 64); if (lane >= o) incl[q] += v; }
-        if (lane == 63) s_scan[q][wv] = incl[q];
-    }
-    __syncthreads();
-    if (tid < 2) {
-        unsigned run = 0;
-        for (int w = 0; w < 16; ++w) { const unsigned c = s_scan[tid][w]; s_scan[tid][w] = run; run += c; }
-        s_tot[tid] = run;
-    }
-    __syncthreads();
-    unsigned pos_less = s_scan[0][wv] + incl[0] - nless, pos_tie = s_scan[1][wv] + incl[1] - ntie;
-    const unsigned total_less = s_tot[0];                         // == below
-    for (int i = i0; i < i1; ++i) {
-        const unsigned v = k[i];
-        if (v < T) out[pos_less++] = i;
-        else if (v == T) { if (pos_tie < need) out[total_less + pos_tie] = i; ++pos_tie; }
+        for (int w = 0; w < 16; ++w) {
+            const unsigned cl = s_w[0][w], ct = s_w[1][w];
+            if (w < wv) { ol += cl; ot += ct; }
+            tl += cl; tt += ct;
+        }
+        if (less) out[ol] = i;
+        else if (tie && ot < need) out[below + ot] = i;
+        base_less += tl;
+        base_tie += tt;
+        __syncthreads();                                          // s_w is rewritten by the next tile
     }
 }
 
