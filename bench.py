@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, dense v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA = 2500e12          # same guide: dense v_mfma_f32_32x32x16_bf16 (no sparsity)
 PEAK_HBM = 8.0e12
-TRAFFIC_FILE = "r04_traffic.json"   # PMC passes of this round (tools/profile_bench.sh): HBM bytes per launch of the dominant kernel
+TRAFFIC_FILE = "r05_traffic.json"   # PMC passes of this round (tools/profile_bench.sh): HBM bytes per launch of the dominant kernel
 
 
 class ModelCfg:
@@ -300,15 +300,17 @@ def roofline_of(stats, ms_per_step, traffic_file):
     peak = PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA
     # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
-    traffic = None
+    traffic = traffic_src = None
     if traffic_file and os.path.exists(traffic_file):
         stem = {"modconv_kernel": "modconv", "gemm_f32_kernel": "gemm"}.get(name, name)
         cands = [t for k, t in json.load(open(traffic_file)).items() if stem in k]
         if cands:
             traffic = max(cands, key=lambda t: t["launches"])["hbm_bytes_per_launch"]
+            traffic_src = (f"from profiles/{os.path.basename(traffic_file)}: rocprofv3 --pmc passes over this same command "
+                           f"(tools/profile_bench.sh), committed; NOT measured in this run")
     step_flops = sum(x["flops_per_step"] for x in kern.values())
     roof = dict(bound="mfma", achieved=ach / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                frac=ach / peak, traffic=traffic, kernel=what,
+                frac=ach / peak, traffic=traffic, traffic_source=traffic_src, kernel=what,
                 engine="bf16x6" if x6 else "f32mfma",
                 mfma_tflops_issued=(6.0 if x6 else 1.0) * ach / 1e12,
                 mfma_peak=(PEAK_BF16_MFMA if x6 else PEAK_F32_MFMA) / 1e12,
@@ -329,6 +331,91 @@ def roofline_of(stats, ms_per_step, traffic_file):
                            gbytes_per_step=h["bytes_per_step"] / 1e9, ms_per_step=h["ms_per_step"],
                            launches_per_step=h["launches_per_step"])
     return roof
+
+
+def nested_record(workload_str, images_per_step, dt, steps, warmup, stats, loss=None, extra=None):
+    """One of the nested per-configuration records of the JSON line: ms per step, images/s, and the dominant kernel of THAT
+    configuration against its roofline (HIP events of this run), the whole step against the MFMA peak, the largest HBM-bound pass."""
+    ms = 1e3 * dt / steps
+    r = roofline_of(stats, ms, None) or {}
+    hb = r.get("hbm")
+    rec = {"workload": workload_str, "steps": steps, "warmup": warmup, "ms_per_step": ms,
+           "value": images_per_step * steps / dt, "unit": "images/s",
+           "roofline": {"kernel": r.get("kernel"), "bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"),
+                        "unit": r.get("unit"), "frac": r.get("frac"), "step_tflop": r.get("step_tflop"),
+                        "step_frac": r.get("step_frac"),
+                        "hbm": None if not hb else {k: hb[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "ms_per_step")},
+                        "ms_per_step_by_kernel": r.get("ms_per_step_by_kernel")}}
+    if loss is not None:
+        rec["loss"] = loss
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def timed_loop(step, steps, warmup):
+    """`warmup` untimed calls of step(), then `steps` timed ones between two synchronizes; (seconds, HIP-event statistics)"""
+    from ganecdotes_amd import ops
+    for _ in range(warmup):
+        step()
+    ops.PROFILE = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    stats = {}
+    for tag, evs in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b, *_ in evs)
+        stats[tag] = dict(ms_per_step=ms / steps, launches_per_step=sum(e[4] for e in evs) / steps,
+                          flops_per_step=sum(e[2] for e in evs) / steps, bytes_per_step=sum(e[3] for e in evs) / steps)
+    return dt, stats
+
+
+def simclr_record(g, dev, iters=200, warmup=20):
+    """BASELINE.json configs[4]: ffhq-256 hfc_with_simclr (baseline/hfc_with_simclr/simclr_clustering.py:131-280) — one image and
+    20 picked pixel pairs per iteration, T = 1.0, the 2-layer MLP with train-mode BatchNorm, LARC-SGD"""
+    from ganecdotes_amd.simclr_clustering import SimCLRClustering
+    a = dict(num_iters=1, batch_size=20, patch_size=20000, hf_interp="nearest", trust_coeff=0.01,
+             train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=512, hlen=5376,
+             epoch_print_freq=1, max_masks=4, use_larc=True, transforms=True)
+    sim = SimCLRClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, simclr_args=a,
+                           perturb_args=dict(truncation=0.7, n_layers=6, n_samples=1, layer_no=None, perturb_std=[1.0] * 6))
+    torch.manual_seed(42)
+    np.random.seed(42)
+    sim.build_heads()
+    last = []
+    dt, stats = timed_loop(lambda: last.append(sim.train_step(sim.draw_iteration())), iters, warmup)
+    return nested_record("ffhq-256 hfc_with_simclr (BASELINE.json configs[4]): 1 image per iteration, both views at 256x256, 20 "
+                         "shared pixel picks per view -> 40 rows, Linear(5376,512)-BatchNorm1d(train)-LeakyReLU-Linear(512,512), "
+                         "NT-Xent at T=1.0 with the reference's wrap-around pairs, LARC-SGD; host draws included",
+                         1, dt, iters, warmup, stats, loss=float(last[-1].item()),
+                         extra={"iterations_per_s": iters / dt})
+
+
+def predict_record(g, dev, batch=4, steps=10, warmup=2):
+    """The evaluate.py loop per test latent (src/one_shot_pipeline.py:632-665): predict_swav_codes (generator with fixed noise,
+    projection of all 65 536 pixels, argmax) + the one-shot head ('XXS': Conv2d(512, 12, 3, pad 1), config :77-78) + argmax"""
+    from ganecdotes_amd.oneshot import OneShotHead
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    wl = workload(batch, 8)
+    sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, **wl)
+    torch.manual_seed(42)
+    sw.build_heads()
+    head = OneShotHead(512, 12, size="XXS", device=dev)
+    lat = g.style(torch.randn(batch, 512, device=dev))
+
+    def step():
+        codes, _ = sw.predict_swav_codes(lat)
+        head.predict(codes.permute(0, 2, 3, 1))
+    dt, stats = timed_loop(step, steps, warmup)
+    return nested_record(f"ffhq-256 predict (evaluate.py / run_tests): {batch} test latents per call -> generator (fixed noise, one "
+                         f"truncation, RGB rendered) -> pyramid projection of every pixel (31 GFLOP per image instead of the "
+                         f"reference's 361: DESIGN 4.1) -> (B,512,256,256) codes + argmax -> 'XXS' one-shot head (3x3 conv 512->12) "
+                         f"-> label map",
+                         batch, dt, steps, warmup, stats)
 
 
 def main():
@@ -354,6 +441,11 @@ def main():
     ap.add_argument("--reference-faithful", default="auto", choices=["auto", "on", "off"],
                     help="also time the reference's own nprototypes = 5000 (hfc_with_swav_ffhq_config.py:52) for a few steps and "
                          "nest the result in the JSON line; auto = on one GPU with the default 8 prototypes only")
+    ap.add_argument("--all-configs", default="auto", choices=["auto", "on", "off"],
+                    help="also time, for a few steps each and nested in the same JSON line, the per-rank shapes of the other "
+                         "BASELINE.json configurations: cat-256 (16 prototypes, 'image' pdf, eps 0.003), car-512 (true 512^2 "
+                         "generator, 4 images, 16 and 4000 prototypes, eps 0.01), hfc_with_simclr, and predict + one-shot head; "
+                         "auto = on one GPU with the default 8 prototypes only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")
     ap.add_argument("--dry-rendezvous", action="store_true",
@@ -408,15 +500,18 @@ def main():
     from ganecdotes_amd.swav_clustering import SwAVClustering
     g = build_generator(256, dev)
 
-    def make(nproto):
-        wl = workload(args.batch, nproto, scope=args.scope)
-        if args.pdf != "uniform":
-            wl["sinkhorn_args"].update(source_pdf=args.pdf, eps=args.eps if args.eps else 0.003)
-        elif args.eps:
-            wl["sinkhorn_args"]["eps"] = args.eps
+    def make(nproto, gen=None, batch=None, size=256, pdf=None, eps=None, nlayers=6):
+        pdf = args.pdf if pdf is None else pdf
+        eps = args.eps if eps is None else eps
+        wl = workload(args.batch if batch is None else batch, nproto, size=size, scope=args.scope)
+        wl["perturb_args"].update(n_layers=nlayers, perturb_std=[1.0] * nlayers)
+        if pdf != "uniform":
+            wl["sinkhorn_args"].update(source_pdf=pdf, eps=eps if eps else 0.003)
+        elif eps:
+            wl["sinkhorn_args"]["eps"] = eps
         if args.ds_table != "auto":
             wl["swav_args"]["ds_table"] = args.ds_table == "on"
-        sw = SwAVClustering(model=g, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
+        sw = SwAVClustering(model=g if gen is None else gen, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
         torch.manual_seed(42 + rank)
         np.random.seed(42 + rank)
         sw.build_heads()
@@ -450,7 +545,8 @@ def main():
                                + ("" if args.pdf == "uniform" else f"source_pdf={args.pdf} (NOT the headline configuration), ") +
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
                                f"the device generator (= the set randperm[:N] selects); views = the 13 feature taps of both "
-                               f"perturbed latents (the RGB image, which enters no loss term, is not rendered)",
+                               f"perturbed latents (the RGB image, which enters no loss term, is not rendered); "
+                               f"{sw.last_route.describe()}",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": loss},
         "roofline": roof,
@@ -459,7 +555,7 @@ def main():
     # the number the reference actually ships is timed by whoever runs this script and not only by the builder
     want_rf = args.reference_faithful == "on" or (args.reference_faithful == "auto" and world == 1 and args.prototypes == 8)
     if want_rf:
-        del sw
+        sw = None
         torch.cuda.empty_cache()
         rf_steps, rf_warm = 8, 2
         sw5 = make(5000)
@@ -474,6 +570,7 @@ def main():
                         f"otherwise the configuration of this line; scores and d(scores) live on per-pixel tables, the three GEMMs run "
                         f"over pixels (5 x 20 000 samples are drawn from 65 536 pixels: --ds-table, DESIGN par. 4.15) and the "
                         f"step's Sinkhorn problems are solved on the tables, every row read once per pass (DESIGN par. 4.16)",
+            "route": sw5.last_route.describe(),
             "prototypes": 5000, "steps": rf_steps, "warmup": rf_warm,
             "ms_per_step": ms5, "value": rf_steps * args.batch * world / dt5, "unit": "images/s", "loss": loss5,
             "roofline": {
@@ -488,9 +585,49 @@ def main():
                 "ms_per_step_by_kernel": None if not r5 else r5["ms_per_step_by_kernel"]}}
         del sw5
         torch.cuda.empty_cache()
+    # every other BASELINE.json configuration at its per-rank shape, a few steps each, in the same line
+    want_all = args.all_configs == "on" or (args.all_configs == "auto" and world == 1 and args.prototypes == 8
+                                            and args.pdf == "uniform")
+    if want_all and world == 1:
+        class _A:                                                        # `measure` reads the batch from here
+            pass
+        sw = None
+        torch.cuda.empty_cache()
+        # configs[2] cat-256 per rank: 16 images, 16 prototypes, source_pdf='image', eps 0.003 (hfc_with_swav_cat_config.py:52-65)
+        a = _A(); a.batch = 16
+        swc = make(16, pdf="image", eps=0.003)
+        dtc, stc, lossc = measure(swc, a, 8, 2, dev, 1)
+        out["cat_per_rank"] = nested_record(
+            "cat-256 hfc_with_swav per-rank shape of BASELINE.json configs[2] (batch 64 over 4 GPUs = 16 images per GPU): 16 "
+            "prototypes, source_pdf='image' (marginals = histograms of the norm maps), eps=0.003, N=20000 x 5 patches; "
+            "same 256x256 StyleGAN2 widths as ffhq; " + swc.last_route.describe(), 16, dtc, 8, 2, stc, loss=lossc)
+        del swc
+        torch.cuda.empty_cache()
+        # configs[3] car-512 per rank: TRUE 512^2 generator (15 taps, hlen 5376 of 5504 channels), 4 images per GPU, eps 0.01;
+        # BASELINE's 16 prototypes and the reference's own 4000 (hfc_with_swav_car_config.py:52, :65)
+        g512 = build_generator(512, dev)
+        a = _A(); a.batch = 4
+        for kk, key in ((16, "car512_per_rank"), (4000, "car512_per_rank_k4000")):
+            swk = make(kk, gen=g512, batch=4, size=512, eps=0.01, nlayers=7)
+            st_, wu_ = (8, 2) if kk == 16 else (5, 2)
+            dtk, stk, lossk = measure(swk, a, st_, wu_, dev, 1)
+            out[key] = nested_record(
+                f"car-512 hfc_with_swav per-rank shape of BASELINE.json configs[3] (batch 32 over 8 GPUs = 4 images per GPU): true "
+                f"512x512 StyleGAN2 generator (15 taps; hlen=5376 drops the two native-512 taps), {kk} prototypes"
+                f"{' (hfc_with_swav_car_config.py:52)' if kk == 4000 else ''}, eps=0.01, uniform marginals, N=20000 of 262144 "
+                f"pixels x 5 patches; " + swk.last_route.describe(), 4, dtk, st_, wu_, stk, loss=lossk)
+            del swk
+            torch.cuda.empty_cache()
+        del g512
+        torch.cuda.empty_cache()
+        out["simclr"] = simclr_record(g, dev)                            # configs[4]
+        out["predict"] = predict_record(g, dev)                          # evaluate.py / run_tests
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.prototypes)
+            if want_rf:     # the reference's own configuration gets its CPU figure too (BASELINE.md par. 3: K = 5000)
+                out["reference_faithful"]["cpu_baseline"] = cpu_baseline(5000)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

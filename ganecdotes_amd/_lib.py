@@ -147,7 +147,7 @@ SIGNATURES = {
                                            c_sz, c_p, c_p]),
     "gx_sinkhorn_small_batch_finish": (c_i, [c_i, c_i, c_f, c_i, c_p, c_l, c_p, c_p, c_p, c_p]),
     "gx_sinkhorn_codes": (c_i, [c_p, c_l, c_i, c_l, c_f, c_p, c_p, c_l, c_p]),
-    "gx_hist_marginal": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
+    "gx_hist_marginal": (c_i, [c_p, c_l, c_i, c_p, c_p, c_i, c_p]),
     "gx_hist_range": (c_i, [c_p, c_l, c_p, c_p, c_p]),
     "gx_hist_counts": (c_i, [c_p, c_l, c_p, c_i, c_p, c_p, c_p]),
     "gx_hist_finish": (c_i, [c_p, c_i, c_p]),
@@ -211,11 +211,19 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    lab = os.environ.get("GX_LAB_LIB")
+    if lab:
+        # a lab build (tools/lab/labbuild.sh: ONE translation unit recompiled with ablation flags, some of which compute wrong
+        # values on purpose) lives in its own file and is only ever loaded on request — and says so
+        import sys
+        print(f"[ganecdotes_amd] GX_LAB_LIB set: loading the LAB library {lab} instead of {LIB_PATH}", file=sys.stderr, flush=True)
+        path = lab
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
+            f"{path} not found: the HIP extension is required (no CPU/PyTorch fallback). "
             "Build it with `python -m ganecdotes_amd.build` (needs hipcc).")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)

@@ -29,6 +29,8 @@ def _hipcc():
 
 def _src_hash():
     h = hashlib.sha256()
+    # the extra compile flags are part of what the library IS: a build made with other flags must not look up to date
+    h.update(("flags:" + " ".join(os.environ.get("GX_EXTRA_FLAGS", "").split())).encode())
     for d in (CSRC, INCLUDE):
         if not os.path.isdir(d):           # a package copied next to a prebuilt .so without the repo's include/
             continue

@@ -1,6 +1,15 @@
 // Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of ganecdotes_amd.
 // Wavefront = 64 lanes everywhere; no CUDA/warp-32 compatibility paths.
 #pragma once
+// Lab switches (tools/lab/*.sh) — compile-time ablations, some of which compute WRONG values on purpose — exist only in
+// lab builds: tools/lab/labbuild.sh passes -DGX_LAB and links a SEPARATE library (libganecdotes_lab.so, loaded only when
+// GX_LAB_LIB names it).  The production build (build.py) never defines GX_LAB, so a stray -D from GX_EXTRA_FLAGS stops here.
+#if !defined(GX_LAB) && (defined(CE_PIX_ABL) || defined(SKT_ABL) || defined(SKT_FORCE_WIDE) || defined(XP_ABL_A2) || \
+                         defined(XP_ABL_B2) || defined(XW_ABL_DIRECT) || defined(FIN_ABL) || defined(FQ_ABL) || \
+                         defined(BK_LOAD_AUX) || defined(BK_STORE_AUX) || defined(BK_PASS_MINB) || defined(CE_PIX_NJ2) || \
+                         defined(BLUR_MINB) || defined(FQ_LATE))
+#error "lab ablation macro set without -DGX_LAB: ablated kernels must not reach libganecdotes_hip.so (use tools/lab/labbuild.sh)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 // the public C ABI: every translation unit sees the prototypes, so a definition that drifts from

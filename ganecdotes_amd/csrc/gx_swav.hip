@@ -1548,8 +1548,9 @@ int gx_hist_finish(float* hist, int bins, void* stream) {
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
-int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream) {
+int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, int scratch_words, void* stream) {
     if (!x || !hist || !scratch || n <= 0 || bins <= 0) return GX_ERR_BAD_ARG;
+    if (scratch_words < 2 || (bins >= 16384 && scratch_words < 2 + HIST_PARTS)) return GX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(scratch, 0xFF, 4, s) != hipSuccess) return GX_ERR_LAUNCH;        // min <- +max
     if (hipMemsetAsync(scratch + 1, 0, 4, s) != hipSuccess) return GX_ERR_LAUNCH;       // max <- lowest

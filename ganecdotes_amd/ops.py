@@ -1369,7 +1369,7 @@ def hist_marginal(x, bins, reduce=None):
     hist = torch.empty(bins, dtype=torch.float32, device=x.device)
     scratch = torch.empty(2 + 256, dtype=torch.int32, device=x.device)      # (min, max) as ordered ints + 256 block partials
     if reduce is None:
-        _lib.check(L.gx_hist_marginal(_p(x), x.numel(), bins, _p(hist), _p(scratch), _stream()), "gx_hist_marginal")
+        _lib.check(L.gx_hist_marginal(_p(x), x.numel(), bins, _p(hist), _p(scratch), scratch.numel(), _stream()), "gx_hist_marginal")
         return hist
     lohi = torch.empty(2, dtype=torch.float32, device=x.device)
     _lib.check(L.gx_hist_range(_p(x), x.numel(), _p(scratch), _p(lohi), _stream()), "gx_hist_range")

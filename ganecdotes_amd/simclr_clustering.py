@@ -21,7 +21,7 @@ from .draws import ImageDraws, ViewDraws, draw_image
 from .hostcfg import limit_host_threads
 from .pyramid import Pyramid
 from .swav_clustering import _NullLogger
-from .views import ViewMixin
+from .views import ViewMixin, check_hf_interp
 
 
 def draw_simclr_iteration(style_dim, gen_num_layers, n_perturb_layers, hw, transforms=True, degrees=10.0,
@@ -56,6 +56,7 @@ class SimCLRClustering(ViewMixin):
         self.model_config = model_config
         self.perturb_args = perturb_args
         self.simclr_args = simclr_args
+        check_hf_interp(simclr_args, 'simclr_args')
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError("SimCLRClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")

@@ -39,6 +39,7 @@ import math
 import os
 import time
 from types import SimpleNamespace
+from typing import NamedTuple
 
 import numpy as np
 import torch
@@ -47,7 +48,7 @@ from torch import nn
 from . import ops, sharded
 from .draws import ImageDraws, draw_image
 from .hostcfg import limit_host_threads
-from .views import PreparedBatch, ViewMixin
+from .views import PreparedBatch, ViewMixin, check_hf_interp
 from .pyramid import Pyramid
 from .projection_head import ProjectionHead, build_projection
 
@@ -55,6 +56,33 @@ from .projection_head import ProjectionHead, build_projection
 class _NullLogger:
     def info(self, *_):
         pass
+
+
+class Route(NamedTuple):
+    """What one optimizer step runs — decided in ONE place (`SwAVClustering.plan_route`) from the configuration and the batch
+    shape.  `train_step` dispatches on `name`; `bench.py` prints `describe()` into `config.workload`."""
+    name: str               # 'lowrank' (K <= 16 on score tables of every pixel) | 'tables' (many prototypes on per-pixel
+    #                         d(score) / score tables) | 'per_sample' (the reference-shaped chain per patch and view)
+    mode: str               # projection_mode: 'pyramid' | 'panel'
+    small: bool             # per_sample: the fused K <= 16 row kernels
+    k_run: int              # prototype columns the kernels see (nprototypes padded to a multiple of 4 past 64 columns)
+    planes: bool            # prototype weights as bf16x6 planes, once per step (weight-plane GEMMs)
+    pad_ds: bool            # d(scores) rows padded to 16-column chunks: dz on the weight-plane kernel
+    score_table: bool       # tables: the scores live on per-pixel tables too (one score GEMM per view)
+    sinkhorn_table: bool    # tables: every Sinkhorn problem of the step solved on the tables, a row read once per pass
+    pgroup: int             # patches per Sinkhorn batch
+    fineq: bool             # lowrank: the finest pyramid level through quadratic forms of its taps (gx_fineq.hip)
+
+    def describe(self):
+        if self.name == 'lowrank':
+            how = "score/rnorm tables of every pixel" + (", finest level as quadratic forms of its taps" if self.fineq else "")
+        elif self.name == 'tables':
+            how = ("d(scores)" + (" and scores" if self.score_table else "") + " on per-pixel tables, backward GEMMs over pixels" +
+                   (", table Sinkhorn" if self.sinkhorn_table else ", per-problem Sinkhorn sweeps"))
+        else:
+            how = ("fused small-K row kernels" if self.small else "per-patch score / gradient GEMMs" +
+                   (" on weight planes" if self.planes else ""))
+        return f"route={self.name} ({self.mode} projection; {how}; {self.k_run} prototype columns, {self.pgroup} patch(es) per Sinkhorn batch)"
 
 
 class SwAVClustering(ViewMixin):
@@ -66,6 +94,7 @@ class SwAVClustering(ViewMixin):
         self.model_config = model_config
         self.perturb_args = perturb_args
         self.swav_args = swav_args
+        check_hf_interp(swav_args, 'swav_args')     # before anything touches a device: a config error, not a device error
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError("SwAVClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
@@ -321,278 +350,427 @@ class SwAVClustering(ViewMixin):
                 ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
             del zt, rnt, dz
 
-    def train_step(self, images, return_aux=False):
-        """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
-        as a 1-element HIP tensor (global mean; no host sync)."""
+    # ------------------------------------------------------------------------------------- route of a step
+    def plan_route(self, B, hw, N):
+        """Which kernels a step over B images of hw x hw pixels with N samples per patch and image will run — decided HERE,
+        once, from the configuration and the shape (`Route`, above); train_step dispatches on it and bench.py prints it."""
         sa = self.swav_args
-        P, N, hlen = sa['num_patches'], self._rows_per_image(), sa['hlen']
-        T = sa['temperature']
-        scope = sa.get('sinkhorn_scope', 'image')
-        use_larc = sa.get('use_larc', True)
-        pb = self.prepare_batch(images)
-        B = pb.n
-        Bg = B * self.world
-        Wp, Wc, bc, *extra = self._params()
+        P = sa['num_patches']
         head = self._proj_head()
+        Wp, Wc = self.projection[0].weight.data, self.prototype.weight.data
         D, K = Wp.shape[0], Wc.shape[0]
-        dev = self.device
-
-        # S7: prototype rows to unit norm (bias untouched)
-        ops.row_l2_normalize_(Wc, want_rnorm=False)
-
-        with self._timed("views"):
-            views, ts_all = self.make_views(pb, want_all=True, want_image=False)
-        hw = views[0][0].size
-        if N is None or N >= hw * hw:
-            N = hw * hw
-        imgs = None
-        if self.sinkhorn_args['source_pdf'] == 'image':
-            imgs = [ops.norm_map(ts, hlen, maps) for ts, maps, _ in views]
-
-        if self._bufs is None:
-            self._bufs = [torch.zeros_like(p) for p in (Wp, Wc, bc, *extra)]
-            self._grads = [torch.empty_like(p) for p in (Wp, Wc, bc, *extra)]
-        gWp, gWc, gb, *gextra = self._grads
-        loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        rows = B * N
-        gscale = 1.0 / (N * P * Bg)
-        first_acc = True
-        aux = {}
         mode = sa.get('projection_mode', 'pyramid')
+        if mode not in ('pyramid', 'panel'):
+            raise NotImplementedError(f"projection_mode={mode!r}: 'pyramid' or 'panel'")
         # the few-prototype routes (fused gather + scores, score tables) need a LINEAR map from descriptor to z
-        small = sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D) and head.linear
-        lowrank = mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D) and head.linear
-        if mode == 'pyramid':
-            with self._timed("pyramid_fwd"):
-                # ONE pyramid over the 2B images of both views: each level is one GEMM, the table Z_all
-                # (2B, H, W, D) holds view s in [0, B) and view t in [B, 2B)
-                pyr = Pyramid(ts_all, hlen)
-                npx = B * hw * hw
-                if lowrank:
-                    # K <= 16: the score / rnorm tables of every pixel of the table level; the finest level's projected
-                    # table is never formed (pyramid.py, csrc/gx_fineq.hip) and levels without taps are skipped (`lshift`)
-                    rn_all, sc_all, lshift = pyr.project_tables(Wp, Wc, bc, quad=sa.get('fineq', True))
-                    Z_all = Zt = None
-                else:
-                    Z_all = pyr.project(Wp)
-                    Zt = [Z_all[v * B:(v + 1) * B] for v in range(2)]          # (B, H, W, D) per view
-            if lowrank:
-                maps_all = None
-                if views[0][1] is not None or views[1][1] is not None:        # (2B, HW) rotate / flip index maps
-                    ident = None
-                    if views[0][1] is None or views[1][1] is None:
-                        ident = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
-                    maps_all = torch.cat([m if m is not None else ident for m in (views[0][1], views[1][1])])
-                Ct_all = ops.lowrank_coeffs(2 * B, pyr.table_pixels(), K, dev)   # (2B * table pixels, K+1 padded) coefficient grid
-                G_all = None
-            else:
-                G_all = torch.zeros_like(Z_all)
-                Gt = [G_all[v * B:(v + 1) * B] for v in range(2)]
-        # 'image' source pdf: the marginals depend on the view (and image), not on the patch
-        marg = None
-        if imgs is not None:
-            if scope == 'global':
-                marg = [self._marginals(imgs[v].contiguous(), K, rows, shared=True) for v in range(2)]
-                r_one = torch.stack([m[0] for m in marg])                       # (2, K)
-                c_one = torch.stack([m[1] for m in marg])                       # (2, rows)
-            else:
-                marg = [[self._marginals(imgs[v][b:b + 1].contiguous(), K, N) for b in range(B)] for v in range(2)]
-                r_one = torch.stack([torch.stack([m[0] for m in mv]) for mv in marg])   # (2, B, K)
-                c_one = torch.stack([torch.stack([m[1] for m in mv]) for mv in marg])   # (2, B, N)
-        if return_aux and marg is not None:                       # what the 'image' pdf prescribes (tests)
-            aux.update(norm_map_s=imgs[0], norm_map_t=imgs[1], r_marginals=r_one, c_marginals=c_one)
-        ngroups = 1 if scope == 'global' else B                  # Sinkhorn problems per (patch, view)
-        hreduce = self._reduce if (scope == 'global' and self.sharded) else None    # BatchNorm batch = Sinkhorn problem
-        grows = rows // ngroups
-        nglob = grows * (self.world if scope == 'global' else 1)
-        # The pyramid path holds only (rows, K) scores per patch, so all patches go through ONE
-        # batched Sinkhorn (as many as fit 16 GB of scores); the panel path keeps a (rows, hlen)
-        # descriptor panel per view alive until its backward, so it goes patch by patch.
-        pgroup = max(1, min(P, int(16e9 // (8.0 * rows * K)))) if mode == 'pyramid' else 1
+        small = bool(sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D) and head.linear)
+        lowrank = bool(mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D) and head.linear)
+        rows = B * N
+        # Past 64 columns the row kernels (Sinkhorn sweeps, fused CE, the weight-plane GEMMs) read 16-byte pieces of a row: the
+        # prototype count is padded to a multiple of 4 with columns that can take no mass (zero weights, bias -16, marginal 1e-30;
+        # _pad_prototypes) instead of falling to the team-per-row kernels (K = 4001: 132 ms per Sinkhorn against 10 at 4000)
+        k_run = K if (K <= 64 or K % 4 == 0) else (K + 3) // 4 * 4
+        # The pyramid path holds only (rows, K) scores per patch, so all patches go through ONE batched Sinkhorn (as many as fit
+        # 16 GB of scores); the panel path keeps a (rows, hlen) descriptor panel per view alive until its backward: patch by patch
+        pgroup = max(1, min(P, int(16e9 // (8.0 * rows * k_run)))) if mode == 'pyramid' else 1
+        if lowrank:
+            return Route('lowrank', mode, small, K, False, False, False, False, pgroup, bool(sa.get('fineq', True)))
         # generic-K scores: the prototype weights as bf16x6 planes, once per step (gemm_xw_kernel)
-        wc_planes = None
-        if not lowrank and not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0:
-            wc_planes = ops.split_gemm_weights(Wc)
+        planes = bool(not (mode == 'pyramid' and small) and ops.get_gemm_mode() == 1 and D % 16 == 0)
         # dz = dS Wc as the NT contraction dS x (Wc^T)^T on the weight-plane kernel: dS rows padded to whole 16-column
         # chunks (zero pad), planes of Wc^T once per step (many prototypes; 7.95 -> 7.45 ms at K = 5000)
-        pad_ds = wc_planes is not None and K % 4 == 0 and K > 64
-        Kp = (K + 15) // 16 * 16
-        wct_planes = ops.split_gemm_weights(Wc.t().contiguous()) if pad_ds else None
+        pad_ds = planes and k_run % 4 == 0 and k_run > 64
+        Kp = (k_run + 15) // 16 * 16
         # Many prototypes: d(scores) of every patch land on per-PIXEL rows (one table per view, DESIGN §4.15): a pixel drawn by
         # several patches has its rows added up by the CE kernel, and the two backward GEMMs (dWc, dz) run ONCE over the
         # B * HW pixels instead of once per patch over P * B * N samples (ffhq: 65 536 pixels against 100 000 samples per image)
         # (memory: the two d(scores) tables + either the two score tables or every patch's per-sample scores, held to half the HBM)
-        want_stab = sa.get('score_table', True)
-        tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * K if want_stab else 8.0 * rows * K * P)
+        want_stab = bool(sa.get('score_table', True))
+        tab_bytes = 8.0 * B * hw * hw * Kp + (8.0 * B * hw * hw * k_run if want_stab else 8.0 * rows * k_run * P)
         # worth it where the tables' live rows are fewer than the samples: always with more samples than pixels, and with uniformly
         # drawn picks where the patches overlap enough — the pixels some patch drew, HW (1 - (1 - N / HW)^P) in expectation, against
         # the P N samples (the kernels only touch the drawn pixels: ffhq 0.55, the car configuration's 20 000 of 262 144 pixels x 5
         # patches 0.86: 94.7 -> 87.9 ms per step)
         live_exp = hw * hw * (1.0 - (1.0 - min(1.0, N / float(hw * hw))) ** P)
         tab_default = hw * hw < P * N or (sa.get('sampling_method', 'random') == 'random' and live_exp <= 0.9 * P * N)
-        dstab = (mode == 'pyramid' and pad_ds and not small and head.linear and 64 < K <= 8192 and P <= 8 and
-                 sa.get('ds_table', tab_default) and
-                 tab_bytes < 0.5 * torch.cuda.get_device_properties(dev).total_memory)
-        # ... and, with one Sinkhorn problem per patch and view (global scope), the SCORES are a per-pixel table
-        # too: one score GEMM per view over the pixels, the Sinkhorn problems and the CE read their rows of it through the pick index
-        stab = dstab and want_stab
-        if dstab:
-            pgroup = P             # every patch's scores stay until the one pixel-major CE pass of the step (8 B rows K P bytes)
-            npix = B * hw * hw
-            dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
-            pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
-        tb = None
-        if stab:
-            tb = self._score_tables(pb, views, Zt, P, B, hw, N, D, K, wc_planes, bc, None if marg is None else c_one,
-                                    by_mask=sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(P, K), by_image=ngroups > 1)
-            stab = tb is not None
-        for p0 in range(0, P, pgroup):
-            pnos = list(range(p0, min(P, p0 + pgroup)))
+        dstab = bool(mode == 'pyramid' and pad_ds and not small and head.linear and 64 < k_run <= 8192 and P <= 8 and
+                     sa.get('ds_table', tab_default) and
+                     tab_bytes < 0.5 * torch.cuda.get_device_properties(self.device).total_memory)
+        if not dstab:
+            return Route('per_sample', mode, small, k_run, planes, pad_ds, False, False, pgroup, False)
+        # ... and, with one Sinkhorn problem per patch and view (global scope) or per image too, the SCORES are a per-pixel table:
+        # one score GEMM per view over the pixels, the Sinkhorn problems and the CE read their rows of it through the pick index;
+        # every patch's scores stay until the one pixel-major CE pass of the step (pgroup = P)
+        sk_tab = bool(want_stab and sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(P, k_run))
+        return Route('tables', mode, small, k_run, planes, pad_ds, want_stab, sk_tab, P, False)
+
+    def _pad_prototypes(self, c):
+        """K -> route.k_run columns: rows of zeros under Wc, bias -16 — a padded column's score is -16 for every
+        sample: exp((-16 - max) / T) and exp((-16 - max) / eps) are 0 in fp32 for every T, eps <= 0.1 against scores that are
+        cosines + a small bias — and EXPLICIT marginals whose padded entries are 1e-30 (a Sinkhorn column receives exactly its
+        marginal, so the padded columns hold 1e-30 of a code's mass whatever their score; 0 would make log r = -inf and
+        poison the step statistics of the shifted sweeps).  The real columns keep r = 1 / K (or the 'image' histogram over
+        K bins): the problem the reference poses (swav_clustering.py:522-537), to 1e-30.  Gradients come back through
+        _unpad_prototypes."""
+        K, Kr, dev = c.K, c.route.k_run, self.device
+        c.K_true = K
+        c.Wc_true, c.bc_true, c.gWc_true, c.gb_true = c.Wc, c.bc, c.gWc, c.gb
+        Wc = torch.zeros(Kr, c.D, dtype=torch.float32, device=dev)
+        Wc[:K] = c.Wc
+        bc = torch.full((Kr,), -16.0, dtype=torch.float32, device=dev)
+        bc[:K] = c.bc
+        c.Wc, c.bc, c.K = Wc, bc, Kr
+        c.gWc = torch.empty_like(Wc)
+        c.gb = torch.empty_like(bc)
+        if c.r_one is None:                        # uniform marginals, spelled out
+            shp_r = (2, K) if c.ngroups == 1 else (2, c.B, K)
+            shp_c = (2, c.rows) if c.ngroups == 1 else (2, c.B, c.N)
+            c.r_one = torch.full(shp_r, 1.0 / K, dtype=torch.float32, device=dev)
+            c.c_one = torch.full(shp_c, 1.0 / c.nglob, dtype=torch.float32, device=dev)
+        pad = torch.full((*c.r_one.shape[:-1], Kr - K), 1e-30, dtype=torch.float32, device=dev)
+        c.r_one = torch.cat([c.r_one, pad], dim=-1).contiguous()
+
+    def _unpad_prototypes(self, c):
+        K = c.K_true
+        c.gWc_true.copy_(c.gWc[:K])
+        c.gb_true.copy_(c.gb[:K])
+        for key in ('scores_s', 'scores_t', 'q_s', 'q_t'):
+            if key in c.aux:
+                c.aux[key] = c.aux[key][:, :K].contiguous()
+        c.Wc, c.bc, c.gWc, c.gb, c.K = c.Wc_true, c.bc_true, c.gWc_true, c.gb_true, K
+
+    # ------------------------------------------------------------------------------------- one step
+    def train_step(self, images, return_aux=False):
+        """One optimizer step over this rank's images (list of ImageDraws).  Returns the loss
+        as a 1-element HIP tensor (global mean; no host sync).  Prologue (views, pyramid forward, marginals) -> ONE of
+        `_step_lowrank` / `_step_tables` / `_step_per_sample`, chosen by plan_route -> epilogue (pyramid backward, gradient
+        all-reduce, LARC-SGD)."""
+        c = self._step_prologue(images, return_aux)
+        getattr(self, '_step_' + c.route.name)(c)
+        return self._step_epilogue(c)
+
+    def _step_prologue(self, images, return_aux):
+        sa = self.swav_args
+        c = SimpleNamespace(sa=sa, return_aux=return_aux, aux={}, first_acc=True)
+        c.P, c.N, c.hlen, c.T = sa['num_patches'], self._rows_per_image(), sa['hlen'], sa['temperature']
+        c.scope = sa.get('sinkhorn_scope', 'image')
+        c.pb = pb = self.prepare_batch(images)
+        c.B = B = pb.n
+        c.Bg = B * self.world
+        c.Wp, c.Wc, c.bc, *c.extra = self._params()
+        c.head = self._proj_head()
+        c.D, c.K = c.Wp.shape[0], c.Wc.shape[0]
+        dev = self.device
+
+        # S7: prototype rows to unit norm (bias untouched)
+        ops.row_l2_normalize_(c.Wc, want_rnorm=False)
+
+        with self._timed("views"):
+            c.views, ts_all = self.make_views(pb, want_all=True, want_image=False)
+        c.hw = hw = c.views[0][0].size
+        if c.N is None or c.N >= hw * hw:
+            c.N = hw * hw
+        imgs = None
+        if self.sinkhorn_args['source_pdf'] == 'image':
+            imgs = [ops.norm_map(ts, c.hlen, maps) for ts, maps, _ in c.views]
+
+        if self._bufs is None:
+            self._bufs = [torch.zeros_like(p) for p in (c.Wp, c.Wc, c.bc, *c.extra)]
+            self._grads = [torch.empty_like(p) for p in (c.Wp, c.Wc, c.bc, *c.extra)]
+        c.gWp, c.gWc, c.gb, *c.gextra = self._grads
+        c.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        c.rows = B * c.N
+        c.gscale = 1.0 / (c.N * c.P * c.Bg)
+        c.route = route = self.plan_route(B, hw, c.N)
+        self.last_route = route
+        c.mode = route.mode
+        c.pyr = c.Z_all = c.Zt = c.G_all = c.Gt = None
+        if route.mode == 'pyramid':
+            with self._timed("pyramid_fwd"):
+                # ONE pyramid over the 2B images of both views: each level is one GEMM, the table Z_all
+                # (2B, H, W, D) holds view s in [0, B) and view t in [B, 2B)
+                c.pyr = Pyramid(ts_all, c.hlen)
+                if route.name == 'lowrank':
+                    # K <= 16: the score / rnorm tables of every pixel of the table level; the finest level's projected
+                    # table is never formed (pyramid.py, csrc/gx_fineq.hip) and levels without taps are skipped (`lshift`)
+                    c.rn_all, c.sc_all, c.lshift = c.pyr.project_tables(c.Wp, c.Wc, c.bc, quad=route.fineq)
+                else:
+                    c.Z_all = c.pyr.project(c.Wp)
+                    c.Zt = [c.Z_all[v * B:(v + 1) * B] for v in range(2)]          # (B, H, W, D) per view
+            if route.name != 'lowrank':
+                c.G_all = torch.zeros_like(c.Z_all)
+                c.Gt = [c.G_all[v * B:(v + 1) * B] for v in range(2)]
+        c.ngroups = 1 if c.scope == 'global' else B                  # Sinkhorn problems per (patch, view)
+        c.sk_reduce = self._reduce if (c.scope == 'global' and self.sharded) else None    # also: BatchNorm batch = Sinkhorn problem
+        c.grows = c.rows // c.ngroups
+        c.nglob = c.grows * (self.world if c.scope == 'global' else 1)
+        # 'image' source pdf: the marginals depend on the view (and image), not on the patch
+        c.r_one = c.c_one = None
+        if imgs is not None:
+            if c.scope == 'global':
+                marg = [self._marginals(imgs[v].contiguous(), c.K, c.rows, shared=True) for v in range(2)]
+                c.r_one = torch.stack([m[0] for m in marg])                       # (2, K)
+                c.c_one = torch.stack([m[1] for m in marg])                       # (2, rows)
+            else:
+                marg = [[self._marginals(imgs[v][b:b + 1].contiguous(), c.K, c.N) for b in range(B)] for v in range(2)]
+                c.r_one = torch.stack([torch.stack([m[0] for m in mv]) for mv in marg])   # (2, B, K)
+                c.c_one = torch.stack([torch.stack([m[1] for m in mv]) for mv in marg])   # (2, B, N)
+            if return_aux:                                            # what the 'image' pdf prescribes (tests)
+                c.aux.update(norm_map_s=imgs[0], norm_map_t=imgs[1], r_marginals=c.r_one, c_marginals=c.c_one)
+        c.K_true = c.K
+        if route.k_run != c.K:
+            self._pad_prototypes(c)
+        return c
+
+    def _step_epilogue(self, c):
+        sa = self.swav_args
+        if c.K_true != c.K:
+            self._unpad_prototypes(c)
+        pending = []
+        if c.mode == 'pyramid':
+            on_level = on_heads = None
+            if self.sharded:
+                # once the prototype gradients and the loss are final their all-reduce travels while the
+                # pyramid backward runs, and every pyramid level's slice of dWp follows as soon as its GEMMs
+                # are queued (finest levels first), so only the coarsest levels' message is exposed
+                on_heads = lambda: pending.append(sharded.allreduce_flat_async([c.gWc, c.gb, c.loss] + c.gextra, self.dist_group))
+                on_level = lambda cols: pending.append(sharded.allreduce_cols_async(c.gWp, cols, self.dist_group))
+            with self._timed("pyramid_bwd"):
+                if c.route.name == 'lowrank':      # from the coefficient grid: dense finish at the table level, the finest level's Gram forms
+                    c.pyr.backward_lowrank(c.Ct_all, c.Wp, c.Wc, c.gWp, c.gWc, on_level=on_level, on_heads=on_heads)
+                else:
+                    if on_heads is not None:
+                        on_heads()
+                    c.pyr.backward(c.G_all, c.gWp, accumulate=False, on_level=on_level)
+            c.Zt = c.Z_all = c.G_all = c.Gt = None
+        elif self.sharded:
+            pending.append(sharded.allreduce_flat_async(list(self._grads) + [c.loss], self.dist_group))
+        for fin in pending:
+            fin()
+        # S8: LARC + momentum SGD
+        lr = sa['train_args']['lr']
+        mom = sa['train_args'].get('momentum', 0.0)
+        if sa.get('use_scheduler', False) and getattr(self, '_lr_schedule', None) is not None:
+            lr = float(self._lr_schedule[min(self._step_no, len(self._lr_schedule) - 1)])
+        for p, g, buf in zip((c.Wp, c.Wc, c.bc, *c.extra), self._grads, self._bufs):
+            ops.larc_sgd_(p, g, buf, lr, mom, sa['trust_coeff'], first_step=(self._step_no == 0), use_larc=sa.get('use_larc', True))
+        self._step_no += 1
+        return (c.loss, c.aux) if c.return_aux else c.loss
+
+    # --- route 'lowrank': K <= 16, pyramid mode, linear projection (DESIGN §4.3, §4.4, §4.11) ---
+    def _step_lowrank(self, c):
+        """gather / Sinkhorn / loss / coefficient scatter of all patches and both views in single launches on the score and
+        rnorm tables of every pixel; the backward of the prototype layer and of the projection comes from the coefficient grid
+        (`Pyramid.backward_lowrank`, epilogue)."""
+        B, K, hw, dev = c.B, c.K, c.hw, self.device
+        views = c.views
+        maps_all = None
+        if views[0][1] is not None or views[1][1] is not None:        # (2B, HW) rotate / flip index maps
+            ident = None
+            if views[0][1] is None or views[1][1] is None:
+                ident = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+            maps_all = torch.cat([m if m is not None else ident for m in (views[0][1], views[1][1])])
+        c.Ct_all = ops.lowrank_coeffs(2 * B, c.pyr.table_pixels(), K, dev)   # (2B * table pixels, K+1 padded) coefficient grid
+        for p0 in range(0, c.P, c.route.pgroup):
+            pnos = list(range(p0, min(c.P, p0 + c.route.pgroup)))
             G = len(pnos)
-            if stab:
-                rowmaps = [tb.rowmaps[pno] for pno in pnos]                               # a patch's samples -> table rows
-                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)           # table row -> its row in patch gi's problem
-                nrow = torch.arange(rows, dtype=torch.int32, device=dev)
-                for gi in range(G):
-                    inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
-                with self._timed("sinkhorn"):
-                    if sa.get('sinkhorn_table', True) and ops.sinkhorn_table_ok(G, K) and (ngroups == 1 or tb.seg is not None):
-                        # ALL problems of the step in one pass over the live rows of the two tables per iteration — a row several
-                        # patches drew is read once (csrc/gx_sktab.hip, DESIGN §4.16); per-image scope: a workgroup stays inside
-                        # one image's run of the table
-                        r_tab = c_tab = None
-                        if marg is not None:              # problem index = (patch * 2 + view) * ngroups + image
-                            if ngroups == 1:
-                                r_tab = torch.stack([r_one[v] for _ in pnos for v in range(2)])
-                            else:
-                                r_tab = torch.stack([r_one[v][g] for _ in pnos for v in range(2) for g in range(ngroups)])
-                            c_tab = torch.stack([tb.c_sorted[pno][v].reshape(-1) for pno in pnos for v in range(2)])
-                        skb = ops.SinkhornTable(tb.S[0], tb.S[1], inv, tb.live, self.eps, self.niters, 1.0 / nglob, rows,
-                                                r=r_tab, c=c_tab, rowmaps=rowmaps if return_aux else None, ngroups=ngroups,
-                                                seg=tb.seg)
-                        with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
-                            skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
-                        if self._sk_probe is not None:                            # tools/soak.py: what the last update vouched for
-                            self._sk_probe.append(skb.stats.clone())
-                    else:
-                        # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
-                        # patch's sorted rows (its pixels are a contiguous run of the table)
-                        tabs, maps, rl, cl = [], [], [], []
-                        for gi, pno in enumerate(pnos):
-                            for v in range(2):
-                                for g in range(ngroups):
-                                    tabs.append(tb.S[v])
-                                    maps.append(rowmaps[gi] if ngroups == 1 else rowmaps[gi].view(B, N)[g])
-                                    if marg is not None:
-                                        rl.append(r_one[v] if ngroups == 1 else r_one[v][g])
-                                        cl.append(tb.c_sorted[pno][v] if ngroups == 1 else tb.c_sorted[pno][v][g])
-                        skb = ops.SinkhornBatch.from_rows(tabs, maps, self.eps, self.niters, 1.0 / nglob, sorted_rows=True,
-                                                          r=rl or None, c=cl or None)
+            Sc_all = torch.empty(G, 2, c.rows, K, dtype=torch.float32, device=dev)
+            gpicks = c.pb.picks[pnos[0]:pnos[-1] + 1].contiguous()
+            Rn_all = ops.gather_scores_batch(c.sc_all, c.rn_all, c.bc, gpicks, maps_all, B, hw * hw, Sc_all, shift=c.lshift)
+            skb = self._sinkhorn_batch(c, Sc_all, G, {})
+            dS_all = torch.empty_like(Sc_all)
+            ops.swapped_ce_batch(Sc_all, c.ngroups, skb, c.T, c.gscale, c.loss, c.gscale, 1.0, dS_all)
+            if c.return_aux and pnos[0] == 0:
+                c.aux.update(scores_s=Sc_all[0, 0, :c.grows].clone(), scores_t=Sc_all[0, 1, :c.grows].clone(),
+                             q_s=skb[0].codes(), q_t=skb[c.ngroups].codes())
+            with self._timed("proto_bwd_lowrank"):
+                ops.proto_bwd_lowrank_batch_(dS_all, Sc_all, Rn_all, c.bc, gpicks, maps_all, c.Ct_all, B, hw * hw, c.gb,
+                                             0.0 if c.first_acc else 1.0, shift=c.lshift)
+            c.first_acc = False
+            del dS_all, Rn_all, Sc_all, skb
+
+    def _sinkhorn_batch(self, c, Sc_all, G, cmax_pre):
+        """S4 on per-sample score matrices: every (patch, view[, image]) problem of a patch group in one batched Sinkhorn;
+        cmax_pre {(patch in group, view): (column maxima, first-pass sums)} where the score GEMM's epilogue left them"""
+        K, ngroups, grows = c.K, c.ngroups, c.grows
+        r_all = c_all = None
+        if c.r_one is not None:
+            r_all = c.r_one.unsqueeze(0).expand(G, *c.r_one.shape).reshape(G * 2 * ngroups, K).contiguous()
+            c_all = c.c_one.unsqueeze(0).expand(G, *c.c_one.shape).reshape(G * 2 * ngroups, grows).contiguous()
+        with self._timed("sinkhorn"):
+            skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
+                                    c=c_all, c_uniform=1.0 / c.nglob)
+            for (gi, v), (cm, uf) in cmax_pre.items():
+                for g in range(ngroups):
+                    sk_ = skb[(gi * 2 + v) * ngroups + g]
+                    sk_.cmax_preset = cm if ngroups == 1 else cm[g]
+                    sk_.u_first_preset = uf if ngroups == 1 else uf[g]
+            skb.run(c.sk_reduce)
+        return skb
+
+    # --- route 'tables': many prototypes, d(scores) (and the scores) on per-pixel tables (DESIGN §4.15, §4.16) ---
+    def _step_tables(self, c):
+        """64 < K <= 8192, pyramid mode, linear projection: the CE of ALL patches pixel-major into one d(scores) table per view,
+        the backward GEMMs once per view over the pixels; with `route.score_table` the score GEMM too runs once per view over
+        the pixels and the Sinkhorn problems are row selections of the two tables (`route.sinkhorn_table`: solved ON the tables,
+        every row read once per pass)."""
+        B, K, hw, P, dev = c.B, c.K, c.hw, c.P, self.device
+        rows, ngroups = c.rows, c.ngroups
+        Kp = (K + 15) // 16 * 16
+        npix = B * hw * hw
+        wc_planes = ops.split_gemm_weights(c.Wc)
+        wct_planes = ops.split_gemm_weights(c.Wc.t().contiguous())
+        dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
+        pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
+        tb = None
+        if c.route.score_table:
+            tb = self._score_tables(c.pb, c.views, c.Zt, P, B, hw, c.N, c.D, K, wc_planes, c.bc, c.c_one,
+                                    by_mask=c.route.sinkhorn_table, by_image=ngroups > 1)
+        pnos = list(range(P))
+        nrow = torch.arange(rows, dtype=torch.int32, device=dev)
+        if tb is not None:
+            rowmaps = [tb.rowmaps[pno] for pno in pnos]                               # a patch's samples -> table rows
+            inv = torch.full((P, npix), -1, dtype=torch.int32, device=dev)           # table row -> its row in patch p's problem
+            for gi in range(P):
+                inv[gi].scatter_(0, rowmaps[gi].long(), nrow)
+            with self._timed("sinkhorn"):
+                if c.route.sinkhorn_table and (ngroups == 1 or tb.seg is not None):
+                    # ALL problems of the step in one pass over the live rows of the two tables per iteration — a row several
+                    # patches drew is read once (csrc/gx_sktab.hip, DESIGN §4.16); per-image scope: a workgroup stays inside
+                    # one image's run of the table
+                    r_tab = c_tab = None
+                    if c.r_one is not None:              # problem index = (patch * 2 + view) * ngroups + image
                         if ngroups == 1:
-                            for sk_ in skb.probs:  # column maxima + first pass of every problem in ONE sweep of its rows
-                                sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
-                        # (per-image scope: 2 B P small problems — their maxima and first pass are two more launches of the batch)
-                        skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
-                        del tabs, maps, rl, cl
-                ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, ngroups, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp,
-                                          gb, 0.0 if first_acc else 1.0, live=tb.live, live_frac=tb.live_frac,
-                                          row_group=tb.row_group if ngroups > 1 else None)
-                first_acc = False
-                if return_aux:
-                    aux.update(scores_s=skb[0].scores(), scores_t=skb[ngroups].scores(), q_s=skb[0].codes(),
-                               q_t=skb[ngroups].codes())
-                del inv, skb, rowmaps
-                continue
+                            r_tab = torch.stack([c.r_one[v] for _ in pnos for v in range(2)])
+                        else:
+                            r_tab = torch.stack([c.r_one[v][g] for _ in pnos for v in range(2) for g in range(ngroups)])
+                        c_tab = torch.stack([tb.c_sorted[pno][v].reshape(-1) for pno in pnos for v in range(2)])
+                    skb = ops.SinkhornTable(tb.S[0], tb.S[1], inv, tb.live, self.eps, self.niters, 1.0 / c.nglob, rows,
+                                            r=r_tab, c=c_tab, rowmaps=rowmaps if c.return_aux else None, ngroups=ngroups,
+                                            seg=tb.seg)
+                    with ops.record("sinkhorn_pass_kernel", 0.0, 8.0 * npix * K * tb.live_frac * self.niters, launches=self.niters):
+                        skb.run(c.sk_reduce)
+                    if self._sk_probe is not None:                            # tools/soak.py: what the last update vouched for
+                        self._sk_probe.append(skb.stats.clone())
+                else:
+                    # problems in (patch, view, image) order; per-image scope: an image's N samples are a contiguous run of the
+                    # patch's sorted rows (its pixels are a contiguous run of the table)
+                    tabs, maps, rl, cl = [], [], [], []
+                    for gi, pno in enumerate(pnos):
+                        for v in range(2):
+                            for g in range(ngroups):
+                                tabs.append(tb.S[v])
+                                maps.append(rowmaps[gi] if ngroups == 1 else rowmaps[gi].view(B, c.N)[g])
+                                if c.r_one is not None:
+                                    rl.append(c.r_one[v] if ngroups == 1 else c.r_one[v][g])
+                                    cl.append(tb.c_sorted[pno][v] if ngroups == 1 else tb.c_sorted[pno][v][g])
+                    skb = ops.SinkhornBatch.from_rows(tabs, maps, self.eps, self.niters, 1.0 / c.nglob, sorted_rows=True,
+                                                      r=rl or None, c=cl or None)
+                    if ngroups == 1:
+                        for sk_ in skb.probs:  # column maxima + first pass of every problem in ONE sweep of its rows
+                            sk_.cmax_preset, sk_.u_first_preset = ops.sinkhorn_first_rows(sk_.S, self.eps, sk_.rowmap)
+                    # (per-image scope: 2 B P small problems — their maxima and first pass are two more launches of the batch)
+                    skb.run(c.sk_reduce)
+                    del tabs, maps, rl, cl
+            ops.swapped_ce_pixels_tab(tb.S[0], tb.S[1], skb, ngroups, inv, c.T, c.gscale, c.loss, c.gscale, 1.0, dS_tab[0], dS_tab[1],
+                                      Kp, c.gb, 0.0, live=tb.live, live_frac=tb.live_frac,
+                                      row_group=tb.row_group if ngroups > 1 else None)
+            if c.return_aux:
+                c.aux.update(scores_s=skb[0].scores(), scores_t=skb[ngroups].scores(), q_s=skb[0].codes(),
+                             q_t=skb[ngroups].codes())
+            del inv, skb, rowmaps
+        else:
+            # per-sample scores of every patch (one score GEMM per patch and view, the Sinkhorn maxima and first pass from its
+            # epilogue), then ONE pass over them all: loss, bias gradient, and each pixel's d(scores) summed over the patches
+            # that drew it, written once (inv[p][pixel] = the pixel's row in patch p, -1 = not drawn)
+            Sc_all = torch.empty(P, 2, rows, K, dtype=torch.float32, device=dev)
+            cmax_pre = {}
+            for gi, pno in enumerate(pnos):
+                for v in range(2):
+                    with self._timed("gather_rows"):
+                        z, _ = ops.gather_rows_normalize(c.Zt[v], c.pb.picks[pno], c.views[v][1])  # z_hat (B*N, D)
+                    self._scores_gemm(c, z, Sc_all[gi, v], wc_planes, cmax_pre, (gi, v))
+                    del z
+            skb = self._sinkhorn_batch(c, Sc_all, P, cmax_pre)
+            inv = torch.full((P, npix), -1, dtype=torch.int32, device=dev)
+            for gi, pno in enumerate(pnos):
+                inv[gi].scatter_(0, (c.pb.picks[pno] + pix_base).reshape(-1).long(), nrow)
+            ops.swapped_ce_pixels(Sc_all, skb, ngroups, inv, c.T, c.gscale, c.loss, c.gscale, 1.0, dS_tab[0], dS_tab[1], Kp, c.gb, 0.0)
+            if c.return_aux:
+                c.aux.update(scores_s=Sc_all[0, 0, :c.grows].clone(), scores_t=Sc_all[0, 1, :c.grows].clone(),
+                             q_s=skb[0].codes(), q_t=skb[ngroups].codes())
+            del inv, Sc_all, skb
+        c.first_acc = False
+        self._tables_backward(dS_tab, tb, c.views, c.Zt, c.Gt, c.Wc, wct_planes, c.gWc, B, hw)
+
+    def _scores_gemm(self, c, z, sc, wc_planes, cmax_pre, key):
+        """scores = z_hat Wc^T + b into sc (rows, K)"""
+        K = c.K
+        if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
+            # Wc split once per step; the Sinkhorn column maxima AND its first pass (the column sums of
+            # exp((scores - max) / eps)) come out of the epilogue: nine sweeps of the score matrix, not eleven
+            if K > 64 and (c.ngroups == 1 or c.grows % 32 == 0):
+                _, cm_, uf_ = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc,
+                                                 want_colmax=True if c.ngroups == 1 else c.ngroups, sk_eps=self.eps)
+                cmax_pre[key] = (cm_, uf_)
+            else:
+                ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc)
+        else:
+            ops.gemm(z, c.Wc, False, True, col_bias=c.bc, out=sc)
+
+    # --- route 'per_sample': everything else (panel mode, projection heads, 16 < K <= 64, shapes the tables do not take) ---
+    def _step_per_sample(self, c):
+        """The reference-shaped chain per patch and view (swav_clustering.py:377-418 with :133-182): gather (or the N x hlen panel
+        and its GEMM) -> [projection head] -> normalise -> scores -> batched Sinkhorn -> swapped CE -> backward GEMMs -> scatter
+        into the projected tables (pyramid mode) or dWp (panel mode)."""
+        B, K, D, hw, dev = c.B, c.K, c.D, c.hw, self.device
+        rows, ngroups, grows = c.rows, c.ngroups, c.grows
+        mode, head, small, views = c.mode, c.head, c.route.small, c.views
+        Wc, bc, gWc, gb = c.Wc, c.bc, c.gWc, c.gb
+        wc_planes = ops.split_gemm_weights(Wc) if c.route.planes else None
+        pad_ds = c.route.pad_ds
+        Kp = (K + 15) // 16 * 16
+        wct_planes = ops.split_gemm_weights(Wc.t().contiguous()) if pad_ds else None
+        for p0 in range(0, c.P, c.route.pgroup):
+            pnos = list(range(p0, min(c.P, p0 + c.route.pgroup)))
+            G = len(pnos)
             Sc_all = torch.empty(G, 2, rows, K, dtype=torch.float32, device=dev)
             keep = []
             cmax_pre = {}
-            batched = lowrank                    # K <= 16: gather / loss / scatter of all patches in single launches
-            if batched:      # every patch and both views in single launches (tables over the 2B-image batch)
-                gpicks = pb.picks[pnos[0]:pnos[-1] + 1].contiguous()
-                Rn_all = ops.gather_scores_batch(sc_all, rn_all, bc, gpicks, maps_all, B, hw * hw, Sc_all, shift=lshift)
-            for gi, pno in enumerate(pnos if not batched else []):
-                picks = pb.picks[pno]
+            for gi, pno in enumerate(pnos):
+                picks = c.pb.picks[pno]
                 X, Zh, Rn, Hc = [], [], [], []
                 for v, (ts, maps, _) in enumerate(views):
                     sc = Sc_all[gi, v]
                     if mode == 'pyramid' and small:
                         with self._timed("proto_fwd_small"):
-                            z, rn, _ = ops.proto_fwd_small(Zt[v], picks, maps, Wc, bc, out=sc)
+                            z, rn, _ = ops.proto_fwd_small(c.Zt[v], picks, maps, Wc, bc, out=sc)
                         Zh.append(z); Rn.append(rn)
                         continue
                     if mode == 'pyramid' and head.linear:
                         with self._timed("gather_rows"):
-                            z, rn = ops.gather_rows_normalize(Zt[v], picks, maps)  # z_hat (B*N, D)
+                            z, rn = ops.gather_rows_normalize(c.Zt[v], picks, maps)  # z_hat (B*N, D)
                     else:
                         if mode == 'pyramid':
                             with self._timed("gather_rows"):
-                                z = ops.gather_rows(Zt[v], picks, maps)            # rows of the first Linear's output
+                                z = ops.gather_rows(c.Zt[v], picks, maps)            # rows of the first Linear's output
                         else:
                             with self._timed("gather"):
-                                x = ops.gather_taps(ts, picks, hlen, maps)         # (B*N, hlen)
+                                x = ops.gather_taps(ts, picks, c.hlen, maps)         # (B*N, hlen)
                             with self._timed("proj_fwd"):
-                                z = ops.gemm(x, Wp, False, True)                   # (B*N, D)
+                                z = ops.gemm(x, c.Wp, False, True)                   # (B*N, D)
                             X.append(x)
                         if not head.linear:        # '1-layer' / '2-layer': one BatchNorm batch per Sinkhorn problem
                             with self._timed("proj_head"):
-                                z, hc = head.forward(z, ngroups, hreduce, self.world if hreduce else 1)
+                                z, hc = head.forward(z, ngroups, c.sk_reduce, self.world if c.sk_reduce else 1)
                             Hc.append(hc)
                         rn = ops.row_l2_normalize_(z)                              # z -> z_hat
-                    if wc_planes is not None and ops.gemm_planes_ok(z, None, K, sc):
-                        # (B*N, K), Wc split once per step; the Sinkhorn column maxima AND its first pass (the column sums of
-                        # exp((scores - max) / eps)) come out of the epilogue: nine sweeps of the score matrix, not eleven
-                        if K > 64 and (ngroups == 1 or grows % 32 == 0):
-                            _, cm_, uf_ = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc,
-                                                             want_colmax=True if ngroups == 1 else ngroups, sk_eps=self.eps)
-                            cmax_pre[(gi, v)] = (cm_, uf_)
-                        else:
-                            ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=bc)
-                    else:
-                        ops.gemm(z, Wc, False, True, col_bias=bc, out=sc)
+                    self._scores_gemm(c, z, sc, wc_planes, cmax_pre, (gi, v))
                     Zh.append(z); Rn.append(rn)
                 keep.append((X, Zh, Rn, Hc))
-            # S4: every (patch, view[, image]) problem of the group in one batched Sinkhorn
-            r_all = c_all = None
-            if marg is not None:
-                r_all = r_one.unsqueeze(0).expand(G, *r_one.shape).reshape(G * 2 * ngroups, K).contiguous()
-                c_all = c_one.unsqueeze(0).expand(G, *c_one.shape).reshape(G * 2 * ngroups, grows).contiguous()
-            with self._timed("sinkhorn"):
-                skb = ops.SinkhornBatch(Sc_all.reshape(G * 2 * ngroups, grows, K), self.eps, self.niters, r=r_all,
-                                        c=c_all, c_uniform=1.0 / nglob)
-                for (gi, v), (cm, uf) in cmax_pre.items():
-                    for g in range(ngroups):
-                        sk_ = skb[(gi * 2 + v) * ngroups + g]
-                        sk_.cmax_preset = cm if ngroups == 1 else cm[g]
-                        sk_.u_first_preset = uf if ngroups == 1 else uf[g]
-                skb.run(self._reduce if (scope == 'global' and self.sharded) else None)
-            if dstab:
-                # ONE pass over the scores of all patches: loss, bias gradient, and each pixel's d(scores) summed over the patches
-                # that drew it, written once (inv[p][pixel] = the pixel's row in patch p, -1 = not drawn)
-                inv = torch.full((G, npix), -1, dtype=torch.int32, device=dev)
-                nrow = torch.arange(rows, dtype=torch.int32, device=dev)
-                for gi, pno in enumerate(pnos):
-                    inv[gi].scatter_(0, (pb.picks[pno] + pix_base).reshape(-1).long(), nrow)
-                ops.swapped_ce_pixels(Sc_all, skb, ngroups, inv, T, gscale, loss, gscale, 1.0, dS_tab[0], dS_tab[1], Kp, gb,
-                                      0.0 if first_acc else 1.0)
-                first_acc = False
-                if return_aux:
-                    aux.update(scores_s=Sc_all[0, 0, :grows].clone(), scores_t=Sc_all[0, 1, :grows].clone(),
-                               q_s=skb[0].codes(), q_t=skb[ngroups].codes())
-                del inv, keep, Sc_all, skb
-                continue
-            if batched:
-                dS_all = torch.empty_like(Sc_all)
-                ops.swapped_ce_batch(Sc_all, ngroups, skb, T, gscale, loss, gscale, 1.0, dS_all)
-                if return_aux and pnos[0] == 0:
-                    aux.update(scores_s=Sc_all[0, 0, :grows].clone(), scores_t=Sc_all[0, 1, :grows].clone(),
-                               q_s=skb[0].codes(), q_t=skb[ngroups].codes())
-                with self._timed("proto_bwd_lowrank"):
-                    ops.proto_bwd_lowrank_batch_(dS_all, Sc_all, Rn_all, bc, gpicks, maps_all, Ct_all, B, hw * hw, gb,
-                                                 0.0 if first_acc else 1.0, shift=lshift)
-                first_acc = False
-                del dS_all, Rn_all
-            for gi, pno in enumerate(pnos if not batched else []):
-                picks = pb.picks[pno]
+            skb = self._sinkhorn_batch(c, Sc_all, G, cmax_pre)
+            for gi, pno in enumerate(pnos):
+                picks = c.pb.picks[pno]
                 X, Zh, Rn, Hc = keep[gi]
                 Sc = [Sc_all[gi, 0], Sc_all[gi, 1]]
                 if pad_ds:   # rows padded to whole 16-column chunks (zero pad) so that dS can be the A operand of the dz GEMM
@@ -609,20 +787,20 @@ class SwAVClustering(ViewMixin):
                     r0, r1 = g * grows, (g + 1) * grows
                     sk = [skb[(gi * 2 + v) * ngroups + g] for v in range(2)]
                     if gb_in_ce:
-                        ops.swapped_ce_fused(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1], gb,
-                                             0.0 if (first_acc and g == 0) else 1.0)
+                        ops.swapped_ce_fused(sk[0], sk[1], c.T, c.gscale, c.loss, c.gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1], gb,
+                                             0.0 if (c.first_acc and g == 0) else 1.0)
                     else:
-                        ops.swapped_ce(sk[0], sk[1], T, gscale, loss, gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
-                    if return_aux and pno == 0 and g == 0:
-                        aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
-                                   q_s=sk[0].codes(), q_t=sk[1].codes())
+                        ops.swapped_ce(sk[0], sk[1], c.T, c.gscale, c.loss, c.gscale, 1.0, dS[0][r0:r1], dS[1][r0:r1])
+                    if c.return_aux and pno == 0 and g == 0:
+                        c.aux.update(scores_s=Sc[0][r0:r1].clone(), scores_t=Sc[1][r0:r1].clone(),
+                                     q_s=sk[0].codes(), q_t=sk[1].codes())
                 # S6: backward (gradients accumulate over views and patches)
                 for v in range(2):
-                    beta = 0.0 if first_acc else 1.0
+                    beta = 0.0 if c.first_acc else 1.0
                     if mode == 'pyramid' and small:
                         with self._timed("proto_bwd_small"):
-                            ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, Gt[v], gWc, gb, beta)
-                        first_acc = False
+                            ops.proto_bwd_small_(dS[v], Zh[v], Rn[v], picks, views[v][1], Wc, c.Gt[v], gWc, gb, beta)
+                        c.first_acc = False
                         continue
                     ops.gemm(dS[v], Zh[v], True, False, out=gWc, beta=beta, split_k=self._split_k(K, D, rows))
                     if not gb_in_ce:
@@ -634,55 +812,22 @@ class SwAVClustering(ViewMixin):
                         dz = ops.gemm(dS[v], Wc, False, False)                     # d z_hat (B*N, D)
                     if mode == 'pyramid' and head.linear:
                         with self._timed("scatter_rows"):
-                            ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], Gt[v])
+                            ops.normalize_bwd_scatter_(dz, Zh[v], Rn[v], picks, views[v][1], c.Gt[v])
                     else:
                         ops.l2_normalize_bwd_(dz, Zh[v], Rn[v])
                         if not head.linear:
                             with self._timed("proj_head"):
-                                dz = head.backward(dz, Zh[v], Hc[v], gextra, beta, split_k=self._split_k(D, D, rows))
+                                dz = head.backward(dz, Zh[v], Hc[v], c.gextra, beta, split_k=self._split_k(D, D, rows))
                         if mode == 'pyramid':
                             with self._timed("scatter_rows"):
-                                ops.scatter_rows_add_(dz, picks, views[v][1], Gt[v])
+                                ops.scatter_rows_add_(dz, picks, views[v][1], c.Gt[v])
                         else:
                             with self._timed("proj_dW"):
-                                ops.gemm(dz, X[v], True, False, out=gWp, beta=beta, split_k=self._split_k(D, hlen, rows))
-                    first_acc = False
+                                ops.gemm(dz, X[v], True, False, out=c.gWp, beta=beta, split_k=self._split_k(D, c.hlen, rows))
+                    c.first_acc = False
                 keep[gi] = None
                 del X, Zh, Rn, Hc, Sc, dS
             del keep, Sc_all, skb
-        if dstab:
-            self._tables_backward(dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw)
-            del dS_tab, tb
-        pending = []
-        if mode == 'pyramid':
-            on_level = on_heads = None
-            if self.sharded:
-                # once the prototype gradients and the loss are final their all-reduce travels while the
-                # pyramid backward runs, and every pyramid level's slice of dWp follows as soon as its GEMMs
-                # are queued (finest levels first), so only the coarsest levels' message is exposed
-                on_heads = lambda: pending.append(sharded.allreduce_flat_async([gWc, gb, loss] + gextra, self.dist_group))
-                on_level = lambda cols: pending.append(sharded.allreduce_cols_async(gWp, cols, self.dist_group))
-            with self._timed("pyramid_bwd"):
-                if lowrank:      # from the coefficient grid: dense finish at the table level, the finest level's Gram forms
-                    pyr.backward_lowrank(Ct_all, Wp, Wc, gWp, gWc, on_level=on_level, on_heads=on_heads)
-                else:
-                    if on_heads is not None:
-                        on_heads()
-                    pyr.backward(G_all, gWp, accumulate=False, on_level=on_level)
-            del Zt, Z_all, G_all
-        elif self.sharded:
-            pending.append(sharded.allreduce_flat_async(list(self._grads) + [loss], self.dist_group))
-        for fin in pending:
-            fin()
-        # S8: LARC + momentum SGD
-        lr = sa['train_args']['lr']
-        mom = sa['train_args'].get('momentum', 0.0)
-        if sa.get('use_scheduler', False) and getattr(self, '_lr_schedule', None) is not None:
-            lr = float(self._lr_schedule[min(self._step_no, len(self._lr_schedule) - 1)])
-        for p, g, buf in zip((Wp, Wc, bc, *extra), self._grads, self._bufs):
-            ops.larc_sgd_(p, g, buf, lr, mom, sa['trust_coeff'], first_step=(self._step_no == 0), use_larc=use_larc)
-        self._step_no += 1
-        return (loss, aux) if return_aux else loss
 
     # ------------------------------------------------------------------------------------- training loop
     def _schedule(self):

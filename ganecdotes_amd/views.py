@@ -25,6 +25,18 @@ class PreparedBatch:
                 t.record_stream(cur)
 
 
+def check_hf_interp(args, where):
+    """`hf_interp` is the `mode` of the reference's F.interpolate over the taps (hfc_with_swav/swav_clustering.py:123-124,
+    baseline/hfc_with_simclr/simclr_clustering.py:102-103).  Every shipped config sets 'nearest', and 'nearest' is what the
+    kernels implement (src = floor(dst * in / out): gx_gather_taps, the pyramid's 2x2 parent indexing).  Any other value would
+    change every descriptor, so it is refused by name rather than silently computed as nearest."""
+    mode = args.get('hf_interp', 'nearest')
+    if mode != 'nearest':
+        raise NotImplementedError(
+            f"{where}['hf_interp']={mode!r}: only 'nearest' (the value of every reference config) is implemented on the HIP "
+            f"path; the feature upsampling would silently differ from F.interpolate(mode={mode!r})")
+
+
 class ViewMixin(object):
     """Needs self.model / mean_latent / truncation / perturb_args / device, `self._hlen` and
     `_pick_spec() -> (pixels per patch, patches, 'host'|'device')`."""

@@ -421,8 +421,10 @@ int gx_sinkhorn_small_batch_finish(int nprob, int K, float eps, int niters, cons
                                    const float* u_last, const float* workspace, float* la, void* stream);
 int gx_sinkhorn_codes(const float* S, long rows, int K, long ld, float eps, const float* la, float* q, long ldq,
                       void* stream);
-/* scratch: 258 words (the data range as two ordered ints + 256 block partials of the normalising sum) */
-int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, void* stream);
+/* scratch: `scratch_words` 32-bit words, >= 2 (the data range as two ordered ints); from 16 384 bins on the normalising sum
+ * is taken over all CUs and needs 256 more words of block partials: with fewer than 258 words such a call returns
+ * GX_ERR_WORKSPACE (it never writes past what the caller said it owns). */
+int gx_hist_marginal(const float* x, long n, int bins, float* hist, unsigned* scratch, int scratch_words, void* stream);
 /* the same in three stages for the sharded form: range (all_reduce MIN/MAX of lohi) -> counts
  * (all_reduce SUM of hist) -> finish */
 int gx_hist_range(const float* x, long n, unsigned* scratch, float* lohi, void* stream);

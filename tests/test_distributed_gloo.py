@@ -199,6 +199,38 @@ def test_sharded_table_sinkhorn_two_ranks_equals_oracle():
     np.testing.assert_allclose(np.concatenate([out[0][2], out[1][2]], 1), one.codes().numpy(), rtol=1e-4, atol=1e-7)
 
 
+def test_eight_ranks_uneven_shards_group_and_table_solvers_equal_the_oracle():
+    """The shape of the real machine, rehearsed on CPU: world_size 8 over gloo, 100 003 rows (not a
+    multiple of 8: shards of 12 501 and 12 500 rows), a step's worth of problems through BOTH exchange protocols —
+    sharded.run_sinkhorn_group (per-problem kernels) and sharded.run_sinkhorn_table (the table solver) — against the
+    reference's sinkhorn_knopp on the concatenation; 11 collectives per protocol for all problems together, whatever the
+    number of ranks."""
+    from oracle import swav_ref as S
+    torch.manual_seed(11)
+    n, kk, eps, nprob, world = 100003, 16, 0.02, 4, 8
+    problems = 0.3 * torch.randn(nprob, n, kk)
+    mgr = mp.Manager()
+    out_g, out_t = mgr.dict(), mgr.dict()
+    mp.spawn(_group_worker, args=(world, _free_port(), [problems[i] for i in range(nprob)], eps, out_g), nprocs=world, join=True)
+    mp.spawn(_table_worker, args=(world, _free_port(), problems, eps, out_t), nprocs=world, join=True)
+    sizes = sorted(out_g[r][1] - out_g[r][0] for r in range(world))
+    assert sizes[0] == 12500 and sizes[-1] == 12501 and sum(sizes) == n
+    for i in range(nprob):
+        ref = S.sinkhorn_knopp(problems[i], eps, 10, fp64=True).numpy()
+        tol = 1e-3 * ref.max(axis=1, keepdims=True)
+        qg, qt = np.zeros_like(ref), np.zeros_like(ref)
+        for r in range(world):
+            lo, hi, qs, calls = out_g[r]
+            assert calls == 11
+            qg[lo:hi] = qs[i]
+            lo, hi, q, calls, nshift = out_t[r]
+            assert calls == 11 and nshift == 8
+            qt[lo:hi] = q[i]
+        assert np.all(np.abs(qg - ref) <= tol) and np.all(np.abs(qt - ref) <= tol)
+        # a transport plan over ALL ranks' rows: every prototype column carries 1 / K of the mass up to Sinkhorn's residual
+        assert abs(float(qt.sum()) - n) < 1e-2 * n
+
+
 def test_shard_range_covers_everything():
     for n in (1, 7, 16, 33):
         for w in (1, 2, 3, 8):
@@ -252,6 +284,16 @@ def test_bench_self_launch_rendezvous_two_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and json.loads(lines[0]) == {"dry_rendezvous": True, "world": 2}
+
+
+def test_bench_self_launch_rendezvous_eight_ranks():
+    """the driver's largest launch, rehearsed: `bench.py --gpus 8 --backend gloo --dry-rendezvous` — eight fresh child processes
+    join the group on 127.0.0.1, pass one barrier and leave; no GPU is touched"""
+    import json
+    p, _ = _bench("--gpus", "8", "--backend", "gloo", "--dry-rendezvous", timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_rendezvous": True, "world": 8}
 
 
 def test_bench_self_launch_returns_fast_when_a_rank_dies():

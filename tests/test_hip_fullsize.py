@@ -117,6 +117,54 @@ def test_ffhq256_full_size_step_vs_oracle(gpu, engine, nproto):
 
 
 
+@pytest.mark.parametrize("nproto,patches", [(5000, 3), (4001, 1)])
+def test_ffhq256_table_sinkhorn_overlapping_patches_vs_oracle(gpu, nproto, patches):
+    """What the table Sinkhorn (csrc/gx_sktab.hip) does that nothing else does — ONE pass over rows that SEVERAL
+    patches drew — against the oracle, directly, at full size and with the configuration's real eps = 0.005 / T = 0.01
+    (VERDICT round 4, item 4): ffhq-256 width, 1 image, K = 5000, 3 patches of 20 000 of the 65 536 pixels (60 % of the drawn pixels
+    are drawn twice or more), scores and d(scores) on per-pixel tables.  Loss, the three gradients and the LARC update.
+    (4001, 1 patch): a prototype count that is not a multiple of 4 — padded to 4004 columns that take no mass
+    (SwAVClustering._pad_prototypes; item 5) — against the oracle's unpadded problem.  Default engine only (oracle time)."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    from ganecdotes_amd.swav_clustering import SwAVClustering
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g, sd = full_generator(256)
+    g = g.to(gpu)
+    sw = SwAVClustering(model=g, model_config=Cfg, out_dir=None, device="cuda",
+                        **ffhq_args(1, nproto, num_patches=patches, pick_source="host", ds_table=True, score_table=True,
+                                    sinkhorn_table=True))
+    torch.manual_seed(6)
+    np.random.seed(6)
+    with torch.no_grad():
+        ml = S.G.mean_latent(sd, 128, 512)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    images = [draw_image(512, 13, 6, 256 * 256, patches, transforms=True)]
+    if patches > 1:       # the patches do overlap: pixels drawn by two or more of them
+        cnt = torch.zeros(256 * 256, dtype=torch.int32)
+        for pk in images[0].picks:
+            cnt[pk[:20000].long()] += 1
+        assert int((cnt >= 2).sum()) > 0.3 * int((cnt >= 1).sum())
+    loss = sw.train_step(images)
+    rt = sw.last_route
+    assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table and rt.k_run == (nproto + 3) // 4 * 4, rt
+    oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                             ops.rotflip_map(v.angle, v.flip, 256, 256, "cuda").cpu().long())
+                                 for v in im.views], im.picks) for im in images]
+    ref_loss, grads, _ = S.swav_train_step(
+        sd, ml, 0.7, oimgs, params, [None] * 3, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=5376,
+        patch_size=20000, num_patches=patches, temperature=0.01, eps=0.005, niters=10, source_pdf="uniform",
+        sinkhorn_scope="global")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_TOL)
+    for got, want in zip(sw._grads, grads):
+        assert got.shape == want.shape and rel(got, want) < GRAD_TOL
+    for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+        assert rel(got, want) < 1e-5
+
+
 @pytest.mark.parametrize("nproto", [8, 5000])
 def test_ffhq256_batch2_two_patches_step_vs_oracle(gpu, engine, nproto):
     """the batched form of the step against the oracle, not only its properties: 2 images x 2 patches x 2 views of
@@ -634,6 +682,22 @@ def test_bench_cli_contract_one_json_line(gpu):
     assert rf["prototypes"] == 5000 and rf["unit"] == d["unit"] and rf["value"] > 0
     assert abs(rf["value"] - 16 * 1e3 / rf["ms_per_step"]) < 1e-3 * rf["value"]
     assert 0.0 < rf["roofline"]["mfma_frac"] < 1.0 and 0.0 < rf["roofline"]["hbm_frac"] < 1.0
+    assert "route=tables" in rf["route"] and "table Sinkhorn" in rf["route"]
+    rc = rf["cpu_baseline"]                                                     # ... with ITS CPU figure beside it (BASELINE.md par. 3)
+    assert rc["kind"] == "port" and rc["value"] > 0 and "K=5000" in rc["sample"]
+    assert "route=lowrank" in d["config"]["workload"]
+    assert r["traffic_source"] is None or "profiles/" in r["traffic_source"]
+    # every other BASELINE.json configuration, driver-timed in the same line
+    per_step = {"cat_per_rank": 16, "car512_per_rank": 4, "car512_per_rank_k4000": 4, "simclr": 1, "predict": 4}
+    for key, imgs in per_step.items():
+        n = d[key]
+        assert n["unit"] == "images/s" and n["value"] > 0 and n["ms_per_step"] > 0 and n["workload"], key
+        assert abs(n["value"] - imgs * 1e3 / n["ms_per_step"]) < 1e-3 * n["value"], key
+        nr = n["roofline"]
+        assert nr["kernel"] and 0.0 < nr["frac"] < 1.0 and 0.0 < nr["step_frac"] < 1.0, key
+    assert "source_pdf='image'" in d["cat_per_rank"]["workload"] and "route=lowrank" in d["cat_per_rank"]["workload"]
+    assert "route=tables" in d["car512_per_rank_k4000"]["workload"] and "512x512" in d["car512_per_rank"]["workload"]
+    assert d["simclr"]["iterations_per_s"] > 0 and np.isfinite(d["simclr"]["loss"])
     d2 = run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert d2["n_gpus"] == 2 and d2["cpu_baseline"] is None and "reference_faithful" not in d2
     assert abs(d2["value"] - 2 * 16 * 1e3 / d2["ms_per_step"]) < 1e-3 * d2["value"]

@@ -307,6 +307,76 @@ def test_train_step_with_per_pixel_dscore_tables_vs_oracle(gpu, tmp_path, scope,
             assert rel(got, want) < 1e-4
 
 
+@pytest.mark.parametrize("scope,batch,nproto,pdf", [("global", 3, 200, "uniform"), ("image", 2, 200, "uniform"),
+                                                    ("global", 2, 203, "uniform"), ("image", 2, 4001, "uniform"),
+                                                    ("global", 2, 203, "image")])
+def test_train_step_tables_at_the_real_eps_and_temperature_vs_oracle(gpu, tmp_path, scope, batch, nproto, pdf):
+    """The per-pixel table route (score tables + table Sinkhorn) with the configurations' OWN eps = 0.005
+    and T = 0.01 (hfc_with_swav_ffhq_config.py:53, :65) — the toy tests above run at eps 0.05 / T 0.1, where the codes are soft —
+    on 3 overlapping patches of 600 of 1024 pixels (most pixels drawn twice or more): two steps against the oracle, gradients
+    to 1e-3.  nprototypes 203 / 4001: not a multiple of 4 — the prototype columns are padded to 204 /
+    4004 with columns that take no mass (SwAVClustering._pad_prototypes; item 5), the oracle solves the unpadded problem."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    sw = make_swav(g, gpu, tmp_path, sinkhorn_scope=scope, batch_size=batch, nprototypes=nproto, nclasses=16, num_patches=3,
+                   patch_size=600, temperature=0.01, ds_table=True, sinkhorn_args=dict(source_pdf=pdf, eps=0.005))
+    torch.manual_seed(77)
+    np.random.seed(77)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    bufs = [None] * 3
+    for step in range(2):
+        images = [draw_image(16, 7, 3, 32 * 32, 3, transforms=True) for _ in range(batch)]
+        loss = sw.train_step(images)
+        rt = sw.last_route
+        assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table and rt.k_run == (nproto + 3) // 4 * 4, rt
+        oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                                 ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
+                                     for v in im.views], im.picks) for im in images]
+        ref_loss, grads, bufs = S.swav_train_step(
+            sd, ml, 0.7, oimgs, params, bufs, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
+            patch_size=600, num_patches=3, temperature=0.01, eps=0.005, niters=10, source_pdf=pdf, sinkhorn_scope=scope,
+            fp64=True)     # the toy generator's cosines pass 0.44: the reference's un-shifted fp32 exp(scores / 0.005) overflows
+        #                    there (GV7 documents its NaN); fp64 runs the same literal algorithm where it is finite
+        assert np.isfinite(ref_loss)
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+        for got, want in zip(sw._grads, grads):
+            assert got.shape == want.shape and rel(got, want) < 1e-3
+        for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+            assert rel(got, want) < 1e-4
+
+
+def test_prototype_count_not_a_multiple_of_four_costs_what_the_next_multiple_does(gpu, tmp_path):
+    """K = 4001 takes the route K = 4004 takes (padded columns, `Route.k_run`), not the team-per-row kernels it used to fall to
+    (132 ms per Sinkhorn against 10 ms at 4000), and returns K-shaped gradients; the per-sample route pads too
+    (K = 201 without the tables)."""
+    from ganecdotes_amd.draws import draw_image
+    d = load_golden("gv10_pretrain")
+    g = mini_gen(golden_sd(d), gpu)
+    for nproto, extra, name in ((4001, dict(ds_table=True), "tables"), (201, dict(ds_table=False), "per_sample")):
+        sw = make_swav(g, gpu, tmp_path, sinkhorn_scope="global", batch_size=2, nprototypes=nproto, nclasses=16, num_patches=3,
+                       patch_size=600, **extra)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        sw.build_heads()
+        images = [draw_image(16, 7, 3, 32 * 32, 3, transforms=True) for _ in range(2)]
+        loss, aux = sw.train_step(images, return_aux=True)
+        rt = sw.last_route
+        assert rt.name == name and rt.k_run == (nproto + 3) // 4 * 4 and rt.pad_ds
+        assert sw._grads[1].shape == (nproto, 16) and sw._grads[2].shape == (nproto,)
+        assert aux["q_s"].shape[1] == nproto and aux["scores_s"].shape[1] == nproto
+        # the padded columns took no mass: the real columns of every code row sum to 1
+        q = aux["q_s"].double()
+        assert float((q.sum(1) - 1).abs().max()) < 1e-5
+        assert torch.isfinite(loss).all() and all(torch.isfinite(g_).all() for g_ in sw._grads)
+
+
 @pytest.mark.parametrize("nproto", [6148, 7001])
 def test_train_step_past_the_fused_ce_limit_vs_oracle(gpu, tmp_path, nproto):
     """More prototypes than the one-pass CE takes (K > 6144): the step falls back to gx_swapped_ce + gx_colsum.  With

@@ -491,7 +491,7 @@ def test_fixtures_regenerate_from_the_reference():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     golden = os.path.join(root, "tests", "golden")
     before = {n: os.path.getmtime(os.path.join(golden, n)) for n in os.listdir(golden)}
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "verify_golden.py")], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "verify_golden.py")], capture_output=True, text=True, timeout=1900)   # >= the sum of verify_golden's per-script budgets (6 x 300 s)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 unexpected difference(s)" in p.stdout
     assert before == {n: os.path.getmtime(os.path.join(golden, n)) for n in os.listdir(golden)}

@@ -1,11 +1,10 @@
 #!/bin/bash
 # cache-policy bits on the many-prototype row kernels' loads / stores (-DBK_LOAD_AUX / -DBK_STORE_AUX), built and timed on the GPU box:
 #   tools/lab/bigk_aux.sh "0 0" "2 0" "0 2" "2 2"
-root=$(pwd); pkg=$root/ganecdotes_amd
+. tools/lab/labbuild.sh
 for pair in "$@"; do
   set -- $pair
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -DBK_LOAD_AUX=$1 -DBK_STORE_AUX=$2 -I $pkg/csrc -I $root/include -c $pkg/csrc/gx_swav.hip -o $pkg/build/gx_swav.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $pkg/libganecdotes_hip.so $pkg/build/*.o || exit 1
+  lab_build gx_swav.hip -DBK_LOAD_AUX=$1 -DBK_STORE_AUX=$2 || exit 1
   echo "== load aux $1, store aux $2"
   python3 tools/lab/sinkhorn_rows_lab.py 2>&1 | grep "sorted    side by side True"
   python3 bench.py --prototypes 5000 --steps 3 --warmup 1 --no-cpu-baseline --reference-faithful off 2>/dev/null | python3 -c "
