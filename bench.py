@@ -250,15 +250,28 @@ def measure(sw, args, steps, warmup, dev, world):
         threading.Thread(target=run, daemon=True).start()
         return q
 
-    q = feed(warmup)
-    for _ in range(warmup):
-        sw.train_step(q.get())
+    overlap = getattr(args, "overlap", "on") == "on"
+
+    def run(q, n):
+        """n steps.  overlap: the views of batch i + 1 are queued on the view stream BEFORE step i is queued (the frozen
+        generator's work runs beside the step, SwAVClustering.prefetch_views — what pretrain() does); the views of the first
+        batch are queued here too, so n steps always contain n view passes and n training passes."""
+        loss = None
+        if n <= 0:
+            return loss
+        nxt = sw.prefetch_views(q.get()) if overlap else q.get()
+        for i in range(n):
+            cur = nxt
+            if i + 1 < n:
+                nxt = sw.prefetch_views(q.get()) if overlap else q.get()
+            loss = sw.train_step(cur)
+        return loss
+
+    run(feed(warmup), warmup)
     ops.PROFILE = {}
     sync()
     t0 = time.perf_counter()
-    q = feed(steps)
-    for _ in range(steps):
-        loss = sw.train_step(q.get())
+    loss = run(feed(steps), steps)
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -446,6 +459,9 @@ def main():
                          "BASELINE.json configurations: cat-256 (16 prototypes, 'image' pdf, eps 0.003), car-512 (true 512^2 "
                          "generator, 4 images, 16 and 4000 prototypes, eps 0.01), hfc_with_simclr, and predict + one-shot head; "
                          "auto = on one GPU with the default 8 prototypes only")
+    ap.add_argument("--overlap", default="on", choices=["on", "off"],
+                    help="on: the views of batch i+1 (frozen generator) are queued on their own stream before step i, so they "
+                         "run beside it (what pretrain() does, swav_args['overlap_views']); off: one stream, views then step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to rehearse N>1")
     ap.add_argument("--dry-rendezvous", action="store_true",
@@ -531,6 +547,23 @@ def main():
                   f"{v['flops_per_step'] / max(v['ms_per_step'], 1e-9) / 1e9:8.1f} TFLOP/s  "
                   f"{v['bytes_per_step'] / max(v['ms_per_step'], 1e-9) / 1e6:8.1f} GB/s", file=sys.stderr)
     roof = roofline_of(stats, ms_step, os.path.join(ROOT, "profiles", TRAFFIC_FILE))
+    if args.overlap == "on" and roof is not None:
+        # The timed region runs TWO streams (the next batch's views beside the step): a launch's HIP-event duration there is the
+        # time it SHARED the chip, not its cost, so `achieved` / `frac` above understate the kernel.  A few more steps on ONE
+        # stream, same process, same state, give the kernel alone (what rocprofv3 shows for `--overlap off`, profiles/r05_*).
+        class _X:
+            batch, overlap = args.batch, "off"
+        dtx, stx, _ = measure(sw, _X, 6, 1, dev, world)
+        rx = roofline_of(stx, 1e3 * dtx / 6, None)
+        roof["concurrent_streams"] = 2
+        roof["note"] = ("timed region: the views of batch i+1 run on their own stream beside step i, so per-launch durations "
+                        "include time shared with the other stream; `exclusive` = the same kernels on one stream (6 steps after "
+                        "the timed region); step_frac is wall-clock and comparable in both")
+        if rx is not None:
+            roof["exclusive"] = dict(achieved=rx["achieved"], peak=rx["peak"], unit=rx["unit"], frac=rx["frac"],
+                                     avg_launch_ms=rx["avg_launch_ms"], launches_per_step=rx["launches_per_step"],
+                                     ms_per_step=1e3 * dtx / 6, step_frac=rx["step_frac"],
+                                     hbm=rx.get("hbm"), ms_per_step_by_kernel=rx["ms_per_step_by_kernel"])
     x6 = ops.get_gemm_mode() == 1
     out = {
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
@@ -594,7 +627,7 @@ def main():
         sw = None
         torch.cuda.empty_cache()
         # configs[2] cat-256 per rank: 16 images, 16 prototypes, source_pdf='image', eps 0.003 (hfc_with_swav_cat_config.py:52-65)
-        a = _A(); a.batch = 16
+        a = _A(); a.batch = 16; a.overlap = args.overlap
         swc = make(16, pdf="image", eps=0.003)
         dtc, stc, lossc = measure(swc, a, 8, 2, dev, 1)
         out["cat_per_rank"] = nested_record(
@@ -606,7 +639,7 @@ def main():
         # configs[3] car-512 per rank: TRUE 512^2 generator (15 taps, hlen 5376 of 5504 channels), 4 images per GPU, eps 0.01;
         # BASELINE's 16 prototypes and the reference's own 4000 (hfc_with_swav_car_config.py:52, :65)
         g512 = build_generator(512, dev)
-        a = _A(); a.batch = 4
+        a = _A(); a.batch = 4; a.overlap = args.overlap
         for kk, key in ((16, "car512_per_rank"), (4000, "car512_per_rank_k4000")):
             swk = make(kk, gen=g512, batch=4, size=512, eps=0.01, nlayers=7)
             st_, wu_ = (8, 2) if kk == 16 else (5, 2)

@@ -61,8 +61,9 @@ def _chk(*ts):
 
 
 def workspace(tag, nbytes, device):
-    """Grow-only scratch arena per (tag, device); all users are ordered on the current stream."""
-    key = (tag, str(device))
+    """Grow-only scratch arena per (tag, device, current stream): the users of one arena are ordered on one stream (the views
+    of the next batch run on their own stream beside the step, ViewMixin.prefetch_views: the two must not share scratch)."""
+    key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
     n = max(1, (int(nbytes) + 3) // 4)
     t = _WS.get(key)
     if t is None or t.numel() < n:

@@ -465,8 +465,7 @@ class SwAVClustering(ViewMixin):
         # S7: prototype rows to unit norm (bias untouched)
         ops.row_l2_normalize_(c.Wc, want_rnorm=False)
 
-        with self._timed("views"):
-            c.views, ts_all = self.make_views(pb, want_all=True, want_image=False)
+        c.views, ts_all = self.take_views(pb)            # prefetched on the view stream (prefetch_views) or made here
         c.hw = hw = c.views[0][0].size
         if c.N is None or c.N >= hw * hw:
             c.N = hw * hw
@@ -898,14 +897,18 @@ class SwAVClustering(ViewMixin):
         self.loss_history = []
         # the next batch is drawn (host RNG, same order) and staged BEFORE a step's loss is read back for the log: the read-back
         # waits for the GPU, and the host-side draws (80 randperms of 65 536 per ffhq batch) would otherwise start only after it
+        # ... and (swav_args['overlap_views'], default on) its views are queued on the view stream before the step itself is queued:
+        # the frozen generator's work for batch i + 1 runs beside step i (ViewMixin.prefetch_views; same arithmetic, same draws)
         total = sa['num_epochs'] * sa['num_samples']
-        nxt = self.draw_batch(batch) if total > 0 else None
+        overlap = bool(sa.get('overlap_views', True))
+        stage = (lambda b: self.prefetch_views(b)) if overlap else (lambda b: b)
+        nxt = stage(self.draw_batch(batch)) if total > 0 else None
         done = 0
         for e in range(sa['num_epochs']):
             for _ in range(sa['num_samples']):
-                loss = self.train_step(nxt)
-                done += 1
-                nxt = self.draw_batch(batch) if done < total else None
+                cur, done = nxt, done + 1
+                nxt = stage(self.draw_batch(batch)) if done < total else None
+                loss = self.train_step(cur)
                 self.loss_history.append(loss)
                 if self.writer is not None:
                     self.writer.add_scalar('swav/loss', loss.item(), e)

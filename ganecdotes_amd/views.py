@@ -10,7 +10,7 @@ from . import ops
 class PreparedBatch:
     """Device-side form of a batch of ImageDraws: staged through pinned host memory and copied
     on a side stream, so drawing / uploading step i+1 overlaps the kernels of step i."""
-    __slots__ = ("n", "z", "map_noise", "mix", "xforms", "picks", "ready", "_keep")
+    __slots__ = ("n", "z", "map_noise", "mix", "xforms", "picks", "ready", "_keep", "views")
 
     def acquire(self):
         """Make the batch usable on the CURRENT stream: wait for the side-stream upload, and tell the
@@ -99,6 +99,7 @@ class ViewMixin(object):
             hi.view(P, B, N).copy_(torch.stack([torch.stack([im.picks[p][:N] for im in images]) for p in range(P)]))
         pb = PreparedBatch()
         pb.n = B
+        pb.views = None
         with torch.cuda.stream(self._copy_stream):
             df = hf.to(self.device, non_blocking=True)
             di = hi.to(self.device, non_blocking=True)
@@ -136,6 +137,52 @@ class ViewMixin(object):
             nw = self.model.style(map_noise)
         return ops.view_latents(w.contiguous(), self.mean_latent.reshape(-1).contiguous(), float(self.truncation),
                                 nw.reshape(w.shape[0], 2, -1).contiguous(), mix.contiguous())
+
+    def prefetch_views(self, images):
+        """Queue the views of a batch (training form: all 2B images as one batch, no RGB) on the VIEW stream and attach them to its
+        PreparedBatch; `train_step` picks them up (take_views).  The generator is frozen, so the views of batch i + 1 depend on
+        nothing step i computes: queued before step i they run beside it — the step's HBM- and latency-bound passes (blur,
+        Sinkhorn, CE, scatter, the mapping network) and the tails of its matrix-core kernels share the chip with the other
+        stream's work instead of leaving it idle.  The view stream first waits for everything queued on the
+        current stream so far (the generator's plane buffers and the previous user of any shared state are then ordered); in a
+        steady pipeline that work — step i - 1 — is finished before step i starts anyway."""
+        pb = self.prepare_batch(images)
+        if getattr(pb, "views", None) is not None:
+            return pb
+        if not hasattr(self, "_view_stream"):
+            self._view_stream = torch.cuda.Stream(device=self.device)     # (stream priority either way: no effect, DESIGN §4.18)
+        vs = self._view_stream
+        vs.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(vs):
+            with self._timed("views"):
+                out = self.make_views(pb, want_all=True, want_image=False)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._last_view_event = ev
+        pb.views = (out, ev)
+        return pb
+
+    def take_views(self, pb):
+        """(views, TapSet of all 2B images) of a batch: the prefetched ones (the current stream waits for them and is recorded
+        as a user of their memory, which belongs to the view stream's pool) or, without a prefetch, made here and now"""
+        pre = getattr(pb, "views", None)
+        if pre is None:
+            ev = getattr(self, "_last_view_event", None)
+            if ev is not None:                      # the generator's plane buffers: one user at a time
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            with self._timed("views"):
+                return self.make_views(pb, want_all=True, want_image=False)
+        (out, ts_all), ev = pre
+        pb.views = None
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        pb.acquire()
+        for t in ts_all.taps:
+            t.record_stream(cur)
+        for _, maps, _ in out:
+            if maps is not None:
+                maps.record_stream(cur)
+        return out, ts_all
 
     def make_views(self, images, want_all=False, want_image=True):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->

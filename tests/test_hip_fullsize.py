@@ -530,6 +530,32 @@ def test_bench_step_properties(gpu, bench_state, nproto):
         assert rel(a_, b_) < 1e-4
 
 
+@pytest.mark.parametrize("nproto", [8, 5000])
+def test_prefetched_views_equal_inline_views_at_the_bench_batch(gpu, bench_state, nproto):
+    """bench.py's pipeline at its own shape: the views of the NEXT batch are made on the view stream while the step of the
+    current one runs (two full-size generator passes and a training step in flight together).  Three pipelined steps against
+    the same three steps on one stream from the same state and draws: every loss and the final gradients agree to what the
+    float atomics allow — i.e. nothing one stream reads is overwritten by the other (plane buffers, scratch arenas, taps)."""
+    g, ml, make = bench_state
+    batch = 16 if nproto == 8 else 4
+    res = []
+    for overlap in (True, False):
+        sw = make(nproto, batch=batch)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        stage = sw.prefetch_views if overlap else sw.prepare_batch
+        losses = []
+        nxt = stage(sw.draw_batch(batch))
+        for i in range(3):
+            cur = nxt
+            nxt = stage(sw.draw_batch(batch)) if i < 2 else None
+            losses.append(sw.train_step(cur))
+        res.append((torch.cat(losses).cpu().numpy(), [x.clone() for x in sw._grads]))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5)
+    for a_, b_ in zip(res[0][1], res[1][1]):
+        assert rel(a_, b_) < 1e-4
+
+
 @pytest.mark.parametrize("scope,nproto", [("global", 5000), ("image", 5000), ("global", 4000), ("global", 8000), ("image", 8000)])
 def test_table_sinkhorn_step_at_bench_patches(gpu, bench_state, scope, nproto):
     """The reference's own prototype counts with the bench's 5 patches of 20 000 samples (4 images per step here): scores and
@@ -674,6 +700,9 @@ def test_bench_cli_contract_one_json_line(gpu):
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     assert 0.0 < r["step_frac"] < 1.0 and r["step_tflop"] > 0                  # the whole step against the same peak
+    # the timed region runs the next batch's views beside the step: the kernel ALONE is timed on one stream right after it
+    ex = r["exclusive"]
+    assert r["concurrent_streams"] == 2 and abs(ex["frac"] - ex["achieved"] / ex["peak"]) < 1e-9 and r["frac"] <= ex["frac"] < 1.0
     h = r["hbm"]                                                                # the largest HBM-bound pass
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and 0.0 < h["frac"] < 1.0
     c = d["cpu_baseline"]

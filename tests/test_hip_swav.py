@@ -553,6 +553,39 @@ def test_host_running_ahead_keeps_batches_intact(gpu, tmp_path):
     np.testing.assert_allclose(out[0], out[1], rtol=2e-3)
 
 
+def test_views_prefetched_on_their_own_stream_keep_the_trajectory(gpu, tmp_path):
+    """The views of batch i + 1 queued on the view stream BEFORE step i (ViewMixin.prefetch_views — what pretrain() and
+    bench.py do): 60 steps without a host sync, the host running ahead, taps / maps / picks crossing from the view stream's
+    memory pool to the step's stream.  Same draws, same arithmetic: the losses equal the one-stream run's, step by step; so
+    do the trained parameters."""
+    d = load_golden("gv10_pretrain")
+    g = mini_gen(golden_sd(d), gpu)
+    ml = g.mean_latent(64)
+    out, par = [], []
+    for overlap in (True, False):
+        sw = make_swav(g, gpu, tmp_path, pick_source="device", batch_size=4, sinkhorn_scope="global")
+        sw.mean_latent = ml
+        torch.manual_seed(78)
+        np.random.seed(78)
+        sw.build_heads()
+        losses = []
+        stage = sw.prefetch_views if overlap else sw.prepare_batch
+        nxt = stage(sw.draw_batch(4))
+        for i in range(60):
+            cur = nxt
+            nxt = stage(sw.draw_batch(4)) if i < 59 else None
+            if overlap:
+                assert cur.views is not None
+            losses.append(sw.train_step(cur))
+            assert cur.views is None                      # taken (or never made)
+        out.append(torch.cat(losses).cpu().numpy())
+        par.append([p.clone() for p in sw._params()])
+    assert np.isfinite(out[0]).all()
+    np.testing.assert_allclose(out[0], out[1], rtol=2e-3)
+    for a_, b_ in zip(*par):
+        assert rel(a_, b_) < 1e-3
+
+
 def test_no_cpu_fallback(tmp_path):
     from ganecdotes_amd.generator import Generator
     g = Generator(32, 16, 2, channels=MINI)
