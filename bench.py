@@ -451,6 +451,9 @@ def main():
     ap.add_argument("--ds-table", default="auto", choices=["auto", "on", "off"],
                     help="many prototypes: d(scores) summed per pixel before the backward GEMMs (DESIGN 4.15); auto = when "
                          "the patches draw more samples than the image has pixels")
+    ap.add_argument("--sinkhorn-table", default="auto", choices=["auto", "on", "off"],
+                    help="many prototypes: the table Sinkhorn (rows grouped by membership, DESIGN 4.16) or — off — the per-problem "
+                         "sweeps on pixel-ordered tables (round 3's form); the A/B of the two table orderings")
     ap.add_argument("--reference-faithful", default="auto", choices=["auto", "on", "off"],
                     help="also time the reference's own nprototypes = 5000 (hfc_with_swav_ffhq_config.py:52) for a few steps and "
                          "nest the result in the JSON line; auto = on one GPU with the default 8 prototypes only")
@@ -527,6 +530,8 @@ def main():
             wl["sinkhorn_args"]["eps"] = eps
         if args.ds_table != "auto":
             wl["swav_args"]["ds_table"] = args.ds_table == "on"
+        if args.sinkhorn_table != "auto":
+            wl["swav_args"]["sinkhorn_table"] = args.sinkhorn_table == "on"
         sw = SwAVClustering(model=g if gen is None else gen, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
         torch.manual_seed(42 + rank)
         np.random.seed(42 + rank)
