@@ -22,6 +22,7 @@ c_sz = ctypes.c_size_t
 SIGNATURES = {
     "gx_head_pad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "gx_head_act_mask": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "gx_head_tap_sum": (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "gx_head_act_mask_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "gx_head_softmax_ce": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gx_head_adam": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p]),

@@ -44,6 +44,30 @@ __global__ void hd_act_mask_kernel(float* __restrict__ y, long R, int C, int Hp,
     }
 }
 
+// A 3x3 (dilated) conv with FEW output channels as ONE product and a tap sum: y9[r][t C + c] = sum_ci x[r][ci] W[t][c][ci] is a
+// single GEMM over the un-shifted rows with the nine taps stacked along N (9 C <= 128 columns: one N tile instead of nine
+// launches that each fill 12 of a tile's 128 columns), and   y[r][c] = interior(r) ? act(bias[c] + sum_t y9[r + shift_t][t C + c]) : 0.
+// Taps are added in the order the nine accumulating GEMMs added them: (acc_0 + bias) + acc_1 + ... — same values.
+__global__ void hd_tap_sum_kernel(const float* __restrict__ y9, long ld9, long R, int C, int Hp, int Wp, int P, int dil,
+                                  const float* __restrict__ bias, int act, float* __restrict__ y) {
+    const long total = R * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float v = 0.f;
+        if (hd_interior(r, Hp, Wp, P)) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const long sh = (long)((t / 3) - 1) * dil * Wp + ((t % 3) - 1) * dil;
+                const float a = y9[(r + sh) * ld9 + t * C + c];
+                v = t == 0 ? a + (bias ? bias[c] : 0.f) : v + a;
+            }
+            if (act) v = v > 0.f ? v : 0.2f * v;
+        }
+        y[i] = v;
+    }
+}
+
 // dy[r][c] = interior(r) ? dy[r][c] * (act ? lrelu'(y[r][c]) : 1) : 0
 __global__ void hd_act_mask_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long R, int C, int Hp, int Wp,
                                        int P, int act) {
@@ -159,6 +183,15 @@ int gx_head_act_mask(float* y, int B, int H, int W, int C, int P, int act, void*
     const long R = (long)B * (H + 2 * P) * (W + 2 * P);
     hipLaunchKernelGGL(hd_act_mask_kernel, dim3(hd_blocks(R * C)), dim3(256), 0, (hipStream_t)stream, y, R, C, H + 2 * P,
                        W + 2 * P, P, act);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+int gx_head_tap_sum(const float* y9, long ld9, int B, int H, int W, int C, int P, int dil, const float* bias, int act, float* y,
+                    void* stream) {
+    if (!y9 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || P < 0 || dil < 1 || dil > P || ld9 < 9L * C) return GX_ERR_BAD_ARG;
+    const long R = (long)B * (H + 2 * P) * (W + 2 * P);
+    hipLaunchKernelGGL(hd_tap_sum_kernel, dim3(hd_blocks(R * C)), dim3(256), 0, (hipStream_t)stream, y9, ld9, R, C, H + 2 * P,
+                       W + 2 * P, P, dil, bias, act, y);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -53,6 +53,7 @@ class OneShotHead:
         self.P = max(p[2] for p in self.plan)
         self.load_module(OneShotSegmentor(in_ch, n_class, size))          # nn.Conv2d's default init
         self._step = 0
+        self.stacked_taps = True       # layers with 9 * Cout <= 128: one stacked-tap GEMM + gx_head_tap_sum (False: nine GEMMs; A/B, tests)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd):
@@ -131,6 +132,16 @@ class OneShotHead:
         acts, x = [], xst
         for i, (cin, cout, d, act, ntap) in enumerate(self.plan):
             yst, y = self._buf(rows, cout)
+            if ntap == 9 and 9 * cout <= 128 and self.stacked_taps:
+                # few output channels (the 'XXS' head: 512 -> 12): nine GEMMs would each fill 12 of a tile's 128 columns.  ONE
+                # GEMM over the un-shifted rows with the taps stacked along N (108 columns), then the tap sum + bias +
+                # activation + border mask in one pass (gx_head_tap_sum): the same sums in the same order
+                y9 = ops.gemm(x, self.W[i].reshape(9 * cout, cin), False, True)
+                _lib.check(lib().gx_head_tap_sum(_p(y9[g:]), y9.stride(0), b, h, w, cout, self.P, d, _p(self.b[i]), int(act),
+                                                 _p(y), _stream()), "gx_head_tap_sum")
+                acts.append((yst, y))
+                x = yst
+                continue
             for tap in range(ntap):
                 sh = self._shift(tap, d, wp, ntap)
                 ops.gemm(x[g + lo + sh:g + hi + sh], self.W[i][tap], False, True, out=yst[g + lo:g + hi],

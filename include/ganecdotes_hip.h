@@ -42,6 +42,11 @@ extern "C" {
  * gradient (softmax_ce workspace: 1024 floats), torch.optim.Adam, argmax, confusion matrix [C][C]. */
 int gx_head_pad(const float* in, int B, int H, int W, int C, int P, float* out, void* stream);
 int gx_head_act_mask(float* y, int B, int H, int W, int C, int P, int act, void* stream);
+/* a (dilated) 3x3 conv with few output channels (9 C <= 128) as one GEMM over the un-shifted padded rows with the nine taps
+ * stacked along N (y9 [rows][ld9], tap t in columns t C .. t C + C - 1) and this tap sum:
+ * y[r][c] = interior(r) ? act(bias[c] + sum_t y9[r + shift_t][t C + c]) : 0  (the conv + gx_head_act_mask in one pass) */
+int gx_head_tap_sum(const float* y9, long ld9, int B, int H, int W, int C, int P, int dil, const float* bias, int act, float* y,
+                    void* stream);
 int gx_head_act_mask_bwd(float* dy, const float* y, int B, int H, int W, int C, int P, int act, void* stream);
 int gx_head_softmax_ce(const float* logits, const long long* labels, int B, int H, int W, int C, int P, float* dlogits,
                        float* loss_out, float* workspace, size_t workspace_bytes, void* stream);

@@ -47,6 +47,24 @@ def test_head_finetune_golden_gv13(gpu, size):
     assert rel(m(T(d[f"{size}_feats"])), head.logits(feats)) < 1e-5
 
 
+def test_head_stacked_taps_equal_nine_gemms(gpu):
+    """A 3x3 head layer with few output channels (9 Cout <= 128: the ffhq 'XXS' head, 512 -> 12) runs as ONE GEMM over the
+    un-shifted padded rows with the nine taps stacked along N plus gx_head_tap_sum (tap sum + bias + LeakyReLU + border mask);
+    the nine accumulating GEMMs it replaces added the same per-tap dot products in the same order: logits bitwise equal, at the
+    evaluate shape (256 x 256 x 512, 2 images) and with a dilated, activated first layer ('XS')."""
+    from ganecdotes_amd.oneshot import OneShotHead
+    torch.manual_seed(3)
+    for size, ncls, hw, cin in (("XXS", 12, 256, 512), ("XS", 12, 64, 64)):
+        head = OneShotHead(cin, ncls, size)
+        feats = torch.randn(2, hw, hw, cin, device="cuda")
+        a = head.logits(feats).clone()
+        pa = head.predict(feats)
+        head.stacked_taps = False
+        b = head.logits(feats)
+        assert torch.equal(a, b), float((a - b).abs().max())
+        assert torch.equal(pa, head.predict(feats))
+
+
 def test_confusion_and_iou_metrics(gpu):
     from oracle import oneshot_ref as O
     from ganecdotes_amd.oneshot import confusion, iou_from_confusion
