@@ -466,17 +466,19 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
 // are three MFMAs (16 cycles each: the same pipe time as six 32x32x16 products per 32 x 32 outputs).  Lane l holds row /
 // column l & 15 and the 8 k of group l >> 4: groups 0, 1 come from the first plane, 2, 3 from the second.  The LDS image
 // is half-major here ([2 halves][128 rows][16 B] per plane): any 16 rows of a fragment read fall in 16 distinct slots.
+template <int ROWS = 128>          // rows of the (half-major) image: [2 halves][ROWS][16 B] per plane
 __device__ __forceinline__ bf16x8 xp16_frag(const char* S, int px, int py, int row, int lane) {
     const int kq = lane >> 4;
-    return *reinterpret_cast<const bf16x8*>(S + (kq < 2 ? px : py) * 4096 + (kq & 1) * 2048 + row * 16);
+    return *reinterpret_cast<const bf16x8*>(S + (kq < 2 ? px : py) * (ROWS * 32) + (kq & 1) * (ROWS * 16) + row * 16);
 }
+template <int AROWS = 128>         // 256: the tall tile of narrow layers (four waves stacked along M, all on the same 64 columns)
 __device__ __forceinline__ void xp16_mfma_ktile(const char* As, const char* Bs, f32x4 (&acc)[4][4], int wr, int wc, int lane) {
     const int ar = wr * 64 + (lane & 15), br = wc * 64 + (lane & 15);
     bf16x8 ahl[4], ahm[4], blh[4], bmh[4], bhm[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ahl[i] = xp16_frag(As, 0, 2, ar + 16 * i, lane); blh[i] = xp16_frag(Bs, 2, 0, br + 16 * i, lane); }
+    for (int i = 0; i < 4; ++i) { ahl[i] = xp16_frag<AROWS>(As, 0, 2, ar + 16 * i, lane); blh[i] = xp16_frag(Bs, 2, 0, br + 16 * i, lane); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ahm[i] = xp16_frag(As, 0, 1, ar + 16 * i, lane); bmh[i] = xp16_frag(Bs, 1, 0, br + 16 * i, lane); }
+    for (int i = 0; i < 4; ++i) { ahm[i] = xp16_frag<AROWS>(As, 0, 1, ar + 16 * i, lane); bmh[i] = xp16_frag(Bs, 1, 0, br + 16 * i, lane); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) bhm[i] = xp16_frag(Bs, 0, 1, br + 16 * i, lane);
 #pragma unroll
@@ -496,9 +498,16 @@ __device__ __forceinline__ void xp16_mfma_ktile(const char* As, const char* Bs, 
             acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[rb], bhm[cb], acc[rb][cb], 0, 0, 0);
 }
 
-template <int NT, bool M16, class ACC>
+// TALL (narrow layers, Cout <= 64: the 512^2 layers of a 512^2 generator): the workgroup's tile is 256 pixels x 64 channels —
+// four waves stacked along M — instead of 128 x 128 with the two right-hand waves multiplying padding.  The A image of a
+// k-tile then has 256 rows (two DMA instructions per plane and thread: rows tid & 127 and + 128), the B image is the same
+// 128-row weight block (its upper 64 rows are the Cout padding, never read).
+template <int NT, bool M16, bool TALL, class ACC>
 __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, ACC& acc,
-                                                 unsigned pixbyte, int n0, int tid, int wr, int wc, int lane) {
+                                                 unsigned pixbyte, unsigned pixbyte2, int n0, int tid, int wr, int wc, int lane) {
+    constexpr int APL = TALL ? 8192 : 4096;                          // bytes of one A plane of a k-tile
+    constexpr int BOFF = 3 * APL;                                    // the B planes follow the A planes
+    constexpr int STAGE = BOFF + 12288;
     const int ncc = g.wtp_ncc;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(reinterpret_cast<const float*>(g.wtp), g.wtp_bytes);
@@ -529,7 +538,13 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             const char* base = xp + (long)(cc * 3 + p) * (long)g.xp_plane_bytes;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)g.xp_plane_bytes, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)va, 0, 0, 0);
+            if constexpr (TALL) {
+                char* d = dst + p * APL + (wid >> 1) * 4096 + (wid & 1) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)d, 16, (int)va, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(d + 2048), 16, (int)(pixbyte2 + (unsigned)to), 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)va, 0, 0, 0);
+            }
         }
         const unsigned blk = wb + (unsigned)cc * 3u * 4096u;
 #ifdef XP_ABL_B2
@@ -537,7 +552,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
 #endif
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + 12288 + p * 4096 + wid * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + BOFF + p * 4096 + wid * 1024), 16,
                                                      (int)wlane, (int)(blk + p * 4096u), 0, 0);
     };
 
@@ -554,22 +569,24 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             // reading the other stage (its MFMAs of tile k-1 were issued before it arrived here)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            char* As = lds + buf * XP_STAGE_BYTES;
+            char* As = lds + buf * STAGE;
             const bool wrap = (tap + 1 == NT);
             if (!(wrap && last_cc))
                 issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
-                      lds + (buf ^ 1) * XP_STAGE_BYTES, NT < 9 || wrap || tap < 1 || (tap + 1) % 3 == 0);
-            if constexpr (M16) xp16_mfma_ktile(As, As + 12288, acc, wr, wc, lane);
-            else x6_mfma_ktile<true, true>(As, As + 12288, acc, wr, wc, lane);
+                      lds + (buf ^ 1) * STAGE, NT < 9 || wrap || tap < 1 || (tap + 1) % 3 == 0);
+            if constexpr (M16) xp16_mfma_ktile<TALL ? 256 : 128>(As, As + BOFF, acc, wr, wc, lane);
+            else x6_mfma_ktile<true, true>(As, As + BOFF, acc, wr, wc, lane);
             buf ^= 1;
         }
     }
 }
 
-template <bool M16>
+template <bool M16, bool TALL = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g) {
-    __shared__ __attribute__((aligned(16))) char lds_raw[2 * XP_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    static_assert(!TALL || M16, "the tall tile exists in the 16x16x32 product form only");
+    constexpr int TBM = TALL ? 2 * BM : BM;                          // pixels per tile
+    __shared__ __attribute__((aligned(16))) char lds_raw[2 * (XP_STAGE_BYTES + (TALL ? 12288 : 0))];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = TALL ? wid : (wid >> 1), wc = TALL ? 0 : (wid & 1);
     int si = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -577,19 +594,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
     const ConvSub& sb = g.sub[si];
     const int local = xcd_remap(blockIdx.x - sb.tile_base, sb.tiles_m * g.tiles_n);
     const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * BN;
     const unsigned ohw = (unsigned)sb.OH * (unsigned)sb.OW;
     const unsigned Mtot = (unsigned)g.B * ohw;
     // this thread DMAs bytes [16 tid, 16 tid + 16) of every plane of the A image: row R = tid >> 1, 16-B slot tid & 1,
     // which under the half-swap swizzle holds channel half (tid & 1) ^ ((R >> 3) & 1) of the row's 16 channels
-    // (half-major image of the 16x16x32 form: row tid & 127, channel half tid >> 7, no swizzle)
+    // (half-major image of the 16x16x32 form: row tid & 127, channel half tid >> 7, no swizzle; tall tile: also row + 128)
     const int R = M16 ? (tid & 127) : (tid >> 1);
-    unsigned m = (unsigned)m0 + (unsigned)R;
-    if (m >= Mtot) m = Mtot - 1;                                     // tail rows: any valid pixel (outputs are dropped)
-    const unsigned b = m / ohw, rem = m - b * ohw;
-    const unsigned oy = rem / (unsigned)sb.OW, ox = rem - oy * (unsigned)sb.OW;
-    const unsigned pixpad = (b * (unsigned)(g.IH + 2) + oy + 1u) * (unsigned)(g.IW + 2) + ox + 1u;
-    const unsigned pixbyte = pixpad * 32u + (unsigned)((M16 ? (tid >> 7) : ((tid & 1) ^ ((R >> 3) & 1))) << 4);
+    auto pixbyte_of = [&](unsigned m) -> unsigned {
+        if (m >= Mtot) m = Mtot - 1;                                 // tail rows: any valid pixel (outputs are dropped)
+        const unsigned b = m / ohw, rem = m - b * ohw;
+        const unsigned oy = rem / (unsigned)sb.OW, ox = rem - oy * (unsigned)sb.OW;
+        const unsigned pixpad = (b * (unsigned)(g.IH + 2) + oy + 1u) * (unsigned)(g.IW + 2) + ox + 1u;
+        return pixpad * 32u + (unsigned)((M16 ? (tid >> 7) : ((tid & 1) ^ ((R >> 3) & 1))) << 4);
+    };
+    const unsigned pixbyte = pixbyte_of((unsigned)m0 + (unsigned)R);
+    const unsigned pixbyte2 = TALL ? pixbyte_of((unsigned)m0 + 128u + (unsigned)R) : 0u;
 
     if constexpr (M16) {
         f32x4 acc[4][4];
@@ -598,10 +618,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
         switch (sb.ntaps) {
-            case 9: conv_mainloop_xp<9, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            case 4: conv_mainloop_xp<4, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            case 2: conv_mainloop_xp<2, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            default: conv_mainloop_xp<1, true>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 9: conv_mainloop_xp<9, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
         }
         __syncthreads();                                             // every wave has read its last fragments
         conv_epilogue_lds(g, sb, StageAcc16{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
@@ -609,10 +629,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
         f32x16 acc[2][2];
         zero_acc(acc);
         switch (sb.ntaps) {
-            case 9: conv_mainloop_xp<9, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            case 4: conv_mainloop_xp<4, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            case 2: conv_mainloop_xp<2, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
-            default: conv_mainloop_xp<1, false>(g, sb, lds_raw, acc, pixbyte, n0, tid, wr, wc, lane); break;
+            case 9: conv_mainloop_xp<9, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
         }
         if ((g.Cout & 3) == 0) {                                     // epilogue through LDS (+ the next layer's planes)
             __syncthreads();                                         // every wave has read its last fragments
@@ -1319,9 +1339,11 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
     g.tiles_n = gx_cdiv(g.Cout, BN);
     const bool x6 = gx_get_gemm_mode() == 1;
     int base = 0, min_kt = 1 << 30;
+    // narrow layers on the x-planes path: 256-pixel x 64-channel tiles (modconv_xp_kernel<true, true>)
+    const bool tall = g.xp && x6 && (g.Cout & 3) == 0 && g.Cout <= 64;
     for (int i = 0; i < g.nsub; ++i) {
         g.sub[i].tile_base = base;
-        g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, BM);
+        g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, tall ? 2 * BM : BM);
         base += g.sub[i].tiles_m * g.tiles_n;
         const int kt = gx_cdiv(g.Cin, BK);                     // split-K granularity = channel chunks (>= this many in either engine)
         min_kt = kt < min_kt ? kt : min_kt;
@@ -1343,7 +1365,8 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         // MFMA shape of the six products: 16x16x32 (plane pairs along K) where Cout allows its epilogue, else 32x32x16.  Equal
         // pipe cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
         // 243-246 -> 256-260 TFLOP/s, same-process A/B (round 2, tools/bench_conv_xp.py)
-        if ((g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
+        if (tall) hipLaunchKernelGGL((modconv_xp_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        else if ((g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
         else hipLaunchKernelGGL(modconv_xp_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
         GX_CHECK_LAUNCH();
         return GX_OK;

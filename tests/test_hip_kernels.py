@@ -1499,7 +1499,10 @@ def test_modconv_xp_golden_gv2_gv3(ops):
 
 
 @pytest.mark.parametrize("b,h,cin,cout,up", [(3, 16, 64, 160, False), (2, 24, 40, 128, True), (5, 8, 512, 512, False),
-                                             (1, 64, 128, 96, True), (2, 33, 20, 72, False)])
+                                             (1, 64, 128, 96, True), (2, 33, 20, 72, False),
+                                             # Cout <= 64: the tall 256-pixel x 64-channel tile (the 512^2 layers of a 512^2 generator)
+                                             (2, 48, 128, 64, False), (2, 40, 128, 64, True), (3, 21, 64, 32, False),
+                                             (1, 131, 64, 64, False), (1, 9, 24, 16, True)])
 def test_modconv_xp_equals_in_kernel_split(ops, b, h, cin, cout, up):
     """random shapes (odd sizes, several images per tile, Cin not a multiple of 16, Cout tails, all four parity
     classes of the transposed conv): the x-planes path computes the bf16x6 sums of the in-kernel-split path — the same
