@@ -250,12 +250,15 @@ __device__ __forceinline__ float skt_reduce4(f32x4 v, int lane) {
 }
 static_assert(SKT_R == 4, "a wave's partials of a group are one float4");
 
-template <int P, bool SHIFT, int NC = 2>
-__global__ __launch_bounds__(NC == 2 ? SKT_MAXT : SKT_T4) void sk_table_sweep_kernel(SkTabArgs a) {
+template <int P, bool SHIFT, int NC = 2, int SMALL = 0>     // SMALL: 0, or the (small) workgroup size 64 / 256
+__global__ __launch_bounds__(SMALL ? 256 : (NC == 2 ? SKT_MAXT : SKT_T4)) void sk_table_sweep_kernel(SkTabArgs a) {
     // NC = 4, the wide form (6144 < K <= 8192: the generic configuration's 8000 prototypes): 16 columns per thread, 512 threads,
-    // two rows per group (the reductions still carry four values, two of them idle), the scaling vectors K apart in LDS
+    // two rows per group (the reductions still carry four values, two of them idle), the scaling vectors K apart in LDS.
+    // SMALL (K <= 2048: workgroups of 256 threads, K <= 512: of ONE wave): the scaling vectors take P x 8 T floats, not the
+    // 128 KB of the general form, so twelve waves share a CU whatever the workgroup size — with one workgroup per CU a sweep
+    // cost 3.6 ms however short the rows were (the 64 < K < 2000 cliff of round 4).
     constexpr int R = NC == 2 ? SKT_R : 2;
-    __shared__ __attribute__((aligned(16))) float la2[NC == 2 ? SKT_LA_CAP : SKT_LA_CAP4];      // [P][8T] (wide: [P][K]), log2 units, -inf past K
+    __shared__ __attribute__((aligned(16))) float la2[SMALL ? P * 8 * SMALL : (NC == 2 ? SKT_LA_CAP : SKT_LA_CAP4)];      // [P][8T] (wide: [P][K]), log2 units, -inf past K
     // the waves' partials, [wave][row]; the sums alternate between two buffers from one patch block to the next (a shifted
     // block has ONE barrier: a fast wave's next sums must not land in the slots a slow wave is still reading)
     __shared__ __attribute__((aligned(16))) float redm[16][SKT_R], reds[2][16][SKT_R];
@@ -474,11 +477,14 @@ static inline int skt_nc(int npatch, int K) {
 }
 static inline int skt_threads(int K, int nc = 2) {
     int t = 64 * ((K + 256 * nc - 1) / (256 * nc));
+    if (nc == 2 && t <= 256) return t == 192 ? 256 : t;          // the small forms: 64 / 128 / 256 threads = up to 512 / 1024 / 2048 columns
     return t < 256 ? 256 : t;
 }
-static inline int skt_blocks(long npix, int ngrp) {             // workgroups per view and image: one per CU in all (LDS)
+// K <= 2048 in the 8-columns-per-thread form: 256-thread workgroups whose scaling vectors leave room for three per CU
+static inline int skt_small(int npatch, int K) { return (skt_nc(npatch, K) == 2 && skt_threads(K) <= 256) ? skt_threads(K) : 0; }
+static inline int skt_blocks(long npix, int ngrp, int small) {   // workgroups per view and image: one per CU in all (LDS); small: 12 waves per CU
     const long groups = (npix / ngrp + SKT_R - 1) / SKT_R;
-    const long nb = (256 + ngrp - 1) / ngrp;
+    const long nb = ((small ? 128 * 768 / small : 256) + ngrp - 1) / ngrp;
     return (int)(groups < nb ? (groups < 1 ? 1 : groups) : nb);
 }
 
@@ -505,7 +511,7 @@ int gx_sinkhorn_table_ok(int npatch, int K) {
 // workspace: partial sums and maxima [2 P][nb][K] each | row weights [2][P][npix] | log2-sum-exp of the rows [2][P][npix]
 // (the last part carries a sweep's row normalisers to the next one: the calls of one solve share their workspace)
 static inline size_t skt_parts_floats(int npatch, long npix, int K, int ngrp) {
-    return (size_t)2 * 2 * npatch * ngrp * skt_blocks(npix, ngrp) * K;
+    return (size_t)2 * 2 * npatch * ngrp * skt_blocks(npix, ngrp, skt_small(npatch, K)) * K;
 }
 size_t gx_sinkhorn_table_workspace_bytes(int npatch, long npix, int K, int ngroups) {
     if (ngroups < 1) ngroups = 1;
@@ -539,7 +545,7 @@ int gx_sinkhorn_table_first(const float* S0, const float* S1, long ld, int K, co
     if (!cmax || !u) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K, ngroups)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = skt_blocks(npix, ngroups), nprob = 2 * npatch * ngroups;
+    const int nb = skt_blocks(npix, ngroups, skt_small(npatch, K)), nprob = 2 * npatch * ngroups;
     SkTabArgs a{};
     a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live; a.seg = ngroups > 1 ? seg : nullptr; a.ngrp = ngroups;
     a.sc = SKT_LOG2E / eps; a.part = workspace; a.partm = workspace + (size_t)nprob * nb * K; a.nb = nb;
@@ -569,7 +575,7 @@ int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, co
     if (!la || !u || (c_all && rows <= 0) || (!c_all && !(c_uniform > 0.f))) return GX_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gx_sinkhorn_table_workspace_bytes(npatch, npix, K, ngroups)) return GX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = skt_blocks(npix, ngroups), nprob = 2 * npatch * ngroups;
+    const int nb = skt_blocks(npix, ngroups, skt_small(npatch, K)), nprob = 2 * npatch * ngroups;
     SkTabArgs a{};
     a.S[0] = S0; a.S[1] = S1; a.ld = ld; a.K = K; a.npix = npix; a.live = live; a.seg = ngroups > 1 ? seg : nullptr; a.ngrp = ngroups;
     a.sc = SKT_LOG2E / eps; a.la = la; a.stats = stats; a.part = workspace; a.nb = nb;
@@ -580,14 +586,27 @@ int gx_sinkhorn_table_sweep(const float* S0, const float* S1, long ld, int K, co
     GX_CHECK_LAUNCH();
     // the exact form for the problems the update does not vouch for (all of them without stats), the shifted form for the others
     const bool wide = skt_nc(npatch, K) == 4;
-    if (!wide) {
+    const int small = skt_small(npatch, K);
+    if (small == 64) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false, 2, 64>), dim3(nb, 2, ngroups), dim3(64), 0, st, a));
+    } else if (small == 128) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false, 2, 128>), dim3(nb, 2, ngroups), dim3(128), 0, st, a));
+    } else if (small) {
+        SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false, 2, 256>), dim3(nb, 2, ngroups), dim3(256), 0, st, a));
+    } else if (!wide) {
         SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
     } else {
         SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, false, 4>), dim3(nb, 2, ngroups), dim3(skt_threads(K, 4)), 0, st, a));
     }
     GX_CHECK_LAUNCH();
     if (stats) {
-        if (!wide) {
+        if (small == 64) {
+            SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true, 2, 64>), dim3(nb, 2, ngroups), dim3(64), 0, st, a));
+        } else if (small == 128) {
+            SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true, 2, 128>), dim3(nb, 2, ngroups), dim3(128), 0, st, a));
+        } else if (small) {
+            SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true, 2, 256>), dim3(nb, 2, ngroups), dim3(256), 0, st, a));
+        } else if (!wide) {
             SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true>), dim3(nb, 2, ngroups), dim3(skt_threads(K)), 0, st, a));
         } else {
             SKT_DISPATCH(npatch, hipLaunchKernelGGL((sk_table_sweep_kernel<P, true, 4>), dim3(nb, 2, ngroups), dim3(skt_threads(K, 4)), 0, st, a));

@@ -1095,6 +1095,9 @@ def test_sinkhorn_problems_of_one_table_side_by_side(ops, k, rows, nprob):
 @pytest.mark.parametrize("k,npix,rows,P,live_n,pdf", [(200, 1500, 600, 5, 1300, False), (5000, 700, 333, 3, None, False),
                                                      (132, 9000, 4097, 2, 8000, True), (4000, 2600, 900, 5, 2401, True),
                                                      (6144, 300, 120, 5, 290, False), (1024, 500, 77, 1, None, False),
+                                                     # the small forms (round 5): 64 / 128 / 256-thread workgroups up to 512 / 1024 / 2048 columns
+                                                     (512, 900, 400, 5, 850, False), (700, 1100, 500, 4, None, True), (1600, 800, 300, 5, 700, True),
+                                                     (2048, 600, 250, 3, 580, False),
                                                      # the wide form (16 columns per thread): the generic configuration's 8000 prototypes
                                                      (8000, 403, 150, 5, 390, False), (6400, 350, 100, 3, None, True),
                                                      (8192, 200, 64, 4, 190, False)])
@@ -1197,7 +1200,7 @@ def test_sinkhorn_table_all_patches_in_one_pass(ops, k, npix, rows, P, live_n, p
 
 
 @pytest.mark.parametrize("k,B,nl,N,P,pdf", [(200, 3, 500, 200, 5, False), (5000, 2, 150, 64, 3, True), (132, 5, 1000, 999, 2, False),
-                                            (8000, 2, 120, 50, 5, False)])
+                                            (8000, 2, 120, 50, 5, False), (700, 3, 300, 120, 4, True), (1600, 2, 200, 90, 5, False)])
 def test_sinkhorn_table_per_image_problems(ops, k, B, nl, N, P, pdf):
     """gx_sinkhorn_table with one problem per image too (the per-image Sinkhorn scope: the reference's batch-1 semantics): image
     b's live rows are the run [seg[b], seg[b + 1]) of the table, a workgroup stays inside one image; against every problem
