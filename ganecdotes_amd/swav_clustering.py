@@ -465,12 +465,11 @@ class SwAVClustering(ViewMixin):
         # S7: prototype rows to unit norm (bias untouched)
         ops.row_l2_normalize_(c.Wc, want_rnorm=False)
 
-        c.views, ts_all = self.take_views(pb)            # prefetched on the view stream (prefetch_views) or made here
+        c.views, ts_all, imgs = self.take_views(pb)      # prefetched on the view stream (prefetch_views) or made here
         c.hw = hw = c.views[0][0].size
         if c.N is None or c.N >= hw * hw:
             c.N = hw * hw
-        imgs = None
-        if self.sinkhorn_args['source_pdf'] == 'image':
+        if imgs is None and self.sinkhorn_args['source_pdf'] == 'image':
             imgs = [ops.norm_map(ts, c.hlen, maps) for ts, maps, _ in c.views]
 
         if self._bufs is None:

@@ -156,14 +156,19 @@ class ViewMixin(object):
         with torch.cuda.stream(vs):
             with self._timed("views"):
                 out = self.make_views(pb, want_all=True, want_image=False)
+            norms = None
+            if getattr(self, "sinkhorn_args", {}).get("source_pdf") == "image":
+                # the norm maps of the 'image' source pdf (swav_clustering.py:361-362) depend on the taps alone: an HBM-bound
+                # pass over every tap that belongs beside the step, not in front of it
+                norms = [ops.norm_map(ts, self._hlen, maps) for ts, maps, _ in out[0]]
             ev = torch.cuda.Event()
             ev.record()
         self._last_view_event = ev
-        pb.views = (out, ev)
+        pb.views = (out, ev, norms)
         return pb
 
     def take_views(self, pb):
-        """(views, TapSet of all 2B images) of a batch: the prefetched ones (the current stream waits for them and is recorded
+        """(views, TapSet of all 2B images, norm maps or None) of a batch: the prefetched ones (the current stream waits for them and is recorded
         as a user of their memory, which belongs to the view stream's pool) or, without a prefetch, made here and now"""
         pre = getattr(pb, "views", None)
         if pre is None:
@@ -171,8 +176,8 @@ class ViewMixin(object):
             if ev is not None:                      # the generator's plane buffers: one user at a time
                 torch.cuda.current_stream(self.device).wait_event(ev)
             with self._timed("views"):
-                return self.make_views(pb, want_all=True, want_image=False)
-        (out, ts_all), ev = pre
+                return (*self.make_views(pb, want_all=True, want_image=False), None)
+        (out, ts_all), ev, norms = pre
         pb.views = None
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
@@ -182,7 +187,9 @@ class ViewMixin(object):
         for _, maps, _ in out:
             if maps is not None:
                 maps.record_stream(cur)
-        return out, ts_all
+        for t in norms or ():
+            t.record_stream(cur)
+        return out, ts_all, norms
 
     def make_views(self, images, want_all=False, want_image=True):
         """Both views of a batch (list of ImageDraws or PreparedBatch) ->

@@ -701,8 +701,9 @@ def test_bench_cli_contract_one_json_line(gpu):
     assert r["bound"] in ("mfma", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     assert 0.0 < r["step_frac"] < 1.0 and r["step_tflop"] > 0                  # the whole step against the same peak
     # the timed region runs the next batch's views beside the step: the kernel ALONE is timed on one stream right after it
-    ex = r["exclusive"]
-    assert r["concurrent_streams"] == 2 and abs(ex["frac"] - ex["achieved"] / ex["peak"]) < 1e-9 and r["frac"] <= ex["frac"] < 1.0
+    tr = r["timed_region"]                       # kernel figures: one-stream steps (agree with rocprofv3); the two-stream brackets beside them
+    assert r["concurrent_streams"] == 2 and tr["frac"] <= r["frac"] < 1.0 and r["one_stream_ms_per_step"] > 0
+    assert 0.0 < r["one_stream_step_frac"] < 1.0
     h = r["hbm"]                                                                # the largest HBM-bound pass
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and 0.0 < h["frac"] < 1.0
     c = d["cpu_baseline"]
