@@ -553,6 +553,11 @@ class SwAVClustering(ViewMixin):
         for p, g, buf in zip((c.Wp, c.Wc, c.bc, *c.extra), self._grads, self._bufs):
             ops.larc_sgd_(p, g, buf, lr, mom, sa['trust_coeff'], first_step=(self._step_no == 0), use_larc=sa.get('use_larc', True))
         self._step_no += 1
+        if getattr(self, "_prefetched_step", False):     # a pipelined step: its end bounds how far prefetch_views may run ahead
+            self._prefetched_step = False
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_done.append(ev)
         return (c.loss, c.aux) if c.return_aux else c.loss
 
     # --- route 'lowrank': K <= 16, pyramid mode, linear projection ---

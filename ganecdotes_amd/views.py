@@ -151,6 +151,12 @@ class ViewMixin(object):
             return pb
         if not hasattr(self, "_view_stream"):
             self._view_stream = torch.cuda.Stream(device=self.device)     # (stream priority either way: no effect)
+        # Bounded lead.  The taps live in the VIEW stream's memory pool and are recorded on the step's stream, so a freed set
+        # returns to the pool only once the step that read it has run on the GPU: a host that queues many steps ahead (it can:
+        # a step is ~125 launches) would pin one 4 GB set of taps per step of lead.  Two steps of lead keep both streams fed.
+        done = getattr(self, "_step_done", None)
+        while done is not None and len(done) > 2:
+            done.popleft().synchronize()
         vs = self._view_stream
         vs.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(vs):
@@ -179,6 +185,10 @@ class ViewMixin(object):
                 return (*self.make_views(pb, want_all=True, want_image=False), None)
         (out, ts_all), ev, norms = pre
         pb.views = None
+        if not hasattr(self, "_step_done"):
+            import collections
+            self._step_done = collections.deque()
+        self._prefetched_step = True               # _step_epilogue marks the end of this step for prefetch_views' bounded lead
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
         pb.acquire()
