@@ -150,7 +150,9 @@ def test_ffhq256_table_sinkhorn_overlapping_patches_vs_oracle(gpu, nproto, patch
         assert int((cnt >= 2).sum()) > 0.3 * int((cnt >= 1).sum())
     loss = sw.train_step(images)
     rt = sw.last_route
-    assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table and rt.k_run == (nproto + 3) // 4 * 4, rt
+    assert rt.k_run == (nproto + 3) // 4 * 4, rt
+    if ops.get_gemm_mode() == 1:     # (the per-pixel tables need the weight-plane GEMMs of the default engine; GX_GEMM_MODE=0 runs per sample)
+        assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table, rt
     oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
                                              ops.rotflip_map(v.angle, v.flip, 256, 256, "cuda").cpu().long())
                                  for v in im.views], im.picks) for im in images]

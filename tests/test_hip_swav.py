@@ -335,7 +335,9 @@ def test_train_step_tables_at_the_real_eps_and_temperature_vs_oracle(gpu, tmp_pa
         images = [draw_image(16, 7, 3, 32 * 32, 3, transforms=True) for _ in range(batch)]
         loss = sw.train_step(images)
         rt = sw.last_route
-        assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table and rt.k_run == (nproto + 3) // 4 * 4, rt
+        assert rt.k_run == (nproto + 3) // 4 * 4, rt
+        if ops.get_gemm_mode() == 1:      # (GX_GEMM_MODE=0, the exact-fp32 engine, has no weight-plane GEMMs: it runs per sample)
+            assert rt.name == "tables" and rt.score_table and rt.sinkhorn_table, rt
         oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
                                                  ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
                                      for v in im.views], im.picks) for im in images]
@@ -368,7 +370,10 @@ def test_prototype_count_not_a_multiple_of_four_costs_what_the_next_multiple_doe
         images = [draw_image(16, 7, 3, 32 * 32, 3, transforms=True) for _ in range(2)]
         loss, aux = sw.train_step(images, return_aux=True)
         rt = sw.last_route
-        assert rt.name == name and rt.k_run == (nproto + 3) // 4 * 4 and rt.pad_ds
+        assert rt.k_run == (nproto + 3) // 4 * 4
+        from ganecdotes_amd import ops
+        if ops.get_gemm_mode() == 1:
+            assert rt.name == name and rt.pad_ds
         assert sw._grads[1].shape == (nproto, 16) and sw._grads[2].shape == (nproto,)
         assert aux["q_s"].shape[1] == nproto and aux["scores_s"].shape[1] == nproto
         # the padded columns took no mass: the real columns of every code row sum to 1
