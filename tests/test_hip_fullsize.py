@@ -714,7 +714,8 @@ def test_bench_cli_contract_one_json_line(gpu):
     assert rf["prototypes"] == 5000 and rf["unit"] == d["unit"] and rf["value"] > 0
     assert abs(rf["value"] - 16 * 1e3 / rf["ms_per_step"]) < 1e-3 * rf["value"]
     assert 0.0 < rf["roofline"]["mfma_frac"] < 1.0 and 0.0 < rf["roofline"]["hbm_frac"] < 1.0
-    assert "route=tables" in rf["route"] and "table Sinkhorn" in rf["route"]
+    x6 = os.environ.get("GX_GEMM_MODE", "1") != "0"          # (the exact-fp32 engine has no weight-plane GEMMs: many prototypes run per sample)
+    assert not x6 or ("route=tables" in rf["route"] and "table Sinkhorn" in rf["route"])
     rc = rf["cpu_baseline"]                                                     # ... with ITS CPU figure beside it (BASELINE.md par. 3)
     assert rc["kind"] == "port" and rc["value"] > 0 and "K=5000" in rc["sample"]
     assert "route=lowrank" in d["config"]["workload"]
@@ -728,7 +729,7 @@ def test_bench_cli_contract_one_json_line(gpu):
         nr = n["roofline"]
         assert nr["kernel"] and 0.0 < nr["frac"] < 1.0 and 0.0 < nr["step_frac"] < 1.0, key
     assert "source_pdf='image'" in d["cat_per_rank"]["workload"] and "route=lowrank" in d["cat_per_rank"]["workload"]
-    assert "route=tables" in d["car512_per_rank_k4000"]["workload"] and "512x512" in d["car512_per_rank"]["workload"]
+    assert (not x6 or "route=tables" in d["car512_per_rank_k4000"]["workload"]) and "512x512" in d["car512_per_rank"]["workload"]
     assert d["simclr"]["iterations_per_s"] > 0 and np.isfinite(d["simclr"]["loss"])
     d2 = run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert d2["n_gpus"] == 2 and d2["cpu_baseline"] is None and "reference_faithful" not in d2
