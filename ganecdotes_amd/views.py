@@ -151,20 +151,6 @@ class ViewMixin(object):
             return pb
         if not hasattr(self, "_view_stream"):
             self._view_stream = torch.cuda.Stream(device=self.device)     # (stream priority either way: no effect)
-            import os
-            ncu = int(os.environ.get("GX_LAB_VIEW_CUS", "0"))            # lab: the view stream on `ncu` of the chip's CUs (CU mask)
-            if ncu > 0:
-                import ctypes
-                hip = ctypes.CDLL("libamdhip64.so")
-                words = (ncu + 31) // 32
-                mask = (ctypes.c_uint32 * 8)(*[0] * 8)
-                for i in range(ncu):
-                    mask[i // 32] |= 1 << (i % 32)
-                st = ctypes.c_void_p()
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, mask)
-                if rc != 0:
-                    raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
-                self._view_stream = torch.cuda.ExternalStream(st.value, device=self.device)
         # Bounded lead.  The taps live in the VIEW stream's memory pool and are recorded on the step's stream, so a freed set
         # returns to the pool only once the step that read it has run on the GPU: a host that queues many steps ahead (it can:
         # a step is ~125 launches) would pin one 4 GB set of taps per step of lead.  Two steps of lead keep both streams fed.
