@@ -77,6 +77,31 @@ def _to_rgb_params(cin, style_dim, upsample, blur_kernel):
 CONV_XP = os.environ.get("GX_CONV_XP", "1") != "0"
 
 
+class _OneStreamAtATime:
+    """Guard of a module's persistent device buffers (the generator's x-plane buffers and derived-weight caches): they are
+    reused call after call, so two calls must not be in flight on two streams at once.  A call on another stream than the
+    previous one first waits for that call's end; calls on one stream are ordered anyway (no wait, no cost).  This is what lets
+    the views of the next batch run on their own stream (ViewMixin.prefetch_views) while predict / plotting calls on the
+    default stream stay correct."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream()
+        last = self.owner.__dict__.get("_last_use")
+        if last is not None and last[0] != cur.cuda_stream:
+            cur.wait_event(last[1])
+        return self
+
+    def __exit__(self, *exc):
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.owner.__dict__["_last_use"] = (cur.cuda_stream, ev)
+        return False
+
+
 class MappingNetwork(nn.Module):
     """`Generator.style`: PixelNorm + n_mlp EqualLinear(fused lrelu), lr_mul 0.01
     (model.py:473-482).  Children are named "1".."n_mlp" like the reference Sequential."""
@@ -100,6 +125,10 @@ class MappingNetwork(nn.Module):
     def forward(self, z):
         if not z.is_cuda:
             raise RuntimeError("ganecdotes_amd.Generator runs on HIP devices only (no CPU fallback)")
+        with _OneStreamAtATime(self):               # the transposed-weight cache is made by the first call
+            return self._forward(z)
+
+    def _forward(self, z):
         shape = z.shape
         h = ops.pixel_norm(z.reshape(-1, shape[-1]).contiguous().float())
         for i in range(self.n_mlp):
@@ -312,6 +341,10 @@ class Generator(nn.Module):
 
     def synthesis(self, latent, noise):
         """latent (B, n_latent, S) -> (image (B,3,size,size) or None, [NHWC taps])."""
+        with _OneStreamAtATime(self):
+            return self._synthesis(latent, noise)
+
+    def _synthesis(self, latent, noise):
         d = self._prepare()
         bsz = latent.shape[0]
         sp, dmp = self._styles(latent.contiguous(), d)

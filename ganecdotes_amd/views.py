@@ -158,7 +158,12 @@ class ViewMixin(object):
         while done is not None and len(done) > 2:
             done.popleft().synchronize()
         vs = self._view_stream
-        vs.wait_stream(torch.cuda.current_stream(self.device))
+        if not done:
+            # pipeline start (or restart after a gap): everything queued so far — the mean latent, a head just built, a predict
+            # call — is ordered before the first views.  In the steady pipeline the views depend on nothing the step's stream
+            # does (frozen generator, draws staged on the copy stream), and the generator orders its own calls across streams
+            # (generator._OneStreamAtATime): no wait, so the views of batch i + 2 may start before step i has ended.
+            vs.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(vs):
             with self._timed("views"):
                 out = self.make_views(pb, want_all=True, want_image=False)
