@@ -1006,6 +1006,168 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
     }
 }
 
+// blur_act_xp_kernel with the T rows arriving by LDS-DMA several rows AHEAD (round 5).  The register version keeps ONE row of
+// loads in flight per wave (four 16-byte loads per thread, each T element fetched by four neighbouring threads) and waits for
+// it before it can issue the next; a prefetch in registers cost occupancy (16 more VGPRs: 10 % slower).  Here a workgroup's
+// 19 (+1) pixel x 64 channel slice of a T row goes into a ring of LDS rows by buffer_load ... lds — no registers, BD_AHEAD rows
+// in flight per workgroup — and every thread reads its four neighbours from LDS.  Waits are COUNTED (the stores of the
+// finished rows sit between the DMAs in the wave's vector-memory queue: loads, stores and LDS-DMA retire in issue order;
+// every wave issues the same two DMAs per T row and three stores per output row, so the counts are uniform), the barriers
+// are raw (a __syncthreads() would drain the DMAs of the rows ahead), and the ring is read by inline asm: hipcc cannot prove
+// that a read of ring slot r % 7 does not alias the DMA it has just issued into slot (r + 5) % 7 and puts s_waitcnt vmcnt(0)
+// in front of every ds_read it sees.  Host: OH % ROWS == 0 (whole strips: every iteration of a strip stores or none does).
+#ifndef BD_AHEAD
+#define BD_AHEAD 5                             // T rows in flight beyond the one being consumed
+#endif
+#ifndef BD_ROWS
+#define BD_ROWS 32                             // output rows per strip
+#endif
+constexpr int BD_RING = BD_AHEAD + 2;          // ring rows: the row being read + BD_AHEAD in flight + one the slow waves may still read
+constexpr int BD_ROWB = 20 * 64 * 4;           // one ring row: 20 pixels (19 used) x 64 channels, fp32
+__device__ __forceinline__ void bd_wait_vm(int n) {            // s_waitcnt takes an immediate; n = 2 (DMAs) + 3 (stores) in flight
+    switch (n) {
+#define BD_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        BD_CASE(1) BD_CASE(2) BD_CASE(3) BD_CASE(4) BD_CASE(5) BD_CASE(6) BD_CASE(7) BD_CASE(8) BD_CASE(9) BD_CASE(10)
+        BD_CASE(11) BD_CASE(12) BD_CASE(13) BD_CASE(14) BD_CASE(15) BD_CASE(16) BD_CASE(17) BD_CASE(18) BD_CASE(19) BD_CASE(20)
+        BD_CASE(21) BD_CASE(22) BD_CASE(23) BD_CASE(24) BD_CASE(25) BD_CASE(26) BD_CASE(27) BD_CASE(28) BD_CASE(29) BD_CASE(30)
+        BD_CASE(31) BD_CASE(32) BD_CASE(33) BD_CASE(34) BD_CASE(35) BD_CASE(36) BD_CASE(37) BD_CASE(38) BD_CASE(39) BD_CASE(40)
+#undef BD_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void bd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int ROWS>
+__global__ __launch_bounds__(256, 3) void blur_act_dma_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
+                                                              const float* __restrict__ kf, const float* __restrict__ demod,
+                                                              const float* __restrict__ noise, long noise_bstride,
+                                                              const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                              int act, float* __restrict__ out, int OH, int OW,
+                                                              const float* __restrict__ s_next, unsigned short* __restrict__ xp_out) {
+    __shared__ __attribute__((aligned(16))) char ring[BD_RING * BD_ROWB];
+    __shared__ __attribute__((aligned(16))) char stage[2][12 * 512];
+    __shared__ float nzs[ROWS * 16];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((address_space(3))) char* lds_char_t;
+    const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
+    const int nseg = OH / ROWS, nxb = OW >> 4, ncg = C >> 6;
+    const int tid = threadIdx.x, px = tid >> 4, c4 = tid & 15, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = kf[i];
+    const float nw = (noise && noise_w) ? *noise_w : 0.f;
+    const long nblk = (long)B * nseg * nxb * ncg;
+    const unsigned rowbytes = (unsigned)TW * (unsigned)C * 4u;
+    const unsigned ring_lds = (unsigned)(size_t)(lds_char_t)ring;          // LDS byte address of the ring
+    const unsigned rd_off = (unsigned)((px * 16 + c4) * 16);               // this thread's first neighbour (pixel x - 1) in a ring row
+    int par = 0;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        long rest = (nblk == (long)gridDim.x) ? (long)xcd_remap((int)blk, (int)nblk) : blk;
+        const int cg = (int)(rest % ncg); rest /= ncg;
+        const int xb = (int)(rest % nxb); rest /= nxb;
+        const int seg = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int c = cg * 64 + c4 * 4, x0 = xb * 16, x = x0 + px, y0 = seg * ROWS;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, dm4 = {1.f, 1.f, 1.f, 1.f}, sn4 = {1.f, 1.f, 1.f, 1.f};
+        if (bias) bias4 = *reinterpret_cast<const f32x4*>(bias + c);
+        if (demod) dm4 = *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
+        if (s_next) sn4 = *reinterpret_cast<const f32x4*>(s_next + (long)b * C + c);
+        // the strip's noise values [row][pixel] into LDS (an ordinary load inside the loop would make hipcc drain the DMAs)
+        for (int i = tid; i < ROWS * 16; i += 256)
+            nzs[i] = noise ? nw * noise[(long)b * noise_bstride + (long)(y0 + (i >> 4)) * OW + x0 + (i & 15)] : 0.f;
+        // every ordinary load of this strip has returned before the first DMA is issued: hipcc then has no reason to wait
+        // for "all vector memory" (vmcnt(0)) at the first use of one of them inside the pipeline
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(bias4), "v"(dm4), "v"(sn4) : "memory");
+        // this wave's 80 of the row's 320 16-byte units: lanes 0 .. 63 and (second instruction) 0 .. 15.  Unit u = pixel
+        // x0 - 1 + (u >> 4), channel quad u & 15 of the slice; a pixel left of the image gives a negative = huge unsigned
+        // offset: out of range, the DMA writes zeros (so does a row above / below T: zero-byte resource)
+        const int u1 = wid * 80 + lane, u2 = wid * 80 + 64 + (lane & 15);
+        const unsigned off1 = (unsigned)(((x0 - 1 + (u1 >> 4)) * C + cg * 64 + (u1 & 15) * 4) * 4);
+        const unsigned off2 = (unsigned)(((x0 - 1 + (u2 >> 4)) * C + cg * 64 + (u2 & 15) * 4) * 4);
+        const float* Tb = T + (long)b * TH * TW * C;
+        auto issue = [&](int r) {                             // T row y0 - 1 + r into ring slot r % BD_RING: 2 DMAs per wave
+            const int ty = y0 - 1 + r;
+            const bool ok = ty >= 0 && ty < TH;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Tb + (long)(ok ? ty : 0) * TW * C, ok ? rowbytes : 0u);
+            char* dst = ring + (r % BD_RING) * BD_ROWB + wid * 1280;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, (int)off1, 0, 0, 0);
+            if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 1024), 16, (int)off2, 0, 0, 0);
+        };
+        constexpr int NIT = ROWS + 3;                         // input rows of a strip
+#pragma unroll
+        for (int r = 0; r < BD_AHEAD; ++r) issue(r);
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int g4 = 0; g4 < (NIT + 3) / 4; ++g4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g4 + j;                     // input row y0 - 1 + r
+                if (r >= NIT) break;
+                if (r + BD_AHEAD < NIT) issue(r + BD_AHEAD);
+                // Row r has landed once all but the operations issued after its DMA have retired: the two DMAs of each of the
+                // up to BD_AHEAD later rows issued since, and the three stores of each output row finished in the BD_AHEAD
+                // iterations before this one (output rows exist from iteration 3 on).
+                {
+                    const int later = min(BD_AHEAD, NIT - 1 - r);                 // rows r + 1 .. issued after row r
+                    const int outs = min(BD_AHEAD, max(0, r - 3));              // iterations r - 5 .. r - 1 that stored
+                    bd_wait_vm(2 * later + 3 * outs);
+                }
+                bd_barrier();
+                f32x4 v[4];
+                {
+                    const unsigned ra = ring_lds + (unsigned)((r % BD_RING) * BD_ROWB) + rd_off;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\t"
+                                 "ds_read_b128 %3, %4 offset:768\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(ra) : "memory");
+                }
+#pragma unroll
+                for (int fy = 0; fy < 4; ++fy) {
+                    const f32x4 h = v[0] * k[fy * 4 + 0] + v[1] * k[fy * 4 + 1] + v[2] * k[fy * 4 + 2] + v[3] * k[fy * 4 + 3];
+                    acc[(j - fy) & 3] += h;
+                }
+                const int o = r - 3;                          // this output row is now complete
+                const int y = y0 + o;
+                if (o >= 0) {                                 // (o < ROWS and y < OH always: whole strips)
+                    const f32x4 a = acc[(j + 1) & 3];
+                    const float nz = nzs[o * 16 + px];
+                    f32x4 ov;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = a[q] * dm4[q] + nz + bias4[q];
+                        ov[q] = act ? lrelu_sqrt2(t) : t;
+                    }
+                    *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;          // store 1
+                    ov *= sn4;
+                    unsigned h[2], m[2], l[2];
+                    split3(ov[0], ov[1], h[0], m[0], l[0]);
+                    split3(ov[2], ov[3], h[1], m[1], l[1]);
+                    char* st = stage[par] + ((c4 >> 2) * 3 * 16 + px) * 32 + (c4 & 3) * 8;
+                    *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
+                    *reinterpret_cast<u32x2*>(st + 512) = (u32x2){m[0], m[1]};
+                    *reinterpret_cast<u32x2*>(st + 1024) = (u32x2){l[0], l[1]};
+                    bd_barrier();
+                    // 12 runs (chunk, plane) of 512 B = 384 16-B units: this wave's 96 — lanes 0 .. 63, then 0 .. 31 (stores 2, 3)
+                    const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + xb * 16 + 1;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int u = wid * 96 + it * 64 + (it ? (lane & 31) : lane);
+                        const int run = u >> 5, chunk = run / 3, plane = run - chunk * 3;
+                        const u32x4 d = *reinterpret_cast<const u32x4*>(stage[par] + u * 16);
+                        unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * 3 + plane) * oplane + ppix * 16 + (u & 31) * 8;
+                        if (it == 0 || lane < 32) *reinterpret_cast<u32x4*>(dst) = d;
+                    }
+                    par ^= 1;
+                }
+                acc[(j + 1) & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        bd_barrier();                                         // every wave is done with the ring and the noise of this strip
+    }
+}
+
 // ToRGB (model.py:445-454): 1x1 modulated conv without demod + bias + FIR-upsampled skip.
 //   img[b][c][y][x] = scale * sum_ci x[b,y,x,ci] s[b,ci] W[c][ci] + bias[c] + up2(prev)[b][c][y][x]
 // up2 = upfirdn2d(up=2, pad=(2,1)) with the flipped 4x4 FIR kf (already x4).  Image is planar
@@ -1581,6 +1743,8 @@ size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout) {
 }
 // Stage 2 of an upsampling StyledConv: blur (pad (1,1)) of the (TH x TW) transposed-conv image +
 // demod + noise + bias + act -> out [B][TH-1][TW-1][C]   (upfirdn2d mode 1 + fused_bias_act).
+static int g_blur_dma = 1;
+int gx_set_blur_dma(int on) { const int prev = g_blur_dma; g_blur_dma = on ? 1 : 0; return prev; }
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                     const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                     float* out, void* stream) {
@@ -1603,8 +1767,13 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
         // 32-row strips another 1 %
         const long nblk32 = (long)B * ((OH + 31) / 32) * (OW >> 4) * (C >> 6);
         if (OH >= 64 && nblk32 >= 2048) {
-            hipLaunchKernelGGL(blur_act_xp_kernel<32>, dim3((int)(nblk32 < 65536 ? nblk32 : 65536)), dim3(256), 0, (hipStream_t)stream,
-                               T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+            const size_t rowb = (size_t)TW * C * 4;
+            if (g_blur_dma && rowb < 0x7FFFFFF0ull && OH % BD_ROWS == 0)   // T rows by LDS-DMA, several ahead (gx_set_blur_dma(0): the register form)
+                hipLaunchKernelGGL(blur_act_dma_kernel<BD_ROWS>, dim3((int)(nblk32 * 32 / BD_ROWS < 65536 ? nblk32 * 32 / BD_ROWS : 65536)), dim3(256), 0, (hipStream_t)stream,
+                                   T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+            else
+                hipLaunchKernelGGL(blur_act_xp_kernel<32>, dim3((int)(nblk32 < 65536 ? nblk32 : 65536)), dim3(256), 0, (hipStream_t)stream,
+                                   T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
             GX_CHECK_LAUNCH();
             return GX_OK;
         }

@@ -243,6 +243,9 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
                        float* out, const float* s_next, unsigned short* planes_out, void* stream);
 int gx_modconv_up_convt_xp(const unsigned short* x_planes, int B, int H, int W, int Cin, const float* wt,
                            const unsigned short* wt_planes, int Cout, float* T, void* stream);
+/* the large blur launches take their T rows by LDS-DMA several rows ahead (1) or through registers (0: the round-2 form; A/B and
+ * tests); returns the previous setting */
+int gx_set_blur_dma(int on);
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                     const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                     float* out, void* stream);                         /* stage 2: blur + epilogue */

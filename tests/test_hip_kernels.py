@@ -1501,6 +1501,45 @@ def test_modconv_xp_golden_gv2_gv3(ops):
         ops.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("b,h,cout,edge", [(16, 64, 256, False), (8, 128, 128, True), (32, 32, 512, False), (8, 64, 128, False)])   # the last: too few strips for the large form (both runs take the same kernel)
+def test_blur_pass_with_lds_dma_rows_equals_the_register_form(ops, b, h, cout, edge):
+    """The blur + activation pass of an up-sampling layer with its T rows arriving by LDS-DMA five rows ahead (gx_conv.hip
+    blur_act_dma_kernel: counted vmcnt waits across the interleaved stores, raw barriers, the ring read by inline asm) against
+    the register form it replaces on the large launches (gx_set_blur_dma(0)): the same FIR sums in the same order — fp32 taps
+    and the three bf16 planes of out * s_next bitwise equal, image borders (zero rows / columns outside T) included."""
+    from ganecdotes_amd import _lib
+    torch.manual_seed(b + h)
+    cin = 64
+    x = dev(torch.randn(b, h, h, cin))
+    wt = dev(torch.randn(9, cout, cin) / math.sqrt(9 * cin))
+    s = dev(torch.rand(b, cin) + 0.5)
+    dm = dev(torch.rand(b, cout) + 0.5)
+    sn = dev(torch.rand(b, cout) + 0.5)
+    kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
+    noise, nw, bias = dev(torch.randn(1, 1, 2 * h, 2 * h)), dev(torch.tensor([0.3])), dev(torch.randn(cout))
+    if edge:                                   # values that make a wrong halo visible: large at the image border
+        x[:, 0] *= 50.0; x[:, -1] *= 50.0; x[:, :, 0] *= 50.0; x[:, :, -1] *= 50.0
+    wtp = ops.split_conv_weights(wt)
+    prev = ops.set_gemm_mode(1)
+    L = _lib.load()
+    try:
+        outs = []
+        for dma in (1, 0):
+            was = L.gx_set_blur_dma(dma)
+            planes = ops.xplanes_buffer(b, 2 * h, 2 * h, cout, x.device, slot=f"blur_dma_test{dma}")
+            planes.zero_()
+            xp = ops.modsplit(x, s)
+            y = ops.modconv_up(x, wt, s, dm, kf, noise, nw, bias, True, wt_planes=wtp, x_planes=xp, next_style=sn, next_planes=planes)
+            outs.append((y.clone(), planes.clone()))
+            L.gx_set_blur_dma(was)
+        assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0] - outs[1][0]).abs().max())
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert float(outs[0][0].abs().max()) > 0
+    finally:
+        ops.set_gemm_mode(prev)
+        L.gx_set_blur_dma(1)
+
+
 @pytest.mark.parametrize("b,h,cin,cout,up", [(3, 16, 64, 160, False), (2, 24, 40, 128, True), (5, 8, 512, 512, False),
                                              (1, 64, 128, 96, True), (2, 33, 20, 72, False),
                                              # Cout <= 64: the tall 256-pixel x 64-channel tile (the 512^2 layers of a 512^2 generator)

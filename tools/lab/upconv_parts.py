@@ -28,7 +28,13 @@ for h, cin, cout in ((16, 512, 512), (32, 512, 512), (64, 512, 256), (128, 256, 
     def blur():
         _lib.check(L.gx_blur_act_fwd_xp(_p(scratch), B, 2 * h + 1, 2 * h + 1, cout, _p(kf), _p(dm), _p(noise), 0, _p(nw), _p(bias), 1,
                                         _p(out), _p(sn), _p(npl), _stream()), "blur")
-    tc, tb = timeit(convt), timeit(blur)
+    tc = timeit(convt)
+    tbs = []
+    for dma in (1, 0, 1, 0):                       # the blur pass with its T rows by LDS-DMA (round 5) / through registers, alternating
+        L.gx_set_blur_dma(dma)
+        tbs.append(timeit(blur, n=20, warm=3))
+    L.gx_set_blur_dma(1)
     gf = 2.0 * B * h * h * cin * cout * 9 / 1e9
     el = B * 4 * h * h * cout
-    print(f"H={h:3d} {cin}->{cout}: convt {tc:.3f} ms {gf / tc:.0f} TF/s | blur {tb:.3f} ms {el * 14 / tb / 1e9:.2f} TB/s (14 B/elem)", flush=True)
+    print(f"H={h:3d} {cin}->{cout}: convt {tc:.3f} ms {gf / tc:.0f} TF/s | blur dma/reg/dma/reg {tbs[0]:.3f} / {tbs[1]:.3f} / {tbs[2]:.3f} / {tbs[3]:.3f} ms "
+          f"= {el * 14 / tbs[2] / 1e9:.2f} / {el * 14 / tbs[3] / 1e9:.2f} TB/s (14 B/elem)", flush=True)
