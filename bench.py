@@ -425,7 +425,7 @@ def predict_record(g, dev, batch=4, steps=10, warmup=2):
         head.predict(codes.permute(0, 2, 3, 1))
     dt, stats = timed_loop(step, steps, warmup)
     return nested_record(f"ffhq-256 predict (evaluate.py / run_tests): {batch} test latents per call -> generator (fixed noise, one "
-                         f"truncation, RGB rendered) -> pyramid projection of every pixel (31 GFLOP per image instead of the "
+                         f"truncation; the RGB image, which predict_swav_codes discards, is not rendered) -> pyramid projection of every pixel (31 GFLOP per image instead of the "
                          f"reference's 361: DESIGN 4.1) -> (B,512,256,256) codes + argmax -> 'XXS' one-shot head (3x3 conv 512->12) "
                          f"-> label map",
                          batch, dt, steps, warmup, stats)

@@ -185,8 +185,7 @@ class SimCLRClustering(ViewMixin):
         descriptor norm; BatchNorm uses the image's own pixel statistics (train mode) and, like the
         reference, updates the running statistics."""
         lat = input_latent.to(self.device).float()
-        img, feats = self.model([lat], truncation=self.model_config.truncation, truncation_latent=self.mean_latent,
-                                input_is_latent=True, randomize_noise=False)
+        feats = self._features_only(lat)
         ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
         hw = ts.size
         w1, gamma, beta, w2 = self._params()

@@ -930,8 +930,7 @@ class SwAVClustering(ViewMixin):
         argmax over the D projection channels).  Like the reference, the latent is always
         treated as a W latent."""
         lat = input_latent.to(self.device).float()
-        img, feats = self.model([lat], truncation=self.model_config.truncation,
-                                truncation_latent=self.mean_latent, input_is_latent=True, randomize_noise=False)
+        feats = self._features_only(lat)
         ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
         hw = ts.size
         wp = self.projection[0].weight.data

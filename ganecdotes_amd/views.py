@@ -41,6 +41,19 @@ class ViewMixin(object):
     """Needs self.model / mean_latent / truncation / perturb_args / device, `self._hlen` and
     `_pick_spec() -> (pixels per patch, patches, 'host'|'device')`."""
 
+    def _features_only(self, lat):
+        """The generator's taps for the predict paths (swav_clustering.py:673-677, simclr_clustering.py predict): fixed noise, ONE
+        truncation, and no RGB image — the reference discards it there (`perturbed_img` is never read; run_tests renders its
+        images with its own generator call, src/one_shot_pipeline.py:618), so the ToRGB branch is not run."""
+        prev = getattr(self.model, "want_image", True)
+        self.model.want_image = False
+        try:
+            _, feats = self.model([lat], truncation=self.model_config.truncation, truncation_latent=self.mean_latent,
+                                  input_is_latent=True, randomize_noise=False)
+        finally:
+            self.model.want_image = prev
+        return feats
+
     def _timed(self, tag, flops=0.0, nbytes=0.0):
         """HIP-event bracket of a phase of the step (active only when ops.PROFILE is a dict)."""
         return ops.record("phase:" + tag, flops, nbytes)
