@@ -434,8 +434,8 @@ def predict_record(g, dev, batch=4, steps=10, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--prototypes", type=int, default=8)
     ap.add_argument("--scope", default="global", choices=["global", "image"],

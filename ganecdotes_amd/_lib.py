@@ -125,7 +125,8 @@ SIGNATURES = {
     "gx_fused_bias_act": (c_i, [c_p, c_l, c_p, c_i, c_l, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "gx_random_subset_picks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_rotflip_map": (c_i, [c_f, c_i, c_i, c_i, c_p, c_p]),
-    "gx_gather_taps": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "gx_gather_taps": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_l, c_p]),
+    "gx_stack_norm_map_bilinear": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_row_sumsq": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p]),
     "gx_norm_map": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_row_l2_normalize": (c_i, [c_p, c_l, c_i, c_l, c_p, c_p]),

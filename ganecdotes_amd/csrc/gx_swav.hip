@@ -158,9 +158,21 @@ struct TapList {
 // X[row][:] = concat_l tap_l[b][(sy*res_l)/H][(sx*res_l)/W][:]  (first hlen channels), where
 // (sy,sx) = map_b[pick] (or the pick itself), zeros where the map says "filled".
 // Never materialises the (1, hlen, H, W) stack of swav_clustering.py:108-130 / :160-167.
+// F.interpolate(mode='bilinear', align_corners=False) source of output coordinate d on an axis of `in` samples upsampled to
+// `out` (ATen area_pixel_compute_source_index + the lambdas of upsample_bilinear2d): src = in / out * (d + 0.5) - 0.5 clamped
+// at 0, i0 = floor(src), i1 = i0 + (i0 < in - 1), l1 = src - i0.
+__device__ __forceinline__ void gx_bilinear_axis(int d, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
 __global__ __launch_bounds__(256) void gather_taps_kernel(TapList taps, const int* __restrict__ picks,
                                                           const int* __restrict__ maps, int rows_per_img,
-                                                          int H, int W, int hlen, float* __restrict__ X,
+                                                          int H, int W, int hlen, int interp, float* __restrict__ X,
                                                           long ldx, int total_rows) {
     const int row = blockIdx.x;
     if (row >= total_rows) return;
@@ -175,6 +187,21 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(TapList taps, const in
         if (off >= hlen) break;
         const int cl = min(taps.C[l], hlen - off);
         const int r = taps.res[l];
+        if (interp == 1 && pix >= 0 && (r != H || r != W)) {
+            // hf_interp = 'bilinear' (swav_clustering.py:123-124): h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11), ATen's order
+            int y0, y1, x0, x1;
+            float h0, h1, w0, w1;
+            gx_bilinear_axis(sy, r, H, y0, y1, h0, h1);
+            gx_bilinear_axis(sx, r, W, x0, x1, w0, w1);
+            const float* base = taps.ptr[l] + (long)b * r * r * taps.C[l];
+            const float* p00 = base + ((long)y0 * r + x0) * taps.C[l];
+            const float* p01 = base + ((long)y0 * r + x1) * taps.C[l];
+            const float* p10 = base + ((long)y1 * r + x0) * taps.C[l];
+            const float* p11 = base + ((long)y1 * r + x1) * taps.C[l];
+            for (int c = threadIdx.x; c < cl; c += blockDim.x)
+                out[off + c] = h0 * (w0 * p00[c] + w1 * p01[c]) + h1 * (w0 * p10[c] + w1 * p11[c]);
+            continue;
+        }
         const float* src = nullptr;
         if (pix >= 0) {
             const int ty = (sy * r) / H, tx = (sx * r) / W;
@@ -190,6 +217,41 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(TapList taps, const in
             for (int c = threadIdx.x; c < cl; c += blockDim.x) out[off + c] = src ? src[c] : 0.f;
         }
     }
+}
+
+// img[b][p] = ||descriptor of (rotated / flipped) pixel p||_2 with the taps BILINEARLY upsampled (hf_interp = 'bilinear'): the
+// per-tap sums of squares of norm_map_kernel do not apply — an interpolated value is not a tap value.  One wave per pixel.
+__global__ __launch_bounds__(256) void stack_norm_bilinear_kernel(TapList taps, const int* __restrict__ maps, int B, int H, int W,
+                                                                  int hlen, float* __restrict__ img) {
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= (long)B * H * W) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(i / (H * W)), p = (int)(i - (long)b * H * W);
+    const int pix = maps ? maps[i] : p;
+    float s = 0.f;
+    if (pix >= 0) {
+        const int sy = pix / W, sx = pix - sy * W;
+        for (int l = 0; l < taps.n; ++l) {
+            const int off = taps.off[l];
+            if (off >= hlen) break;
+            const int cl = min(taps.C[l], hlen - off), r = taps.res[l];
+            int y0, y1, x0, x1;
+            float h0, h1, w0, w1;
+            gx_bilinear_axis(sy, r, H, y0, y1, h0, h1);
+            gx_bilinear_axis(sx, r, W, x0, x1, w0, w1);
+            const float* base = taps.ptr[l] + (long)b * r * r * taps.C[l];
+            const float* p00 = base + ((long)y0 * r + x0) * taps.C[l];
+            const float* p01 = base + ((long)y0 * r + x1) * taps.C[l];
+            const float* p10 = base + ((long)y1 * r + x0) * taps.C[l];
+            const float* p11 = base + ((long)y1 * r + x1) * taps.C[l];
+            for (int c = lane; c < cl; c += 64) {
+                const float v = (r == H && r == W) ? p00[c] : h0 * (w0 * p00[c] + w1 * p01[c]) + h1 * (w0 * p10[c] + w1 * p11[c]);
+                s = fmaf(v, v, s);
+            }
+        }
+    }
+    s = gx_wave_sum(s);
+    if (lane == 0) img[i] = sqrtf(s);
 }
 
 // ===================================================================== row reductions
@@ -865,11 +927,33 @@ int gx_random_subset_picks(const float* keys, int rows, int HW, int N, int* pick
     return GX_OK;
 }
 
+static int gx_tap_list(TapList& t, int ntaps, const float* const* tap_ptrs, const int* tap_channels, const int* tap_res, int hlen) {
+    if (ntaps <= 0 || ntaps > MAX_TAPS || !tap_ptrs || !tap_channels || !tap_res || hlen <= 0) return GX_ERR_BAD_ARG;
+    t.n = ntaps;
+    int off = 0;
+    for (int l = 0; l < ntaps; ++l) {
+        if (!tap_ptrs[l] || tap_channels[l] <= 0 || tap_res[l] <= 0) return GX_ERR_BAD_ARG;
+        t.ptr[l] = tap_ptrs[l]; t.C[l] = tap_channels[l]; t.res[l] = tap_res[l]; t.off[l] = off;
+        off += tap_channels[l];
+    }
+    return off < hlen ? GX_ERR_BAD_ARG : GX_OK;
+}
+int gx_stack_norm_map_bilinear(int ntaps, const float* const* tap_ptrs, const int* tap_channels, const int* tap_res, int hlen,
+                               const int* maps, int B, int H, int W, float* img, void* stream) {
+    if (!img || B <= 0 || H <= 0 || W <= 0) return GX_ERR_BAD_ARG;
+    TapList t;
+    const int rc = gx_tap_list(t, ntaps, tap_ptrs, tap_channels, tap_res, hlen);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stack_norm_bilinear_kernel, dim3(gx_cdiv((long)B * H * W, 4)), dim3(256), 0, (hipStream_t)stream, t, maps, B,
+                       H, W, hlen, img);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 int gx_gather_taps(int ntaps, const float* const* tap_ptrs, const int* tap_channels, const int* tap_res,
-                   int B, int H, int W, int hlen, const int* picks, int rows_per_img, const int* maps,
+                   int B, int H, int W, int hlen, const int* picks, int rows_per_img, const int* maps, int interp,
                    float* X, long ldx, void* stream) {
     if (ntaps <= 0 || ntaps > MAX_TAPS || !tap_ptrs || !tap_channels || !tap_res || !picks || !X || B <= 0 ||
-        rows_per_img <= 0 || hlen <= 0 || ldx < hlen)
+        rows_per_img <= 0 || hlen <= 0 || ldx < hlen || interp < 0 || interp > 1)
         return GX_ERR_BAD_ARG;
     TapList t;
     t.n = ntaps;
@@ -882,7 +966,7 @@ int gx_gather_taps(int ntaps, const float* const* tap_ptrs, const int* tap_chann
     if (off < hlen) return GX_ERR_BAD_ARG;
     const int total = B * rows_per_img;
     hipLaunchKernelGGL(gather_taps_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, t, picks, maps,
-                       rows_per_img, H, W, hlen, X, ldx, total);
+                       rows_per_img, H, W, hlen, interp, X, ldx, total);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

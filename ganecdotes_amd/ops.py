@@ -904,8 +904,12 @@ class TapSet:
         self.size = max(t.shape[1] for t in taps)
 
 
-def gather_taps(tapset, picks, hlen, maps=None, out=None):
-    """picks (B, N) int32 pixel indices; maps (B, H*W) int32 or None -> X (B*N, hlen)."""
+INTERP = {"nearest": 0, "bilinear": 1}      # swav_args['hf_interp'] -> gx_gather_taps' interp
+
+
+def gather_taps(tapset, picks, hlen, maps=None, out=None, interp="nearest"):
+    """picks (B, N) int32 pixel indices; maps (B, H*W) int32 or None -> X (B*N, hlen).  interp: F.interpolate's mode over the
+    taps ('nearest' | 'bilinear')."""
     b, n = picks.shape
     if b != tapset.B or picks.dtype != torch.int32 or not picks.is_cuda or not picks.is_contiguous():
         raise RuntimeError("picks must be a contiguous (B, N) int32 HIP tensor")
@@ -915,7 +919,7 @@ def gather_taps(tapset, picks, hlen, maps=None, out=None):
     if out is None:
         out = torch.empty(b * n, hlen, dtype=torch.float32, device=picks.device)
     _lib.check(lib().gx_gather_taps(tapset.n, tapset.ptrs, tapset.chans, tapset.res, b, hw, hw, hlen, _p(picks), n,
-                                    _p(maps), _p(out), out.stride(0), _stream()), "gx_gather_taps")
+                                    _p(maps), INTERP[interp], _p(out), out.stride(0), _stream()), "gx_gather_taps")
     return out
 
 
@@ -927,8 +931,14 @@ def row_sumsq(x2d, cused=None):
     return out
 
 
-def norm_map(tapset, hlen, maps=None):
+def norm_map(tapset, hlen, maps=None, interp="nearest"):
     """(B, H, W) per-pixel L2 norm of the (rotated/flipped) first-hlen-channel stack."""
+    if interp == "bilinear":
+        hw = tapset.size
+        img = torch.empty(tapset.B, hw, hw, dtype=torch.float32, device=tapset.taps[0].device)
+        _lib.check(lib().gx_stack_norm_map_bilinear(tapset.n, tapset.ptrs, tapset.chans, tapset.res, hlen, _p(maps), tapset.B, hw,
+                                                    hw, _p(img), _stream()), "gx_stack_norm_map_bilinear")
+        return img
     ss, off = [], 0
     for t in tapset.taps:
         c = t.shape[3]

@@ -94,7 +94,8 @@ class SwAVClustering(ViewMixin):
         self.model_config = model_config
         self.perturb_args = perturb_args
         self.swav_args = swav_args
-        check_hf_interp(swav_args, 'swav_args')     # before anything touches a device: a config error, not a device error
+        # before anything touches a device: a config error, not a device error
+        self._interp = check_hf_interp(swav_args, 'swav_args', allowed=('nearest', 'bilinear'))
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError("SwAVClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
@@ -362,6 +363,8 @@ class SwAVClustering(ViewMixin):
         mode = sa.get('projection_mode', 'pyramid')
         if mode not in ('pyramid', 'panel'):
             raise NotImplementedError(f"projection_mode={mode!r}: 'pyramid' or 'panel'")
+        if self._interp != 'nearest':
+            mode = 'panel'      # the pyramid factorisation IS the nearest upsampling (a pixel's descriptor = its ancestors' taps)
         # the few-prototype routes (fused gather + scores, score tables) need a LINEAR map from descriptor to z
         small = bool(sa.get('small_proto_kernels', True) and ops.proto_small_ok(K, D) and head.linear)
         lowrank = bool(mode == 'pyramid' and sa.get('lowrank_proto', True) and ops.lowrank_ok(K, D) and head.linear)
@@ -470,7 +473,7 @@ class SwAVClustering(ViewMixin):
         if c.N is None or c.N >= hw * hw:
             c.N = hw * hw
         if imgs is None and self.sinkhorn_args['source_pdf'] == 'image':
-            imgs = [ops.norm_map(ts, c.hlen, maps) for ts, maps, _ in c.views]
+            imgs = [ops.norm_map(ts, c.hlen, maps, interp=self._interp) for ts, maps, _ in c.views]
 
         if self._bufs is None:
             self._bufs = [torch.zeros_like(p) for p in (c.Wp, c.Wc, c.bc, *c.extra)]
@@ -759,7 +762,7 @@ class SwAVClustering(ViewMixin):
                                 z = ops.gather_rows(c.Zt[v], picks, maps)            # rows of the first Linear's output
                         else:
                             with self._timed("gather"):
-                                x = ops.gather_taps(ts, picks, c.hlen, maps)         # (B*N, hlen)
+                                x = ops.gather_taps(ts, picks, c.hlen, maps, interp=self._interp)         # (B*N, hlen)
                             with self._timed("proj_fwd"):
                                 z = ops.gemm(x, c.Wp, False, True)                   # (B*N, D)
                             X.append(x)
@@ -934,11 +937,11 @@ class SwAVClustering(ViewMixin):
         ts = ops.TapSet([f.permute(0, 2, 3, 1) for f in feats])
         hw = ts.size
         wp = self.projection[0].weight.data
-        if self.swav_args.get('projection_mode', 'pyramid') == 'pyramid':
+        if self.swav_args.get('projection_mode', 'pyramid') == 'pyramid' and self._interp == 'nearest':
             z = Pyramid(ts, self.swav_args['hlen']).project(wp).reshape(ts.B * hw * hw, -1)
         else:
             picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
-            x = ops.gather_taps(ts, picks, self.swav_args['hlen'])
+            x = ops.gather_taps(ts, picks, self.swav_args['hlen'], interp=self._interp)
             z = ops.gemm(x, wp, False, True)                                   # (b*h*w, D) == NHWC
         head = self._proj_head()
         if not head.linear:          # BatchNorm in train mode here too (the reference never calls .eval()): per image

@@ -25,16 +25,18 @@ class PreparedBatch:
                 t.record_stream(cur)
 
 
-def check_hf_interp(args, where):
+def check_hf_interp(args, where, allowed=("nearest",)):
     """`hf_interp` is the `mode` of the reference's F.interpolate over the taps (hfc_with_swav/swav_clustering.py:123-124,
-    baseline/hfc_with_simclr/simclr_clustering.py:102-103).  Every shipped config sets 'nearest', and 'nearest' is what the
-    kernels implement (src = floor(dst * in / out): gx_gather_taps, the pyramid's 2x2 parent indexing).  Any other value would
-    change every descriptor, so it is refused by name rather than silently computed as nearest."""
+    baseline/hfc_with_simclr/simclr_clustering.py:102-103).  Every shipped config sets 'nearest'; hfc_with_swav also runs
+    'bilinear' (align_corners=False — on the reference-shaped panel route: the pyramid factorisation needs the nearest
+    upsampling).  Any other value would change every descriptor, so it is refused by name rather than silently computed as
+    nearest."""
     mode = args.get('hf_interp', 'nearest')
-    if mode != 'nearest':
+    if mode not in allowed:
         raise NotImplementedError(
-            f"{where}['hf_interp']={mode!r}: only 'nearest' (the value of every reference config) is implemented on the HIP "
-            f"path; the feature upsampling would silently differ from F.interpolate(mode={mode!r})")
+            f"{where}['hf_interp']={mode!r}: the HIP path implements {' / '.join(repr(a) for a in allowed)}; the feature "
+            f"upsampling would silently differ from F.interpolate(mode={mode!r})")
+    return mode
 
 
 class ViewMixin(object):
@@ -65,7 +67,7 @@ class ViewMixin(object):
         ts = ops.TapSet(taps)
         hw = ts.size * ts.size
         picks = torch.arange(hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
-        x = ops.gather_taps(ts, picks, self._hlen)
+        x = ops.gather_taps(ts, picks, self._hlen, interp=getattr(self, "_interp", "nearest"))
         return x.reshape(ts.B, ts.size, ts.size, -1).permute(0, 3, 1, 2)
 
     def prepare_batch(self, images):
@@ -184,7 +186,7 @@ class ViewMixin(object):
             if getattr(self, "sinkhorn_args", {}).get("source_pdf") == "image":
                 # the norm maps of the 'image' source pdf (swav_clustering.py:361-362) depend on the taps alone: an HBM-bound
                 # pass over every tap that belongs beside the step, not in front of it
-                norms = [ops.norm_map(ts, self._hlen, maps) for ts, maps, _ in out[0]]
+                norms = [ops.norm_map(ts, self._hlen, maps, interp=getattr(self, "_interp", "nearest")) for ts, maps, _ in out[0]]
             ev = torch.cuda.Event()
             ev.record()
         self._last_view_event = ev

@@ -292,9 +292,15 @@ int gx_random_subset_picks(const float* keys, int rows, int HW, int N, int* pick
 int gx_rotflip_map(float angle_deg, int flip, int H, int W, int* map, void* stream);
 /* the maps of a whole view batch in one launch (angles / flips are host arrays of n entries) */
 int gx_rotflip_map_batch(const float* angles_deg, const int* flips, int n, int H, int W, int* maps, void* stream);
+/* interp: the `mode` of the reference's F.interpolate over the taps (swav_args['hf_interp'], swav_clustering.py:123-124):
+ * 0 = 'nearest' (every shipped config), 1 = 'bilinear' (align_corners=False, ATen's arithmetic) */
 int gx_gather_taps(int ntaps, const float* const* tap_ptrs /*host array of device ptrs*/, const int* tap_channels /*host*/,
                    const int* tap_res /*host*/, int B, int H, int W, int hlen, const int* picks, int rows_per_img,
-                   const int* maps, float* X, long ldx, void* stream);
+                   const int* maps, int interp, float* X, long ldx, void* stream);
+/* img [B][H][W] = L2 norm of every (rotated / flipped: maps, or NULL) pixel's descriptor with the taps bilinearly upsampled
+ * (torch.norm(stack, dim=1), swav_clustering.py:361-362, under hf_interp='bilinear'; 'nearest' uses gx_row_sumsq + gx_norm_map) */
+int gx_stack_norm_map_bilinear(int ntaps, const float* const* tap_ptrs, const int* tap_channels, const int* tap_res, int hlen,
+                               const int* maps, int B, int H, int W, float* img, void* stream);
 int gx_row_sumsq(const float* x, long rows, int cused, long ld, float* out, void* stream);
 int gx_norm_map(int ntaps, const float* const* ss_ptrs /*host array*/, const int* tap_res /*host*/, const int* maps,
                 int B, int H, int W, float* img, void* stream);

@@ -265,7 +265,7 @@ def view_latents(w, mean_latent, psi, n_latent, vd: ViewDraws, sd, perturb_std=1
     return new
 
 
-def make_view(sd, w, mean_latent, psi, vd: ViewDraws, hlen, perturb_std=1.0):
+def make_view(sd, w, mean_latent, psi, vd: ViewDraws, hlen, perturb_std=1.0, hf_interp="nearest"):
     """One augmented view -> (stack (1,hlen,H,W), image).  The second forward truncates
     AGAIN (image_augmentor.py:75-79 -> model.py:594-602) and uses the registered
     noise buffers."""
@@ -273,7 +273,7 @@ def make_view(sd, w, mean_latent, psi, vd: ViewDraws, hlen, perturb_std=1.0):
     new = view_latents(w, mean_latent, psi, n_latent, vd, sd, perturb_std)
     img, taps, _ = G.generator_forward(new, sd, truncation=psi, truncation_latent=mean_latent,
                                        input_is_latent=True)
-    stack = pixel_features(taps, hlen)
+    stack = pixel_features(taps, hlen, hf_interp)          # F.interpolate(mode=swav_args['hf_interp']), swav_clustering.py:123-124
     if vd.index_map is not None:
         stack = apply_index_map(stack, vd.index_map)
     elif vd.angle is not None:
@@ -293,7 +293,7 @@ class SwavParams:
 
 def swav_step_loss(sd, mean_latent, psi, images: List[ImageDraws], params: SwavParams, *, hlen,
                    patch_size, num_patches, temperature, eps, niters, source_pdf="uniform",
-                   sinkhorn_scope="image", fp64=False, perturb_std=1.0, return_aux=False):
+                   sinkhorn_scope="image", fp64=False, perturb_std=1.0, return_aux=False, hf_interp="nearest"):
     """Loss of one optimizer step over a batch of images (SURVEY §8e semantics).
 
     scope 'image' : per-image Sinkhorn; loss = mean over images of the reference's
@@ -305,7 +305,7 @@ def swav_step_loss(sd, mean_latent, psi, images: List[ImageDraws], params: SwavP
     with torch.no_grad():
         for im in images:
             w = G.mapping(im.z, sd)
-            vs = [make_view(sd, w, mean_latent, psi, vd, hlen, perturb_std)[0] for vd in im.views]
+            vs = [make_view(sd, w, mean_latent, psi, vd, hlen, perturb_std, hf_interp)[0] for vd in im.views]
             stacks.append(vs)
             imgs.append([norm_map(v) for v in vs])
     loss = 0.0
@@ -410,13 +410,13 @@ def pretrain_reference_order(sd, style_dim, *, num_latents_for_mean, psi, n_pert
 
 
 # ----------------------------------------------------------------------------- P1
-def predict_swav_codes(sd, w, mean_latent, psi, proj_w, hlen, head=None):
+def predict_swav_codes(sd, w, mean_latent, psi, proj_w, hlen, head=None, hf_interp="nearest"):
     """predict_swav_codes (swav_clustering.py:659-693): one truncation, registered noise,
     projection on every pixel, argmax over the D projection channels."""
     with torch.no_grad():
         _, taps, _ = G.generator_forward(w, sd, truncation=psi, truncation_latent=mean_latent,
                                          input_is_latent=True)
-        stack = pixel_features(taps, hlen)
+        stack = pixel_features(taps, hlen, hf_interp)
         b, c, h, wd = stack.shape
         x = torch.squeeze(stack).flatten(1).t()
         preds = codes(x, proj_w, train=False, head=head).reshape(b, proj_w.shape[0], h, wd)

@@ -593,6 +593,35 @@ def test_gather_rotflip_batch(ops):
         np.testing.assert_allclose(img[i].numpy(), S.norm_map(stack)[0].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_gather_and_norm_map_bilinear_vs_torch_interpolate(ops):
+    """swav_args['hf_interp'] = 'bilinear' (the `mode` of the reference's F.interpolate over the taps,
+    hfc_with_swav/swav_clustering.py:123-124): gx_gather_taps(interp=1) and gx_stack_norm_map_bilinear against the stack torch
+    itself makes (oracle pixel_features -> F.interpolate(mode='bilinear'), align_corners=False), with rotate / flip maps and an
+    hlen that cuts a tap; taps at 4, 16 and the full 32 (a tap at full resolution is taken as it is)."""
+    from oracle import swav_ref as S
+    torch.manual_seed(19)
+    b, hw, hlen = 3, 32, 22
+    taps = [torch.randn(b, 8, 4, 4), torch.randn(b, 12, 16, 16), torch.randn(b, 4, 32, 32)]
+    ts = ops.TapSet([dev(t.permute(0, 2, 3, 1)) for t in taps])
+    angles, flips = [7.3, -4.1, 0.0], [True, False, True]
+    maps = torch.stack([ops.rotflip_map(a, f, hw, hw, "cuda") for a, f in zip(angles, flips)])
+    picks = torch.stack([torch.randperm(hw * hw)[:300] for _ in range(b)]).int().cuda()
+    for use_maps in (True, False):
+        m = maps if use_maps else None
+        x = ops.gather_taps(ts, picks, hlen, m, interp="bilinear").cpu().reshape(b, 300, hlen)
+        img = ops.norm_map(ts, hlen, m, interp="bilinear").cpu()
+        for i in range(b):
+            stack = S.pixel_features([t[i:i + 1] for t in taps], hlen, "bilinear")
+            if use_maps:
+                stack = S.apply_index_map(stack, maps[i].cpu().long())
+            ref = S.sample_pixels(stack, picks[i].cpu().long(), 300)
+            np.testing.assert_allclose(x[i].numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(img[i].numpy(), S.norm_map(stack)[0].numpy(), rtol=1e-5, atol=1e-6)
+    # and it is NOT the nearest stack
+    xn = ops.gather_taps(ts, picks, hlen, None).cpu()
+    assert float((xn - ops.gather_taps(ts, picks, hlen, None, interp="bilinear").cpu()).abs().max()) > 0.1
+
+
 def test_gemm_cat_and_strided_views(ops, engine):
     torch.manual_seed(8)
     m, k1, k2, n = 300, 64, 40, 72

@@ -258,6 +258,55 @@ def test_train_step_vs_oracle(gpu, tmp_path, scope, batch, pdf, mode):
             assert rel(got, want) < 1e-4
 
 
+@pytest.mark.parametrize("scope,batch,pdf,nproto", [("image", 1, "uniform", 12), ("global", 2, "image", 12), ("global", 2, "uniform", 200)])
+def test_train_step_and_predict_with_bilinear_hf_interp_vs_oracle(gpu, tmp_path, scope, batch, pdf, nproto):
+    """swav_args['hf_interp'] = 'bilinear': F.interpolate's other upsampling of the taps (hfc_with_swav/swav_clustering.py:
+    123-124; every shipped config says 'nearest').  The pyramid factorisation IS the nearest upsampling, so the step runs the
+    reference-shaped panel route (Route.mode == 'panel') on bilinearly gathered descriptors; two steps (loss, gradients,
+    updated parameters; the 'image' marginals from the bilinear stack's norm maps) and predict_swav_codes against the oracle,
+    whose stack is torch's own F.interpolate(mode='bilinear')."""
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.draws import draw_image
+    d = load_golden("gv10_pretrain")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    sw = make_swav(g, gpu, tmp_path, sinkhorn_scope=scope, batch_size=batch, hf_interp="bilinear", nprototypes=nproto,
+                   sinkhorn_args=dict(source_pdf=pdf))
+    torch.manual_seed(124)
+    np.random.seed(124)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sw.mean_latent = ml.cuda()
+    sw.build_heads()
+    params = S.SwavParams(*[p.detach().cpu().clone() for p in sw._params()])
+    bufs = [None] * 3
+    for step in range(2):
+        images = [draw_image(16, 7, 3, 32 * 32, 2, transforms=True) for _ in range(batch)]
+        loss = sw.train_step(images)
+        assert sw.last_route.mode == "panel" and sw.last_route.name == "per_sample"
+        oimgs = [S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                                 ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long())
+                                     for v in im.views], im.picks) for im in images]
+        ref_loss, grads, bufs = S.swav_train_step(
+            sd, ml, 0.7, oimgs, params, bufs, lr=0.01, momentum=0.9, trust=0.01, use_larc=True, hlen=56,
+            patch_size=300, num_patches=2, temperature=0.1, eps=0.05, niters=10, source_pdf=pdf,
+            sinkhorn_scope=scope, hf_interp="bilinear")
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-3)
+        for got, want in zip(sw._grads, grads):
+            assert rel(got, want) < 2e-3
+        for got, want in zip(sw._params(), (params.proj_w, params.proto_w, params.proto_b)):
+            assert rel(got, want) < 1e-4
+    for _ in range(2):                                   # (the reference's predict is one latent per call, :685-690)
+        w = S.G.mapping(torch.randn(1, 16), sd)
+        preds, labels = sw.predict_swav_codes(w.cuda())
+        ref_preds, ref_labels = S.predict_swav_codes(sd, w, ml, 0.7, params.proj_w, 56, hf_interp="bilinear")
+        assert rel(preds, ref_preds) < 5e-5
+        assert (labels.cpu() == ref_labels).float().mean() > 0.995
+        # the nearest stack gives other codes: the option is not silently ignored
+        nn_preds, _ = S.predict_swav_codes(sd, w, ml, 0.7, params.proj_w, 56)
+        assert rel(preds, nn_preds) > 1e-2
+
+
 @pytest.mark.parametrize("scope,batch,transforms,score_table,nproto,pdf", [
     ("global", 3, True, True, 200, "uniform"), ("global", 3, True, False, 200, "uniform"), ("image", 2, True, True, 200, "uniform"),
     ("global", 2, False, True, 200, "uniform"), ("global", 2, True, True, 6148, "uniform"), ("image", 2, True, True, 6148, "uniform"),

@@ -254,19 +254,22 @@ def test_host_thread_cap_only_lowers():
     torch.set_num_threads(before)
 
 
-def test_hf_interp_other_than_nearest_is_refused_by_name():
-    """`hf_interp` is F.interpolate's mode in the reference (hfc_with_swav/swav_clustering.py:123-124; simclr_clustering.py:102-103);
-    the HIP path implements 'nearest' (every shipped config) and must refuse anything else instead of computing nearest silently
-    (VERDICT round 4, item 5).  The check runs before any device is touched."""
+def test_hf_interp_values_the_path_does_not_implement_are_refused_by_name():
+    """`hf_interp` is F.interpolate's mode in the reference (hfc_with_swav/swav_clustering.py:123-124; simclr_clustering.py:102-103).
+    hfc_with_swav implements 'nearest' (every shipped config) and 'bilinear'; hfc_with_simclr 'nearest'.  Anything else is
+    refused by name instead of being computed as nearest silently; the check runs before any device
+    is touched."""
     import pytest
     from ganecdotes_amd.swav_clustering import SwAVClustering
     from ganecdotes_amd.simclr_clustering import SimCLRClustering
+    for mode in ("bicubic", "area", "nearest-exact"):
+        with pytest.raises(NotImplementedError, match="hf_interp"):
+            SwAVClustering(model=None, model_config=None, perturb_args={}, swav_args=dict(hf_interp=mode), sinkhorn_args={},
+                           device='cpu')
     with pytest.raises(NotImplementedError, match="hf_interp"):
-        SwAVClustering(model=None, model_config=None, perturb_args={}, swav_args=dict(hf_interp='bilinear'), sinkhorn_args={},
-                       device='cpu')
-    with pytest.raises(NotImplementedError, match="hf_interp"):
-        SimCLRClustering(model=None, model_config=None, perturb_args={}, simclr_args=dict(hf_interp='bicubic'), device='cpu')
-    # 'nearest' passes the check and reaches the next one (no HIP device here / a CPU device was asked for)
-    with pytest.raises(RuntimeError, match="HIP device"):
-        SwAVClustering(model=None, model_config=None, perturb_args={}, swav_args=dict(hf_interp='nearest'), sinkhorn_args={},
-                       device='cpu')
+        SimCLRClustering(model=None, model_config=None, perturb_args={}, simclr_args=dict(hf_interp='bilinear'), device='cpu')
+    # 'nearest' and (hfc_with_swav) 'bilinear' pass the check and reach the next one (no HIP device here / a CPU device was asked for)
+    for mode in ("nearest", "bilinear"):
+        with pytest.raises(RuntimeError, match="HIP device"):
+            SwAVClustering(model=None, model_config=None, perturb_args={}, swav_args=dict(hf_interp=mode), sinkhorn_args={},
+                           device='cpu')
