@@ -41,6 +41,9 @@ struct FineqArgs {
 #ifndef FQ_ABL
 #define FQ_ABL 0                           // lab ablations (tools/lab/fineq_abl.sh): 2 no MFMAs, 11 / 12 the backward kernel's
 #endif
+#ifndef FQ_PRIO
+#define FQ_PRIO 0                          // lab (tools/lab/fineq_flags.sh -DFQ_PRIO=n): wave priority around the MFMA bursts / of the consumer waves
+#endif
 // The coarse tables travel as ONE table of FQ_YLD floats per parent pixel: columns 0 .. 255 = Y2 = 2 Zc Wf, 256 .. 271 =
 // Ac = Zc Wc^T (K of them live), 272 = nc = |Zc|^2 — so that the score block's share is a ninth "column block" of it.
 constexpr int FQ_YLD = 288;
@@ -248,8 +251,10 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                             }
                     }
                 };
+                if (FQ_PRIO) __builtin_amdgcn_s_setprio(FQ_PRIO);
                 if (isL) run(std::integral_constant<bool, true>{});
                 else run(std::integral_constant<bool, false>{});
+                if (FQ_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             if ((t & 1) && FQ_ABL != 6 && (isL ? nb0 <= 5 : (nb0 >= 6))) {                 // block nb0 is final and this wave owns it: fold it
                 // sp += sum over the lane's 16 columns j of t[row][j] (U[row][j] + Y2[parent][j]): four 16-byte reads of t
@@ -427,6 +432,7 @@ __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* l
         return f;
     };
     __syncthreads();                                                 // barrier 0
+    if (FQ_PRIO) __builtin_amdgcn_s_setprio(FQ_PRIO);
     for (int t = 0; t < nkt; ++t) {
         const char* As = lds + (t & 1) * FB_SLOT;
         const char* Bs = As + AIMG;
