@@ -63,7 +63,8 @@ def _worker(rank, world, port, sd, scope, pdf, out, nproto=12, projn="linear"):
     imgs = _images(4)
     loss = None
     for _ in range(2):
-        loss = sw.train_step(imgs[rank * 2:(rank + 1) * 2])
+        # the ranks run the pipelined form (views on their own stream, ViewMixin.prefetch_views), the 1-rank reference the plain one
+        loss = sw.train_step(sw.prefetch_views(imgs[rank * 2:(rank + 1) * 2]))
     out[rank] = (float(loss.item()), [p.cpu().numpy() for p in sw._params()])
     dist.barrier()
     dist.destroy_process_group()
@@ -73,7 +74,9 @@ def _worker(rank, world, port, sd, scope, pdf, out, nproto=12, projn="linear"):
     ("global", "uniform", 12, "linear"), ("image", "uniform", 12, "linear"), ("global", "image", 12, "linear"),
     ("global", "uniform", 200, "linear"), ("image", "uniform", 200, "linear"),
     ("global", "uniform", 12, "1-layer"), ("global", "uniform", 200, "2-layer"), ("image", "uniform", 12, "2-layer"),
-    ("global", "uniform", 200, "linear+table"), ("image", "uniform", 200, "linear+table"), ("global", "image", 200, "linear+table")])
+    ("global", "uniform", 200, "linear+table"), ("image", "uniform", 200, "linear+table"), ("global", "image", 200, "linear+table"),
+    # a prototype count that is not a multiple of 4: padded columns and explicit marginals under the sharded protocol (round 5)
+    ("global", "uniform", 203, "linear+table"), ("global", "image", 203, "linear+table")])
 def test_two_ranks_equal_one_rank(scope, pdf, nproto, projn):
     """nproto = 200: the many-prototype path (score GEMM on weight planes with the Sinkhorn column maxima from its
     epilogue, one-pass CE with the bias gradient) under the sharded protocol; projn '2-layer' with the global scope:
