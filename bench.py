@@ -282,7 +282,7 @@ def measure(sw, args, steps, warmup, dev, world):
     # HIP events on the launch stream over the timed region (ops.record brackets the launches of the MFMA kernels with
     # their algorithmic FLOPs and of the large HBM-bound passes with their algorithmic bytes: SURVEY par. 8d figures x the
     # units the launch processes)
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, ops.PROFILE = ops.PROFILE or {}, None
     stats = {}
     for tag, evs in prof.items():
         ms = sum(a.elapsed_time(b) for a, b, *_ in evs)
