@@ -158,9 +158,9 @@ class ViewMixin(object):
         PreparedBatch; `train_step` picks them up (take_views).  The generator is frozen, so the views of batch i + 1 depend on
         nothing step i computes: queued before step i they run beside it — the step's HBM- and latency-bound passes (blur,
         Sinkhorn, CE, scatter, the mapping network) and the tails of its matrix-core kernels share the chip with the other
-        stream's work instead of leaving it idle.  The view stream first waits for everything queued on the
-        current stream so far (the generator's plane buffers and the previous user of any shared state are then ordered); in a
-        steady pipeline that work — step i - 1 — is finished before step i starts anyway."""
+        stream's work instead of leaving it idle.  At a pipeline start the view stream waits for everything
+        queued on the current stream so far; in the steady pipeline it waits for nothing (see below), and the host's lead is
+        bounded to two steps."""
         pb = self.prepare_batch(images)
         if getattr(pb, "views", None) is not None:
             return pb
@@ -169,9 +169,11 @@ class ViewMixin(object):
         # Bounded lead.  The taps live in the VIEW stream's memory pool and are recorded on the step's stream, so a freed set
         # returns to the pool only once the step that read it has run on the GPU: a host that queues many steps ahead (it can:
         # a step is ~125 launches) would pin one 4 GB set of taps per step of lead.  Two steps of lead keep both streams fed.
-        done = getattr(self, "_step_done", None)
-        while done is not None and len(done) > 2:
+        done = getattr(self, "_step_done", None) or ()
+        while len(done) > 2:
             done.popleft().synchronize()
+        while done and done[0].query():            # steps that have already run
+            done.popleft()
         vs = self._view_stream
         if not done:
             # pipeline start (or restart after a gap): everything queued so far — the mean latent, a head just built, a predict
