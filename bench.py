@@ -408,7 +408,7 @@ def simclr_record(g, dev, iters=200, warmup=20):
                          extra={"iterations_per_s": iters / dt})
 
 
-def predict_record(g, dev, batch=4, steps=10, warmup=2):
+def predict_record(g, dev, batch=16, steps=6, warmup=2):
     """The evaluate.py loop per test latent (src/one_shot_pipeline.py:632-665): predict_swav_codes (generator with fixed noise,
     projection of all 65 536 pixels, argmax) + the one-shot head ('XXS': Conv2d(512, 12, 3, pad 1), config :77-78) + argmax"""
     from ganecdotes_amd.oneshot import OneShotHead

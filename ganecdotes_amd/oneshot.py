@@ -313,7 +313,7 @@ def write_result_files(test_dir, results, classes):
     np.savez_compressed(os.path.join(test_dir, 'results.npz'), **results)
 
 
-def run_tests(preprocessor, head, test_latents, test_labels, classes, batch=4):
+def run_tests(preprocessor, head, test_latents, test_labels, classes, batch=16):
     """The numeric core of OneShotPipeline.run_tests (:611-748, tester 'all'): per batch of test latents
     predict_swav_codes -> head -> argmax; then per sample the IoU / Dice block, and the PD-vs-IoU summaries.
     test_labels (n, H, W).  Returns (pred_labels (n, H, W) int64 on the host, results dict with the

@@ -721,7 +721,7 @@ def test_bench_cli_contract_one_json_line(gpu):
     assert "route=lowrank" in d["config"]["workload"]
     assert r["traffic_source"] is None or "profiles/" in r["traffic_source"]
     # every other BASELINE.json configuration, driver-timed in the same line
-    per_step = {"cat_per_rank": 16, "car512_per_rank": 4, "car512_per_rank_k4000": 4, "simclr": 1, "predict": 4}
+    per_step = {"cat_per_rank": 16, "car512_per_rank": 4, "car512_per_rank_k4000": 4, "simclr": 1, "predict": 16}
     for key, imgs in per_step.items():
         n = d[key]
         assert n["unit"] == "images/s" and n["value"] > 0 and n["ms_per_step"] > 0 and n["workload"], key
