@@ -56,7 +56,7 @@ class SimCLRClustering(ViewMixin):
         self.model_config = model_config
         self.perturb_args = perturb_args
         self.simclr_args = simclr_args
-        check_hf_interp(simclr_args, 'simclr_args')
+        self._interp = check_hf_interp(simclr_args, 'simclr_args', allowed=('nearest', 'bilinear'))
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError("SimCLRClustering (ganecdotes_amd) needs a HIP device: there is no CPU fallback")
@@ -121,7 +121,7 @@ class SimCLRClustering(ViewMixin):
         pb_picks = pb.picks[0]                                                 # (1, bsz) int32
         xs = []
         for ts, maps, _ in views:
-            x = ops.gather_taps(ts, pb_picks, hlen, maps)                      # (bsz, hlen)
+            x = ops.gather_taps(ts, pb_picks, hlen, maps, interp=self._interp)  # (bsz, hlen)
             ops.row_l2_normalize_(x, want_rnorm=False)                         # F.normalize(dim=1) per pixel
             xs.append(x)
         x = torch.stack(xs, 1).reshape(2 * bsz, hlen).contiguous()             # s0, t0, s1, t1, ...
@@ -190,8 +190,14 @@ class SimCLRClustering(ViewMixin):
         hw = ts.size
         w1, gamma, beta, w2 = self._params()
         bn = self.projection[1]
-        z = Pyramid(ts, self._hlen).project(w1).reshape(ts.B * hw * hw, -1)
-        ops.row_div_(z, ops.norm_map(ts, self._hlen).reshape(-1))
+        if self._interp == 'nearest':
+            z = Pyramid(ts, self._hlen).project(w1).reshape(ts.B * hw * hw, -1)
+            ops.row_div_(z, ops.norm_map(ts, self._hlen).reshape(-1))
+        else:       # hf_interp='bilinear': the descriptor panel itself (the pyramid factorisation is the nearest upsampling)
+            picks = torch.arange(hw * hw, dtype=torch.int32, device=self.device).repeat(ts.B, 1)
+            x = ops.gather_taps(ts, picks, self._hlen, interp=self._interp)
+            ops.row_l2_normalize_(x, want_rnorm=False)
+            z = ops.gemm(x, w1, False, True)
         mean, var = ops.col_stats(z)
         a, _ = ops.bn_lrelu_fwd(z, mean, var, gamma, beta, bn.eps, 0.01, want_xhat=False)
         n = z.shape[0]

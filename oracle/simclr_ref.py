@@ -74,10 +74,10 @@ def draw_iteration_reference_order(style_dim, gen_num_layers, n_perturb_layers, 
     return S.ImageDraws(z, views, [torch.randperm(hw)])
 
 
-def simclr_step_loss(sd, mean_latent, psi, im, w1, gamma, beta, w2, *, hlen, batch, temperature):
+def simclr_step_loss(sd, mean_latent, psi, im, w1, gamma, beta, w2, *, hlen, batch, temperature, hf_interp="nearest"):
     with torch.no_grad():
         w = G.mapping(im.z, sd)
-        stacks = [S.make_view(sd, w, mean_latent, psi, vd, hlen)[0] for vd in im.views]
+        stacks = [S.make_view(sd, w, mean_latent, psi, vd, hlen, hf_interp=hf_interp)[0] for vd in im.views]
         x = sample_pair(stacks[0], stacks[1], im.picks[0], batch)
     out, mean, var_unbiased = projection_mlp(x, w1, gamma, beta, w2)
     return ntxent_feature_rows(out, batch, temperature), mean.detach(), var_unbiased.detach()
@@ -117,13 +117,13 @@ def pretrain_reference_order(sd, style_dim, *, num_latents_for_mean, psi, n_pert
     return losses, dict(w1=w1, gamma=gamma, beta=beta, w2=w2, running_mean=run_mean, running_var=run_var), mean_lat
 
 
-def predict_simclr_codes(sd, w, mean_latent, psi, params, hlen):
+def predict_simclr_codes(sd, w, mean_latent, psi, params, hlen, hf_interp="nearest"):
     """predict_simclr_codes (simclr_clustering.py:365-400): the projection module is still in
     train mode, so BatchNorm uses the statistics of the image's own H*W pixels."""
     with torch.no_grad():
         _, taps, _ = G.generator_forward(w, sd, truncation=psi, truncation_latent=mean_latent,
                                          input_is_latent=True)
-        stack = F.normalize(S.pixel_features(taps, hlen), dim=1)
+        stack = F.normalize(S.pixel_features(taps, hlen, hf_interp), dim=1)
         b, c, h, wd = stack.shape
         x = stack.squeeze(0).flatten(1).t()
         out, _, _ = projection_mlp(x, params["w1"], params["gamma"], params["beta"], params["w2"])

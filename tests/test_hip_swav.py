@@ -680,6 +680,52 @@ def test_simclr_head_kernels_vs_autograd(gpu):
     assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
 
 
+def test_simclr_iteration_and_predict_with_bilinear_hf_interp_vs_oracle(gpu, tmp_path):
+    """simclr_args['hf_interp'] = 'bilinear' (baseline/hfc_with_simclr/simclr_clustering.py:102-103): two iterations (loss, the
+    four gradients) and predict_simclr_codes against the oracle on torch's own bilinear stack."""
+    from oracle import simclr_ref as C
+    from oracle import swav_ref as S
+    from ganecdotes_amd import ops
+    from ganecdotes_amd.simclr_clustering import SimCLRClustering
+    d = load_golden("gv12_simclr")
+    sd = golden_sd(d)
+    g = mini_gen(sd, gpu)
+    args = dict(num_iters=2, batch_size=5, patch_size=30, hf_interp="bilinear", trust_coeff=0.01,
+                train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=8, hlen=56, epoch_print_freq=1,
+                max_masks=4, use_larc=True, transforms=True)
+    sim = SimCLRClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", simclr_args=args,
+                           perturb_args=dict(truncation=0.7, n_layers=3, n_samples=1, layer_no=None, perturb_std=[1.0] * 3))
+    torch.manual_seed(5)
+    np.random.seed(5)
+    ml = S.G.mean_latent(sd, 64, 16)
+    sim.mean_latent = ml.cuda()
+    sim.build_heads()
+    leaves = [p.detach().cpu().clone() for p in sim._params()]
+    for it in range(2):
+        im = sim.draw_iteration()
+        loss = sim.train_step(im)
+        oim = S.ImageDraws(im.z, [S.ViewDraws(v.layer_no, v.map_noise, v.angle, v.flip,
+                                              ops.rotflip_map(v.angle, v.flip, 32, 32, "cuda").cpu().long()) for v in im.views], im.picks)
+        for p in leaves:
+            p.requires_grad_(True)
+            p.grad = None
+        ref, _, _ = C.simclr_step_loss(sd, ml, 0.7, oim, *leaves, hlen=56, batch=5, temperature=1.0, hf_interp="bilinear")
+        ref.backward()
+        np.testing.assert_allclose(loss.item(), float(ref.detach()), rtol=1e-3)
+        for got, p in zip(sim._grads, leaves):
+            assert rel(got, p.grad) < 2e-3
+        for p, q in zip(leaves, sim._params()):           # continue from the HIP parameters
+            p.requires_grad_(False)
+            p.copy_(q.cpu())
+    w = S.G.mapping(torch.randn(1, 16), sd)
+    params = dict(w1=leaves[0], gamma=leaves[1], beta=leaves[2], w2=leaves[3])
+    preds, labels = sim.predict_simclr_codes(w.cuda())
+    ref_preds, ref_labels = C.predict_simclr_codes(sd, w, ml, 0.7, params, 56, hf_interp="bilinear")
+    assert rel(preds, ref_preds) < 1e-3
+    assert (labels.cpu() == ref_labels).float().mean() > 0.99
+    assert rel(preds, C.predict_simclr_codes(sd, w, ml, 0.7, params, 56)[0]) > 1e-2      # not the nearest stack
+
+
 def test_simclr_pretrain_golden_gv12(gpu, tmp_path):
     from ganecdotes_amd.simclr_clustering import SimCLRClustering
     d = load_golden("gv12_simclr")

@@ -256,7 +256,7 @@ def test_host_thread_cap_only_lowers():
 
 def test_hf_interp_values_the_path_does_not_implement_are_refused_by_name():
     """`hf_interp` is F.interpolate's mode in the reference (hfc_with_swav/swav_clustering.py:123-124; simclr_clustering.py:102-103).
-    hfc_with_swav implements 'nearest' (every shipped config) and 'bilinear'; hfc_with_simclr 'nearest'.  Anything else is
+    Both preprocessors implement 'nearest' (every shipped config) and 'bilinear'.  Anything else is
     refused by name instead of being computed as nearest silently; the check runs before any device
     is touched."""
     import pytest
@@ -267,7 +267,7 @@ def test_hf_interp_values_the_path_does_not_implement_are_refused_by_name():
             SwAVClustering(model=None, model_config=None, perturb_args={}, swav_args=dict(hf_interp=mode), sinkhorn_args={},
                            device='cpu')
     with pytest.raises(NotImplementedError, match="hf_interp"):
-        SimCLRClustering(model=None, model_config=None, perturb_args={}, simclr_args=dict(hf_interp='bilinear'), device='cpu')
+        SimCLRClustering(model=None, model_config=None, perturb_args={}, simclr_args=dict(hf_interp='bicubic'), device='cpu')
     # 'nearest' and (hfc_with_swav) 'bilinear' pass the check and reach the next one (no HIP device here / a CPU device was asked for)
     for mode in ("nearest", "bilinear"):
         with pytest.raises(RuntimeError, match="HIP device"):
