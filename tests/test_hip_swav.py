@@ -690,7 +690,7 @@ def test_simclr_iteration_and_predict_with_bilinear_hf_interp_vs_oracle(gpu, tmp
     d = load_golden("gv12_simclr")
     sd = golden_sd(d)
     g = mini_gen(sd, gpu)
-    args = dict(num_iters=2, batch_size=5, patch_size=30, hf_interp="bilinear", trust_coeff=0.01,
+    args = dict(num_iters=2, batch_size=4, patch_size=30, hf_interp="bilinear", trust_coeff=0.01,
                 train_args=dict(lr=0.01, momentum=0.9), temperature=1.0, nclasses=8, hlen=56, epoch_print_freq=1,
                 max_masks=4, use_larc=True, transforms=True)
     sim = SimCLRClustering(model=g, model_config=Cfg, out_dir=None, device="cuda", simclr_args=args,
@@ -709,7 +709,7 @@ def test_simclr_iteration_and_predict_with_bilinear_hf_interp_vs_oracle(gpu, tmp
         for p in leaves:
             p.requires_grad_(True)
             p.grad = None
-        ref, _, _ = C.simclr_step_loss(sd, ml, 0.7, oim, *leaves, hlen=56, batch=5, temperature=1.0, hf_interp="bilinear")
+        ref, _, _ = C.simclr_step_loss(sd, ml, 0.7, oim, *leaves, hlen=56, batch=4, temperature=1.0, hf_interp="bilinear")
         ref.backward()
         np.testing.assert_allclose(loss.item(), float(ref.detach()), rtol=1e-3)
         for got, p in zip(sim._grads, leaves):
