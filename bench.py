@@ -451,6 +451,9 @@ def main():
     ap.add_argument("--ds-table", default="auto", choices=["auto", "on", "off"],
                     help="many prototypes: d(scores) summed per pixel before the backward GEMMs (DESIGN 4.15); auto = when "
                          "the patches draw more samples than the image has pixels")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="swav_args['deterministic']: fixed-point coefficient scatter on the K <= 16 route — bitwise run-to-run "
+                         "reproducible steps (not the headline configuration: a line with it says so in config.workload)")
     ap.add_argument("--sinkhorn-table", default="auto", choices=["auto", "on", "off"],
                     help="many prototypes: the table Sinkhorn (rows grouped by membership, DESIGN 4.16) or — off — the per-problem "
                          "sweeps on pixel-ordered tables (round 3's form); the A/B of the two table orderings")
@@ -532,6 +535,8 @@ def main():
             wl["swav_args"]["ds_table"] = args.ds_table == "on"
         if args.sinkhorn_table != "auto":
             wl["swav_args"]["sinkhorn_table"] = args.sinkhorn_table == "on"
+        if args.deterministic:
+            wl["swav_args"]["deterministic"] = True
         sw = SwAVClustering(model=g if gen is None else gen, model_config=ModelCfg, out_dir=None, device=dev, dist_group=group, **wl)
         torch.manual_seed(42 + rank)
         np.random.seed(42 + rank)
@@ -590,7 +595,8 @@ def main():
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
                                f"N=20000 pixels x 5 patches, D=512, C=5376, 10 Sinkhorn iters, "
                                f"eps={args.eps if args.eps else (0.005 if args.pdf == 'uniform' else 0.003)}, "
-                               + ("" if args.pdf == "uniform" else f"source_pdf={args.pdf} (NOT the headline configuration), ") +
+                               + ("" if args.pdf == "uniform" else f"source_pdf={args.pdf} (NOT the headline configuration), ")
+                               + ("deterministic=True (NOT the headline configuration), " if args.deterministic else "") +
                                f"T=0.01, sinkhorn_scope={args.scope}, pixel picks = the N smallest of H*W uniform keys drawn on "
                                f"the device generator (= the set randperm[:N] selects); views = the 13 feature taps of both "
                                f"perturbed latents (the RGB image, which enters no loss term, is not rendered); "

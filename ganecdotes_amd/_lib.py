@@ -84,7 +84,7 @@ SIGNATURES = {
     "gx_gather_scores": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_fwd_lowrank": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "gx_gather_scores_batch": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
-    "gx_proto_bwd_lowrank_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_sz,
+    "gx_proto_bwd_lowrank_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,
                                          c_p]),
     "gx_swapped_ce_batch": (c_i, [c_p, c_i, c_i, c_l, c_l, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "gx_proto_bwd_lowrank": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),

@@ -1914,9 +1914,16 @@ __global__ void sk_pass_small_kernel(const float* __restrict__ S, long sprob, lo
         if (live) ul += expf(w + lb);
     }
     for (int o = team; o < 64; o <<= 1) ul += __shfl_xor(ul, o, 64);
-    if ((threadIdx.x & 63) < team && tl < K) atomicAdd(&uacc[tl], ul);
+    // the block's column sums in a FIXED order (one slot per wave, added by thread k): LDS float atomics made the step differ
+    // from run to run in the last bits
+    __syncthreads();                                          // (red: sk_fold_update is done with it)
+    if ((threadIdx.x & 63) < team && tl < K) red[(threadIdx.x >> 6) * 64 + tl] = ul;
     __syncthreads();
-    if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
+    if (threadIdx.x < K) {
+        float t = red[threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w * 64 + threadIdx.x];
+        upart[(long)blockIdx.x * K + threadIdx.x] = t;
+    }
 }
 
 // The same pass with a ROW PER LANE for K = 4 KQ <= 16 (16-B aligned rows): a lane reads its row as KQ float4, so the
@@ -1974,13 +1981,14 @@ __global__ __launch_bounds__(256) void sk_pass_small_rowlane_kernel(
             for (int k = 0; k < K; ++k) ul[k] += bk_exp(w[k]);
         }
     }
+    __syncthreads();                                          // (red: sk_fold_update is done with it)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float t = gx_wave_sum(ul[k]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&uacc[k], t);
+        if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 64 + k] = t;      // one slot per wave: the block sum in a fixed order
     }
     __syncthreads();
-    if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = uacc[threadIdx.x];
+    if (threadIdx.x < K) upart[(long)blockIdx.x * K + threadIdx.x] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
 }
 
 // grid = nprob blocks
@@ -2561,17 +2569,26 @@ __global__ void gather_scores_batch_kernel(const float* __restrict__ T, const fl
     scores[idx] = q >= 0 ? T[q * K + k] : (bias ? bias[k] : 0.f);
     if (k == 0) rnorm[r] = q >= 0 ? rnT[q] : 1e12f;
 }
+// DET (swav_args['deterministic']): the coefficients are accumulated as 64-bit FIXED-POINT integers (2^-44 units) — integer
+// adds commute, so the sums no longer depend on the order the atomics land in — into Cfix, which lr_fix_to_float_kernel turns
+// into the float grid the consumers read.  Resolution 5.7e-14 against coefficients of 1e-6 .. 1e-3 (a contribution below 1e-9
+// loses relative precision, not the sum), range +-5e5.  The bias-gradient partial of a block is summed in a fixed order in
+// both forms.
+constexpr float LR_FIX_SCALE = 17592186044416.f;                 // 2^44
+__global__ void lr_fix_to_float_kernel(const long long* __restrict__ Cfix, long n, float* __restrict__ C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        C[i] = (float)((double)Cfix[i] * (1.0 / (double)LR_FIX_SCALE));
+}
+template <bool DET>
 __global__ void proto_bwd_lowrank_batch_kernel(const float* __restrict__ dS, const float* __restrict__ scores,
                                                const float* __restrict__ rnorm, const float* __restrict__ bias, int B,
                                                int HW, int K, int N, const int* __restrict__ picks,
                                                const int* __restrict__ maps, long rows, float* __restrict__ C,
-                                               float* __restrict__ part_b, int shift, int wlog2) {
-    __shared__ float sb[LR_MAXK];
+                                               long long* __restrict__ Cfix, float* __restrict__ part_b, int shift, int wlog2) {
+    __shared__ float sb[4 * LR_MAXK];
     const int ls = lr_stride(K);
     const int team = (K + 1 <= 16) ? 16 : 32;
     const int tpb = blockDim.x / team, ti = threadIdx.x / team, tl = threadIdx.x % team;
-    if (threadIdx.x < LR_MAXK) sb[threadIdx.x] = 0.f;
-    __syncthreads();
     const float myb = (bias && tl < K) ? bias[tl] : 0.f;
     float gbl = 0.f;
     const long niter = (rows + (long)gridDim.x * tpb - 1) / ((long)gridDim.x * tpb);
@@ -2587,12 +2604,20 @@ __global__ void proto_bwd_lowrank_batch_kernel(const float* __restrict__ dS, con
         }
         const float dot = gx_team_sum(d * sc, team);
         gbl += d;
-        if (q >= 0 && tl <= K) atomicAdd(C + q * ls + tl, tl < K ? rn * d : -rn * rn * dot);
+        if (q >= 0 && tl <= K) {
+            const float v = tl < K ? rn * d : -rn * rn * dot;
+            if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(Cfix + q * ls + tl), (unsigned long long)__float2ll_rn(v * LR_FIX_SCALE));
+            else atomicAdd(C + q * ls + tl, v);
+        }
     }
     for (int o = team; o < 64; o <<= 1) gbl += __shfl_xor(gbl, o, 64);
-    if ((threadIdx.x & 63) < team && tl < K) atomicAdd(&sb[tl], gbl);
+    if ((threadIdx.x & 63) < team && tl < K) sb[(threadIdx.x >> 6) * LR_MAXK + tl] = gbl;      // one slot per wave
     __syncthreads();
-    if (threadIdx.x < K) part_b[(long)blockIdx.x * K + threadIdx.x] = sb[threadIdx.x];
+    if (threadIdx.x < K) {
+        float t = sb[threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += sb[w * LR_MAXK + threadIdx.x];
+        part_b[(long)blockIdx.x * K + threadIdx.x] = t;
+    }
 }
 
 // Dense finish: G[q] = sum_k C[q][k] Wc_k + C[q][K] Z[q]; block partials of gWc[k] += C[q][k] Z[q].
@@ -2862,8 +2887,8 @@ int gx_gather_scores_batch(const float* table, const float* rn_table, const floa
 // the matching coefficient scatter: C [2B*HW][gx_lowrank_stride(K)] += ..., gb = beta*gb + colsum(dS).
 // workspace >= 1024*K floats.
 int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
-                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, float* gb,
-                               float beta, float* workspace, size_t workspace_bytes, void* stream) {
+                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, long long* Cfix,
+                               float* gb, float beta, float* workspace, size_t workspace_bytes, void* stream) {
     if (!dS || !scores || !rnorm || !picks || !C || !gb || B <= 0 || HW <= 0 || npatch <= 0 || N <= 0 || K < 1 ||
         K > gx::LR_MAXK)
         return GX_ERR_BAD_ARG;
@@ -2873,8 +2898,17 @@ int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float
     const long rows = (long)npatch * 2 * B * N;
     long nb = (rows + 15) / 16;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(gx::proto_bwd_lowrank_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores,
-                       rnorm, bias, B, HW, K, N, picks, maps, rows, C, workspace, shift, wlog2);
+    if (Cfix) {     // deterministic form: fixed-point accumulation, then the float grid from ALL that has been accumulated so far
+        hipLaunchKernelGGL(gx::proto_bwd_lowrank_batch_kernel<true>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores,
+                           rnorm, bias, B, HW, K, N, picks, maps, rows, C, Cfix, workspace, shift, wlog2);
+        GX_CHECK_LAUNCH();
+        const long n = (long)2 * B * (HW >> (2 * shift)) * gx::lr_stride(K);
+        hipLaunchKernelGGL(gx::lr_fix_to_float_kernel, dim3(gx_cdiv(n, 1024) < 4096 ? gx_cdiv(n, 1024) : 4096), dim3(256), 0,
+                           (hipStream_t)stream, Cfix, n, C);
+    } else {
+        hipLaunchKernelGGL(gx::proto_bwd_lowrank_batch_kernel<false>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dS, scores,
+                           rnorm, bias, B, HW, K, N, picks, maps, rows, C, Cfix, workspace, shift, wlog2);
+    }
     GX_CHECK_LAUNCH();
     gx::launch_partial_reduce(workspace, (int)nb, K, 1.f, beta, gb, (hipStream_t)stream);
     GX_CHECK_LAUNCH();

@@ -383,15 +383,20 @@ def gather_scores_batch(table, rn_table, bias, picks, maps, b, hw, out, shift=0)
     return rn
 
 
-def proto_bwd_lowrank_batch_(ds, scores, rnorm, bias, picks, maps, coeffs, b, hw, gb, beta, shift=0):
+def proto_bwd_lowrank_batch_(ds, scores, rnorm, bias, picks, maps, coeffs, b, hw, gb, beta, shift=0, coeffs_fix=None):
+    """coeffs_fix (int64, coeffs' shape, zeroed once per step): the deterministic form — fixed-point accumulation, coeffs
+    overwritten with its float value"""
     _chk(ds, scores, rnorm, bias, coeffs, gb)
+    if coeffs_fix is not None and (coeffs_fix.dtype != torch.int64 or tuple(coeffs_fix.shape) != tuple(coeffs.shape) or
+                                   not coeffs_fix.is_contiguous() or not coeffs_fix.is_cuda):
+        raise RuntimeError("proto_bwd_lowrank_batch_: coeffs_fix must be a contiguous int64 HIP tensor of coeffs' shape")
     p, pb, n = picks.shape
     k = ds.shape[-1]
     if coeffs.shape[0] != 2 * b * (hw >> (2 * shift)):
         raise RuntimeError("proto_bwd_lowrank_batch_: coefficient grid does not match (2B, hw, shift)")
     ws = workspace("lowrank_b", 1024 * k * 4, ds.device)
     _lib.check(lib().gx_proto_bwd_lowrank_batch(_p(ds), _p(scores), _p(rnorm), _p(bias), b, hw, k, _p(picks), p, n, _p(maps),
-                                                shift, _p(coeffs), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
+                                                shift, _p(coeffs), _p(coeffs_fix), _p(gb), beta, _p(ws), 1024 * k * 4, _stream()),
                "gx_proto_bwd_lowrank_batch")
 
 

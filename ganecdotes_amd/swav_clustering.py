@@ -484,6 +484,10 @@ class SwAVClustering(ViewMixin):
         c.gscale = 1.0 / (c.N * c.P * c.Bg)
         c.route = route = self.plan_route(B, hw, c.N)
         self.last_route = route
+        if sa.get('deterministic', False) and route.name != 'lowrank':
+            # the other routes scatter 2 KB rows with float atomics (normalize_bwd_scatter): a promise they cannot keep is refused
+            raise NotImplementedError("swav_args['deterministic']=True: bitwise run-to-run reproducibility is implemented on the "
+                                      f"K <= 16 route (score tables of every pixel); this step would take {route.describe()}")
         c.mode = route.mode
         c.pyr = c.Z_all = c.Zt = c.G_all = c.Gt = None
         if route.mode == 'pyramid':
@@ -577,6 +581,9 @@ class SwAVClustering(ViewMixin):
                 ident = torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
             maps_all = torch.cat([m if m is not None else ident for m in (views[0][1], views[1][1])])
         c.Ct_all = ops.lowrank_coeffs(2 * B, c.pyr.table_pixels(), K, dev)   # (2B * table pixels, K+1 padded) coefficient grid
+        # swav_args['deterministic']: the coefficient scatter accumulates fixed-point integers (order-independent); with the
+        # fixed-order block sums everywhere else on this route two runs from the same state are then bitwise equal
+        ct_fix = torch.zeros(c.Ct_all.shape, dtype=torch.int64, device=dev) if c.sa.get('deterministic', False) else None
         for p0 in range(0, c.P, c.route.pgroup):
             pnos = list(range(p0, min(c.P, p0 + c.route.pgroup)))
             G = len(pnos)
@@ -591,7 +598,7 @@ class SwAVClustering(ViewMixin):
                              q_s=skb[0].codes(), q_t=skb[c.ngroups].codes())
             with self._timed("proto_bwd_lowrank"):
                 ops.proto_bwd_lowrank_batch_(dS_all, Sc_all, Rn_all, c.bc, gpicks, maps_all, c.Ct_all, B, hw * hw, c.gb,
-                                             0.0 if c.first_acc else 1.0, shift=c.lshift)
+                                             0.0 if c.first_acc else 1.0, shift=c.lshift, coeffs_fix=ct_fix)
             c.first_acc = False
             del dS_all, Rn_all, Sc_all, skb
 

@@ -354,9 +354,12 @@ int gx_gather_scores(const float* table, const float* rn_table, const float* bia
 int gx_gather_scores_batch(const float* table, const float* rn_table, const float* bias, int B, int HW, int K,
                            const int* picks, int npatch, int N, const int* maps, int shift, float* scores, float* rnorm,
                            void* stream);
+/* Cfix (optional, [rows of C][gx_lowrank_stride(K)] 64-bit integers, zeroed by the caller once per step): the DETERMINISTIC form —
+ * the coefficients are accumulated as fixed-point integers (2^-44 units; integer atomics commute, float atomics do not) and C
+ * is overwritten with the float value of everything accumulated in Cfix so far.  NULL: float atomics into C. */
 int gx_proto_bwd_lowrank_batch(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
-                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, float* gb,
-                               float beta, float* workspace, size_t workspace_bytes, void* stream);
+                               int K, const int* picks, int npatch, int N, const int* maps, int shift, float* C, long long* Cfix,
+                               float* gb, float beta, float* workspace, size_t workspace_bytes, void* stream);
 int gx_proto_bwd_lowrank(const float* dS, const float* scores, const float* rnorm, const float* bias, int B, int HW,
                          int K, const int* picks, int rows_per_img, const int* maps, float* C, float* gb, float beta,
                          float* workspace, size_t workspace_bytes, void* stream);

@@ -532,6 +532,34 @@ def test_bench_step_properties(gpu, bench_state, nproto):
         assert rel(a_, b_) < 1e-4
 
 
+@pytest.mark.parametrize("nproto,pdf", [(8, "uniform"), (16, "image")])
+def test_deterministic_mode_is_bitwise_reproducible_at_the_bench_batch(gpu, bench_state, nproto, pdf):
+    """swav_args['deterministic'] = True on the K <= 16 route (BASELINE configs 2 and 3 per rank, 16 images, 5 patches): the
+    coefficient scatter accumulates 64-bit fixed-point integers instead of float atomics, and every block sum on the route has
+    a fixed order — two runs of three steps from the same state and draws give BITWISE equal losses, gradients and parameters
+    (the reference sets cudnn.deterministic, lib/util/util.py:21-28); and the deterministic step is the default step to fp32
+    rounding (loss 1e-6, gradients 1e-5)."""
+    g, ml, make = bench_state
+    runs = []
+    for det in (True, True, False):
+        sw = make(nproto, batch=16, deterministic=det)
+        if pdf == "image":
+            sw.sinkhorn_args["source_pdf"] = "image"
+            sw.eps = sw.sinkhorn_args["eps"] = 0.003
+        torch.manual_seed(31)
+        np.random.seed(31)
+        losses = []
+        for _ in range(3):
+            losses.append(sw.train_step(sw.draw_batch(16)))
+        runs.append((torch.cat(losses).cpu(), [x.clone() for x in sw._grads], [p.clone() for p in sw._params()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a_, b_ in zip(runs[0][1] + runs[0][2], runs[1][1] + runs[1][2]):
+        assert torch.equal(a_, b_)
+    np.testing.assert_allclose(runs[0][0].numpy(), runs[2][0].numpy(), rtol=1e-5)
+    for a_, b_ in zip(runs[0][1], runs[2][1]):
+        assert rel(a_, b_) < 1e-4
+
+
 @pytest.mark.parametrize("nproto", [8, 5000])
 def test_prefetched_views_equal_inline_views_at_the_bench_batch(gpu, bench_state, nproto):
     """bench.py's pipeline at its own shape: the views of the NEXT batch are made on the view stream while the step of the
