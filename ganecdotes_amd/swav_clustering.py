@@ -484,10 +484,12 @@ class SwAVClustering(ViewMixin):
         c.gscale = 1.0 / (c.N * c.P * c.Bg)
         c.route = route = self.plan_route(B, hw, c.N)
         self.last_route = route
-        if sa.get('deterministic', False) and route.name != 'lowrank':
-            # the other routes scatter 2 KB rows with float atomics (normalize_bwd_scatter): a promise they cannot keep is refused
-            raise NotImplementedError("swav_args['deterministic']=True: bitwise run-to-run reproducibility is implemented on the "
-                                      f"K <= 16 route (score tables of every pixel); this step would take {route.describe()}")
+        if sa.get('deterministic', False) and route.name == 'per_sample':
+            # this route scatters 2 KB rows with float atomics (normalize_bwd_scatter) and sums the Sinkhorn columns with them:
+            # a promise it cannot keep is refused.  'lowrank' switches its coefficient scatter to fixed point; 'tables' needs
+            # nothing — every d(scores) row is written once, by the pixel's own thread, and every block sum has a fixed order
+            raise NotImplementedError("swav_args['deterministic']=True: bitwise run-to-run reproducibility holds on the routes "
+                                      f"'lowrank' (K <= 16) and 'tables' (64 < K <= 8192); this step would take {route.describe()}")
         c.mode = route.mode
         c.pyr = c.Z_all = c.Zt = c.G_all = c.Gt = None
         if route.mode == 'pyramid':

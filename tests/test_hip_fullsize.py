@@ -560,6 +560,34 @@ def test_deterministic_mode_is_bitwise_reproducible_at_the_bench_batch(gpu, benc
         assert rel(a_, b_) < 1e-4
 
 
+@pytest.mark.parametrize("nproto,scope", [(5000, "global"), (4001, "image")])
+def test_table_route_is_bitwise_reproducible(gpu, bench_state, nproto, scope):
+    """The route of the reference's own prototype counts needs no switch: every d(scores) row is written once by its pixel's own
+    thread, the table Sinkhorn and the loss / bias-gradient sums reduce block partials in a fixed order, and the backward is
+    GEMMs — two runs of three steps from the same state and draws are BITWISE equal with swav_args['deterministic'] (accepted
+    here as a no-op) and without it.  (`make` seeds the constructor's mean latent: bench_state builds every instance alike.)"""
+    from ganecdotes_amd import ops
+    if ops.get_gemm_mode() != 1:
+        pytest.skip("the 'tables' route is the bf16x6 engine's")
+    g, ml, make = bench_state
+    runs = []
+    for det in (True, False, False):
+        sw = make(nproto, batch=4, deterministic=det, sinkhorn_scope=scope)
+        torch.manual_seed(33)
+        np.random.seed(33)
+        losses = [sw.train_step(sw.draw_batch(4)) for _ in range(3)]
+        assert sw.last_route.name == "tables"
+        runs.append((torch.cat(losses).cpu(), [x.clone() for x in sw._grads], [p.clone() for p in sw._params()]))
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0])
+        for a_, b_ in zip(runs[0][1] + runs[0][2], other[1] + other[2]):
+            assert torch.equal(a_, b_)
+    # the route that cannot promise it says so
+    sw = make(40, batch=4, deterministic=True)
+    with pytest.raises(NotImplementedError, match="deterministic"):
+        sw.train_step(sw.draw_batch(4))
+
+
 @pytest.mark.parametrize("nproto", [8, 5000])
 def test_prefetched_views_equal_inline_views_at_the_bench_batch(gpu, bench_state, nproto):
     """bench.py's pipeline at its own shape: the views of the NEXT batch are made on the view stream while the step of the
