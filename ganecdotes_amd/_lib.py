@@ -42,6 +42,8 @@ SIGNATURES = {
     "gx_kmeans_label_maps": (c_i, [c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "gx_version": (ctypes.c_char_p, []),
     "gx_set_blur_dma": (c_i, [c_i]),
+    "gx_set_conv_planes": (c_i, [c_i]),
+    "gx_get_conv_planes": (c_i, []),
     "gx_set_gemm_mode": (c_i, [c_i]),
     "gx_get_gemm_mode": (c_i, []),
     "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

@@ -49,6 +49,8 @@ struct ConvArgs {
     unsigned xp_plane_bytes;                   // bytes of one (chunk, plane) image = B*(IH+2)*(IW+2)*32
     const float* s_next;                       // [B][Cout] modulation of the NEXT conv, or nullptr
     unsigned short* xp_out;                    // x planes of the output for the next conv (out * s_next), or nullptr
+    int h2;                                    // plane format of xp / wtp / xp_out: 0 = three bf16 planes (bf16x6), 1 = two fp16 planes (f16x3)
+    float acc_scale;                           // what the accumulators are multiplied by on their way out (f16x3: 1 / (scale_x scale_w), else 1)
 };
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * 1.41421356237309515f; }
@@ -101,7 +103,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& g, const ConvSub& 
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (!cok[nt]) continue;
-                float v = acc[mt][nt][r];
+                float v = acc[mt][nt][r] * g.acc_scale;
                 if (!to_slab) {
                     v = fmaf(v, dm[nt], nz + bias_c[nt]);
                     if (g.act) v = lrelu_sqrt2(v);
@@ -374,12 +376,52 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 // Main loop per wave and k-tile: 6 DMA + 20 ds_read_b128 + 48 MFMA 16x16x32 (or 12 reads + 24 MFMA 32x32x16).
 constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + B planes of one k-tile: 24 KB
 
+// the same four channels into an LDS staging row whose planes are 512 B apart (blur_act_xp_kernel / blur_act_dma_kernel)
+template <bool H2>
+__device__ __forceinline__ void stage_xplanes4(const f32x4& v, char* st) {
+    if (H2) {
+        unsigned h[2], l[2];
+        split2h(v[0], v[1], XH_SCALE_X, h[0], l[0]);
+        split2h(v[2], v[3], XH_SCALE_X, h[1], l[1]);
+        *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
+        *reinterpret_cast<u32x2*>(st + 512) = (u32x2){l[0], l[1]};
+    } else {
+        unsigned h[2], m[2], l[2];
+        split3(v[0], v[1], h[0], m[0], l[0]);
+        split3(v[2], v[3], h[1], m[1], l[1]);
+        *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
+        *reinterpret_cast<u32x2*>(st + 512) = (u32x2){m[0], m[1]};
+        *reinterpret_cast<u32x2*>(st + 1024) = (u32x2){l[0], l[1]};
+    }
+}
+
 // Epilogue of modconv_xp_kernel, through LDS: the wave parks one 32 x 64 accumulator block at a time in its own
 // 8.5 KB of (now idle) stage memory and reads it back as 16 pixels x one 16-channel chunk, 4 channels per lane — 16-B
 // fp32 stores instead of 64 dword stores per lane, the demod / noise / bias / activation on float4, and,
 // when the next conv reads x planes, that conv's modulated input split RIGHT HERE (out * s_next -> three bf16
 // planes, 8 B per lane and plane): the activation is split once, by its producer, not per tap and Cout tile.
 constexpr int EPI_LDW = 68;
+// four consecutive channels of one pixel into the x planes of chunk `chunk` at element offset `off` of a (chunk, plane) image
+// of `oplane` elements: three bf16 planes, or (h2) two fp16 planes of 8 v — 8 B per plane
+__device__ __forceinline__ void store_xplanes4(const f32x4& v, int h2, unsigned short* __restrict__ xp, long chunk, long oplane,
+                                               long off) {
+    if (h2) {
+        unsigned h[2], l[2];
+        split2h(v[0], v[1], XH_SCALE_X, h[0], l[0]);
+        split2h(v[2], v[3], XH_SCALE_X, h[1], l[1]);
+        unsigned short* d = xp + chunk * 2 * oplane + off;
+        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+        *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){l[0], l[1]};
+    } else {
+        unsigned h[2], m[2], l[2];
+        split3(v[0], v[1], h[0], m[0], l[0]);
+        split3(v[2], v[3], h[1], m[1], l[1]);
+        unsigned short* d = xp + chunk * 3 * oplane + off;
+        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+        *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
+        *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
+    }
+}
 // staging writers: one 32-row half (mt) of a wave's 64 x 64 accumulators -> S [32][EPI_LDW]
 struct StageAcc32 {          // 2 x 2 tiles of v_mfma_f32_32x32x16_bf16: lane = column, 16 registers = rows
     const f32x16 (&acc)[2][2];
@@ -436,6 +478,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
                 if (!rok || c4 >= g.Cout) continue;                  // host: Cout % 4 == 0
                 f32x4 dm4 = {1.f, 1.f, 1.f, 1.f}, bias4 = zero4();
                 if (g.demod) dm4 = *reinterpret_cast<const f32x4*>(g.demod + (long)b * g.Cout + c4);
+                dm4 *= g.acc_scale;
                 if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + c4);
                 f32x4 v;
 #pragma unroll
@@ -446,14 +489,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
                 *reinterpret_cast<f32x4*>(g.out + pix * g.Cout + c4) = v;
                 if (g.xp_out) {
                     if (g.s_next) v *= *reinterpret_cast<const f32x4*>(g.s_next + (long)b * g.Cout + c4);
-                    unsigned h[2], m[2], l[2];
-                    split3(v[0], v[1], h[0], m[0], l[0]);
-                    split3(v[2], v[3], h[1], m[1], l[1]);
                     const long ppix = ((long)b * (g.outH + 2) + y + 1) * (g.outW + 2) + x + 1;
-                    unsigned short* d = g.xp_out + ((long)(c4 >> 4) * 3) * oplane + ppix * 16 + (c4 & 15);
-                    *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
-                    *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
-                    *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
+                    store_xplanes4(v, g.h2, g.xp_out, (long)(c4 >> 4), oplane, ppix * 16 + (c4 & 15));
                 }
             }
         }
@@ -502,12 +539,13 @@ __device__ __forceinline__ void xp16_mfma_ktile(const char* As, const char* Bs, 
 // four waves stacked along M — instead of 128 x 128 with the two right-hand waves multiplying padding.  The A image of a
 // k-tile then has 256 rows (two DMA instructions per plane and thread: rows tid & 127 and + 128), the B image is the same
 // 128-row weight block (its upper 64 rows are the Cout padding, never read).
-template <int NT, bool M16, bool TALL, class ACC>
+template <int NT, bool M16, bool TALL, bool H2, class ACC>
 __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSub& sb, char* lds, ACC& acc,
                                                  unsigned pixbyte, unsigned pixbyte2, int n0, int tid, int wr, int wc, int lane) {
+    constexpr int NPL = H2 ? 2 : 3;                                  // planes per operand
     constexpr int APL = TALL ? 8192 : 4096;                          // bytes of one A plane of a k-tile
-    constexpr int BOFF = 3 * APL;                                    // the B planes follow the A planes
-    constexpr int STAGE = BOFF + 12288;
+    constexpr int BOFF = NPL * APL;                                  // the B planes follow the A planes
+    constexpr int STAGE = BOFF + NPL * 4096;
     const int ncc = g.wtp_ncc;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(reinterpret_cast<const float*>(g.wtp), g.wtp_bytes);
@@ -518,7 +556,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         tapoff[t] = (sb.dy[t] * IWp + sb.dx[t]) * 32;
-        wblk[t] = (unsigned)(((sb.tw[t] * wp_ntn + (n0 >> 7)) * ncc) * 3) * 4096u;
+        wblk[t] = (unsigned)(((sb.tw[t] * wp_ntn + (n0 >> 7)) * ncc) * NPL) * 4096u;
     }
     // this thread's 16 bytes of a pre-split weight plane (stored in the half-swap layout): linear for the 32x32 image,
     // (row tid & 127, half tid >> 7) for the half-major image
@@ -531,11 +569,11 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
     auto issue = [&](int cc, int to, unsigned wb, char* dst, bool with_a = true) {
         const unsigned va = pixbyte + (unsigned)to;                  // signed add: the padded pixel is never negative
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #ifdef XP_ABL_A2
             if (!with_a) break;
 #endif
-            const char* base = xp + (long)(cc * 3 + p) * (long)g.xp_plane_bytes;
+            const char* base = xp + (long)(cc * NPL + p) * (long)g.xp_plane_bytes;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)g.xp_plane_bytes, 0x00020000);
             if constexpr (TALL) {
@@ -546,12 +584,12 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)va, 0, 0, 0);
             }
         }
-        const unsigned blk = wb + (unsigned)cc * 3u * 4096u;
+        const unsigned blk = wb + (unsigned)cc * (unsigned)NPL * 4096u;
 #ifdef XP_ABL_B2
         if (!with_a) return;
 #endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (lds_ptr_t)(dst + BOFF + p * 4096 + wid * 1024), 16,
                                                      (int)wlane, (int)(blk + p * 4096u), 0, 0);
     };
@@ -575,17 +613,22 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
                 issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
                       lds + (buf ^ 1) * STAGE, NT < 9 || wrap || tap < 1 || (tap + 1) % 3 == 0);
             if constexpr (M16) xp16_mfma_ktile<TALL ? 256 : 128>(As, As + BOFF, acc, wr, wc, lane);
+            else if constexpr (H2) xh_mfma_tile<2, 2, 128, 128>(As, As + BOFF, acc, wr * 64, wc * 64, lane);
             else x6_mfma_ktile<true, true>(As, As + BOFF, acc, wr, wc, lane);
             buf ^= 1;
         }
     }
 }
 
-template <bool M16, bool TALL = false>
+template <bool M16, bool TALL = false, bool H2 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g) {
     static_assert(!TALL || M16, "the tall tile exists in the 16x16x32 product form only");
+    static_assert(!H2 || !M16, "the two-plane fp16 engine uses the 32x32x16 products");
     constexpr int TBM = TALL ? 2 * BM : BM;                          // pixels per tile
-    __shared__ __attribute__((aligned(16))) char lds_raw[2 * (XP_STAGE_BYTES + (TALL ? 12288 : 0))];
+    // two stages of (A planes + B planes); never less than the epilogue's 4 x 32 x EPI_LDW floats
+    constexpr int LDS_MAIN = 2 * ((H2 ? 2 : 3) * ((TALL ? 8192 : 4096) + 4096));
+    constexpr int LDS_EPI = 4 * 32 * EPI_LDW * 4;
+    __shared__ __attribute__((aligned(16))) char lds_raw[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = TALL ? wid : (wid >> 1), wc = TALL ? 0 : (wid & 1);
     int si = 0;
 #pragma unroll
@@ -618,10 +661,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
         switch (sb.ntaps) {
-            case 9: conv_mainloop_xp<9, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
-            case 4: conv_mainloop_xp<4, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
-            case 2: conv_mainloop_xp<2, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
-            default: conv_mainloop_xp<1, true, TALL>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 9: conv_mainloop_xp<9, true, TALL, false>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, true, TALL, false>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, true, TALL, false>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, true, TALL, false>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
         }
         __syncthreads();                                             // every wave has read its last fragments
         conv_epilogue_lds(g, sb, StageAcc16{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
@@ -629,10 +672,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
         f32x16 acc[2][2];
         zero_acc(acc);
         switch (sb.ntaps) {
-            case 9: conv_mainloop_xp<9, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            case 4: conv_mainloop_xp<4, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            case 2: conv_mainloop_xp<2, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            default: conv_mainloop_xp<1, false, false>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 9: conv_mainloop_xp<9, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
         }
         if ((g.Cout & 3) == 0) {                                     // epilogue through LDS (+ the next layer's planes)
             __syncthreads();                                         // every wave has read its last fragments
@@ -647,7 +690,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
 // pixel (float4 load, 8 B per plane); the channel padding up to ncc*16 is written as zeros, the spatial border is not
 // touched (the host zeroes the buffer once).
 __global__ void modsplit_kernel(const float* __restrict__ x, const float* __restrict__ s, int B, int H, int W, int Cin,
-                                int ncc, unsigned short* __restrict__ xp) {
+                                int ncc, int h2, unsigned short* __restrict__ xp) {
     const int q4 = ncc * 4;
     const long total = (long)B * H * W * q4;
     const long plane = (long)B * (H + 2) * (W + 2) * 16;            // bf16 elements of one (chunk, plane) image
@@ -667,14 +710,8 @@ __global__ void modsplit_kernel(const float* __restrict__ x, const float* __rest
                 for (int e = 0; e < 4 && c + e < Cin; ++e) v[e] = x[src + e] * (s ? s[(long)b * Cin + c + e] : 1.f);
             }
         }
-        unsigned h[2], m[2], l[2];
-        split3(v[0], v[1], h[0], m[0], l[0]);
-        split3(v[2], v[3], h[1], m[1], l[1]);
         const long ppix = ((long)b * (H + 2) + y + 1) * (W + 2) + xx + 1;
-        unsigned short* d = xp + ((long)(c >> 4) * 3) * plane + ppix * 16 + (c & 15);
-        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
-        *reinterpret_cast<u32x2*>(d + plane) = (u32x2){m[0], m[1]};
-        *reinterpret_cast<u32x2*>(d + 2 * plane) = (u32x2){l[0], l[1]};
+        store_xplanes4(v, h2, xp, (long)(c >> 4), plane, ppix * 16 + (c & 15));
     }
 }
 
@@ -716,7 +753,8 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
 // w = h + m + l exactly) of that weight tile, each plane already in the LDS image layout (32-B rows with
 // the half-swap swizzle).  A workgroup copies a block linearly: thread t moves bytes [16 t, 16 t + 16) of each plane.
 __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps, int Cout, int Cin, long ld, int ntn,
-                                          int ncc, unsigned short* __restrict__ planes) {
+                                          int ncc, int h2, unsigned short* __restrict__ planes) {
+    // h2: two fp16 planes of 16 w per block (8 KB blocks) for the f16x3 conv engine
     const long total = (long)taps * ntn * ncc * 128 * 16;          // padded element count
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
@@ -725,10 +763,18 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
         const int tn = (int)(blk % ntn); const int tap = (int)(blk / ntn);
         const int co = tn * 128 + row, ci = cc * 16 + k;
         const float x = (co < Cout && ci < Cin) ? wt[((long)tap * Cout + co) * ld + ci] : 0.f;
+        const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
+        if (h2) {
+            unsigned h, l;
+            split2h(x, 0.f, XH_SCALE_W, h, l);
+            unsigned short* base = planes + ((((long)tap * ntn + tn) * ncc + cc) * 2) * 2048;
+            base[off] = (unsigned short)(h & 0xffffu);
+            base[2048 + off] = (unsigned short)(l & 0xffffu);
+            continue;
+        }
         unsigned h, m, l;
         split3(x, 0.f, h, m, l);
         unsigned short* base = planes + ((((long)tap * ntn + tn) * ncc + cc) * 3) * 2048;      // 2048 bf16 per plane
-        const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
         base[off] = (unsigned short)(h & 0xffffu);
         base[2048 + off] = (unsigned short)(m & 0xffffu);
         base[4096 + off] = (unsigned short)(l & 0xffffu);
@@ -803,7 +849,7 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
                                 const float* __restrict__ demod, const float* __restrict__ noise, long noise_bstride,
                                 const float* __restrict__ noise_w, const float* __restrict__ bias, int act,
                                 float* __restrict__ out, int OH, int OW, const float* __restrict__ s_next,
-                                unsigned short* __restrict__ xp_out) {
+                                unsigned short* __restrict__ xp_out, int h2) {
     // s_next / xp_out (optional): also write the NEXT conv's modulated input out * s_next as x planes (modconv_xp_kernel)
     const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
     const int c4n = C >> 2;
@@ -884,14 +930,8 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
                     *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;
                     if (xp_out) {
                         ov *= sn4;
-                        unsigned h[2], m[2], l[2];
-                        split3(ov[0], ov[1], h[0], m[0], l[0]);
-                        split3(ov[2], ov[3], h[1], m[1], l[1]);
                         const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + x + 1;
-                        unsigned short* d = xp_out + ((long)(c >> 4) * 3) * oplane + ppix * 16 + (c & 15);
-                        *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
-                        *reinterpret_cast<u32x2*>(d + oplane) = (u32x2){m[0], m[1]};
-                        *reinterpret_cast<u32x2*>(d + 2 * oplane) = (u32x2){l[0], l[1]};
+                        store_xplanes4(ov, h2, xp_out, (long)(c >> 4), oplane, ppix * 16 + (c & 15));
                     }
                 }
                 acc[(j + 1) & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -908,13 +948,15 @@ __global__ void blur_act_kernel(const float* __restrict__ T, int B, int TH, int 
 #ifndef BLUR_MINB
 #define BLUR_MINB 1      // lab: workgroups per CU the register allocation is held to (tools/lab/blur_lb.sh)
 #endif
-template <int ROWS>      // output rows per strip: 32 on the large layers (vertical halo 35 / 32 instead of 19 / 16), 16 on the small
+// H2: the planes are the two fp16 planes of the f16x3 conv engine ([4 chunks][2 planes] = 8 runs: one 16-B store per thread)
+template <int ROWS, bool H2>   // output rows per strip: 32 on the large layers (vertical halo 35 / 32 instead of 19 / 16), 16 on the small
 __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
                                                           const float* __restrict__ kf, const float* __restrict__ demod,
                                                           const float* __restrict__ noise, long noise_bstride,
                                                           const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                           int act, float* __restrict__ out, int OH, int OW,
                                                           const float* __restrict__ s_next, unsigned short* __restrict__ xp_out) {
+    constexpr int NPL = H2 ? 2 : 3;
     __shared__ __attribute__((aligned(16))) char stage[2][12 * 512];
     const long oplane = (long)B * (OH + 2) * (OW + 2) * 16;
     const int nseg = (OH + ROWS - 1) / ROWS, nxb = OW >> 4, ncg = C >> 6;
@@ -978,23 +1020,17 @@ __global__ __launch_bounds__(256, BLUR_MINB) void blur_act_xp_kernel(const float
                     }
                     *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;
                     ov *= sn4;
-                    unsigned h[2], m[2], l[2];
-                    split3(ov[0], ov[1], h[0], m[0], l[0]);
-                    split3(ov[2], ov[3], h[1], m[1], l[1]);
-                    char* st = stage[par] + ((c4 >> 2) * 3 * 16 + px) * 32 + (c4 & 3) * 8;
-                    *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
-                    *reinterpret_cast<u32x2*>(st + 512) = (u32x2){m[0], m[1]};
-                    *reinterpret_cast<u32x2*>(st + 1024) = (u32x2){l[0], l[1]};
+                    stage_xplanes4<H2>(ov, stage[par] + ((c4 >> 2) * NPL * 16 + px) * 32 + (c4 & 3) * 8);
                     __syncthreads();
-                    // 12 runs (chunk, plane) of 512 B = 384 16-B units
+                    // 4 NPL runs (chunk, plane) of 512 B = 384 (256) 16-B units
                     const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + xb * 16 + 1;
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
+                    for (int it = 0; it < (H2 ? 1 : 2); ++it) {
                         const int u = it * 256 + tid;
-                        if (u < 384) {
-                            const int run = u >> 5, chunk = run / 3, plane = run - chunk * 3;
+                        if (u < NPL * 128) {
+                            const int run = u >> 5, chunk = run / NPL, plane = run - chunk * NPL;
                             const u32x4 d = *reinterpret_cast<const u32x4*>(stage[par] + u * 16);
-                            unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * 3 + plane) * oplane + ppix * 16 + (u & 31) * 8;
+                            unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * NPL + plane) * oplane + ppix * 16 + (u & 31) * 8;
                             *reinterpret_cast<u32x4*>(dst) = d;
                         }
                     }
@@ -1037,13 +1073,15 @@ __device__ __forceinline__ void bd_wait_vm(int n) {            // s_waitcnt take
 }
 __device__ __forceinline__ void bd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int ROWS>
+template <int ROWS, bool H2>
 __global__ __launch_bounds__(256, 3) void blur_act_dma_kernel(const float* __restrict__ T, int B, int TH, int TW, int C,
                                                               const float* __restrict__ kf, const float* __restrict__ demod,
                                                               const float* __restrict__ noise, long noise_bstride,
                                                               const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                               int act, float* __restrict__ out, int OH, int OW,
                                                               const float* __restrict__ s_next, unsigned short* __restrict__ xp_out) {
+    constexpr int NPL = H2 ? 2 : 3;                   // planes per chunk
+    constexpr int NST = H2 ? 2 : 3;                   // stores per wave and output row: the fp32 row + 1 (2) of plane units
     __shared__ __attribute__((aligned(16))) char ring[BD_RING * BD_ROWB];
     __shared__ __attribute__((aligned(16))) char stage[2][12 * 512];
     __shared__ float nzs[ROWS * 16];
@@ -1113,7 +1151,7 @@ __global__ __launch_bounds__(256, 3) void blur_act_dma_kernel(const float* __res
                 {
                     const int later = min(BD_AHEAD, NIT - 1 - r);                 // rows r + 1 .. issued after row r
                     const int outs = min(BD_AHEAD, max(0, r - 3));              // iterations r - 5 .. r - 1 that stored
-                    bd_wait_vm(2 * later + 3 * outs);
+                    bd_wait_vm(2 * later + NST * outs);
                 }
                 bd_barrier();
                 f32x4 v[4];
@@ -1141,22 +1179,17 @@ __global__ __launch_bounds__(256, 3) void blur_act_dma_kernel(const float* __res
                     }
                     *reinterpret_cast<f32x4*>(out + (((long)b * OH + y) * OW + x) * C + c) = ov;          // store 1
                     ov *= sn4;
-                    unsigned h[2], m[2], l[2];
-                    split3(ov[0], ov[1], h[0], m[0], l[0]);
-                    split3(ov[2], ov[3], h[1], m[1], l[1]);
-                    char* st = stage[par] + ((c4 >> 2) * 3 * 16 + px) * 32 + (c4 & 3) * 8;
-                    *reinterpret_cast<u32x2*>(st) = (u32x2){h[0], h[1]};
-                    *reinterpret_cast<u32x2*>(st + 512) = (u32x2){m[0], m[1]};
-                    *reinterpret_cast<u32x2*>(st + 1024) = (u32x2){l[0], l[1]};
+                    stage_xplanes4<H2>(ov, stage[par] + ((c4 >> 2) * NPL * 16 + px) * 32 + (c4 & 3) * 8);
                     bd_barrier();
-                    // 12 runs (chunk, plane) of 512 B = 384 16-B units: this wave's 96 — lanes 0 .. 63, then 0 .. 31 (stores 2, 3)
+                    // 12 runs (chunk, plane) of 512 B = 384 16-B units: this wave's 96 — lanes 0 .. 63, then 0 .. 31 (stores 2, 3);
+                    // two fp16 planes: 8 runs = 256 units, this wave's 64 (store 2)
                     const long ppix = ((long)b * (OH + 2) + y + 1) * (OW + 2) + xb * 16 + 1;
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int u = wid * 96 + it * 64 + (it ? (lane & 31) : lane);
-                        const int run = u >> 5, chunk = run / 3, plane = run - chunk * 3;
+                    for (int it = 0; it < NST - 1; ++it) {
+                        const int u = H2 ? wid * 64 + lane : wid * 96 + it * 64 + (it ? (lane & 31) : lane);
+                        const int run = u >> 5, chunk = run / NPL, plane = run - chunk * NPL;
                         const u32x4 d = *reinterpret_cast<const u32x4*>(stage[par] + u * 16);
-                        unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * 3 + plane) * oplane + ppix * 16 + (u & 31) * 8;
+                        unsigned short* dst = xp_out + ((long)(cg * 4 + chunk) * NPL + plane) * oplane + ppix * 16 + (u & 31) * 8;
                         if (it == 0 || lane < 32) *reinterpret_cast<u32x4*>(dst) = d;
                     }
                     par ^= 1;
@@ -1484,6 +1517,19 @@ static int conv_pick_splits(long max_m, int Cout, int nsub_tiles_total, int min_
     return s < 1 ? 1 : s;
 }
 
+// Plane format of the x-planes conv path: 0 = three bf16 planes, six products (bf16x6); 1 = two fp16 planes, three products
+// (f16x3, gx_mfma_x6.h).  Read at launch time by the producers (gx_split_conv_weights, gx_modsplit, the conv / blur epilogues
+// that write the next conv's planes) and by the conv: planes made under one format must be consumed under the same.
+#define GX_DEFAULT_CONV_PLANES 1
+static int g_conv_planes = -1;
+static int conv_planes() {
+    if (g_conv_planes < 0) {
+        const char* e = getenv("GX_CONV_PLANES");
+        g_conv_planes = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : GX_DEFAULT_CONV_PLANES;
+    }
+    return g_conv_planes;
+}
+
 static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t stream) {
     int wtaps = 1;
     for (int i = 0; i < g.nsub; ++i)
@@ -1500,9 +1546,13 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
     g.style_bytes = (unsigned)((size_t)g.B * g.Cin * 4);
     g.tiles_n = gx_cdiv(g.Cout, BN);
     const bool x6 = gx_get_gemm_mode() == 1;
+    const bool h2 = x6 && conv_planes() == 1;
+    g.h2 = (h2 && g.xp) ? 1 : 0;
+    g.acc_scale = g.h2 ? XH_UNSCALE : 1.f;
+    if (h2 && !g.xp) g.wtp = nullptr;      // the kernels that split x in flight (bf16x6) cannot read fp16 weight planes: they split w too
     int base = 0, min_kt = 1 << 30;
     // narrow layers on the x-planes path: 256-pixel x 64-channel tiles (modconv_xp_kernel<true, true>)
-    const bool tall = g.xp && x6 && (g.Cout & 3) == 0 && g.Cout <= 64;
+    const bool tall = g.xp && x6 && !h2 && (g.Cout & 3) == 0 && g.Cout <= 64;
     for (int i = 0; i < g.nsub; ++i) {
         g.sub[i].tile_base = base;
         g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, tall ? 2 * BM : BM);
@@ -1527,7 +1577,8 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         // MFMA shape of the six products: 16x16x32 (plane pairs along K) where Cout allows its epilogue, else 32x32x16.  Equal
         // pipe cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
         // 243-246 -> 256-260 TFLOP/s, same-process A/B (round 2, tools/bench_conv_xp.py)
-        if (tall) hipLaunchKernelGGL((modconv_xp_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        if (h2) hipLaunchKernelGGL((modconv_xp_kernel<false, false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        else if (tall) hipLaunchKernelGGL((modconv_xp_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
         else if ((g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
         else hipLaunchKernelGGL(modconv_xp_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
         GX_CHECK_LAUNCH();
@@ -1574,7 +1625,7 @@ int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned
     const long total = (long)taps * ntn * ncc * 2048;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       wt, taps, Cout, Cin, (long)Cin, ntn, ncc, planes);
+                       wt, taps, Cout, Cin, (long)Cin, ntn, ncc, (gx_get_gemm_mode() == 1 && conv_planes() == 1) ? 1 : 0, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1586,7 +1637,7 @@ int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short
     const long total = (long)ntn * ncc * 2048;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       B, 1, N, K, ldb, ntn, ncc, planes);
+                       B, 1, N, K, ldb, ntn, ncc, 0, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1679,7 +1730,7 @@ int gx_modsplit(const float* x, int B, int H, int W, int Cin, const float* s, un
     const long total = (long)B * H * W * ncc * 4;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(modsplit_kernel, dim3((int)(want < 32768 ? want : 32768)), dim3(256), 0, (hipStream_t)stream, x, s, B,
-                       H, W, Cin, ncc, planes);
+                       H, W, Cin, ncc, (gx_get_gemm_mode() == 1 && conv_planes() == 1) ? 1 : 0, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1743,6 +1794,12 @@ size_t gx_modconv_up_scratch_bytes(int B, int H, int W, int Cout) {
 }
 // Stage 2 of an upsampling StyledConv: blur (pad (1,1)) of the (TH x TW) transposed-conv image +
 // demod + noise + bias + act -> out [B][TH-1][TW-1][C]   (upfirdn2d mode 1 + fused_bias_act).
+int gx_set_conv_planes(int fmt) {
+    const int prev = gx::conv_planes();
+    if (fmt == 0 || fmt == 1) gx::g_conv_planes = fmt;
+    return prev;
+}
+int gx_get_conv_planes(void) { return gx::conv_planes(); }
 static int g_blur_dma = 1;
 int gx_set_blur_dma(int on) { const int prev = g_blur_dma; g_blur_dma = on ? 1 : 0; return prev; }
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
@@ -1751,12 +1808,22 @@ int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* k
     return gx_blur_act_fwd_xp(T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, nullptr, nullptr,
                               stream);
 }
+// one of the strip kernels in the plane format of the moment (h2: two fp16 planes)
+#define GX_BLUR_LAUNCH(KERNEL, ROWS_, NBLK)                                                                                  \
+    do {                                                                                                                     \
+        const dim3 grid_((int)((NBLK) < 65536 ? (NBLK) : 65536));                                                            \
+        if (h2) hipLaunchKernelGGL((KERNEL<ROWS_, true>), grid_, dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod, noise, \
+                                   noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);                      \
+        else hipLaunchKernelGGL((KERNEL<ROWS_, false>), grid_, dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod, noise,  \
+                                noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);                         \
+    } while (0)
 // ... and, optionally, the x planes of out * s_next for the next conv (planes_out: gx_xplanes_bytes(B, TH-1, TW-1, C))
 int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,
                        const float* noise, long noise_bstride, const float* noise_w, const float* bias, int act,
                        float* out, const float* s_next, unsigned short* planes_out, void* stream) {
     if (!T || !kf || !out || B <= 0 || TH < 2 || TW < 2 || C <= 0 || (C & 3)) return GX_ERR_BAD_ARG;
     const int OH = TH - 1, OW = TW - 1;
+    const bool h2 = gx_get_gemm_mode() == 1 && conv_planes() == 1;               // format of planes_out
     long total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * OW * (C >> 2);
     if (planes_out && (C & 15) == 0) total = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * ((OW + 15) / 16) * (C >> 4) * 64;
     long want = (total + 255) / 256;
@@ -1769,23 +1836,20 @@ int gx_blur_act_fwd_xp(const float* T, int B, int TH, int TW, int C, const float
         if (OH >= 64 && nblk32 >= 2048) {
             const size_t rowb = (size_t)TW * C * 4;
             if (g_blur_dma && rowb < 0x7FFFFFF0ull && OH % BD_ROWS == 0)   // T rows by LDS-DMA, several ahead (gx_set_blur_dma(0): the register form)
-                hipLaunchKernelGGL(blur_act_dma_kernel<BD_ROWS>, dim3((int)(nblk32 * 32 / BD_ROWS < 65536 ? nblk32 * 32 / BD_ROWS : 65536)), dim3(256), 0, (hipStream_t)stream,
-                                   T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+                GX_BLUR_LAUNCH(blur_act_dma_kernel, BD_ROWS, nblk32 * 32 / BD_ROWS);
             else
-                hipLaunchKernelGGL(blur_act_xp_kernel<32>, dim3((int)(nblk32 < 65536 ? nblk32 : 65536)), dim3(256), 0, (hipStream_t)stream,
-                                   T, B, TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+                GX_BLUR_LAUNCH(blur_act_xp_kernel, 32, nblk32);
             GX_CHECK_LAUNCH();
             return GX_OK;
         }
         const long nblk = (long)B * ((OH + BLUR_ROWS - 1) / BLUR_ROWS) * (OW >> 4) * (C >> 6);
-        hipLaunchKernelGGL(blur_act_xp_kernel<BLUR_ROWS>, dim3((int)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, (hipStream_t)stream, T, B,
-                           TH, TW, C, kf, demod, noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+        GX_BLUR_LAUNCH(blur_act_xp_kernel, BLUR_ROWS, nblk);
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
     const int nb = (int)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(blur_act_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, B, TH, TW, C, kf, demod,
-                       noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out);
+                       noise, noise_bstride, noise_w, bias, act, out, OH, OW, s_next, planes_out, h2 ? 1 : 0);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -189,6 +189,51 @@ __device__ __forceinline__ void x6_mfma_tile(const char* __restrict__ As, const 
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][TA[t]], b[nt][TB[t]], acc[mt][nt], 0, 0, 0);
 }
+// ---- "f16x3": fp32 contractions as THREE fp16 products (the conv engine of round 5; tools/lab/mfma_f16x3.hip) ------------
+//     s x = x_h + x_l + O(2^-23 |s x|)        two fp16 planes of the SCALED element (11 + 11 significant bits; below the fp16
+//                                             normal range x_l keeps an absolute 2^-25: the matrix cores do not flush fp16
+//                                             subnormals, measured)
+//     a b = (a_h b_h + a_h b_l + a_l b_h) / (s_a s_b) + the dropped a_l b_l: <= 2^-22 |a b|, ~ 2^-25 in the mean
+// Measured against fp64 beside bf16x6 and an fp32 fma chain (K = 512 / 4608, N(0,1) x N(0, 0.02 .. 30), heavy tails): the
+// same 3e-7 / 7e-7 norm-wise — while the matrix cores do HALF the work and each operand is 4 B, not 6, in HBM and LDS.
+// The price is RANGE: |s x| must stay below 65504 (fp16 max), and elements below 2^-14 / s lose relative (not absolute)
+// precision.  The scales are powers of two, fixed per operand kind (activations x 8: |x| < 8188; weights x 16), and leave the
+// accumulator exactly in the epilogue; an element out of range becomes inf - inf = NaN in its low plane — loud, not wrong.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float XH_SCALE_X = 8.f, XH_SCALE_W = 16.f, XH_UNSCALE = 1.f / (XH_SCALE_X * XH_SCALE_W);
+// (x0, x1) * scale -> packed fp16 pairs h, l (element 0 in the low half); the remainder is exact in fp32
+__device__ __forceinline__ void split2h(float x0, float x1, float scale, unsigned& h, unsigned& l) {
+    const f32x2 v = {x0 * scale, x1 * scale};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);                 // v_cvt_f16_f32: round to nearest even
+    h = __builtin_bit_cast(unsigned, hh);
+    const f32x2 r = v - __builtin_convertvector(hh, f32x2);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+// One 16-deep k-tile of the two-plane images (plane 0 = h, 1 = l; the KC layout of the bf16 images), smallest terms first
+template <int MT, int NT, int RA, int RB>
+__device__ __forceinline__ void xh_mfma_tile(const char* __restrict__ As, const char* __restrict__ Bs, f32x16 (&acc)[MT][NT],
+                                             int a_row0, int b_row0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    f16x8 a[MT][2], b[NT][2];
+    constexpr int PA[2] = {1, 0}, PB[2] = {0, 1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t][PA[q]] = __builtin_bit_cast(f16x8, x6_frag<true, RA>(As, PA[q], a_row0 + t * 32 + r, h));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t][PB[q]] = __builtin_bit_cast(f16x8, x6_frag<true, RB>(Bs, PB[q], b_row0 + t * 32 + r, h));
+    }
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                  // l*h, h*l, h*h
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][TA[t]], b[nt][TB[t]], acc[mt][nt], 0, 0, 0);
+}
+
 template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void x6_mfma_ktile(const char* __restrict__ As, const char* __restrict__ Bs,
                                               f32x16 (&acc)[2][2], int wr, int wc, int lane) {

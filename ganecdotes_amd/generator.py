@@ -199,9 +199,10 @@ class Generator(nn.Module):
         """Weight re-layouts for the kernels, computed once (the generator is frozen on this
         path): conv weights tap-major [k*k][Cout][Cin], sum-of-squares for demodulation,
         flipped FIR kernels, the NHWC constant input."""
-        if self._derived is not None:
+        fmt = (ops.get_gemm_mode(), ops.get_conv_planes()) if self.input.input.is_cuda else None
+        if self._derived is not None and self._derived["plane_format"] == fmt:
             return self._derived
-        d = {}
+        d = {"plane_format": fmt}          # the frozen weight planes below are in the conv engine's format of the moment
 
         def conv(m, key):
             w = m.conv.weight.detach()[0]                                  # (Cout, Cin, k, k)

@@ -82,6 +82,17 @@ def get_gemm_mode():
     return lib().gx_get_gemm_mode()
 
 
+def set_conv_planes(fmt):
+    """Plane format of the x-planes conv path (engine 1): 0 = three bf16 planes / six products (bf16x6), 1 = two fp16 planes /
+    three products (f16x3).  Frozen weight planes are re-made when the format changes (Generator._prepare).  Returns the
+    previous format."""
+    return lib().gx_set_conv_planes(int(fmt))
+
+
+def get_conv_planes():
+    return lib().gx_get_conv_planes()
+
+
 def _chk2d(*ts):
     """2-D fp32 HIP tensors with unit inner stride (row-strided views such as W[:, a:b] are fine)."""
     for t in ts:

@@ -69,6 +69,15 @@ const char* gx_version(void);
  * gx_set_gemm_mode returns the previous mode; env GX_GEMM_MODE=0|1 sets the initial one. */
 int gx_set_gemm_mode(int mode);
 int gx_get_gemm_mode(void);
+/* Plane format of the x-planes conv path under engine 1 (read at launch time by the producers of planes — gx_split_conv_weights,
+ * gx_modsplit, the conv / blur passes that write the next conv's planes — and by the convs that read them; planes made under
+ * one format must be consumed under the same): 0 = three bf16 planes, six products per fp32 product ("bf16x6"); 1 = two fp16
+ * planes of the element scaled by a power of two, three products ("f16x3": fp32-class error measured against fp64, half the
+ * matrix-core work; needs |x * style| < 8188 and |w| < 4094, an element out of range comes out NaN).  Buffer sizes
+ * (gx_xplanes_bytes, gx_conv_weight_planes_bytes) are the three-plane ones under either format.  Returns the previous
+ * format; env GX_CONV_PLANES=0|1 sets the initial one (default 1). */
+int gx_set_conv_planes(int fmt);
+int gx_get_conv_planes(void);
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k);
 int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                 float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
