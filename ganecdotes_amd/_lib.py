@@ -53,12 +53,13 @@ SIGNATURES = {
     "gx_gemm_f32_tn_cat": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_i, c_p, c_sz, c_p]),
     "gx_gemm_weight_planes_bytes": (c_sz, [c_i, c_i]),
     "gx_split_gemm_weights": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
+    "gx_split_gemm_weights_h2": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
-                                    c_p, c_f, c_p]),
+                                    c_p, c_f, c_f, c_p]),
     "gx_sinkhorn_first_from_parts_workspace_bytes": (c_sz, [c_i, c_i]),
     "gx_sinkhorn_first_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_first_preset": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p]),
-    "gx_gemm_f32_nt_planes_mlive": (c_i, [c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
+    "gx_gemm_f32_nt_planes_mlive": (c_i, [c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_f, c_p]),
     "gx_gemm_f32_klive": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
                                 c_p]),
     "gx_gemm_finish_ok": (c_i, [c_i, c_i, c_i, c_i]),

@@ -748,13 +748,27 @@ __global__ void demod_kernel(const float* __restrict__ s, const float* __restric
     if (lane == 0) demod[idx] = scale * rsqrtf(scale * scale * a + 1e-8f);
 }
 
+// max |x| over an [N][K] matrix (row stride ld) into *out as float bits (non-negative floats order like unsigned integers;
+// *out zeroed by the caller): the per-tensor scale of the f16x3 weight planes
+__global__ void absmax_kernel(const float* __restrict__ x, int N, int K, long ld, unsigned* __restrict__ out) {
+    __shared__ float red[16];
+    const long n = (long)N * K;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[(i / K) * ld + (i % K)]));
+    m = gx_block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // Pre-split conv weights for the bf16x6 engine, stored in the order the kernel consumes them: for every
 // (tap, 128-row Cout tile, 16-channel chunk) one 12 KB block = the three bf16 planes (h, m, l with
 // w = h + m + l exactly) of that weight tile, each plane already in the LDS image layout (32-B rows with
 // the half-swap swizzle).  A workgroup copies a block linearly: thread t moves bytes [16 t, 16 t + 16) of each plane.
 __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps, int Cout, int Cin, long ld, int ntn,
-                                          int ncc, int h2, unsigned short* __restrict__ planes) {
-    // h2: two fp16 planes of 16 w per block (8 KB blocks) for the f16x3 conv engine
+                                          int ncc, int h2, const float* __restrict__ amax, unsigned short* __restrict__ planes) {
+    // h2: two fp16 planes of scale * w per block (8 KB blocks) for the f16x3 forms; scale = 16 (conv weights) or, with `amax`
+    // (device: the maximum magnitude of wt), xh_scale_of(*amax) (gx_split_gemm_weights_h2)
+    const float wscale = amax ? xh_scale_of(*amax) : XH_SCALE_W;
     const long total = (long)taps * ntn * ncc * 128 * 16;          // padded element count
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i & 15), row = (int)((i >> 4) & 127);
@@ -766,7 +780,7 @@ __global__ void split_conv_weights_kernel(const float* __restrict__ wt, int taps
         const int off = (x_kc_off(row, k >> 3) >> 1) + (k & 7);
         if (h2) {
             unsigned h, l;
-            split2h(x, 0.f, XH_SCALE_W, h, l);
+            split2h(x, 0.f, wscale, h, l);
             unsigned short* base = planes + ((((long)tap * ntn + tn) * ncc + cc) * 2) * 2048;
             base[off] = (unsigned short)(h & 0xffffu);
             base[2048 + off] = (unsigned short)(l & 0xffffu);
@@ -1625,7 +1639,7 @@ int gx_split_conv_weights(const float* wt, int taps, int Cout, int Cin, unsigned
     const long total = (long)taps * ntn * ncc * 2048;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       wt, taps, Cout, Cin, (long)Cin, ntn, ncc, (gx_get_gemm_mode() == 1 && conv_planes() == 1) ? 1 : 0, planes);
+                       wt, taps, Cout, Cin, (long)Cin, ntn, ncc, (gx_get_gemm_mode() == 1 && conv_planes() == 1) ? 1 : 0, nullptr, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }
@@ -1637,7 +1651,27 @@ int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short
     const long total = (long)ntn * ncc * 2048;
     long want = (total + 255) / 256;
     hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       B, 1, N, K, ldb, ntn, ncc, 0, planes);
+                       B, 1, N, K, ldb, ntn, ncc, 0, nullptr, planes);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+// ... as the two fp16 planes of the f16x3 form: B scaled by the power of two that brings its largest magnitude to [2^13, 2^14)
+// (found here, on the device: one pass over B) and that magnitude left in the 16-byte trailer of `planes`, where
+// gx_gemm_f32_nt_planes(..., a_range > 0) reads it back.
+int gx_split_gemm_weights_h2(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream) {
+    if (!B || !planes || N <= 0 || K <= 0 || ldb < K) return GX_ERR_BAD_ARG;
+    const int ntn = gx_cdiv(N, 128), ncc = gx_cdiv(K, 16);
+    float* trailer = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (size_t)ntn * ncc * 3 * 4096);
+    if (hipMemsetAsync(trailer, 0, 16, (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
+    const long n = (long)N * K;
+    long wantm = (n + 1023) / 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((int)(wantm < 1024 ? wantm : 1024)), dim3(256), 0, (hipStream_t)stream, B, N, K, ldb,
+                       reinterpret_cast<unsigned*>(trailer));
+    GX_CHECK_LAUNCH();
+    const long total = (long)ntn * ncc * 2048;
+    long want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_conv_weights_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       B, 1, N, K, ldb, ntn, ncc, 1, trailer, planes);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

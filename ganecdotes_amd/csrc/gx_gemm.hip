@@ -54,6 +54,10 @@ struct GemmArgs {
     // it return at once), the k rows of a TN contraction (its k range is cut there).  The many-prototype tables hold the drawn
     // pixels first and their count is only known on the device: no host sync, the launch covers the capacity (DESIGN par. 4.15)
     const int* live;
+    // f16x3 form (gx_mfma_x6.h): the A elements are multiplied by a_scale (a power of two) before their two-plane fp16 split;
+    // the B planes are two fp16 planes of B * xh_scale_of(*b_amax) (the trailer gx_split_gemm_weights_h2 leaves behind the planes)
+    float a_scale; const float* b_amax;
+    float b_scale;        // x6ws: B's host-given power-of-two scale
 };
 
 // (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
@@ -531,13 +535,19 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
 // the kernel above (its threads split 8 A + 8 B elements), no plane stores, no staging registers, NS-deep prefetch.
 // Products and their order equal x6_mfma_tile's, so results are bitwise those of gemm_x6_kernel.
 //   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
-constexpr int XW_A = 8192, XW_B = 3 * 4096;                          // one A tile (raw fp32), one B tile (planes)
-template <bool USUM, bool FIN = false>   // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part); FIN: the
+// H2: the f16x3 form — B planes are two fp16 planes (8 KB per k-tile), a lane splits its 8 scaled A values into two fp16
+// vectors, three products; the accumulators are un-scaled once after the k loop.
+constexpr int XW_A = 8192;                                           // one A tile (raw fp32)
+template <bool USUM, bool FIN = false, bool H2 = false>   // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part); FIN: the
                                          // low-rank path's dense finish in the epilogue, rows in 2 x 64-pixel tiles (xw_epilogue_fin)
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
-    // A ring of NS tiles, B ring of 2; FIN: + the four waves' coefficient rows [32][ls <= 20], DMA'd in before the k loop
-    __shared__ __attribute__((aligned(16))) char lds[NS * XW_A + 2 * XW_B + (FIN ? 4 * 32 * 20 * 4 : 0)];
+    constexpr int NPL = H2 ? 2 : 3, XW_B = NPL * 4096;               // one B tile (planes)
+    // A ring of NS tiles, B ring of 2; FIN: + the four waves' coefficient rows [32][ls <= 20], DMA'd in before the k loop;
+    // never less than the epilogues' staging (4 waves x EP_STAGE_FLOATS)
+    constexpr int LDS_RING = NS * XW_A + 2 * XW_B, LDS_EPI = 4 * EP_STAGE_FLOATS * 4;
+    constexpr int CST_OFF = LDS_RING > LDS_EPI ? LDS_RING : LDS_EPI;  // the coefficient rows outlive the ring: past the staging too
+    __shared__ __attribute__((aligned(16))) char lds[CST_OFF + (FIN ? 4 * 32 * 20 * 4 : 0)];
     char* const ldsB = lds + NS * XW_A;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,12 +582,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.A2 ? g.A2 + pix0 * g.lda2 : g.A, 0x7FFFFFF0u);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(reinterpret_cast<const float*>(g.Bp), g.Bp_bytes);
     const unsigned boff = (unsigned)tid * 16u;
-    const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * 3u * 4096u;
+    const unsigned bblk0 = (unsigned)tn * (unsigned)nkt * (unsigned)NPL * 4096u;
 
     auto issue_b = [&](int kt, char* dst) {
-        const unsigned blk = bblk0 + (unsigned)kt * 3u * 4096u;
+        const unsigned blk = bblk0 + (unsigned)kt * (unsigned)NPL * 4096u;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + p * 4096 + wid * 1024), 16, (int)boff,
                                                      (int)(blk + p * 4096u), 0, 0);
     };
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     if (FIN) {      // the wave's 32 coefficient rows (2 image rows x 16 pixels = two runs of 16 * ls floats) -> LDS, 4 B per lane
         const int ls = g.fin_ls;
         const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(g.fin_C + (pix0 + wid * 16) * ls, 0x7FFFFFF0u);
-        char* const cdst = lds + NS * XW_A + 2 * XW_B + wid * (32 * 20 * 4);
+        char* const cdst = lds + CST_OFF + wid * (32 * 20 * 4);
         for (int dy = 0; dy < 2; ++dy)
             for (int i = 0; i < (ls >> 2); ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_ptr_t)(cdst + (dy * 16 * ls + i * 64) * 4), 4, lane * 4,
@@ -612,9 +622,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     const int arow = wid * 32 + r32;
     const int af = (arow >> 2) & 3;
     const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
+    const float a_scale = g.a_scale;
     auto compute = [&](const char* st, const char* Bs) {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
+        if constexpr (H2) {
+            f16x8 b[4][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t][q] = __builtin_bit_cast(f16x8, x6_frag<true, 128>(Bs, q, t * 32 + r32, hh));
+            unsigned h[4], l[4];
+            split2h(x0[0], x0[1], a_scale, h[0], l[0]);
+            split2h(x0[2], x0[3], a_scale, h[1], l[1]);
+            split2h(x1[0], x1[1], a_scale, h[2], l[2]);
+            split2h(x1[2], x1[3], a_scale, h[3], l[3]);
+            const f16x8 a[2] = {__builtin_bit_cast(f16x8, (u32x4){h[0], h[1], h[2], h[3]}),
+                                __builtin_bit_cast(f16x8, (u32x4){l[0], l[1], l[2], l[3]})};
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                      // l*h, h*l, h*h
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc0[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[0][TB[t]], acc0[0][0], 0, 0, 0);
+                acc0[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[1][TB[t]], acc0[0][1], 0, 0, 0);
+                acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[2][TB[t]], acc1[0][0], 0, 0, 0);
+                acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[3][TB[t]], acc1[0][1], 0, 0, 0);
+            }
+            return;
+        }
         bf16x8 b[4][3];
         constexpr int PB[3] = {0, 2, 1};
 #pragma unroll
@@ -659,11 +693,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
     __syncthreads();                                                 // every wave has read its last fragments
+    if constexpr (H2) {                                              // the scales leave: both are powers of two, the product is exact
+        const float un = 1.f / (a_scale * xh_scale_of(*g.b_amax));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[0][j][r] *= un; acc1[0][j][r] *= un; }
+    }
     float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
     if (FIN) {
         const GemmArgs& q = *gemm_late_args();
         const long pw = pix0 + wid * 16;
-        const float* cst = reinterpret_cast<const float*>(lds + NS * XW_A + 2 * XW_B) + wid * (32 * 20);
+        const float* cst = reinterpret_cast<const float*>(lds + CST_OFF) + wid * (32 * 20);
         {       // (both halves' Z rows in flight up front measured 4 % slower: 16 more live registers, spills)
             f32x4 z[8];
             xw_fin_load_z(q, g.N, pw + (lane >> 4), n0 + (lane & 15) * 4, z);
@@ -882,7 +923,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
                           float* usum_part = nullptr, float sk_eps = 0.f, const GemmArgs* fin = nullptr,
-                          const int* m_live = nullptr) {
+                          const int* m_live = nullptr, float a_range = 0.f) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -904,9 +945,13 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
     g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
-    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * 3 * 4096;
+    const bool h2 = a_range > 0.f;            // the planes are two fp16 planes + the amax trailer (gx_split_gemm_weights_h2)
+    const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h2 ? 2 : 3) * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
+    g.a_scale = h2 ? xh_scale_of(a_range) : 1.f;
+    g.b_scale = 1.f;
+    g.b_amax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + (size_t)g.tiles_n * (K >> 4) * 3 * 4096);
     {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
         const long per_tile = (long)K * 128 * 6;
         long gn = (2L << 20) / per_tile;
@@ -926,11 +971,14 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     if (fin) {
         g.fin_C = fin->fin_C; g.fin_Z = fin->fin_Z; g.fin_Wc = fin->fin_Wc; g.fin_pool = fin->fin_pool; g.fin_part = fin->fin_part;
         g.fin_K = fin->fin_K; g.fin_ls = fin->fin_ls; g.fin_rlog = fin->fin_rlog;
-        hipLaunchKernelGGL((gemm_xw_kernel<false, true>), grid, block, 0, stream, g);
+        if (h2) hipLaunchKernelGGL((gemm_xw_kernel<false, true, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((gemm_xw_kernel<false, true>), grid, block, 0, stream, g);
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
-    if (usum_part) hipLaunchKernelGGL(gemm_xw_kernel<true>, grid, block, 0, stream, g);
+    if (h2 && usum_part) hipLaunchKernelGGL((gemm_xw_kernel<true, false, true>), grid, block, 0, stream, g);
+    else if (h2) hipLaunchKernelGGL((gemm_xw_kernel<false, false, true>), grid, block, 0, stream, g);
+    else if (usum_part) hipLaunchKernelGGL(gemm_xw_kernel<true>, grid, block, 0, stream, g);
     else hipLaunchKernelGGL(gemm_xw_kernel<false>, grid, block, 0, stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
@@ -998,13 +1046,19 @@ int gx_gemm_f32_upadd(int transB, int M, int N, int K1, const float* A1, long ld
 // = NULL / col_bias = NULL switch the optional parts off.  colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N]
 // partial column maxima of C (rows past M: -inf) — max over its rows = the Sinkhorn column maxima, without a pass over C.  Results are bitwise those of gx_gemm_f32 / _cat / _upadd on
 // the bf16x6 engine.
-size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 3 * 4096; }
+// (+ 16 B: the trailer of the f16x3 form — max |B| as a float, written by gx_split_gemm_weights_h2)
+size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128) * gx_cdiv(K, 16) * 3 * 4096 + 16; }
+// a_range: 0 = b_planes are the three bf16 planes of gx_split_gemm_weights (bf16x6); > 0 = an upper bound of |A| (rounded up
+// to a power of two inside), b_planes the two fp16 planes of gx_split_gemm_weights_h2 (f16x3: half the matrix-core work).
+// An A element above a_range x 4 overflows fp16 and comes out NaN; every element carries an absolute error of a_range x 2^-38
+// (the fp16 subnormal step): the bound should sit within ~2^14 of A's RMS.
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, float* usum_part, float sk_eps, void* stream) {
+                          float* colmax_part, float* usum_part, float sk_eps, float a_range, void* stream) {
+    if (a_range < 0.f) return GX_ERR_BAD_ARG;
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps);
+                              fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps, nullptr, nullptr, a_range);
 }
 // The gradient of the level below the finest one of the low-rank prototype path (K <= 16, pyramid.backward_lowrank) in ONE
 // kernel: G = A B^T (A = Tt (M, K1) from gx_fineq_bwd, B = Wf as planes) and, in the epilogue, the dense finish
@@ -1038,10 +1092,11 @@ int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long ld
 // gx_gemm_f32_nt_planes (one A source, no coarse table, no column maxima) for an A whose rows carry data only below *m_live
 // (a device int): 128-row tiles at or past it are skipped and their rows of C left untouched.
 int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* C,
-                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, void* stream) {
-    if (!m_live) return GX_ERR_BAD_ARG;
+                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, float a_range,
+                                void* stream) {
+    if (!m_live || a_range < 0.f) return GX_ERR_BAD_ARG;
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, C, ldc, alpha, beta, nullptr, col_bias, nullptr, 0,
-                              nullptr, (hipStream_t)stream, nullptr, 0.f, nullptr, m_live);
+                              nullptr, (hipStream_t)stream, nullptr, 0.f, nullptr, m_live, a_range);
 }
 // bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
 size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }

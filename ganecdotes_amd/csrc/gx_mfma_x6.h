@@ -197,11 +197,27 @@ __device__ __forceinline__ void x6_mfma_tile(const char* __restrict__ As, const 
 // Measured against fp64 beside bf16x6 and an fp32 fma chain (K = 512 / 4608, N(0,1) x N(0, 0.02 .. 30), heavy tails): the
 // same 3e-7 / 7e-7 norm-wise — while the matrix cores do HALF the work and each operand is 4 B, not 6, in HBM and LDS.
 // The price is RANGE: |s x| must stay below 65504 (fp16 max), and elements below 2^-14 / s lose relative (not absolute)
-// precision.  The scales are powers of two, fixed per operand kind (activations x 8: |x| < 8188; weights x 16), and leave the
+// precision.  The scales are powers of two, fixed per operand kind (activations x 2: |x| < 32752, absolute floor 1.5e-8;
+// weights x 16: |w| < 4094), and leave the
 // accumulator exactly in the epilogue; an element out of range becomes inf - inf = NaN in its low plane — loud, not wrong.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float XH_SCALE_X = 8.f, XH_SCALE_W = 16.f, XH_UNSCALE = 1.f / (XH_SCALE_X * XH_SCALE_W);
+constexpr float XH_SCALE_X = 2.f, XH_SCALE_W = 16.f, XH_UNSCALE = 1.f / (XH_SCALE_X * XH_SCALE_W);
+// The power of two that brings a tensor of maximum magnitude `amax` to [2^13, 2^14): two binades below the fp16 maximum (a
+// bound that is exceeded by less than 4 x still converts); elements down to amax 2^-16 keep their full 22 bits, below that
+// the low plane is an fp16 subnormal: an absolute error of amax 2^-38.
+__host__ __device__ __forceinline__ float xh_scale_of(float amax) {
+    unsigned bits;
+    __builtin_memcpy(&bits, &amax, 4);
+    int be = (int)((bits >> 23) & 0xffu);                              // biased exponent (0: zero / subnormal -> no scaling)
+    if (be == 0 || be == 255) return 1.f;
+    int se = 267 - be;                                                  // 127 + 13 - (be - 127)
+    se = se > 254 ? 254 : (se < 1 ? 1 : se);
+    const unsigned sb = (unsigned)se << 23;
+    float sc;
+    __builtin_memcpy(&sc, &sb, 4);
+    return sc;
+}
 // (x0, x1) * scale -> packed fp16 pairs h, l (element 0 in the low half); the remainder is exact in fp32
 __device__ __forceinline__ void split2h(float x0, float x1, float scale, unsigned& h, unsigned& l) {
     const f32x2 v = {x0 * scale, x1 * scale};

@@ -5,6 +5,7 @@ computation below is a hand-written gfx950 kernel reached through ctypes.  No fu
 this module has a CPU or eager-PyTorch fallback.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -190,15 +191,45 @@ def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
     return out
 
 
-def split_gemm_weights(b):
-    """bf16x6 planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed; int16 buffer).
-    Made once per optimizer step: the projection / prototype weights only change there."""
+FEATURE_RANGE = 4096.0       # the a_range of generator taps: the x-planes convs' own contract (|x * style| < 32752, x 2 = scale 2)
+GEMM_H2 = os.environ.get("GX_GEMM_PLANES", "1") != "0"     # the f16x3 form of the weight-plane GEMMs where the caller knows |A|'s range
+
+
+class WeightPlanes:
+    """Planes of a weight operand (N, K) for gemm_nt_planes: .buf (int16), .h2 (False: three bf16 planes, bf16x6; True: two
+    fp16 planes scaled on the device + the max-|B| trailer, f16x3)"""
+    __slots__ = ("buf", "h2")
+
+    def __init__(self, buf, h2):
+        self.buf, self.h2 = buf, h2
+
+    def numel(self):
+        return self.buf.numel()
+
+
+def split_gemm_weights(b, h2=False):
+    """Planes of the weight operand b (N, K) of gemm_nt_planes (row-strided views allowed).  Made once per optimizer step: the
+    projection / prototype weights only change there.  h2: the f16x3 form (a call that passes a_range) — honoured only while
+    ops.GEMM_H2 (env GX_GEMM_PLANES=0 switches every such call back to bf16x6)."""
     _chk2d(b)
     n, k = b.shape
     L = lib()
+    h2 = bool(h2 and GEMM_H2)
     planes = torch.empty(L.gx_gemm_weight_planes_bytes(n, k) // 2, dtype=torch.int16, device=b.device)
-    _lib.check(L.gx_split_gemm_weights(_p(b), n, k, b.stride(0), _p(planes), _stream()), "gx_split_gemm_weights")
-    return planes
+    if h2:
+        _lib.check(L.gx_split_gemm_weights_h2(_p(b), n, k, b.stride(0), _p(planes), _stream()), "gx_split_gemm_weights_h2")
+    else:
+        _lib.check(L.gx_split_gemm_weights(_p(b), n, k, b.stride(0), _p(planes), _stream()), "gx_split_gemm_weights")
+    return WeightPlanes(planes, h2)
+
+
+def _a_range(b_planes, a_range, who):
+    """the a_range argument of the C call: 0 for bf16 planes; for f16x3 planes the caller's bound on |A| is mandatory"""
+    if not b_planes.h2:
+        return 0.0
+    if a_range is None or not a_range > 0:
+        raise RuntimeError(f"{who}: f16x3 weight planes need a_range, an upper bound of |A|")
+    return float(a_range)
 
 
 def gemm_planes_ok(a1, a2, n, out):
@@ -211,7 +242,7 @@ def gemm_planes_ok(a1, a2, n, out):
     return True
 
 
-def gemm_nt_planes_live(a, b_planes, out, live, live_frac, col_bias=None, alpha=1.0, beta=0.0):
+def gemm_nt_planes_live(a, b_planes, out, live, live_frac, col_bias=None, alpha=1.0, beta=0.0, a_range=None):
     """gemm_nt_planes(a, None, b_planes, out, col_bias=...) for an `a` whose rows carry data only below the int32 device scalar
     `live`: the 128-row tiles at or past it are skipped (their rows of `out` stay as they are); live_frac: expected share, for
     the FLOP accounting"""
@@ -225,13 +256,14 @@ def gemm_nt_planes_live(a, b_planes, out, live, live_frac, col_bias=None, alpha=
     if live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1:
         raise RuntimeError("gemm_nt_planes_live: `live` is an int32 HIP scalar")
     with record("gemm_f32_kernel", 2.0 * m * n * k1 * live_frac):
-        _lib.check(L.gx_gemm_f32_nt_planes_mlive(m, n, k1, _p(a), a.stride(0), _p(b_planes), _p(out), out.stride(0), alpha, beta,
-                                                 _p(col_bias), _p(live), _stream()), "gx_gemm_f32_nt_planes_mlive")
+        _lib.check(L.gx_gemm_f32_nt_planes_mlive(m, n, k1, _p(a), a.stride(0), _p(b_planes.buf), _p(out), out.stride(0), alpha, beta,
+                                                 _p(col_bias), _p(live), _a_range(b_planes, a_range, "gemm_nt_planes_live"),
+                                                 _stream()), "gx_gemm_f32_nt_planes_mlive")
     return out
 
 
 def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0,
-                   want_colmax=False, sk_eps=None):
+                   want_colmax=False, sk_eps=None, a_range=None):
     """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
     split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd.
     want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out); an int g > 1:
@@ -260,9 +292,9 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
             upart = workspace("gemm_usum", pb, a1.device)[:pb // 4]
     with record("gemm_f32_kernel", 2.0 * m * n * (k1 + k2)):
         _lib.check(L.gx_gemm_f32_nt_planes(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
-                                           _p(b_planes), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
+                                           _p(b_planes.buf), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
                                            _p(coarse), fine_res, _p(part), _p(upart), 0.0 if sk_eps is None else float(sk_eps),
-                                           _stream()), "gx_gemm_f32_nt_planes")
+                                           _a_range(b_planes, a_range, "gemm_nt_planes"), _stream()), "gx_gemm_f32_nt_planes")
     if want_colmax:
         g = 1 if want_colmax is True else int(want_colmax)
         if g > 1 and m % (32 * g):
@@ -532,7 +564,7 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
     L = lib()
     if tuple(ytable.shape) != (rows // 4, L.gx_fineq_ytable_ld()) or (t2 is not None and t2.shape[0] != rows):
         raise RuntimeError("fineq_fwd: shape mismatch")
-    if bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
+    if bq_planes.h2 or bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
         raise RuntimeError("fineq_fwd: planes do not match (CF + 16, CF)")
     rn = torch.empty(rows, dtype=torch.float32, device=t1.device)
     sc = torch.empty(rows, k, dtype=torch.float32, device=t1.device)
@@ -540,7 +572,7 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
     flops = 2.0 * rows * 16 * 32 * (sum(cf // 32 - (t >> 1) for t in range(cf // 16)) + cf // 16)   # blocks on / below the diagonal + scores
     with record("fineq_fwd_kernel", flops):
         _lib.check(L.gx_fineq_fwd(rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2), 0 if t2 is None else t2.stride(0),
-                                  _p(bq_planes), _p(ytable), _p(bias), k, _p(rn), _p(sc), _stream()),
+                                  _p(bq_planes.buf), _p(ytable), _p(bias), k, _p(rn), _p(sc), _stream()),
                    "gx_fineq_fwd")
     return rn, sc
 
@@ -690,8 +722,8 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool)
     if r != res or z.shape[2] != r or a.shape[0] != rows or tuple(wc.shape) != (k, d) or tuple(gwc.shape) != (k, d) or \
             tuple(coeffs.shape) != (rows, L.gx_lowrank_stride(k)):
         raise RuntimeError("gemm_nt_planes_finish: shape mismatch")
-    if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(d, a.shape[1]):
-        raise RuntimeError("gemm_nt_planes_finish: planes do not match (N, K)")
+    if b_planes.h2 or b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(d, a.shape[1]):
+        raise RuntimeError("gemm_nt_planes_finish: planes do not match (N, K) (bf16 planes)")
     if not L.gx_gemm_finish_ok(d, a.shape[1], r, k):
         raise RuntimeError("gemm_nt_planes_finish: not this shape / engine (gemm_finish_ok)")
     g = torch.empty_like(z)
@@ -699,7 +731,7 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool)
     wsb = L.gx_gemm_finish_workspace_bytes(rows, d, k)
     ws = workspace("gemm_finish", wsb, z.device)
     with record("gemm_f32_kernel", 2.0 * rows * d * a.shape[1], 0.0):
-        _lib.check(L.gx_gemm_f32_nt_planes_finish(rows, d, a.shape[1], _p(a), a.stride(0), _p(b_planes), _p(g), r, _p(coeffs),
+        _lib.check(L.gx_gemm_f32_nt_planes_finish(rows, d, a.shape[1], _p(a), a.stride(0), _p(b_planes.buf), _p(g), r, _p(coeffs),
                                                   _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _stream()),
                    "gx_gemm_f32_nt_planes_finish")
     return g, gp

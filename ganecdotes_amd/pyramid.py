@@ -62,7 +62,9 @@ class Pyramid:
                 ta, off, ca = used[0]
                 tb = used[1][0][:, :used[1][2]] if len(used) == 2 else None
                 kk = ca + (used[1][2] if len(used) == 2 else 0)
-                ops.gemm_nt_planes(ta, tb, ops.split_gemm_weights(wp[:, off:off + kk]), p, coarse=up, fine_res=r if up is not None else 0)
+                # (f16x3 form: the taps are generator activations, whose range is the x-planes convs' contract)
+                ops.gemm_nt_planes(ta, tb, ops.split_gemm_weights(wp[:, off:off + kk], h2=True), p, coarse=up,
+                                   fine_res=r if up is not None else 0, a_range=ops.FEATURE_RANGE)
             elif (len(used) == 2 and used[0][2] == used[0][0].shape[1] and used[0][2] % 32 == 0 and
                   used[1][1] == used[0][1] + used[0][2]):
                 (ta, off, ca), (tb, _, cb) = used

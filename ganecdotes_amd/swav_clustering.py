@@ -316,12 +316,12 @@ class SwAVClustering(ViewMixin):
             st = torch.empty(npix, K, dtype=torch.float32, device=dev)
             if not ops.gemm_planes_ok(zt, None, K, st):
                 return None
-            ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc)
+            ops.gemm_nt_planes_live(zt, wc_planes, st, live, live_frac, col_bias=bc, a_range=1.0)      # |z_hat| <= 1
             zt_tab.append(zt); rn_tab.append(rnt); S_tab.append(st)
         return SimpleNamespace(live=live, live_frac=live_frac, seg=seg, rowmaps=rowmaps_all, c_sorted=c_sorted, scat_picks=scat_picks,
                                maps_flat=maps_flat, zt=zt_tab, rn=rn_tab, S=S_tab, row_group=row_group)
 
-    def _tables_backward(self, dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw):
+    def _tables_backward(self, dS_tab, tb, views, Zt, Gt, Wc, wct_planes, gWc, B, hw, ds_range):
         """Backward of the prototype layer from the per-pixel d(scores) tables (swav_clustering.py:459 through
         :171-182), once per view over the pixels: gWc = dS^T z_hat, dz = dS Wc, normalise-backward + scatter into the projected
         tables Gt through the rotate / flip maps.  tb: the score tables of _score_tables (their z_hat, pixel order and live
@@ -336,7 +336,7 @@ class SwAVClustering(ViewMixin):
                 zt, rnt = tb.zt[v], tb.rn[v]
                 ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
                          split_k=self._split_k(K, D, npix), live=tb.live, live_frac=tb.live_frac)
-                ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac)
+                ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac, a_range=ds_range)
                 with self._timed("scatter_rows"):
                     ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
                 continue
@@ -344,7 +344,7 @@ class SwAVClustering(ViewMixin):
                 zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
             ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0, split_k=self._split_k(K, D, npix))
             if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
-                ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz)
+                ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz, a_range=ds_range)
             else:
                 ops.gemm(dS_tab[v][:, :K], Wc, False, False, out=dz)
             with self._timed("scatter_rows"):
@@ -633,8 +633,11 @@ class SwAVClustering(ViewMixin):
         rows, ngroups = c.rows, c.ngroups
         Kp = (K + 15) // 16 * 16
         npix = B * hw * hw
-        wc_planes = ops.split_gemm_weights(c.Wc)
-        wct_planes = ops.split_gemm_weights(c.Wc.t().contiguous())
+        # f16x3 forms of the two big NT GEMMs: z_hat rows are unit vectors, and |d(scores)| <= P gscale / T (a pixel is in at
+        # most P patches, |softmax - code| <= 1 per entry)
+        wc_planes = ops.split_gemm_weights(c.Wc, h2=True)
+        wct_planes = ops.split_gemm_weights(c.Wc.t().contiguous(), h2=True)
+        ds_range = P * c.gscale / c.T
         dS_tab = [torch.empty(npix, Kp, dtype=torch.float32, device=dev) for _ in range(2)]
         pix_base = (torch.arange(B, dtype=torch.int32, device=dev) * (hw * hw)).unsqueeze(1)
         tb = None
@@ -716,7 +719,7 @@ class SwAVClustering(ViewMixin):
                              q_s=skb[0].codes(), q_t=skb[ngroups].codes())
             del inv, Sc_all, skb
         c.first_acc = False
-        self._tables_backward(dS_tab, tb, c.views, c.Zt, c.Gt, c.Wc, wct_planes, c.gWc, B, hw)
+        self._tables_backward(dS_tab, tb, c.views, c.Zt, c.Gt, c.Wc, wct_planes, c.gWc, B, hw, ds_range)
 
     def _scores_gemm(self, c, z, sc, wc_planes, cmax_pre, key):
         """scores = z_hat Wc^T + b into sc (rows, K)"""
@@ -725,11 +728,11 @@ class SwAVClustering(ViewMixin):
             # Wc split once per step; the Sinkhorn column maxima AND its first pass (the column sums of
             # exp((scores - max) / eps)) come out of the epilogue: nine sweeps of the score matrix, not eleven
             if K > 64 and (c.ngroups == 1 or c.grows % 32 == 0):
-                _, cm_, uf_ = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc,
+                _, cm_, uf_ = ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc, a_range=1.0,
                                                  want_colmax=True if c.ngroups == 1 else c.ngroups, sk_eps=self.eps)
                 cmax_pre[key] = (cm_, uf_)
             else:
-                ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc)
+                ops.gemm_nt_planes(z, None, wc_planes, sc, col_bias=c.bc, a_range=1.0)
         else:
             ops.gemm(z, c.Wc, False, True, col_bias=c.bc, out=sc)
 

@@ -73,7 +73,7 @@ int gx_get_gemm_mode(void);
  * gx_modsplit, the conv / blur passes that write the next conv's planes — and by the convs that read them; planes made under
  * one format must be consumed under the same): 0 = three bf16 planes, six products per fp32 product ("bf16x6"); 1 = two fp16
  * planes of the element scaled by a power of two, three products ("f16x3": fp32-class error measured against fp64, half the
- * matrix-core work; needs |x * style| < 8188 and |w| < 4094, an element out of range comes out NaN).  Buffer sizes
+ * matrix-core work; needs |x * style| < 32752 and |w| < 4094, an element out of range comes out NaN).  Buffer sizes
  * (gx_xplanes_bytes, gx_conv_weight_planes_bytes) are the three-plane ones under either format.  Returns the previous
  * format; env GX_CONV_PLANES=0|1 sets the initial one (default 1). */
 int gx_set_conv_planes(int fmt);
@@ -110,10 +110,18 @@ int gx_gemm_f32_tn_cat(int M, int N1, int N2, int K, const float* A, long lda, c
  * engine.  Same reference ops as gx_gemm_f32 (swav_clustering.py:171-175). */
 size_t gx_gemm_weight_planes_bytes(int N, int K);
 int gx_split_gemm_weights(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream);
+/* ... as the two fp16 planes of the f16x3 form (same buffer size): B times the power of two that brings max |B| (found on the
+ * device) to [2^13, 2^14); max |B| is left in the buffer's 16-byte trailer for gx_gemm_f32_nt_planes(..., a_range > 0). */
+int gx_split_gemm_weights_h2(const float* B, int N, int K, long ldb, unsigned short* planes, void* stream);
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, float* usum_part, float sk_eps, void* stream);
+                          float* colmax_part, float* usum_part, float sk_eps, float a_range, void* stream);
+/* a_range: 0 = b_planes from gx_split_gemm_weights (three bf16 planes, six products per fp32 product); > 0 = an upper bound of
+ * |A1|, |A2| and b_planes from gx_split_gemm_weights_h2 (two fp16 planes, three products — csrc/gx_mfma_x6.h "f16x3": fp32-class
+ * error, half the matrix-core work).  The A elements are scaled by the power of two that brings a_range to [2^13, 2^14): an
+ * element above 4 x a_range overflows fp16 and comes out NaN; every element carries an absolute error of a_range x 2^-38
+ * (the fp16 subnormal step), so the bound should sit within ~2^14 of A's RMS for fp32-class results. */
 /* colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N] partial column maxima of C, one row per 32 rows
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
@@ -122,7 +130,8 @@ size_t gx_gemm_colmax_part_bytes(int M, int N);
  * DESIGN.md par. 4.15): gx_gemm_f32_nt_planes_mlive skips the 128-row tiles at or past *m_live (their rows of C keep what they
  * held), gx_gemm_f32_klive (TN only) contracts over the first *k_live rows only, shared among its split_k splits */
 int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* C,
-                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, void* stream);
+                                long ldc, float alpha, float beta, const float* col_bias, const int* m_live, float a_range,
+                                void* stream);
 int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                       float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                       int split_k, float* workspace, size_t workspace_bytes, const int* k_live, void* stream);

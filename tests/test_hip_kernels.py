@@ -799,6 +799,84 @@ def test_gemm_nt_planes_bitwise_and_fp64(ops):
         ops.set_gemm_mode(prev)
 
 
+def test_gemm_nt_planes_f16x3_form_is_fp32_class(ops):
+    """The f16x3 form of gx_gemm_f32_nt_planes (two fp16 planes of the weights scaled by the power of two found on the device,
+    the A elements scaled from the caller's bound a_range, three MFMA products instead of six): against fp64 its error is that
+    of the bf16x6 form on the same data — unit-scale, tiny (gradient-like, 1e-6) and large (1e3) operands, weights of 0.01,
+    every epilogue term, ragged tails, two A sources, the upsample-add, the column maxima / first Sinkhorn pass, the device-
+    counted live rows; a bound 2^10 above the data keeps fp32-class error (2^20: not any more); an element past 4 x a_range comes out
+    NaN (loud), a missing a_range is refused."""
+    torch.manual_seed(29)
+    prev = ops.set_gemm_mode(1)
+    was = ops.GEMM_H2
+    ops.GEMM_H2 = True
+    try:
+        for (m, n, k1, k2, up, sa, sw) in ((300, 132, 32, 0, 0, 1.0, 1.0), (1024, 512, 64, 16, 8, 1e-6, 0.01),
+                                           (4160, 260, 128, 128, 0, 1e3, 3.0), (4096, 512, 256, 0, 16, 1.0, 0.0136),
+                                           (77, 8, 16, 0, 0, 1.0, 1.0), (2048, 640, 5376, 0, 0, 1.0, 0.0136)):
+            a1 = torch.randn(m, k1 + 8) * sa
+            a2 = torch.randn(m, k2 + 4) * sa if k2 else None
+            w = torch.randn(n, k1 + k2 + 12) * sw
+            rs, cb = torch.rand(m) + 0.5, torch.randn(n) * sa * sw
+            co = torch.randn(m // 4, n) * sa * sw if up else None
+            a1d, a2d, wd = dev(a1)[:, :k1], (dev(a2)[:, :k2] if k2 else None), dev(w)[:, 4:4 + k1 + k2]
+            bp6, bp3 = ops.split_gemm_weights(wd), ops.split_gemm_weights(wd, h2=True)
+            assert bp3.h2 and not bp6.h2
+            acat = (a1[:, :k1] if not k2 else torch.cat([a1[:, :k1], a2[:, :k2]], 1)).double()
+            base = acat @ w[:, 4:4 + k1 + k2].double().t()
+            prior = torch.randn(m, n) * sa * sw
+            o6, o3 = dev(prior.clone()), dev(prior.clone())
+            rng = float(acat.abs().max()) * 1.5
+            if up:
+                upd = co.reshape(-1, up // 2, up // 2, n).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(m, n).double()
+                ops.gemm_nt_planes(a1d, a2d, bp6, o6, coarse=dev(co), fine_res=up)
+                ops.gemm_nt_planes(a1d, a2d, bp3, o3, coarse=dev(co), fine_res=up, a_range=rng)
+                want = base + upd
+            elif k2:
+                ops.gemm_nt_planes(a1d, a2d, bp6, o6, alpha=0.7, beta=0.25)
+                ops.gemm_nt_planes(a1d, a2d, bp3, o3, alpha=0.7, beta=0.25, a_range=rng)
+                want = 0.7 * base + 0.25 * prior.double()
+            else:
+                ops.gemm_nt_planes(a1d, None, bp6, o6, alpha=1.3, row_scale=dev(rs), col_bias=dev(cb))
+                ops.gemm_nt_planes(a1d, None, bp3, o3, alpha=1.3, row_scale=dev(rs), col_bias=dev(cb), a_range=rng)
+                want = 1.3 * rs.double()[:, None] * base + cb.double()[None, :]
+            e6 = float((o6.double().cpu() - want).norm() / want.norm())
+            e3 = float((o3.double().cpu() - want).norm() / want.norm())
+            assert e3 < 1.5 * e6 + 1e-7, (m, n, k1, k2, e3, e6)
+            assert rel_err(o3, want) < 3e-6
+        # a loose bound: 2^10 above the data still fp32-class; every element keeps an ABSOLUTE error of a_range 2^-38, so 2^20
+        # above, the error is 2^-18 of the data's scale over sqrt(K)-fold averaging — the bound has to be within ~2^14 of the RMS
+        a, w = dev(torch.randn(512, 256)), dev(torch.randn(256, 256))
+        want = a.double().cpu() @ w.double().cpu().t()
+        out = torch.empty(512, 256, device="cuda")
+        bp3 = ops.split_gemm_weights(w, h2=True)
+        ops.gemm_nt_planes(a, None, bp3, out, a_range=4.0 * 2 ** 10)
+        assert rel_err(out, want) < 3e-6
+        ops.gemm_nt_planes(a, None, bp3, out, a_range=4.0 * 2 ** 20)
+        assert 3e-6 < rel_err(out, want) < 3e-5
+        # the epilogue's by-products and the live-row form
+        cb = dev(torch.randn(256))
+        _, cm, uf = ops.gemm_nt_planes(a, None, bp3, out, col_bias=cb, want_colmax=True, sk_eps=0.05, a_range=8.0)
+        assert torch.equal(cm, out.amax(0))
+        assert rel_err(uf, torch.exp((out.double() - cm.double()) / 0.05).sum(0)) < 2e-5
+        live = torch.tensor([300], dtype=torch.int32, device="cuda")
+        out2 = torch.full((512, 256), 7.0, device="cuda")
+        ops.gemm_nt_planes_live(a, bp3, out2, live, 300 / 512, col_bias=cb, a_range=8.0)
+        assert torch.equal(out2[:256], out[:256]) and bool((out2[384:] == 7.0).all())
+        # out of range: loud
+        a[3, 5] = 100.0
+        ops.gemm_nt_planes(a, None, bp3, out, a_range=1.0)
+        assert bool(torch.isnan(out[3]).all()) and not bool(torch.isnan(out[4]).any())
+        with pytest.raises(RuntimeError, match="a_range"):
+            ops.gemm_nt_planes(a, None, bp3, out)
+        # GX_GEMM_PLANES=0: every such call falls back to the bf16 planes
+        ops.GEMM_H2 = False
+        assert not ops.split_gemm_weights(w, h2=True).h2
+    finally:
+        ops.GEMM_H2 = was
+        ops.set_gemm_mode(prev)
+
+
 def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
     """gx_gemm_f32_tn_cat: A^T [B1 | B2] in one launch == the two per-tap TN GEMMs (bitwise at equal split) == fp64"""
     torch.manual_seed(29)
