@@ -302,15 +302,23 @@ def roofline_of(stats, ms_per_step, traffic_file):
     v = kern[name]
     ach = v["flops_per_step"] / (v["ms_per_step"] * 1e-3)
     x6 = ops.get_gemm_mode() == 1
-    eng = ("bf16 MFMA, bf16x6: each fp32 operand split exactly into three bf16, six MFMA products per fp32 "
+    # products per fp32 product on the matrix cores: 3 (f16x3: two scaled fp16 planes per operand) where the named kernel class
+    # runs that form — the x-planes convs under ops.get_conv_planes() == 1, the weight-plane GEMMs under ops.GEMM_H2 (the
+    # TN gradient GEMMs still run bf16x6: pricing the whole class at the f16x3 peak is the conservative choice) — else 6
+    h3 = x6 and ((name == "modconv_kernel" and ops.get_conv_planes() == 1) or (name == "gemm_f32_kernel" and ops.GEMM_H2))
+    nprod = 3.0 if h3 else 6.0
+    eng = ("fp16 MFMA, f16x3: each fp32 operand scaled by a power of two and split into two fp16 planes, three MFMA products "
+           "per fp32 product, fp32 accumulate (fp32-class error against fp64, tools/lab/mfma_f16x3.hip)" if h3 else
+           "bf16 MFMA, bf16x6: each fp32 operand split exactly into three bf16, six MFMA products per fp32 "
            "product, fp32 accumulate" if x6 else "fp32 MFMA")
     what = {"modconv_kernel": f"gx::modconv_xp_kernel / gx::modconv_kernel (3x3 modulated conv, implicit GEMM on {eng}; "
                               "the modulated activations are split once by their producer and both operands reach LDS by "
                               "LDS-DMA; algorithmic FLOPs = 2*B*Hin*Win*Cin*Cout*9 per layer)",
             "gemm_f32_kernel": f"gx::gemm kernels (pyramid projection / prototype / gradient GEMMs on {eng}; "
                                "algorithmic FLOPs = 2*M*N*K per launch)"}.get(name, name)
-    # peak for ALGORITHMIC fp32 FLOPs: the fp32 MFMA peak, or (bf16x6) the dense bf16 MFMA peak / 6
-    peak = PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA
+    # peak for ALGORITHMIC fp32 FLOPs: the fp32 MFMA peak, or the dense 16-bit MFMA peak / the products per fp32 product
+    # (bf16x6: / 6; f16x3: / 3 — fp16 and bf16 share the 2.5 PFLOP/s dense peak)
+    peak = PEAK_BF16_MFMA / nprod if x6 else PEAK_F32_MFMA
     # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     # tools/pmc_traffic.py; counters cannot be read live without the profiler attached)
     traffic = traffic_src = None
@@ -324,8 +332,8 @@ def roofline_of(stats, ms_per_step, traffic_file):
     step_flops = sum(x["flops_per_step"] for x in kern.values())
     roof = dict(bound="mfma", achieved=ach / 1e12, peak=peak / 1e12, unit="TFLOP/s",
                 frac=ach / peak, traffic=traffic, traffic_source=traffic_src, kernel=what,
-                engine="bf16x6" if x6 else "f32mfma",
-                mfma_tflops_issued=(6.0 if x6 else 1.0) * ach / 1e12,
+                engine=("f16x3" if h3 else "bf16x6") if x6 else "f32mfma",
+                mfma_tflops_issued=(nprod if x6 else 1.0) * ach / 1e12,
                 mfma_peak=(PEAK_BF16_MFMA if x6 else PEAK_F32_MFMA) / 1e12,
                 fp32_mfma_peak=PEAK_F32_MFMA / 1e12,
                 launches_per_step=v["launches_per_step"],
@@ -589,7 +597,14 @@ def main():
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ("fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (every operand bit kept: fp32-level "
+        "arithmetic": (("fp32 in / fp32 out; the modulated convs" + (" and the weight-plane GEMMs" if ops.GEMM_H2 else "") +
+                        " as f16x3 on the fp16 matrix cores (operands scaled by powers of two and split into two fp16 planes, "
+                        "three products, fp32 accumulate: the error against fp64 is that of an fp32 fma chain — "
+                        "tools/lab/mfma_f16x3.hip, tests/test_hip_kernels.py::test_gemm_nt_planes_f16x3_form_is_fp32_class; operands "
+                        "out of the fp16 range come out NaN), the other contractions as bf16x6 (three bf16 planes, six products); "
+                        "GX_CONV_PLANES=0 GX_GEMM_PLANES=0 select bf16x6 throughout, GX_GEMM_MODE=0 the exact-fp32 MFMA")
+                       if x6 and ops.get_conv_planes() == 1 else
+                       "fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (every operand bit kept: fp32-level "
                        "error, tests/test_hip_kernels.py::test_gemm_x6_accuracy); GX_GEMM_MODE=0 selects the exact-fp32 MFMA"
                        if x6 else "fp32 MFMA (exact fmaf chains)"),
         "config": {"workload": f"ffhq-256 hfc_with_swav, {args.prototypes} prototypes, batch={args.batch}/GPU, "
@@ -616,7 +631,7 @@ def main():
         dt5, st5, loss5 = measure(sw5, args, rf_steps, rf_warm, dev, world)
         ms5 = 1e3 * dt5 / rf_steps
         r5 = roofline_of(st5, ms5, None)
-        peak = (PEAK_BF16_MFMA / 6.0 if x6 else PEAK_F32_MFMA)
+        peak = (PEAK_BF16_MFMA / (3.0 if ops.GEMM_H2 else 6.0) if x6 else PEAK_F32_MFMA)   # (the TN GEMM still runs bf16x6: conservative)
         gemm = st5.get("gemm_f32_kernel")
         hb = (r5 or {}).get("hbm")
         out["reference_faithful"] = {
