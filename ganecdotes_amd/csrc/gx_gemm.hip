@@ -740,7 +740,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
 constexpr int WS_BM = 256, WS_BN = 128, WS_THREADS = 512;
 constexpr int WS_SLOT = XImg<WS_BM>::BYTES + XImg<WS_BN>::BYTES;          // 27648 + 15360 B
 
-template <bool TA, bool TB, bool VEC>
+// H2: the f16x3 form — the producers scale each operand by its power of two (g.a_scale / g.b_scale, from the caller's bounds)
+// and write two fp16 planes, the consumers issue three products per tile pair and un-scale their accumulators once.
+template <bool TA, bool TB, bool VEC, bool H2 = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     constexpr bool A_KC = !TA, B_KC = TB;
     __shared__ __attribute__((aligned(16))) char lds[2 * WS_SLOT];
@@ -774,8 +776,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
             x6_load_tile<B_KC, VEC, WS_BN>(Bsrc, ldbs, nb0, nbN, k0, kend, rb, p);
         };
         auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
-            x6_store_tile<A_KC, WS_BM>(slot, ra, p);
-            x6_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p);
+            if constexpr (H2) {
+                xh_store_tile<A_KC, WS_BM>(slot, ra, p, g.a_scale);
+                xh_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p, g.b_scale);
+            } else {
+                x6_store_tile<A_KC, WS_BM>(slot, ra, p);
+                x6_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p);
+            }
         };
         load_tiles(0, ra0, rb0);
         load_tiles(1, ra1, rb1);
@@ -804,8 +811,18 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     __syncthreads();                                                 // barrier 0
     for (int t = 0; t < nkt; ++t) {
         const char* slot = (t & 1) ? slot1 : slot0;
-        x6_mfma_tile<A_KC, B_KC, 4, 2, WS_BM, WS_BN>(slot, slot + XImg<WS_BM>::BYTES, acc, wr * 128, wc * 64, lane);
+        if constexpr (H2) xh_mfma_tile<4, 2, WS_BM, WS_BN, A_KC, B_KC>(slot, slot + XImg<WS_BM>::BYTES, acc, wr * 128, wc * 64, lane);
+        else x6_mfma_tile<A_KC, B_KC, 4, 2, WS_BM, WS_BN>(slot, slot + XImg<WS_BM>::BYTES, acc, wr * 128, wc * 64, lane);
         __syncthreads();                                             // barrier t+1
+    }
+    if constexpr (H2) {
+        const float un = 1.f / (g.a_scale * g.b_scale);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= un;
     }
     if (g.ep_vec)
         gemm_epilogue_staged<4, 2>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS, split);
@@ -850,10 +867,11 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1, const int* k_live = nullptr) {
+                       int N1 = -1, const int* k_live = nullptr, float a_range = 0.f, float b_range = 0.f) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.live = k_live;
+    g.a_scale = g.b_scale = 1.f; g.b_amax = nullptr;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.usum_part = nullptr; g.sk_inv_eps = 0.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
@@ -873,6 +891,9 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     // wave-specialised 256 x 128 tiles (one workgroup per CU) pay off once the k loop is long enough
     // to amortise a tile's prologue / epilogue, which nothing overlaps there
     const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= WS_MIN_K;
+    // f16x3 form: both operands' bounds given, on the wave-specialised kernel (the 4-wave kernels keep bf16x6: short k loops)
+    const bool h2 = ws && a_range > 0.f && b_range > 0.f;
+    if (h2) { g.a_scale = xh_scale_of(a_range); g.b_scale = xh_scale_of(b_range); }
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -893,7 +914,9 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     dim3 grid(g.tiles_m * g.tiles_n, split_k), block(GEMM_THREADS);
 #define GX_LAUNCH_GEMM(TA_, TB_)                                                                             \
     do {                                                                                                       \
-        if (ws && g.vec_ok) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, true>), grid, dim3(WS_THREADS), 0, stream, g); \
+        if (h2 && g.vec_ok) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, true, true>), grid, dim3(WS_THREADS), 0, stream, g); \
+        else if (h2) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, false, true>), grid, dim3(WS_THREADS), 0, stream, g); \
+        else if (ws && g.vec_ok) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, true>), grid, dim3(WS_THREADS), 0, stream, g); \
         else if (ws) hipLaunchKernelGGL((gemm_x6ws_kernel<TA_, TB_, false>), grid, dim3(WS_THREADS), 0, stream, g); \
         else if (x6 && g.vec_ok) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, true>), grid, block, 0, stream, g);  \
         else if (x6) hipLaunchKernelGGL((gemm_x6_kernel<TA_, TB_, false>), grid, block, 0, stream, g);        \
@@ -1018,6 +1041,21 @@ int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* 
     return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
                            split_k, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1,
                            k_live);
+}
+
+// gx_gemm_f32 / gx_gemm_f32_klive (k_live may be NULL) with the caller's bounds on |A| and |B|: where the wave-specialised
+// kernel takes the launch (long k loops: the gradient GEMMs over pixels) it runs the f16x3 form — operands scaled by the
+// powers of two that bring the bounds to [2^13, 2^14), two fp16 planes, three products (csrc/gx_mfma_x6.h); elsewhere the
+// bounds are ignored (bf16x6).  An element above 4 x its bound comes out NaN; every element carries an absolute error of
+// bound x 2^-38, so a bound should sit within ~2^14 of its operand's RMS.
+int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                       float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                       int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
+                       void* stream) {
+    if ((k_live && !transA) || !(a_range > 0.f) || !(b_range > 0.f)) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
+                           split_k, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1,
+                           k_live, a_range, b_range);
 }
 
 // C = alpha * [A1 | A2] opB + ... : A1 is [M][K1], A2 is [M][K2]; K1 must be a multiple of 32.

@@ -226,8 +226,36 @@ __device__ __forceinline__ void split2h(float x0, float x1, float scale, unsigne
     const f32x2 r = v - __builtin_convertvector(hh, f32x2);
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
+// registers -> the two fp16 planes (0 = h, 1 = l) of one operand image, in the layouts of x6_store_tile
+template <bool KC, int R = 128>
+__device__ __forceinline__ void xh_store_tile(char* __restrict__ S, const f32x4 (&v)[R / 64], int t, float scale) {
+    constexpr int NV = R / 64;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned h[2], l[2];
+            split2h(v[i][0], v[i][1], scale, h[0], l[0]);
+            split2h(v[i][2], v[i][3], scale, h[1], l[1]);
+            char* p = S + x_kc_off((t >> 2) + 64 * i, (t >> 1) & 1) + (t & 1) * 8;
+            *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[1]};
+            *reinterpret_cast<u32x2*>(p + XImg<R>::KC_PLANE) = (u32x2){l[0], l[1]};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned h[2], l[2];
+                split2h(v[2 * j + i][0], v[2 * j + i][1], scale, h[0], l[0]);
+                split2h(v[2 * j + i][2], v[2 * j + i][3], scale, h[1], l[1]);
+                char* p = S + (2 * (t >> 5) + i) * XImg<R>::MC_RS + ((t & 31) * 4 + 128 * j) * 2;
+                *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[1]};
+                *reinterpret_cast<u32x2*>(p + XImg<R>::MC_PLANE) = (u32x2){l[0], l[1]};
+            }
+    }
+}
 // One 16-deep k-tile of the two-plane images (plane 0 = h, 1 = l; the KC layout of the bf16 images), smallest terms first
-template <int MT, int NT, int RA, int RB>
+template <int MT, int NT, int RA, int RB, bool A_KC = true, bool B_KC = true>
 __device__ __forceinline__ void xh_mfma_tile(const char* __restrict__ As, const char* __restrict__ Bs, f32x16 (&acc)[MT][NT],
                                              int a_row0, int b_row0, int lane) {
     const int r = lane & 31, h = lane >> 5;
@@ -236,9 +264,9 @@ __device__ __forceinline__ void xh_mfma_tile(const char* __restrict__ As, const 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a[t][PA[q]] = __builtin_bit_cast(f16x8, x6_frag<true, RA>(As, PA[q], a_row0 + t * 32 + r, h));
+        for (int t = 0; t < MT; ++t) a[t][PA[q]] = __builtin_bit_cast(f16x8, x6_frag<A_KC, RA>(As, PA[q], a_row0 + t * 32 + r, h));
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t][PB[q]] = __builtin_bit_cast(f16x8, x6_frag<true, RB>(Bs, PB[q], b_row0 + t * 32 + r, h));
+        for (int t = 0; t < NT; ++t) b[t][PB[q]] = __builtin_bit_cast(f16x8, x6_frag<B_KC, RB>(Bs, PB[q], b_row0 + t * 32 + r, h));
     }
     constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                  // l*h, h*l, h*h
 #pragma unroll

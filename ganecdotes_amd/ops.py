@@ -104,8 +104,10 @@ def _chk2d(*ts):
 
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
-         split_k=1, live=None, live_frac=1.0):
+         split_k=1, live=None, live_frac=1.0, a_range=None, b_range=None):
     """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
+    a_range / b_range (both, optional): upper bounds of |a|, |b| — the long-k launches then run the f16x3 form
+    (gx_gemm_f32_ranged: half the matrix-core work; each bound within ~2^14 of its operand's RMS).
     op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K).
     a, b, out may be row-strided views (leading dimension = stride(0)).
     live (trans_a only): int32 device scalar, the k rows that carry data (the rest is not read; the launch covers K with no
@@ -127,9 +129,15 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
     if split_k > 1:
         wsb = L.gx_gemm_f32_workspace_bytes(m, n, split_k)
         ws = workspace("gemm", wsb, a.device)
+    if live is not None and (not trans_a or live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1):
+        raise RuntimeError("gemm: `live` is an int32 HIP scalar and needs trans_a")
+    if GEMM_H2 and a_range is not None and b_range is not None and a_range > 0 and b_range > 0:
+        with record("gemm_f32_kernel", 2.0 * m * n * k * (live_frac if live is not None else 1.0)):
+            _lib.check(L.gx_gemm_f32_ranged(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
+                                            _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
+                                            wsb, _p(live), float(a_range), float(b_range), _stream()), "gx_gemm_f32_ranged")
+        return out
     if live is not None:
-        if not trans_a or live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1:
-            raise RuntimeError("gemm: `live` is an int32 HIP scalar and needs trans_a")
         with record("gemm_f32_kernel", 2.0 * m * n * k * live_frac):
             _lib.check(L.gx_gemm_f32_klive(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
                                            _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),

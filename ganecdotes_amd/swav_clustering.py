@@ -335,14 +335,15 @@ class SwAVClustering(ViewMixin):
             if tb is not None:
                 zt, rnt = tb.zt[v], tb.rn[v]
                 ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0,
-                         split_k=self._split_k(K, D, npix), live=tb.live, live_frac=tb.live_frac)
+                         split_k=self._split_k(K, D, npix), live=tb.live, live_frac=tb.live_frac, a_range=ds_range, b_range=1.0)
                 ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac, a_range=ds_range)
                 with self._timed("scatter_rows"):
                     ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
                 continue
             with self._timed("gather_rows"):
                 zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
-            ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0, split_k=self._split_k(K, D, npix))
+            ops.gemm(dS_tab[v][:, :K], zt, True, False, out=gWc, beta=0.0 if v == 0 else 1.0, split_k=self._split_k(K, D, npix),
+                     a_range=ds_range, b_range=1.0)
             if ops.gemm_planes_ok(dS_tab[v], None, D, dz):
                 ops.gemm_nt_planes(dS_tab[v], None, wct_planes, dz, a_range=ds_range)
             else:

@@ -135,6 +135,15 @@ int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1
 int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                       float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                       int split_k, float* workspace, size_t workspace_bytes, const int* k_live, void* stream);
+/* gx_gemm_f32 / gx_gemm_f32_klive (k_live may be NULL) with the caller's bounds on |A| and |B|: where the wave-specialised
+ * kernel takes the launch (long k loops: the gradient GEMMs over pixels) it runs the f16x3 form (operands scaled by the powers
+ * of two that bring the bounds to [2^13, 2^14), two fp16 planes each, three MFMA products per fp32 product — half the
+ * matrix-core work of bf16x6 at fp32-class error); elsewhere the bounds are ignored.  An element above 4 x its bound comes out
+ * NaN; every element carries an absolute error of bound x 2^-38: a bound should sit within ~2^14 of its operand's RMS. */
+int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                       float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
+                       int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
+                       void* stream);
 /* gx_gemm_f32_nt_planes_finish: G = A1 B^T with the low-rank path's dense finish in the epilogue (autograd of
  * swav_clustering.py:171-175 through the pyramid, K <= 16): G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q], gWc = beta gWc +
  * coeffs[:, :K]^T Z, Gpool (may be NULL) = the 2x2 sums of G; rows = pixels of res x res images (DESIGN.md par. 4.14) */

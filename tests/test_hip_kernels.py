@@ -877,6 +877,42 @@ def test_gemm_nt_planes_f16x3_form_is_fp32_class(ops):
         ops.set_gemm_mode(prev)
 
 
+def test_gemm_ranged_f16x3_form_of_the_long_k_gemms(ops):
+    """gx_gemm_f32_ranged: the wave-specialised kernel's f16x3 form (the TN prototype-gradient GEMM over the pixels at many
+    prototypes: A = d(scores), bounded by P gscale / T, B = unit rows) against fp64 beside the bf16x6 form — gradient-sized
+    operands, split-K, a device-counted k range, NT / NN / TN layouts; short-k launches ignore the bounds (bitwise bf16x6)."""
+    torch.manual_seed(30)
+    prev = ops.set_gemm_mode(1)
+    was = ops.GEMM_H2
+    ops.GEMM_H2 = True
+    try:
+        for (ta, tb, m, n, k, sa, sb, split) in ((True, False, 640, 512, 40000, 3e-7, 0.044, 8), (False, True, 1000, 260, 4096, 1.0, 0.02, 1),
+                                                 (False, False, 512, 384, 2048, 50.0, 1.0, 2), (True, False, 5000, 512, 20000, 1e-5, 0.044, 4)):
+            a = torch.randn((k, m) if ta else (m, k)) * sa
+            b = torch.randn((n, k) if tb else (k, n)) * sb
+            want = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+            ad, bd = dev(a), dev(b)
+            o6 = ops.gemm(ad, bd, ta, tb, split_k=split)
+            o3 = ops.gemm(ad, bd, ta, tb, split_k=split, a_range=float(a.abs().max()) * 2, b_range=float(b.abs().max()) * 3)
+            e6 = float((o6.double().cpu() - want).norm() / want.norm())
+            e3 = float((o3.double().cpu() - want).norm() / want.norm())
+            assert e3 < 1.5 * e6 + 1e-7 and e3 < 3e-6, (ta, tb, m, n, k, e3, e6)
+            assert not torch.equal(o3, o6)                                   # (it did take the other form)
+        # the device-counted k range
+        k, m, n = 30000, 640, 512
+        a, b = dev(torch.randn(k, m) * 1e-4), dev(torch.randn(k, n) * 0.05)
+        live = torch.tensor([17000], dtype=torch.int32, device="cuda")
+        o3 = ops.gemm(a, b, True, False, split_k=4, live=live, live_frac=17 / 30, a_range=1e-3, b_range=0.5)
+        want = a[:17000].double().cpu().t() @ b[:17000].double().cpu()
+        assert rel_err(o3, want) < 3e-6
+        # short k: the 4-wave kernel, bounds ignored
+        a, b = dev(torch.randn(300, 64)), dev(torch.randn(200, 64))
+        assert torch.equal(ops.gemm(a, b, a_range=8.0, b_range=8.0), ops.gemm(a, b))
+    finally:
+        ops.GEMM_H2 = was
+        ops.set_gemm_mode(prev)
+
+
 def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
     """gx_gemm_f32_tn_cat: A^T [B1 | B2] in one launch == the two per-tap TN GEMMs (bitwise at equal split) == fp64"""
     torch.manual_seed(29)
