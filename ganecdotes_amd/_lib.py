@@ -44,6 +44,7 @@ SIGNATURES = {
     "gx_set_blur_dma": (c_i, [c_i]),
     "gx_set_conv_planes": (c_i, [c_i]),
     "gx_get_conv_planes": (c_i, []),
+    "gx_set_conv_tall": (c_i, [c_i]),
     "gx_set_gemm_mode": (c_i, [c_i]),
     "gx_get_gemm_mode": (c_i, []),
     "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

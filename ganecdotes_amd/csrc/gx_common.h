@@ -7,7 +7,8 @@
 #if !defined(GX_LAB) && (defined(CE_PIX_ABL) || defined(SKT_ABL) || defined(SKT_FORCE_WIDE) || defined(XP_ABL_A2) || \
                          defined(XP_ABL_B2) || defined(XW_ABL_DIRECT) || defined(FIN_ABL) || defined(FQ_ABL) || \
                          defined(BK_LOAD_AUX) || defined(BK_STORE_AUX) || defined(BK_PASS_MINB) || defined(CE_PIX_NJ2) || \
-                         defined(BLUR_MINB) || defined(FQ_LATE) || defined(BD_AHEAD) || defined(BD_ROWS) || defined(FQ_PRIO))
+                         defined(BLUR_MINB) || defined(FQ_LATE) || defined(BD_AHEAD) || defined(BD_ROWS) || defined(FQ_PRIO) || \
+                         defined(XH_STAGES))
 #error "lab ablation macro set without -DGX_LAB: ablated kernels must not reach libganecdotes_hip.so (use tools/lab/labbuild.sh)"
 #endif
 #include <hip/hip_runtime.h>

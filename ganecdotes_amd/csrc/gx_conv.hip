@@ -375,6 +375,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_kernel(ConvArgs g) {
 // 32x32x16 form) is applied on the per-lane SOURCE address, the LDS side of a DMA is linear.
 // Main loop per wave and k-tile: 6 DMA + 20 ds_read_b128 + 48 MFMA 16x16x32 (or 12 reads + 24 MFMA 32x32x16).
 constexpr int XP_STAGE_BYTES = 2 * 3 * XImg<128>::KC_PLANE;       // A planes + B planes of one k-tile: 24 KB
+#ifndef XH_STAGES
+#define XH_STAGES 3                                                  // ring depth of the f16x3 form (16 KB per stage); lab: tools/lab/conv_stages.sh
+#endif
 
 // the same four channels into an LDS staging row whose planes are 512 B apart (blur_act_xp_kernel / blur_act_dma_kernel)
 template <bool H2>
@@ -423,8 +426,10 @@ __device__ __forceinline__ void store_xplanes4(const f32x4& v, int h2, unsigned 
     }
 }
 // staging writers: one 32-row half (mt) of a wave's 64 x 64 accumulators -> S [32][EPI_LDW]
-struct StageAcc32 {          // 2 x 2 tiles of v_mfma_f32_32x32x16_bf16: lane = column, 16 registers = rows
-    const f32x16 (&acc)[2][2];
+template <int MT = 2>
+struct StageAcc32 {          // MT x 2 tiles of v_mfma_f32_32x32x16_*: lane = column, 16 registers = rows
+    static constexpr int NMT = MT;
+    const f32x16 (&acc)[MT][2];
     __device__ __forceinline__ void operator()(int mt, float* S, int lane) const {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -434,6 +439,7 @@ struct StageAcc32 {          // 2 x 2 tiles of v_mfma_f32_32x32x16_bf16: lane = 
     }
 };
 struct StageAcc16 {          // 4 x 4 tiles of v_mfma_f32_16x16x32_bf16: column = lane & 15, row = 4 (lane >> 4) + register
+    static constexpr int NMT = 2;
     const f32x4 (&acc)[4][4];
     __device__ __forceinline__ void operator()(int mt, float* S, int lane) const {
 #pragma unroll
@@ -458,7 +464,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& g, const ConvS
     // (chunk, plane) image is one contiguous 512-B run when the 16 pixels are neighbours in an image row
     const int q4 = (lane & 3) * 4, lrow = lane >> 2;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < STAGE::NMT; ++mt) {
         stage_write(mt, S, lane);
         // (same wave wrote and reads: program order + the LDS counter, no barrier)
 #pragma unroll
@@ -576,7 +582,11 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
             const char* base = xp + (long)(cc * NPL + p) * (long)g.xp_plane_bytes;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)g.xp_plane_bytes, 0x00020000);
-            if constexpr (TALL) {
+            if constexpr (TALL && H2) {          // KC image of 256 rows: rows tid >> 1 and + 128, 4 KB apart
+                char* d = dst + p * APL + wid * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)d, 16, (int)va, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(d + 4096), 16, (int)(pixbyte2 + (unsigned)to), 0, 0, 0);
+            } else if constexpr (TALL) {
                 char* d = dst + p * APL + (wid >> 1) * 4096 + (wid & 1) * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)d, 16, (int)va, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(d + 2048), 16, (int)(pixbyte2 + (unsigned)to), 0, 0, 0);
@@ -594,6 +604,36 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
                                                      (int)wlane, (int)(blk + p * 4096u), 0, 0);
     };
 
+    if constexpr (H2) {
+        // f16x3: a k-tile is 12 MFMAs per wave — half the bf16x6 tile — and 16 KB of LDS, so the ring is XH_STAGES deep:
+        // the DMAs of tiles k+1 .. k+NS-2 stay in flight across the barrier that retires tile k (counted vmcnt: a thread
+        // issues PER = 4 DMAs per tile, in tile order), tile k+NS-1 is issued into the slot tile k-1 left.  Raw barrier: a
+        // __syncthreads() would drain the DMAs of the tiles ahead.
+        constexpr int NS = XH_STAGES, PER = (TALL ? 3 : 2) * NPL;      // DMAs per thread and tile: A (x 2 rows when tall) + B
+        static_assert(NS >= 2 && NS <= 4, "ring depth");
+        const int total = ncc * NT;
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < total) issue(t / NT, tapoff[t % NT], wblk[t % NT], lds + t * STAGE);
+        int rd = 0, ws = NS - 1, k = 0;                                  // ring slots being read / written
+        for (int cc = 0; cc < ncc; ++cc) {
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap, ++k) {
+                const int ahead = min(NS - 2, total - 1 - k);           // newer tiles whose DMAs may still be in flight
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const int nt_ = (tap + NS - 1) % NT, dc_ = (tap + NS - 1) / NT;      // (constants once the tap loop is unrolled)
+                if (k + NS - 1 < total) issue(cc + dc_, tapoff[nt_], wblk[nt_], lds + ws * STAGE);
+                const char* As = lds + rd * STAGE;
+                xh_mfma_tile<TALL ? 4 : 2, 2, TALL ? 256 : 128, 128>(As, As + BOFF, acc, wr * (TALL ? 128 : 64), wc * 64, lane);
+                rd = (rd + 1 == NS) ? 0 : rd + 1;
+                ws = (ws + 1 == NS) ? 0 : ws + 1;
+            }
+        }
+        return;
+    }
     // Two stages: the DMAs of tile k+1 are issued right after the barrier that retires tile k and have the 24 MFMAs
     // of tile k to land; three workgroups per CU (48 KB of LDS, 118 VGPRs) cover what that does not.  (A three-stage
     // ring with a counted vmcnt(6) and a raw s_barrier measured 3.5 % SLOWER: 72 KB of LDS = two workgroups per CU.)
@@ -613,8 +653,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
                 issue(wrap ? cc + 1 : cc, tapoff[wrap ? 0 : tap + 1], wblk[wrap ? 0 : tap + 1],
                       lds + (buf ^ 1) * STAGE, NT < 9 || wrap || tap < 1 || (tap + 1) % 3 == 0);
             if constexpr (M16) xp16_mfma_ktile<TALL ? 256 : 128>(As, As + BOFF, acc, wr, wc, lane);
-            else if constexpr (H2) xh_mfma_tile<2, 2, 128, 128>(As, As + BOFF, acc, wr * 64, wc * 64, lane);
-            else x6_mfma_ktile<true, true>(As, As + BOFF, acc, wr, wc, lane);
+            else if constexpr (!H2) x6_mfma_ktile<true, true>(As, As + BOFF, acc, wr, wc, lane);
             buf ^= 1;
         }
     }
@@ -622,14 +661,15 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
 
 template <bool M16, bool TALL = false, bool H2 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g) {
-    static_assert(!TALL || M16, "the tall tile exists in the 16x16x32 product form only");
+    static_assert(!TALL || M16 || H2, "the tall tile: the 16x16x32 product form of bf16x6 (256 x 64), or f16x3 (256 x 128)");
     static_assert(!H2 || !M16, "the two-plane fp16 engine uses the 32x32x16 products");
     constexpr int TBM = TALL ? 2 * BM : BM;                          // pixels per tile
     // two stages of (A planes + B planes); never less than the epilogue's 4 x 32 x EPI_LDW floats
-    constexpr int LDS_MAIN = 2 * ((H2 ? 2 : 3) * ((TALL ? 8192 : 4096) + 4096));
+    constexpr int LDS_MAIN = (H2 ? XH_STAGES : 2) * ((H2 ? 2 : 3) * ((TALL ? 8192 : 4096) + 4096));   // f16x3 tall: 3 x 24 KB
     constexpr int LDS_EPI = 4 * 32 * EPI_LDW * 4;
     __shared__ __attribute__((aligned(16))) char lds_raw[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = TALL ? wid : (wid >> 1), wc = TALL ? 0 : (wid & 1);
+    // waves: 2 x 2 over the tile (f16x3 tall: each 128 x 64 of 256 x 128); bf16x6 tall: four stacked along M on the same 64 columns
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = (TALL && !H2) ? wid : (wid >> 1), wc = (TALL && !H2) ? 0 : (wid & 1);
     int si = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -669,19 +709,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void modconv_xp_kernel(ConvArgs g)
         __syncthreads();                                             // every wave has read its last fragments
         conv_epilogue_lds(g, sb, StageAcc16{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
     } else {
-        f32x16 acc[2][2];
-        zero_acc(acc);
+        constexpr int MT = TALL ? 4 : 2;                             // 32-row MFMA tiles of a wave along M
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         switch (sb.ntaps) {
-            case 9: conv_mainloop_xp<9, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            case 4: conv_mainloop_xp<4, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            case 2: conv_mainloop_xp<2, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
-            default: conv_mainloop_xp<1, false, false, H2>(g, sb, lds_raw, acc, pixbyte, 0u, n0, tid, wr, wc, lane); break;
+            case 9: conv_mainloop_xp<9, false, TALL, H2>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 4: conv_mainloop_xp<4, false, TALL, H2>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            case 2: conv_mainloop_xp<2, false, TALL, H2>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
+            default: conv_mainloop_xp<1, false, TALL, H2>(g, sb, lds_raw, acc, pixbyte, pixbyte2, n0, tid, wr, wc, lane); break;
         }
         if ((g.Cout & 3) == 0) {                                     // epilogue through LDS (+ the next layer's planes)
             __syncthreads();                                         // every wave has read its last fragments
-            conv_epilogue_lds(g, sb, StageAcc32{acc}, lds_raw, (unsigned)m0 + wr * 64, n0 + wc * 64, wid, lane);
+            conv_epilogue_lds(g, sb, StageAcc32<MT>{acc}, lds_raw, (unsigned)m0 + wr * (32 * MT), n0 + wc * 64, wid, lane);
         } else {
-            conv_epilogue<2>(g, sb, acc, (unsigned)m0 + wr * 64, n0 + wc * 64, lane);
+            conv_epilogue<MT>(g, sb, acc, (unsigned)m0 + wr * (32 * MT), n0 + wc * 64, lane);
         }
     }
 }
@@ -1536,6 +1582,8 @@ static int conv_pick_splits(long max_m, int Cout, int nsub_tiles_total, int min_
 // that write the next conv's planes) and by the conv: planes made under one format must be consumed under the same.
 #define GX_DEFAULT_CONV_PLANES 1
 static int g_conv_planes = -1;
+static int g_xh_tall = 1;                      // lab: gx_set_conv_tall(0) keeps the 128 x 128 tile everywhere
+constexpr long XH_TALL_MIN_TILES = 512;
 static int conv_planes() {
     if (g_conv_planes < 0) {
         const char* e = getenv("GX_CONV_PLANES");
@@ -1566,7 +1614,13 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
     if (h2 && !g.xp) g.wtp = nullptr;      // the kernels that split x in flight (bf16x6) cannot read fp16 weight planes: they split w too
     int base = 0, min_kt = 1 << 30;
     // narrow layers on the x-planes path: 256-pixel x 64-channel tiles (modconv_xp_kernel<true, true>)
-    const bool tall = g.xp && x6 && !h2 && (g.Cout & 3) == 0 && g.Cout <= 64;
+    bool tall = g.xp && x6 && !h2 && (g.Cout & 3) == 0 && g.Cout <= 64;
+    if (g.xp && h2) {       // f16x3: 256 x 128 tiles (a wave 128 x 64: 12 fragment reads per 24 MFMAs instead of 8 per 12 — the
+                            // 128 x 128 tile is LDS-bound) where that still leaves every CU two workgroups
+        long t256 = 0;
+        for (int i = 0; i < g.nsub; ++i) t256 += (long)gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, 2 * BM) * g.tiles_n;
+        tall = g_xh_tall && t256 >= XH_TALL_MIN_TILES;
+    }
     for (int i = 0; i < g.nsub; ++i) {
         g.sub[i].tile_base = base;
         g.sub[i].tiles_m = gx_cdiv((long)g.B * g.sub[i].OH * g.sub[i].OW, tall ? 2 * BM : BM);
@@ -1591,7 +1645,8 @@ static int launch_conv(ConvArgs& g, float* slab, size_t slab_bytes, hipStream_t 
         // MFMA shape of the six products: 16x16x32 (plane pairs along K) where Cout allows its epilogue, else 32x32x16.  Equal
         // pipe cycles per FLOP; on random data the power-limited chip holds a higher clock on the 16x16 shape: plain convs
         // 243-246 -> 256-260 TFLOP/s, same-process A/B (round 2, tools/bench_conv_xp.py)
-        if (h2) hipLaunchKernelGGL((modconv_xp_kernel<false, false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        if (h2 && tall) hipLaunchKernelGGL((modconv_xp_kernel<false, true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        else if (h2) hipLaunchKernelGGL((modconv_xp_kernel<false, false, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
         else if (tall) hipLaunchKernelGGL((modconv_xp_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
         else if ((g.Cout & 3) == 0) hipLaunchKernelGGL(modconv_xp_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, g);
         else hipLaunchKernelGGL(modconv_xp_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, g);
@@ -1834,6 +1889,7 @@ int gx_set_conv_planes(int fmt) {
     return prev;
 }
 int gx_get_conv_planes(void) { return gx::conv_planes(); }
+int gx_set_conv_tall(int on) { const int prev = gx::g_xh_tall; gx::g_xh_tall = on ? 1 : 0; return prev; }
 static int g_blur_dma = 1;
 int gx_set_blur_dma(int on) { const int prev = g_blur_dma; g_blur_dma = on ? 1 : 0; return prev; }
 int gx_blur_act_fwd(const float* T, int B, int TH, int TW, int C, const float* kf, const float* demod,

@@ -78,6 +78,8 @@ int gx_get_gemm_mode(void);
  * format; env GX_CONV_PLANES=0|1 sets the initial one (default 1). */
 int gx_set_conv_planes(int fmt);
 int gx_get_conv_planes(void);
+/* lab / tests: 0 keeps the 128 x 128 tile of the f16x3 convs on every layer (default 1: 256 x 128 on the large ones) */
+int gx_set_conv_tall(int on);
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k);
 int gx_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                 float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,

@@ -1,5 +1,5 @@
 """The 3x3 modulated conv on the x-planes path (modconv_xp_kernel), layer by layer at the bench batch (32 views).
-   usage: python tools/lab/conv_lab.py [views]"""
+   usage: python tools/lab/conv_lab.py [views] [tall 0|1] [planes 0|1]"""
 import math
 import sys
 
@@ -24,6 +24,10 @@ def timeit(fn, n=8, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    if len(sys.argv) > 2:                                  # f16x3 tile: 1 = 256 x 128 on the large layers (default), 0 = 128 x 128
+        ops.lib().gx_set_conv_tall(int(sys.argv[2]))
+    if len(sys.argv) > 3:                                  # plane format: 1 = f16x3 (default), 0 = bf16x6
+        ops.set_conv_planes(int(sys.argv[3]))
     dev = torch.device("cuda")
     torch.manual_seed(0)
     tot = 0.0
