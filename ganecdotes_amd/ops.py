@@ -83,6 +83,19 @@ def get_gemm_mode():
     return lib().gx_get_gemm_mode()
 
 
+RANGE_HINT = ("a value left the fp16 range of the f16x3 contractions (|activation * style| < 32752 in the modulated convs, the "
+              "stated bounds of the weight-plane GEMMs) or the computation diverged: the matrix cores then return NaN instead "
+              "of a wrong number.  GX_CONV_PLANES=0 GX_GEMM_PLANES=0 select the bf16x6 forms, which have fp32's range")
+
+
+def check_finite(x, what):
+    """Raise FloatingPointError when `x` (a HIP tensor or a float already read back) holds a NaN / inf — the loud end of the
+    f16x3 range contract.  A tensor costs one reduction and one read-back: call it where the host waits anyway."""
+    ok = math.isfinite(x) if isinstance(x, float) else bool(torch.isfinite(x).all())
+    if not ok:
+        raise FloatingPointError(f"{what}: not finite — {RANGE_HINT}")
+
+
 def set_conv_planes(fmt):
     """Plane format of the x-planes conv path (engine 1): 0 = three bf16 planes / six products (bf16x6), 1 = two fp16 planes /
     three products (f16x3).  Frozen weight planes are re-made when the format changes (Generator._prepare).  Returns the

@@ -174,7 +174,9 @@ class SimCLRClustering(ViewMixin):
             self.loss_history.append(loss)
             if self.writer is not None:
                 self.writer.add_scalar('simclr/loss', loss.item(), e)
-            self.logger.info(f" (Iter:{e}):\tLoss: {loss.item():.03f},\tTime: {time.time() - t0:.03f}\t")
+            lv = float(loss.item())
+            ops.check_finite(lv, "SimCLR loss")
+            self.logger.info(f" (Iter:{e}):\tLoss: {lv:.03f},\tTime: {time.time() - t0:.03f}\t")
         if self.projection_file is not None:
             torch.save(self.projection, self.projection_file)
 

@@ -933,7 +933,11 @@ class SwAVClustering(ViewMixin):
                 if self.writer is not None:
                     self.writer.add_scalar('swav/loss', loss.item(), e)
             if e % sa['epoch_print_freq'] == 0:
-                self.logger.info(f" E:{e}\t|\tLoss: {loss.item():.03f} \t|\tT: {time.time() - t0:.03f}")
+                lv = float(loss.item())
+                ops.check_finite(lv, "SwAV loss")                      # (where the host reads the loss back anyway)
+                self.logger.info(f" E:{e}\t|\tLoss: {lv:.03f} \t|\tT: {time.time() - t0:.03f}")
+        if self.loss_history:
+            ops.check_finite(float(self.loss_history[-1].item()), "SwAV loss")
         self.logger.info("Finished pretraining - Saving projection file")
         if self.prototype_file is not None and self.rank == 0:
             torch.save(self.prototype, self.prototype_file)

@@ -54,6 +54,9 @@ class ViewMixin(object):
                                   input_is_latent=True, randomize_noise=False)
         finally:
             self.model.want_image = prev
+        # a NaN anywhere in the conv chain reaches the last tap (every later 3x3 conv spreads it): one small reduction here
+        # keeps the predict paths from turning an out-of-range activation into silent garbage labels
+        ops.check_finite(feats[-1][:, :, ::8, ::8], "generator taps")
         return feats
 
     def _timed(self, tag, flops=0.0, nbytes=0.0):

@@ -147,6 +147,52 @@ def test_generator_xp_path_equals_in_kernel_split(gpu):
         ops.set_gemm_mode(prev_mode)
 
 
+def test_generator_plane_formats_agree_and_the_f16x3_range_is_loud(gpu, tmp_path):
+    """ffhq-width generator at 64 x 64, 16 images under the two plane formats of the x-planes convs (ops.set_conv_planes: three
+    bf16 planes / six products, two scaled fp16 planes / three products): both within 1e-5 of the exact-fp32 MFMA engine, the
+    frozen weight planes re-made when the format changes.  The price of f16x3 is range: activations scaled past |x * style| =
+    32752 come out NaN — and predict_swav_codes says so (FloatingPointError naming the switch) instead of returning labels,
+    while bf16x6 (fp32's range) still computes them."""
+    from ganecdotes_amd import generator as GM
+    from ganecdotes_amd import ops
+    torch.manual_seed(18)
+    g = GM.Generator(64, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)
+    g = g.eval().to(gpu)
+    w = g.style(torch.randn(16, 512, device="cuda"))
+    ml = g.mean_latent(64)
+    kw = dict(truncation=0.7, truncation_latent=ml, input_is_latent=True, randomize_noise=False)
+    prev_mode, prev_fmt = ops.set_gemm_mode(0), ops.get_conv_planes()
+    try:
+        ref = [t.clone() for t in g([w], **kw)[1]]
+        ops.set_gemm_mode(1)
+        outs = {}
+        for fmt in (1, 0, 1):
+            ops.set_conv_planes(fmt)
+            outs[fmt] = [t.clone() for t in g([w], **kw)[1]]
+            assert g._derived["plane_format"] == (1, fmt)
+            for a, b in zip(outs[fmt], ref):
+                assert rel(a, b) < 1e-5
+        assert any(not torch.equal(a, b) for a, b in zip(outs[0], outs[1]))       # (two different engines did run)
+        # out of range: the constant input x 3e5 (demodulation keeps the later layers at that scale)
+        sw = make_swav(g, gpu, tmp_path)
+        sw.build_heads()
+        lat = w[:2]
+        sw.predict_swav_codes(lat)
+        g.input.input.data.mul_(3e5)
+        g._invalidate()
+        with pytest.raises(FloatingPointError, match="GX_CONV_PLANES=0"):
+            sw.predict_swav_codes(lat)
+        ops.set_conv_planes(0)
+        preds, labels = sw.predict_swav_codes(lat)
+        assert bool(torch.isfinite(preds).all())
+    finally:
+        ops.set_conv_planes(prev_fmt)
+        ops.set_gemm_mode(prev_mode)
+
+
 def test_baggan_generator_golden_gv14(gpu):
     """pidray-* models: the reference BagGAN StyleGANGenerator's mapping, image and
     7 feature taps, loaded from its own state_dict through the key translation"""
