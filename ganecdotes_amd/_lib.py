@@ -64,11 +64,13 @@ SIGNATURES = {
     "gx_gemm_f32_klive": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
                                 c_p]),
     "gx_gemm_f32_ranged": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
-                                 c_f, c_f, c_p]),
+                                 c_f, c_f, c_p, c_p]),
+    "gx_gemm_f32_tn_cat_ranged": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_i, c_p, c_sz, c_p,
+                                        c_f, c_f, c_p]),
     "gx_gemm_finish_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "gx_gemm_finish_workspace_bytes": (c_sz, [c_l, c_i, c_i]),
     "gx_gemm_f32_nt_planes_finish": (c_i, [c_l, c_i, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_sz,
-                                           c_p]),
+                                           c_p, c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),

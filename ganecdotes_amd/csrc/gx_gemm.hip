@@ -58,6 +58,9 @@ struct GemmArgs {
     // the B planes are two fp16 planes of B * xh_scale_of(*b_amax) (the trailer gx_split_gemm_weights_h2 leaves behind the planes)
     float a_scale; const float* b_amax;
     float b_scale;        // x6ws: B's host-given power-of-two scale
+    // x6ws: A's bound on the DEVICE (max |A| left behind by A's producer — fin_amax below —, times a host factor); NULL: a_scale
+    const float* a_amax; float a_amax_mul;
+    unsigned* fin_amax;   // gemm_xw_kernel<.., FIN>: optional, max |G| over everything the launch writes (float bits, atomicMax)
 };
 
 // (tile, K-split) of this workgroup.  The grid is (tiles, splits) and workgroups are dealt to the 8 XCDs in dispatch
@@ -477,6 +480,15 @@ __device__ __forceinline__ void xw_epilogue_fin(const GemmArgs& g, f32x16 (&acc)
     }
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f32x4*>(g.C + FIN_PIX(ps) * g.ldc + col) = v[ps];
+    if (q.fin_amax) {                                     // the bound the f16x3 gradient GEMMs of the levels below scale G by
+        float m = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[ps][e]));
+        m = gx_wave_max(m);
+        if (lane == 0) atomicMax(q.fin_amax, __float_as_uint(m));
+    }
     if (q.fin_pool && FIN_ABL != 2 && FIN_ABL != 5) {
         // pooled pixel of (image row pair, x / 2): the wave's 8 of them, lanes with an even row lane write
         const long rhalf = 1L << (rlog - 1);
@@ -762,6 +774,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     const int nkt = (kend - kbeg + XK - 1) / XK;
     char* slot0 = lds;
     char* slot1 = lds + WS_SLOT;
+    float a_scale = 1.f;
+    if constexpr (H2) a_scale = g.a_amax ? xh_scale_of(*g.a_amax * g.a_amax_mul) : g.a_scale;
 
     if (wid >= 4) {
         // ------------------------------------------------------------------ producers
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         };
         auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
             if constexpr (H2) {
-                xh_store_tile<A_KC, WS_BM>(slot, ra, p, g.a_scale);
+                xh_store_tile<A_KC, WS_BM>(slot, ra, p, a_scale);
                 xh_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p, g.b_scale);
             } else {
                 x6_store_tile<A_KC, WS_BM>(slot, ra, p);
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         __syncthreads();                                             // barrier t+1
     }
     if constexpr (H2) {
-        const float un = 1.f / (g.a_scale * g.b_scale);
+        const float un = 1.f / (a_scale * g.b_scale);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -867,11 +881,12 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        const float* col_bias, int split_k, float* workspace, size_t workspace_bytes,
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
-                       int N1 = -1, const int* k_live = nullptr, float a_range = 0.f, float b_range = 0.f) {
+                       int N1 = -1, const int* k_live = nullptr, float a_range = 0.f, float b_range = 0.f,
+                       const float* a_amax_dev = nullptr) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.live = k_live;
-    g.a_scale = g.b_scale = 1.f; g.b_amax = nullptr;
+    g.a_scale = g.b_scale = 1.f; g.b_amax = nullptr; g.a_amax = nullptr; g.a_amax_mul = 1.f; g.fin_amax = nullptr;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.usum_part = nullptr; g.sk_inv_eps = 0.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
@@ -893,7 +908,10 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     const bool ws = x6 && M > BM && (split_k > 1 ? K / split_k : K) >= WS_MIN_K;
     // f16x3 form: both operands' bounds given, on the wave-specialised kernel (the 4-wave kernels keep bf16x6: short k loops)
     const bool h2 = ws && a_range > 0.f && b_range > 0.f;
-    if (h2) { g.a_scale = xh_scale_of(a_range); g.b_scale = xh_scale_of(b_range); }
+    if (h2) {
+        g.a_scale = xh_scale_of(a_range); g.b_scale = xh_scale_of(b_range);
+        if (a_amax_dev) { g.a_amax = a_amax_dev; g.a_amax_mul = a_range; }     // the bound is *a_amax_dev x a_range, read on the device
+    }
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -973,7 +991,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
     g.a_scale = h2 ? xh_scale_of(a_range) : 1.f;
-    g.b_scale = 1.f;
+    g.b_scale = 1.f; g.a_amax = nullptr; g.a_amax_mul = 1.f; g.fin_amax = nullptr;
     g.b_amax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + (size_t)g.tiles_n * (K >> 4) * 3 * 4096);
     {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
         const long per_tile = (long)K * 128 * 6;
@@ -993,7 +1011,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     const dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
     if (fin) {
         g.fin_C = fin->fin_C; g.fin_Z = fin->fin_Z; g.fin_Wc = fin->fin_Wc; g.fin_pool = fin->fin_pool; g.fin_part = fin->fin_part;
-        g.fin_K = fin->fin_K; g.fin_ls = fin->fin_ls; g.fin_rlog = fin->fin_rlog;
+        g.fin_K = fin->fin_K; g.fin_ls = fin->fin_ls; g.fin_rlog = fin->fin_rlog; g.fin_amax = fin->fin_amax;
         if (h2) hipLaunchKernelGGL((gemm_xw_kernel<false, true, true>), grid, block, 0, stream, g);
         else hipLaunchKernelGGL((gemm_xw_kernel<false, true>), grid, block, 0, stream, g);
         GX_CHECK_LAUNCH();
@@ -1051,11 +1069,20 @@ int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* 
 int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                        int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
-                       void* stream) {
+                       const float* a_amax_dev, void* stream) {
     if ((k_live && !transA) || !(a_range > 0.f) || !(b_range > 0.f)) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
                            split_k, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1,
-                           k_live, a_range, b_range);
+                           k_live, a_range, b_range, a_amax_dev);
+}
+// gx_gemm_f32_tn_cat with the bounds of gx_gemm_f32_ranged (A's on the device: *a_amax_dev x a_mul; |B1|, |B2| <= b_range)
+int gx_gemm_f32_tn_cat_ranged(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
+                              long ldb2, float* C, long ldc, float alpha, float beta, int split_k, float* workspace,
+                              size_t workspace_bytes, const float* a_amax_dev, float a_mul, float b_range, void* stream) {
+    if (!B2 || N2 <= 0 || !a_amax_dev || !(a_mul > 0.f) || !(b_range > 0.f)) return GX_ERR_BAD_ARG;
+    return gx::launch_gemm(1, 0, M, N1 + N2, K, A, lda, B1, ldb1, C, ldc, alpha, beta, nullptr, nullptr, split_k, workspace,
+                           workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, B2, ldb2, N1, nullptr, a_mul, b_range,
+                           a_amax_dev);
 }
 
 // C = alpha * [A1 | A2] opB + ... : A1 is [M][K1], A2 is [M][K2]; K1 must be a multiple of 32.
@@ -1110,7 +1137,7 @@ int gx_gemm_finish_ok(int N, int K1, int res, int K) {
 size_t gx_gemm_finish_workspace_bytes(long M, int N, int K) { return ((size_t)(M / 128) + 8) * K * N * sizeof(float); }
 int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
                                  int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
-                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream) {
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, void* stream) {
     if (!gx_gemm_finish_ok(N, K1, res, K) || !coeffs || !Z || !Wc || !gWc || M <= 0 || M % ((long)res * res) ||
         M >= (1L << 31) || (((uintptr_t)coeffs | (uintptr_t)Z | (uintptr_t)Wc | (uintptr_t)Gpool) & 15))
         return GX_ERR_BAD_ARG;
@@ -1118,6 +1145,7 @@ int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long ld
     gx::GemmArgs fin{};
     fin.fin_C = coeffs; fin.fin_Z = Z; fin.fin_Wc = Wc; fin.fin_pool = Gpool; fin.fin_part = workspace;
     fin.fin_K = K; fin.fin_ls = (K + 1 + 3) & ~3; fin.fin_rlog = 0;
+    fin.fin_amax = reinterpret_cast<unsigned*>(g_amax);            // optional: max |G| (the caller zeroes it)
     while ((1 << fin.fin_rlog) < res) ++fin.fin_rlog;
     const int rc = gx::launch_gemm_xw((int)M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, G, N, 1.f, 0.f, nullptr, nullptr, nullptr,
                                       0, nullptr, (hipStream_t)stream, nullptr, 0.f, &fin);

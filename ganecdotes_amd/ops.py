@@ -117,10 +117,11 @@ def _chk2d(*ts):
 
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
-         split_k=1, live=None, live_frac=1.0, a_range=None, b_range=None):
+         split_k=1, live=None, live_frac=1.0, a_range=None, b_range=None, a_amax=None):
     """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
     a_range / b_range (both, optional): upper bounds of |a|, |b| — the long-k launches then run the f16x3 form
-    (gx_gemm_f32_ranged: half the matrix-core work; each bound within ~2^14 of its operand's RMS).
+    (gx_gemm_f32_ranged: half the matrix-core work; each bound within ~2^14 of its operand's RMS).  a_amax: a one-element HIP
+    tensor holding max |a| (left by a's producer); a_range is then the factor it is multiplied by (default 1).
     op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K).
     a, b, out may be row-strided views (leading dimension = stride(0)).
     live (trans_a only): int32 device scalar, the k rows that carry data (the rest is not read; the launch covers K with no
@@ -144,11 +145,14 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
         ws = workspace("gemm", wsb, a.device)
     if live is not None and (not trans_a or live.dtype != torch.int32 or not live.is_cuda or live.numel() != 1):
         raise RuntimeError("gemm: `live` is an int32 HIP scalar and needs trans_a")
+    if a_amax is not None and a_range is None:
+        a_range = 1.0
     if GEMM_H2 and a_range is not None and b_range is not None and a_range > 0 and b_range > 0:
         with record("gemm_f32_kernel", 2.0 * m * n * k * (live_frac if live is not None else 1.0)):
             _lib.check(L.gx_gemm_f32_ranged(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
                                             _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
-                                            wsb, _p(live), float(a_range), float(b_range), _stream()), "gx_gemm_f32_ranged")
+                                            wsb, _p(live), float(a_range), float(b_range), _p(a_amax), _stream()),
+                       "gx_gemm_f32_ranged")
         return out
     if live is not None:
         with record("gemm_f32_kernel", 2.0 * m * n * k * live_frac):
@@ -194,8 +198,9 @@ def gemm_upadd(a1, a2, b, out, coarse, fine_res, beta=0.0):
     return out
 
 
-def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
-    """out (M, N1+N2) = alpha * a.T @ [b1 | b2] + beta*out for a stored (K, M), b1 (K, N1), b2 (K, N2); N1 % 128 == 0."""
+def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1, a_amax=None, a_mul=1.0, b_range=None):
+    """out (M, N1+N2) = alpha * a.T @ [b1 | b2] + beta*out for a stored (K, M), b1 (K, N1), b2 (K, N2); N1 % 128 == 0.
+    a_amax (one-element HIP tensor: max |a| / a_mul) and b_range: the bounds of the f16x3 form (gemm's a_amax / b_range)."""
     _chk2d(a, b1, b2, out)
     k, m = a.shape
     n1, n2 = b1.shape[1], b2.shape[1]
@@ -206,6 +211,12 @@ def gemm_tn_cat(a, b1, b2, out, alpha=1.0, beta=0.0, split_k=1):
     if split_k > 1:
         wsb = L.gx_gemm_f32_workspace_bytes(m, n1 + n2, split_k)
         ws = workspace("gemm", wsb, a.device)
+    if GEMM_H2 and a_amax is not None and b_range is not None:
+        with record("gemm_f32_kernel", 2.0 * m * (n1 + n2) * k):
+            _lib.check(L.gx_gemm_f32_tn_cat_ranged(m, n1, n2, k, _p(a), a.stride(0), _p(b1), b1.stride(0), _p(b2), b2.stride(0),
+                                                   _p(out), out.stride(0), alpha, beta, split_k, _p(ws), wsb, _p(a_amax),
+                                                   float(a_mul), float(b_range), _stream()), "gx_gemm_f32_tn_cat_ranged")
+        return out
     with record("gemm_f32_kernel", 2.0 * m * (n1 + n2) * k):
         _lib.check(L.gx_gemm_f32_tn_cat(m, n1, n2, k, _p(a), a.stride(0), _p(b1), b1.stride(0), _p(b2), b2.stride(0), _p(out),
                                         out.stride(0), alpha, beta, split_k, _p(ws), wsb, _stream()), "gx_gemm_f32_tn_cat")
@@ -731,7 +742,7 @@ def gemm_finish_ok(n, k1, res, k):
     return bool(lib().gx_gemm_finish_ok(n, k1, res, k))
 
 
-def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool):
+def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool, want_amax=False):
     """G = a b^T with the low-rank path's dense finish in the GEMM's epilogue (gx_gemm_f32_nt_planes_finish):
     G += coeffs[:, :K] wc + coeffs[:, K] .* z, gwc = beta gwc + coeffs[:, :K]^T z, and the 2x2 sums of G.
     a (rows, K1) = pixels of res x res images, z (B, res, res, D); -> (G (B, res, res, D), Gpool (B, res/2, res/2, D) or None)"""
@@ -749,13 +760,14 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool)
         raise RuntimeError("gemm_nt_planes_finish: not this shape / engine (gemm_finish_ok)")
     g = torch.empty_like(z)
     gp = torch.empty(bsz, r // 2, r // 2, d, dtype=torch.float32, device=z.device) if want_pool else None
+    amax = torch.zeros(1, dtype=torch.float32, device=z.device) if want_amax else None     # max |G|, for the f16x3 GEMMs below
     wsb = L.gx_gemm_finish_workspace_bytes(rows, d, k)
     ws = workspace("gemm_finish", wsb, z.device)
     with record("gemm_f32_kernel", 2.0 * rows * d * a.shape[1], 0.0):
         _lib.check(L.gx_gemm_f32_nt_planes_finish(rows, d, a.shape[1], _p(a), a.stride(0), _p(b_planes.buf), _p(g), r, _p(coeffs),
-                                                  _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _stream()),
+                                                  _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _p(amax), _stream()),
                    "gx_gemm_f32_nt_planes_finish")
-    return g, gp
+    return (g, gp, amax) if want_amax else (g, gp)
 
 
 def xplanes_buffer(b, h, w, cin, device, slot="", cache=None):

@@ -140,12 +140,15 @@ class Pyramid:
         return r * r
 
     # ------------------------------------------------------------------------------------- backward
-    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None, nlev=None):
+    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None, nlev=None, g_amax=None):
         """g (B, r, r, D) = d loss / d Z of level nlev - 1 (default: the finest) -> gwp (D, hlen) (+)= sum over the
         taps of the first nlev levels of G_level^T tap.  g_pooled: sumpool2(g) if the caller already has it.
         on_level([(off, width), ...]) is called once the GEMMs of a level are queued (its columns of gwp are final:
-        a sharded caller starts their all-reduce there)."""
+        a sharded caller starts their all-reduce there).  g_amax (one-element HIP tensor, optional): max |g| as its producer left
+        it — the level GEMMs then run the f16x3 form (the taps' range is the convs' contract; a 2x2 sum-pooling multiplies the
+        bound by 4)."""
         first = not accumulate
+        gmul = 1.0
         nlev = len(self.res) if nlev is None else nlev
         res, levels = self.res[:nlev], self.levels[:nlev]
         for r, taps in zip(reversed(res), reversed(levels)):
@@ -157,17 +160,20 @@ class Pyramid:
                 (ta, off, ca), (tb, _, cb) = used
                 tiles = ((g2.shape[1] + 127) // 128) * ((ca + cb + 127) // 128)
                 split = int(max(1, min(512 // tiles, rows // 256)))
-                ops.gemm_tn_cat(g2, ta[:, :ca], tb[:, :cb], gwp[:, off:off + ca + cb], beta=0.0 if first else 1.0, split_k=split)
+                ops.gemm_tn_cat(g2, ta[:, :ca], tb[:, :cb], gwp[:, off:off + ca + cb], beta=0.0 if first else 1.0, split_k=split,
+                                a_amax=g_amax, a_mul=gmul, b_range=ops.FEATURE_RANGE if g_amax is not None else None)
                 used = []
             for t, off, cu in used:
                 tiles = ((g2.shape[1] + 127) // 128) * ((cu + 127) // 128)
                 split = int(max(1, min(512 // tiles, rows // 256)))
                 ops.gemm(g2, t[:, :cu], True, False, out=gwp[:, off:off + cu], beta=0.0 if first else 1.0,
-                         split_k=split)
+                         split_k=split, a_amax=g_amax, a_range=gmul if g_amax is not None else None,
+                         b_range=ops.FEATURE_RANGE if g_amax is not None else None)
             if on_level is not None and any(cu > 0 for _, _, cu in taps):
                 on_level([(off, cu) for _, off, cu in taps if cu > 0])
             if r != res[0]:
                 g = g_pooled if (g_pooled is not None and r == res[-1]) else ops.sumpool2(g)
+                gmul *= 4.0
         return gwp
 
     def backward_lowrank(self, coeffs, wp, wc, gwp, gwc, on_level=None, on_heads=None, fused_finish=True):
@@ -192,12 +198,14 @@ class Pyramid:
         zc2 = zc.reshape(-1, d)
         # ONE pass over the level's taps: S = sum_q e[q] t t^T (e = C[:, K]), P = C[:, :K]^T t, Tt = 2x2-pooled e t, Cpool
         s, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, k, r)
+        g_amax = None
         # gradient of the level below: Gc = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc  (+ its 2x2 sum-pooling), gWc
         pool = top > 1
         rc = zc.shape[1]
         if fused_finish and ops.get_gemm_mode() == 1 and ops.gemm_finish_ok(d, cf, rc, k):
             # ... in ONE kernel: the finish rides on the GEMM's epilogue, G is written once (csrc/gx_gemm.hip)
-            gcz, gp = ops.gemm_nt_planes_finish(tt, ops.split_gemm_weights(wf), cpool, zc, wc, gwc, 0.0, rc, pool)
+            gcz, gp, g_amax = ops.gemm_nt_planes_finish(tt, ops.split_gemm_weights(wf), cpool, zc, wc, gwc, 0.0, rc, pool,
+                                                        want_amax=True)
         else:
             gc = torch.empty_like(zc2)
             ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
@@ -215,4 +223,4 @@ class Pyramid:
         ops.gemm(wc, pm, True, False, out=gcols, beta=1.0)
         if on_level is not None:
             on_level([(o, cu) for _, o, cu in self._used(top)])
-        return self.backward(gcz, gwp, accumulate=False, g_pooled=gp, on_level=on_level, nlev=top)
+        return self.backward(gcz, gwp, accumulate=False, g_pooled=gp, on_level=on_level, nlev=top, g_amax=g_amax)

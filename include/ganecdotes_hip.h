@@ -145,7 +145,13 @@ int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* 
 int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                        int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
-                       void* stream);
+                       const float* a_amax_dev, void* stream);
+/* a_amax_dev (optional): A's bound lives on the device — max |A| as left behind by A's producer (g_amax of
+ * gx_gemm_f32_nt_planes_finish) — and a_range is then the host factor it is multiplied by (4 per 2x2 sum-pooling since).
+ * gx_gemm_f32_tn_cat_ranged: gx_gemm_f32_tn_cat the same way (|B1|, |B2| <= b_range). */
+int gx_gemm_f32_tn_cat_ranged(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
+                              long ldb2, float* C, long ldc, float alpha, float beta, int split_k, float* workspace,
+                              size_t workspace_bytes, const float* a_amax_dev, float a_mul, float b_range, void* stream);
 /* gx_gemm_f32_nt_planes_finish: G = A1 B^T with the low-rank path's dense finish in the epilogue (autograd of
  * swav_clustering.py:171-175 through the pyramid, K <= 16): G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q], gWc = beta gWc +
  * coeffs[:, :K]^T Z, Gpool (may be NULL) = the 2x2 sums of G; rows = pixels of res x res images (DESIGN.md par. 4.14) */
@@ -153,7 +159,8 @@ int gx_gemm_finish_ok(int N, int K1, int res, int K);
 size_t gx_gemm_finish_workspace_bytes(long M, int N, int K);
 int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
                                  int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
-                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, void* stream);
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, void* stream);
+/* g_amax (optional; one float the caller has zeroed): max |G| over the launch, for gx_gemm_f32_ranged's a_amax_dev */
 /* usum_part (optional, with colmax_part; same size): per 32-row slice and column the sum of exp((C - that slice's maximum) /
  * sk_eps) — the FIRST Sinkhorn pass (swav_clustering.py:519-520: Q = exp(scores / eps), its row sums) left behind by the GEMM
  * that writes the scores.  gx_sinkhorn_first_from_parts merges the slices of `groups` equal row groups by log-sum-exp:

@@ -905,6 +905,16 @@ def test_gemm_ranged_f16x3_form_of_the_long_k_gemms(ops):
         o3 = ops.gemm(a, b, True, False, split_k=4, live=live, live_frac=17 / 30, a_range=1e-3, b_range=0.5)
         want = a[:17000].double().cpu().t() @ b[:17000].double().cpu()
         assert rel_err(o3, want) < 3e-6
+        # A's bound on the device (max |A| left by its producer, times a host factor), also for the two-source TN form
+        k, m = 24000, 512
+        a, b1, b2 = dev(torch.randn(k, m) * 3e-6), dev(torch.randn(k, 256)), dev(torch.randn(k, 128) * 2)
+        amax = (a.abs().max() / 4).reshape(1).contiguous()
+        want = a.double().cpu().t() @ torch.cat([b1, b2], 1).double().cpu()
+        o3 = ops.gemm_tn_cat(a, b1, b2, torch.empty(m, 384, device="cuda"), split_k=4, a_amax=amax, a_mul=4.0, b_range=16.0)
+        o6 = ops.gemm_tn_cat(a, b1, b2, torch.empty(m, 384, device="cuda"), split_k=4)
+        assert rel_err(o3, want) < 3e-6 and not torch.equal(o3, o6)
+        o3 = ops.gemm(a, b1, True, False, split_k=4, a_amax=amax, a_range=4.0, b_range=8.0)
+        assert rel_err(o3, a.double().cpu().t() @ b1.double().cpu()) < 3e-6
         # short k: the 4-wave kernel, bounds ignored
         a, b = dev(torch.randn(300, 64)), dev(torch.randn(200, 64))
         assert torch.equal(ops.gemm(a, b, a_range=8.0, b_range=8.0), ops.gemm(a, b))
