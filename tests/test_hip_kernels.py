@@ -863,6 +863,32 @@ def test_gemm_nt_planes_f16x3_form_is_fp32_class(ops):
         out2 = torch.full((512, 256), 7.0, device="cuda")
         ops.gemm_nt_planes_live(a, bp3, out2, live, 300 / 512, col_bias=cb, a_range=8.0)
         assert torch.equal(out2[:256], out[:256]) and bool((out2[384:] == 7.0).all())
+        # large launches take 256-row tiles (a wave 64 rows: the 128-row form is LDS-bound); same products in the same order per
+        # element -> BITWISE the 128-row result, ragged tail, per-slice by-products and the live-row form included
+        from ganecdotes_amd import _lib
+        L = _lib.load()
+        for (m, n, k) in ((33000, 512, 64), (16500, 1028, 32)):
+            a2, w2, cb2 = dev(torch.randn(m, k)), dev(torch.randn(n, k) * 0.05), dev(torch.randn(n))
+            bp = ops.split_gemm_weights(w2, h2=True)
+            res = []
+            for tall in (1, 0):
+                was_t = L.gx_set_gemm_tall(tall)
+                o = torch.empty(m, n, device="cuda")
+                _, cm_, uf_ = ops.gemm_nt_planes(a2, None, bp, o, col_bias=cb2, want_colmax=True, sk_eps=0.05, a_range=8.0)
+                o2 = torch.full((m, n), 3.0, device="cuda")
+                lv = torch.tensor([m - 5000], dtype=torch.int32, device="cuda")
+                ops.gemm_nt_planes_live(a2, bp, o2, lv, 0.8, a_range=8.0)
+                o3 = dev(torch.ones(m, n))
+                ops.gemm_nt_planes(a2, None, bp, o3, alpha=0.5, beta=2.0, a_range=8.0)
+                res.append((o, cm_, uf_, o2, o3))
+                L.gx_set_gemm_tall(was_t)
+            for i, (x, y) in enumerate(zip(res[0], res[1])):
+                if i == 3:      # live rows: a tile is skipped whole, so rows past the count inside the last live tile differ by tile height
+                    x, y = x[:m - 5000], y[:m - 5000]
+                assert torch.equal(x, y), (m, n, k, i, float((x - y).abs().max()))
+            assert torch.equal(res[0][1], res[0][0].amax(0))
+            assert rel_err(res[0][0], a2.double().cpu() @ w2.double().cpu().t() + cb2.double().cpu()) < 3e-6
+            assert bool((res[0][3][m - 5000 + 256:] == 3.0).all())
         # out of range: loud
         a[3, 5] = 100.0
         ops.gemm_nt_planes(a, None, bp3, out, a_range=1.0)
