@@ -633,6 +633,25 @@ def main():
                    "generator": "StyleGAN2 256x256 random-init (seed 42)", "loss": loss},
         "roofline": roof,
     }
+    # the same headline step on the bf16x6 forms (three bf16 planes, six products: every operand bit kept, fp32's range) — a
+    # reader who does not accept f16x3's range contract as fp32 arithmetic finds the number of the engine that needs none here,
+    # timed by the same command in the same process (GX_CONV_PLANES=0 GX_GEMM_PLANES=0 make it the headline)
+    if x6 and world == 1 and args.all_configs != "off" and (ops.get_conv_planes() == 1 or ops.GEMM_H2):
+        sw = None
+        torch.cuda.empty_cache()
+        prev_fmt, prev_h2 = ops.set_conv_planes(0), ops.GEMM_H2
+        ops.GEMM_H2 = False
+        try:
+            swb = make(args.prototypes)
+            dtb, stb, lossb = measure_nested(swb, args, 12, 3, dev, world)
+            out["engine_bf16x6"] = nested_record(
+                "the headline configuration with every contraction on the bf16x6 forms (ops.set_conv_planes(0), ops.GEMM_H2 = False); "
+                + swb.last_route.describe(), args.batch, dtb, 12, 3, stb, loss=lossb)
+            del swb
+        finally:
+            ops.set_conv_planes(prev_fmt)
+            ops.GEMM_H2 = prev_h2
+        torch.cuda.empty_cache()
     # the reference's own configuration (nprototypes = 5000): a second, short measurement inside the same line, so that
     # the number the reference actually ships is timed by whoever runs this script and not only by the builder
     want_rf = args.reference_faithful == "on" or (args.reference_faithful == "auto" and world == 1 and args.prototypes == 8)
