@@ -1719,6 +1719,44 @@ def test_blur_pass_with_lds_dma_rows_equals_the_register_form(ops, b, h, cout, e
         L.gx_set_blur_dma(1)
 
 
+@pytest.mark.parametrize("b,h,cin,cout,up,xs", [(4, 64, 128, 128, False, 1.0), (2, 64, 256, 128, True, 1.0), (16, 128, 64, 128, False, 1.0),
+                                                (4, 64, 128, 128, False, 300.0), (4, 64, 128, 128, False, 0.02)])
+def test_modconv_plane_formats_against_the_exact_engine(ops, b, h, cin, cout, up, xs):
+    """The x-planes conv under its two plane formats — three bf16 planes / six products, two fp16 planes of the scaled operands /
+    three products (gx_set_conv_planes) — against the exact-fp32 MFMA engine (bitwise an fmaf chain) on the same inputs: plain
+    and up-sampling layers, 128- and 256-row tiles, activations of scale 1, 300 and 0.02 (inside the f16x3 window): the f16x3
+    error is within 1.5 x the bf16x6 one and both stay at fp32 summation-order level (K = 9 Cin up to 2304)."""
+    torch.manual_seed(b + h + cin)
+    x = dev(torch.randn(b, h, h, cin) * xs)
+    wt = dev(torch.randn(9, cout, cin) / math.sqrt(9 * cin))
+    s = dev(torch.rand(b, cin) + 0.5)
+    dm = dev((torch.rand(b, cout) + 0.5) / xs)
+    kf = dev(torch.flip(T(load_golden("gv1_upfirdn2d")["kernel"]) * 4, [0, 1]))
+    oh = 2 * h if up else h
+    noise, nw, bias = dev(torch.randn(1, 1, oh, oh)), dev(torch.tensor([0.3])), dev(torch.randn(cout))
+    prev, prev_fmt = ops.set_gemm_mode(0), ops.get_conv_planes()
+    try:
+        if up:
+            ref = ops.modconv_up(x, wt, s, dm, kf, noise, nw, bias, True)
+        else:
+            ref = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True)
+        ops.set_gemm_mode(1)
+        err = {}
+        for fmt in (0, 1):
+            ops.set_conv_planes(fmt)
+            wtp = ops.split_conv_weights(wt)
+            xp = ops.modsplit(x, s)
+            if up:
+                got = ops.modconv_up(x, wt, s, dm, kf, noise, nw, bias, True, wt_planes=wtp, x_planes=xp)
+            else:
+                got = ops.modconv(x, wt, 3, s, dm, noise, nw, bias, True, wt_planes=wtp, x_planes=xp)
+            err[fmt] = float((got.double() - ref.double()).norm() / ref.double().norm())
+        assert err[1] < 1.5 * err[0] + 5e-8 and err[1] < 1e-6, err
+    finally:
+        ops.set_conv_planes(prev_fmt)
+        ops.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("b,h,cin,cout,up", [(3, 16, 64, 160, False), (2, 24, 40, 128, True), (5, 8, 512, 512, False),
                                              (1, 64, 128, 96, True), (2, 33, 20, 72, False),
                                              # Cout <= 64: the tall 256-pixel x 64-channel tile (the 512^2 layers of a 512^2 generator)
