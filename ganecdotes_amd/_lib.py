@@ -76,7 +76,7 @@ SIGNATURES = {
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gx_fineq_ytable_ld": (c_i, []),
-    "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p]),
     "gx_fineq_bwd_workspace_bytes": (c_sz, []),
     "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gx_proto_raw_tables": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p]),

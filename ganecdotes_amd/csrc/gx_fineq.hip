@@ -36,6 +36,7 @@ struct FineqArgs {
     float* sc_table;                       // [rows][K]
     int M, K, shift;                       // rows, prototypes, log2(fine resolution)
     int ntile;                             // 128-row tiles
+    float a_scale; const float* b_amax;    // f16x3 form (gx_mfma_x6.h): the taps' power-of-two scale, max |Bq| behind the planes
 };
 
 #ifndef FQ_ABL
@@ -58,11 +59,11 @@ constexpr int FQ_LDS = FQ_NSA * FQ_A + FQ_NSB * FQ_B + 3 * FQ_Y + 512;
 // per-wave DMA instruction counts of k-tile kt (compile-time): B = the 1 KB chunks (plane, column block >= kt / 2) dealt to
 // 8 waves; Y = one per wave at odd k-tiles (block (kt + 1) / 2 of this / the next tile) and at kt = 12 (the score block)
 __host__ __device__ constexpr int fq_nblk(int kt) { return 9 - ((kt & 15) >> 1); }
-__host__ __device__ constexpr int fq_nb_dma(int kt) { return (3 * fq_nblk(kt) + 7) / 8; }
+__host__ __device__ constexpr int fq_nb_dma(int kt, int npl = 3) { return (npl * fq_nblk(kt) + 7) / 8; }
 __host__ __device__ constexpr int fq_ny_dma(int kt) { return ((kt & 1) || (kt & 15) == 12) ? 1 : 0; }
 // outstanding vector-memory operations allowed at the top of k-tile t: everything issued in k-tile t - 1 (the DMAs of
 // k-tile t itself were issued in t - 2, before them, and complete in order)
-__host__ __device__ constexpr int fq_vmcnt(int t) { return fq_ny_dma(t + 15) + fq_nb_dma(t + 1) + 1; }
+__host__ __device__ constexpr int fq_vmcnt(int t, int npl = 3) { return fq_ny_dma(t + 15) + fq_nb_dma(t + 1, npl) + 1; }
 __device__ __forceinline__ void fq_wait_vm(int n) {        // n is a constant once the k loop is unrolled: one case survives
     switch (n) {
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -90,8 +91,12 @@ __device__ __forceinline__ void fq_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // right there (t and Y2 from LDS).  Nothing of U is staged or stored and the taps leave HBM exactly once.  History: U parked
 // in LDS after the loop with t / Y2 re-read from global 2.4 ms (4.2 GB of L2 misses with little in flight); folding in the
 // loop, 4 waves x all 9 blocks, 2 workgroups per CU 1.7 ms (256 VGPRs: the Y2 loads spilled one by one behind vmcnt(0)).
+// H2: the f16x3 form — Bq as two fp16 planes scaled on the device (gx_split_gemm_weights_h2), the taps scaled by g.a_scale
+// (their range is the convs' contract), three products per block-k-tile; a block's sums are un-scaled where they are folded.
+template <bool H2>
 __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
-    constexpr int CF = 256, NKT = 16;
+    constexpr int CF = 256, NKT = 16, NPL = H2 ? 2 : 3;
+    const float un = H2 ? 1.f / (g.a_scale * xh_scale_of(*g.b_amax)) : 1.f;
     __shared__ __attribute__((aligned(16))) char lds[FQ_LDS];
     char* const ldsB = lds + FQ_NSA * FQ_A;
     char* const ldsY = ldsB + FQ_NSB * FQ_B;
@@ -140,13 +145,13 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     // B: the 1 KB chunks (plane p, column block nb >= kt / 2) of k-tile kt, chunk c = wave + 8 i (clamped: a few duplicates)
     auto issue_b = [&](int kt, int slot) {
         if (FQ_ABL == 4) return;
-        const int nblk = fq_nblk(kt), nch = 3 * nblk, nbmin = 9 - nblk;
+        const int nblk = fq_nblk(kt), nch = NPL * nblk, nbmin = 9 - nblk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i >= fq_nb_dma(kt)) continue;
+            if (i >= fq_nb_dma(kt, NPL)) continue;
             const int c = min(wid + 8 * i, nch - 1);
             const int p = c / nblk, nb = nbmin + c - p * nblk;
-            const unsigned src = (unsigned)(((nb >> 2) * NKT + kt) * 3 + p) * 4096u + (unsigned)(nb & 3) * 1024u;
+            const unsigned src = (unsigned)(((nb >> 2) * NKT + kt) * NPL + p) * 4096u + (unsigned)(nb & 3) * 1024u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(ldsB + slot * FQ_B + p * FQ_PST + nb * 1024), 16,
                                                      (int)(lane * 16), (int)src, 0, 0);
         }
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             if (FQ_ABL >= 3 && FQ_ABL <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else fq_wait_vm(fq_vmcnt(t));
+            else fq_wait_vm(fq_vmcnt(t, NPL));
             if (FQ_ABL != 7) fq_barrier();
             // issue: [Y] B(t + 2) A(t + 2) — Y first: its consumer (two k-tiles on) only waits for the A / B issued after it
             if (t & 1) issue_y(t == 15 ? tn : tm, ((t + 1) >> 1) & 7, ((t + 1) >> 1) & 1);
@@ -215,12 +220,22 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
                 unsigned h[4], m[4], l[4];
-                split3(x0[0], x0[1], h[0], m[0], l[0]);
-                split3(x0[2], x0[3], h[1], m[1], l[1]);
-                split3(x1[0], x1[1], h[2], m[2], l[2]);
-                split3(x1[2], x1[3], h[3], m[3], l[3]);
+                if constexpr (H2) {
+                    split2h(x0[0], x0[1], g.a_scale, h[0], l[0]);
+                    split2h(x0[2], x0[3], g.a_scale, h[1], l[1]);
+                    split2h(x1[0], x1[1], g.a_scale, h[2], l[2]);
+                    split2h(x1[2], x1[3], g.a_scale, h[3], l[3]);
+                    m[0] = m[1] = m[2] = m[3] = 0u;
+                } else {
+                    split3(x0[0], x0[1], h[0], m[0], l[0]);
+                    split3(x0[2], x0[3], h[1], m[1], l[1]);
+                    split3(x1[0], x1[1], h[2], m[2], l[2]);
+                    split3(x1[2], x1[3], h[3], m[3], l[3]);
+                }
+                // (f16x3: planes 0 = h, 1 = l of both operands — a[1] holds l, a[2] is unused)
                 const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]}),
-                                     __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
+                                     H2 ? __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})
+                                        : __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]}),
                                      __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]})};
                 // this wave's column blocks that k-tile t still meets: L: nb0 .. 5 -> acc[nb]; R: max(nb0, 6) .. 8 -> acc[nb - 6]
                 auto run = [&](auto role) {
@@ -234,20 +249,26 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                             const int nb = gb + j;
                             if (nb > hi || nb < nb0) continue;
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) {
+                            for (int q = 0; q < NPL; ++q) {
                                 if (FQ_ABL == 8 && (gb != lo || j != 0)) { b[j][q] = b[0][q]; continue; }   // lab: one block's fragments for all
                                 b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * FQ_PST + x_kc_off(nb * 32 + r32, hh));
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 6; ++u)
+                        for (int u = 0; u < (H2 ? 3 : 6); ++u)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const int nb = gb + j;
                                 if (nb > hi || nb < nb0 || FQ_ABL == 2) continue;
                                 // operands swapped: the accumulator is the block of U TRANSPOSED — lane = the row of t (r32),
                                 // register r = column (r & 3) + 8 (r >> 2) + 4 hh of the block — so that a row's fold is lane-local
-                                acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][TB[u]], a[TA[u]], acc[nb - lo], 0, 0, 0);
+                                if constexpr (H2) {
+                                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};          // l*h, h*l, h*h
+                                    acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[j][HB[u]]),
+                                                                                           __builtin_bit_cast(f16x8, a[HA[u]]), acc[nb - lo], 0, 0, 0);
+                                } else {
+                                    acc[nb - lo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][TB[u]], a[TA[u]], acc[nb - lo], 0, 0, 0);
+                                }
                             }
                     }
                 };
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                                      *reinterpret_cast<const f32x4*>(ysrc + 64), *reinterpret_cast<const f32x4*>(ysrc + 96)};
                 auto fold = [&](const f32x16& u) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sp = fmaf(tv[r >> 2][r & 3], u[r] + yv[r >> 2][r & 3], sp);
+                    for (int r = 0; r < 16; ++r) sp = fmaf(tv[r >> 2][r & 3], (H2 ? u[r] * un : u[r]) + yv[r >> 2][r & 3], sp);
                 };
                 if (isL) fold(acc[nb0 <= 5 ? nb0 : 5]);
                 else fold(acc[nb0 >= 6 ? nb0 - 6 : 0]);
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                 const f32x4 ac = *reinterpret_cast<const f32x4*>(yp + k0 * 4);
                 f32x4 o;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = fmaf(acc[2][4 * g2 + q] + ac[q], rn, myb[g2][q]);
+                for (int q = 0; q < 4; ++q) o[q] = fmaf((H2 ? acc[2][4 * g2 + q] * un : acc[2][4 * g2 + q]) + ac[q], rn, myb[g2][q]);
                 float* dst = g.sc_table + row * g.K + k0;
                 if (k0 + 3 < g.K && (g.K & 3) == 0) *reinterpret_cast<f32x4*>(dst) = o;
                 else
@@ -654,8 +675,8 @@ static int fineq_num_cus() {
 }
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
-                 float* sc_table, void* stream) {
-    if (!t1 || !bq_planes || !ytable || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
+                 float* sc_table, float a_range, void* stream) {
+    if (!t1 || !bq_planes || !ytable || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2) || a_range < 0.f) return GX_ERR_BAD_ARG;
     if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
     if (gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;                   // a bf16x6 kernel
     // >= 32: a wave's 32 rows are consecutive pixels of one image row (fineq_fwd_kernel's parent arithmetic); rows is then
@@ -675,7 +696,11 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
     while ((1 << g.shift) < fine_res) ++g.shift;
     g.ntile = rows / 128;
     const int nwg = g.ntile < fineq_num_cus() ? g.ntile : fineq_num_cus();
-    hipLaunchKernelGGL(gx::fineq_fwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
+    // a_range > 0: bq_planes are gx_split_gemm_weights_h2's (two fp16 planes + the max-|Bq| trailer), the taps bounded by a_range
+    g.a_scale = a_range > 0.f ? gx::xh_scale_of(a_range) : 1.f;
+    g.b_amax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bq_planes) + gx_gemm_weight_planes_bytes(CF + 16, CF) - 16);
+    if (a_range > 0.f) hipLaunchKernelGGL(gx::fineq_fwd_kernel<true>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gx::fineq_fwd_kernel<false>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -586,7 +586,7 @@ def fineq_pack_weights(mg, wcf):
     return bq
 
 
-def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
+def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res, a_range=None):
     """the finest level's score / rnorm tables from its taps t1 (rows, K1) [| t2 (rows, K2)] and the coarse table of the
     level below (fineq_ytable: y2 = 2 Zc Wf | ac = Zc Wc^T | nc = |Zc|^2): returns (rn_table (rows,), sc_table (rows, K))"""
     _chk2d(t1, t2)
@@ -596,7 +596,7 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
     L = lib()
     if tuple(ytable.shape) != (rows // 4, L.gx_fineq_ytable_ld()) or (t2 is not None and t2.shape[0] != rows):
         raise RuntimeError("fineq_fwd: shape mismatch")
-    if bq_planes.h2 or bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
+    if bq_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(k1 + k2 + 16, k1 + k2):
         raise RuntimeError("fineq_fwd: planes do not match (CF + 16, CF)")
     rn = torch.empty(rows, dtype=torch.float32, device=t1.device)
     sc = torch.empty(rows, k, dtype=torch.float32, device=t1.device)
@@ -604,8 +604,8 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res):
     flops = 2.0 * rows * 16 * 32 * (sum(cf // 32 - (t >> 1) for t in range(cf // 16)) + cf // 16)   # blocks on / below the diagonal + scores
     with record("fineq_fwd_kernel", flops):
         _lib.check(L.gx_fineq_fwd(rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2), 0 if t2 is None else t2.stride(0),
-                                  _p(bq_planes.buf), _p(ytable), _p(bias), k, _p(rn), _p(sc), _stream()),
-                   "gx_fineq_fwd")
+                                  _p(bq_planes.buf), _p(ytable), _p(bias), k, _p(rn), _p(sc), _a_range(bq_planes, a_range, "fineq_fwd"),
+                                  _stream()), "gx_fineq_fwd")
     return rn, sc
 
 

@@ -130,7 +130,7 @@ class Pyramid:
         yt = ops.fineq_ytable(zc2.shape[0], wp.device)                  # per parent pixel: 2 Zc Wf | Zc Wc^T | |Zc|^2
         ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous()), yt[:, :cf], alpha=2.0)
         ops.proto_raw_tables(zc2, wc, ytable=yt)
-        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq), yt, bias, k, r)
+        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq, h2=True), yt, bias, k, r, a_range=ops.FEATURE_RANGE)
         self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf)
         return rn, sc, shift
 

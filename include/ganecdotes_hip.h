@@ -198,7 +198,9 @@ int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, floa
 int gx_fineq_ytable_ld(void);   /* floats per parent pixel of the coarse table: [0, 256) Y2 | [256, 272) Ac | 272 nc | pad */
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
-                 float* sc_table, void* stream);
+                 float* sc_table, float a_range, void* stream);
+/* a_range: 0 = bq_planes from gx_split_gemm_weights (bf16x6); > 0 = a bound of |t1|, |t2| and bq_planes from
+ * gx_split_gemm_weights_h2 (the f16x3 form, as in gx_gemm_f32_nt_planes) */
 size_t gx_fineq_bwd_workspace_bytes(void);
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream);

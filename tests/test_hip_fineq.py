@@ -34,11 +34,14 @@ def _taps(b, res_top, chans, seed=5, scale=1.0):
     return taps
 
 
+@pytest.mark.parametrize("h2", [True, False], ids=["f16x3", "bf16x6"])
 @pytest.mark.parametrize("k,two_taps", [(8, True), (16, True), (5, False)])
-def test_fineq_tables_equal_the_projected_table_route(ops, k, two_taps):
+def test_fineq_tables_equal_the_projected_table_route(ops, k, two_taps, h2, monkeypatch):
     """rn / score tables of every pixel: gx_fineq_fwd (CF-wide forms of the finest taps + three tables of the level below)
-    against the tables computed from the projected table Z (gx_upsample2_add_scores), and against fp64."""
+    against the tables computed from the projected table Z (gx_upsample2_add_scores), and against fp64 — with the weight-plane
+    contractions (the level GEMMs and the quadratic-form kernel) on their f16x3 forms and on bf16x6."""
     from ganecdotes_amd.pyramid import Pyramid
+    monkeypatch.setattr(ops, "GEMM_H2", h2)
     b, d = 3, 512
     chans = {16: [64], 32: [128, 128], 64: [128, 128] if two_taps else [256]}
     taps = _taps(b, 64, chans)
