@@ -48,6 +48,7 @@ SIGNATURES = {
     "gx_set_gemm_mode": (c_i, [c_i]),
     "gx_get_gemm_mode": (c_i, []),
     "gx_set_gemm_tall": (c_i, [c_i]),
+    "gx_set_gemm_ngroup": (c_i, [c_i]),
     "gx_gemm_f32_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "gx_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p,
                           c_sz, c_p]),

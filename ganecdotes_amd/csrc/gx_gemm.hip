@@ -996,6 +996,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
 // C = alpha * row_scale .* ([A1 | A2] B^T) + col_bias + beta * C (+ upsample2(coarse)) with B given as pre-split planes
 // (gx_split_gemm_weights of the [N][K1 + K2] weight).  bf16x6 engine only; K1, K2 multiples of 16, rows 16-B aligned.
 static int g_xw_tall = 1;                 // lab / tests: gx_set_gemm_tall(0) keeps the 128-row tile of the f16x3 weight-plane GEMM
+static int g_xw_ngroup = 0;               // lab: gx_set_gemm_ngroup(n > 0) overrides the N tiles per group of the tile order
 static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
@@ -1039,6 +1040,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
         // tile streamed the whole A matrix from HBM by itself — 26 GB per launch for 6.4 GB of dS (profiles/r03_traffic_k5000.json);
         // pairs share it through L2 and the planes come from the Infinity Cache: 7.72 -> 7.46 ms, same-process A/B (dz_lab.py)
         gn = gn < 2 ? 2 : gn;
+        if (g_xw_ngroup > 0) gn = g_xw_ngroup;
         gn = gn > g.tiles_n ? g.tiles_n : gn;
         g.n_group = (int)gn;
     }
@@ -1080,6 +1082,7 @@ int gx_set_gemm_mode(int mode) {
 }
 int gx_get_gemm_mode(void) { return gx::gemm_mode(); }
 int gx_set_gemm_tall(int on) { const int prev = gx::g_xw_tall; gx::g_xw_tall = on ? 1 : 0; return prev; }
+int gx_set_gemm_ngroup(int n) { const int prev = gx::g_xw_ngroup; gx::g_xw_ngroup = n > 0 ? n : 0; return prev; }
 
 size_t gx_gemm_f32_workspace_bytes(int M, int N, int split_k) {
     return split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;

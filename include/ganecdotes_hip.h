@@ -71,6 +71,8 @@ int gx_set_gemm_mode(int mode);
 int gx_get_gemm_mode(void);
 /* lab / tests: 0 keeps the 128-row tile of the f16x3 weight-plane GEMM (default 1: 256-row tiles on the large launches) */
 int gx_set_gemm_tall(int on);
+/* lab: n > 0 overrides how many N tiles of the weight-plane GEMM share a sweep over the M tiles (0: chosen from the planes' size) */
+int gx_set_gemm_ngroup(int n);
 /* Plane format of the x-planes conv path under engine 1 (read at launch time by the producers of planes — gx_split_conv_weights,
  * gx_modsplit, the conv / blur passes that write the next conv's planes — and by the convs that read them; planes made under
  * one format must be consumed under the same): 0 = three bf16 planes, six products per fp32 product ("bf16x6"); 1 = two fp16

@@ -43,3 +43,18 @@ t = timeit(lambda: ops.gemm_nt_planes(ds, None, wt, dz))
 print(f"dz     {rows} x 512 x {kp}: {t:7.3f} ms  {2.0 * rows * kp * 512 / t / 1e9:6.1f} TFLOP/s")
 t = timeit(lambda: ops.gemm_nt_planes(a, None, wp, out, col_bias=bias, want_colmax=True, sk_eps=0.005))
 print(f"scores + per-slice column maxima and first-pass sums (and their merge over all rows): {t:7.3f} ms")
+
+
+# round 5: the same two GEMMs on the f16x3 form (DESIGN par. 4.21) — 128- / 256-row tiles, N tiles per group of the tile order
+L = ops.lib()
+wp3 = ops.split_gemm_weights(w, h2=True)
+wt3 = ops.split_gemm_weights(torch.nn.functional.pad(w, (0, 0, 0, kp - K)).t().contiguous(), h2=True)
+for tall in (1, 0):
+    L.gx_set_gemm_tall(tall)
+    for ng in (0, 1, 2, 4, 8, 40):
+        L.gx_set_gemm_ngroup(ng)
+        t1 = timeit(lambda: ops.gemm_nt_planes(a, None, wp3, out, col_bias=bias, a_range=1.0))
+        t2 = timeit(lambda: ops.gemm_nt_planes(ds, None, wt3, dz, a_range=8e-3)) if ng <= 4 else float("nan")
+        print(f"f16x3 tall={tall} ngroup={ng:2d}: scores {t1:7.3f} ms {2.0 * rows * K * 512 / t1 / 1e9:6.1f} TFLOP/s   dz {t2:7.3f} ms {2.0 * rows * kp * 512 / t2 / 1e9:6.1f} TFLOP/s", flush=True)
+L.gx_set_gemm_tall(1)
+L.gx_set_gemm_ngroup(0)
