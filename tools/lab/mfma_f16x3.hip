@@ -112,6 +112,41 @@ __global__ __launch_bounds__(256) void rate_kernel(const uint4* __restrict__ fra
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// the same with the 32x32x16 shape (what the f16x3 kernels issue): 2 x 2 tiles, three products per step
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <bool F16>
+__global__ __launch_bounds__(256) void rate32_kernel(const uint4* __restrict__ frag, float* __restrict__ out, long iters,
+                                                     unsigned long long* __restrict__ clk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4 a[2][2], b[2][2];
+    const uint4* f = frag + ((size_t)(blockIdx.x & 63) * 4 + wave) * 16 * 64 + lane;
+    for (int t = 0; t < 2; ++t)
+        for (int p = 0; p < 2; ++p) { a[t][p] = f[(t * 2 + p) * 64]; b[t][p] = f[(8 + t * 2 + p) * 64]; }
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    unsigned long long t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (long it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][p & 1]), __builtin_bit_cast(f16x8, b[j][p >> 1]), acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][p & 1]), __builtin_bit_cast(bf16x8, b[j][p >> 1]), acc[i][j], 0, 0, 0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][7];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
 static uint16_t bf16_of(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -216,11 +251,13 @@ int main() {
     CK(hipEventCreate(&e1));
     const long iters = 60000;
     for (int rep = 0; rep < 3; ++rep)
-        for (int eng = 0; eng < 2; ++eng) {
+        for (int eng = 0; eng < 4; ++eng) {
             for (int warm = 0; warm < 2; ++warm) {
                 CK(hipEventRecord(e0));
                 if (eng == 0) hipLaunchKernelGGL(rate_kernel<false>, dim3(grid), dim3(256), 0, 0, (const uint4*)db, dO, iters, clk);
-                else hipLaunchKernelGGL(rate_kernel<true>, dim3(grid), dim3(256), 0, 0, (const uint4*)df, dO, iters, clk);
+                else if (eng == 1) hipLaunchKernelGGL(rate_kernel<true>, dim3(grid), dim3(256), 0, 0, (const uint4*)df, dO, iters, clk);
+                else if (eng == 2) hipLaunchKernelGGL(rate32_kernel<false>, dim3(grid), dim3(256), 0, 0, (const uint4*)db, dO, 2 * iters, clk);
+                else hipLaunchKernelGGL(rate32_kernel<true>, dim3(grid), dim3(256), 0, 0, (const uint4*)df, dO, 2 * iters, clk);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
             }
@@ -229,10 +266,12 @@ int main() {
             unsigned long long hc[2];
             CK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
             const double ghz = (double)hc[0] / ((double)hc[1] / 100e6) / 1e9;
+            // 48 x 16x16x32 (16384 FLOP each) per step, or 12 x 32x32x16 (32768 FLOP each) over twice the steps: the same FLOPs
             const double flops = 2.0 * 16 * 16 * 32 * 48.0 * iters * 4.0 * grid;
-            const double busy = 2.0 * 48.0 * 8.0 * iters / (double)hc[0];        // 8 cycles per 16x16x32; two waves share a SIMD
+            const double busy = 2.0 * 48.0 * 8.0 * iters / (double)hc[0];        // 8 cycles per 16x16x32 (16 per 32x32x16); two waves share a SIMD
+            const char* names[4] = {"16x16x32 bf16", "16x16x32 f16", "32x32x16 bf16", "32x32x16 f16"};
             printf("(3) %-22s %8.2f ms  %8.1f TFLOP/s  clock %.3f GHz  busy %.3f  busy x GHz %.3f\n",
-                   eng == 0 ? "16x16x32 bf16" : "16x16x32 f16", ms, flops / ms / 1e9, ghz, busy, busy * ghz);
+                   names[eng], ms, flops / ms / 1e9, ghz, busy, busy * ghz);
         }
     return 0;
 }
