@@ -58,7 +58,8 @@ SIGNATURES = {
     "gx_split_gemm_weights": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gx_split_gemm_weights_h2": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gx_gemm_f32_nt_planes": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_i, c_p,
-                                    c_p, c_f, c_f, c_p]),
+                                    c_p, c_f, c_f, c_p, c_p]),
+    "gx_absmax": (c_i, [c_p, c_l, c_i, c_l, c_i, c_p, c_p]),
     "gx_sinkhorn_first_from_parts_workspace_bytes": (c_sz, [c_i, c_i]),
     "gx_sinkhorn_first_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "gx_sinkhorn_first_preset": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p]),
@@ -66,20 +67,20 @@ SIGNATURES = {
     "gx_gemm_f32_klive": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
                                 c_p]),
     "gx_gemm_f32_ranged": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_p, c_i, c_p, c_sz, c_p,
-                                 c_f, c_f, c_p, c_p]),
+                                 c_f, c_f, c_p, c_p, c_p]),
     "gx_gemm_f32_tn_cat_ranged": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_f, c_i, c_p, c_sz, c_p,
                                         c_f, c_f, c_p]),
     "gx_gemm_finish_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "gx_gemm_finish_workspace_bytes": (c_sz, [c_l, c_i, c_i]),
     "gx_gemm_f32_nt_planes_finish": (c_i, [c_l, c_i, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_sz,
-                                           c_p, c_p]),
+                                           c_p, c_f, c_p, c_p]),
     "gx_gemm_colmax_part_bytes": (c_sz, [c_i, c_i]),
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gx_fineq_ytable_ld": (c_i, []),
     "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p]),
     "gx_fineq_bwd_workspace_bytes": (c_sz, []),
-    "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     "gx_proto_raw_tables": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p]),
     "gx_gemm_f32_upadd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p]),
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -390,6 +390,7 @@ struct FineqBwdArgs {
     float* slab;                           // [gridDim][272][256]
     float* Tt;                             // [rows / 4][256]
     float* Cpool;                          // [rows / 4][ls]
+    unsigned* tt_amax;                     // optional: max |Tt| over the launch (float bits, atomicMax; zeroed by the launcher)
 };
 
 // Consumer wave W of fineq_bwd_kernel.  Tasks (row block of the A image, column block of the B image), four MFMA tiles each:
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
         const int s = g.shift, res = 1 << s, rc = res >> 1;
         const int xbs = s - 3;                                              // x-blocks per image row = res / 8
         struct Tile { f32x4 v[4]; float c0, c1, e0, e1; long q0, par; bool live; };
+        float ttm = 0.f;                                                   // max |Tt| of what this thread wrote
         auto load_tile = [&](int t, Tile& T) {
             T.live = t < nkt;
             const long bid = kt0 + min(t, max(nkt - 1, 0));
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tt[e] = fb_half_sum(tt[e]);
                 if (half == 0 && T.live) *reinterpret_cast<f32x4*>(g.Tt + T.par * 256 + c4 + 128 * j) = tt;
+                ttm = fmaxf(fmaxf(ttm, fmaxf(fabsf(tt[0]), fabsf(tt[1]))), fmaxf(fabsf(tt[2]), fabsf(tt[3])));
             }
             if (mm < 16) {                                                   // coefficient columns 256 .. 271 of the A image
                 const bool kok = mm < g.K;
@@ -606,6 +609,10 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
             if (t + 4 < nkt) stage(slot0, T0);
             load_tile(t + 8, T0);
             __syncthreads();                                         // barrier t + 4
+        }
+        if (g.tt_amax) {                     // the bound the f16x3 GEMMs on Tt scale it by (gx_gemm_f32_nt_planes_finish, Zc^T Tt)
+            ttm = gx_wave_max(ttm);
+            if (lane == 0 && __float_as_uint(ttm) > *reinterpret_cast<volatile unsigned*>(g.tt_amax)) atomicMax(g.tt_amax, __float_as_uint(ttm));
         }
         return;
     }
@@ -707,10 +714,12 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
 
 // One pass over the finest taps for the whole backward of the level (fineq_bwd_kernel): S [256][256] = sum_q e[q] t t^T,
 // P [K][256], Tt [rows / 4][256], Cpool [rows / 4][stride].  bf16x6 engine; fine_res a power of two >= 16.
+// tt_amax (optional device float): max |Tt|, the a_amax_dev / b_amax_dev of the f16x3 GEMMs that contract Tt.
 #define GX_FINEQ_BWD_WGS 256
 size_t gx_fineq_bwd_workspace_bytes(void) { return (size_t)GX_FINEQ_BWD_WGS * 272 * 256 * sizeof(float); }
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
-                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream) {
+                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, float* tt_amax,
+                 void* stream) {
     if (!C || !t1 || !S || !P || !Tt || !Cpool || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
     if (!gx_fineq_ok(K1, K2, K) || gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;
     if (fine_res < 16 || (fine_res & (fine_res - 1)) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
@@ -728,6 +737,8 @@ int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1
     nwg = (int)((g.nkt + g.kt_per - 1) / g.kt_per);
     g.slab = workspace; g.Tt = Tt; g.Cpool = Cpool;
     hipStream_t st = (hipStream_t)stream;
+    g.tt_amax = reinterpret_cast<unsigned*>(tt_amax);
+    if (tt_amax && hipMemsetAsync(tt_amax, 0, sizeof(float), st) != hipSuccess) return GX_ERR_LAUNCH;
     hipLaunchKernelGGL(gx::fineq_bwd_kernel, dim3(nwg), dim3(768), 0, st, g);
     GX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gx::fineq_bwd_reduce_kernel, dim3(gx_cdiv((256 + K) * 256, 256)), dim3(256), 0, st, workspace, nwg, K, S, P);

@@ -59,7 +59,9 @@ struct GemmArgs {
     float a_scale; const float* b_amax;
     float b_scale;        // x6ws: B's host-given power-of-two scale
     // x6ws: A's bound on the DEVICE (max |A| left behind by A's producer — fin_amax below —, times a host factor); NULL: a_scale
+    // (gemm_xw_kernel<.., H2> reads the same pair: A = a table some kernel left its maximum of — Zc, Tt)
     const float* a_amax; float a_amax_mul;
+    const float* b_amax_ws; float b_amax_mul;   // x6ws: the same for B (NULL: b_scale)
     unsigned* fin_amax;   // gemm_xw_kernel<.., FIN>: optional, max |G| over everything the launch writes (float bits, atomicMax)
 };
 
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 2 : 3) void gemm_xw_kernel(Gem
     const int arow = wid * (32 * NRT) + r32;                         // the wave's first row tile (TALL: the second is 32 rows down)
     const int af = (arow >> 2) & 3;
     const int au0 = (arow * 4 + ((2 * hh) ^ af)) * 16, au1 = (arow * 4 + ((2 * hh + 1) ^ af)) * 16;
-    const float a_scale = g.a_scale;
+    float a_scale = g.a_scale;
+    if constexpr (H2) { if (g.a_amax) a_scale = xh_scale_of(*g.a_amax * g.a_amax_mul); }
     auto compute = [&](const char* st, const char* Bs) {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
@@ -810,7 +813,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
     char* slot0 = lds;
     char* slot1 = lds + WS_SLOT;
     float a_scale = 1.f;
-    if constexpr (H2) a_scale = g.a_amax ? xh_scale_of(*g.a_amax * g.a_amax_mul) : g.a_scale;
+    float b_scale = 1.f;
+    if constexpr (H2) {
+        a_scale = g.a_amax ? xh_scale_of(*g.a_amax * g.a_amax_mul) : g.a_scale;
+        b_scale = g.b_amax_ws ? xh_scale_of(*g.b_amax_ws * g.b_amax_mul) : g.b_scale;
+    }
 
     if (wid >= 4) {
         // ------------------------------------------------------------------ producers
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         auto stage = [&](char* slot, const f32x4 (&ra)[4], const f32x4 (&rb)[2]) {
             if constexpr (H2) {
                 xh_store_tile<A_KC, WS_BM>(slot, ra, p, a_scale);
-                xh_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p, g.b_scale);
+                xh_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p, b_scale);
             } else {
                 x6_store_tile<A_KC, WS_BM>(slot, ra, p);
                 x6_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p);
@@ -865,7 +872,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
         __syncthreads();                                             // barrier t+1
     }
     if constexpr (H2) {
-        const float un = 1.f / (a_scale * g.b_scale);
+        const float un = 1.f / (a_scale * b_scale);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -899,6 +906,20 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, int sp
     }
 }
 
+// max |x| (or max sqrt |x|) of a strided matrix as float bits (non-negative floats order like unsigned integers)
+__global__ void absmax_strided_kernel(const float* __restrict__ x, long n, int cols, long ld, int sqrt_of,
+                                      unsigned* __restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = cols == 1 ? i : i / cols;
+        const float v = fabsf(x[r * ld + (i - r * cols)]);
+        m = fmaxf(m, sqrt_of ? sqrtf(v) : v);
+    }
+    m = gx_block_max(m, red);
+    if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); 1: bf16x6 on the bf16 MFMA.
 static int g_gemm_mode = -1;
 static int gemm_mode() {
@@ -917,11 +938,12 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
                        hipStream_t stream, const float* A2 = nullptr, long lda2 = 0, int K1 = -1,
                        const float* up_src = nullptr, int up_rf = 0, const float* B2 = nullptr, long ldb2 = 0,
                        int N1 = -1, const int* k_live = nullptr, float a_range = 0.f, float b_range = 0.f,
-                       const float* a_amax_dev = nullptr) {
+                       const float* a_amax_dev = nullptr, const float* b_amax_dev = nullptr) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return GX_ERR_BAD_ARG;
     GemmArgs g;
     g.live = k_live;
     g.a_scale = g.b_scale = 1.f; g.b_amax = nullptr; g.a_amax = nullptr; g.a_amax_mul = 1.f; g.fin_amax = nullptr;
+    g.b_amax_ws = nullptr; g.b_amax_mul = 1.f;
     g.Bp = nullptr; g.Bp_bytes = 0; g.colmax_part = nullptr; g.usum_part = nullptr; g.sk_inv_eps = 0.f; g.n_group = 1;
     g.up_src = up_src; g.up_shift = 0;
     if (up_src) {
@@ -946,6 +968,7 @@ static int launch_gemm(int transA, int transB, int M, int N, int K, const float*
     if (h2) {
         g.a_scale = xh_scale_of(a_range); g.b_scale = xh_scale_of(b_range);
         if (a_amax_dev) { g.a_amax = a_amax_dev; g.a_amax_mul = a_range; }     // the bound is *a_amax_dev x a_range, read on the device
+        if (b_amax_dev) { g.b_amax_ws = b_amax_dev; g.b_amax_mul = b_range; }
     }
     g.tiles_m = gx_cdiv(M, ws ? WS_BM : BM); g.tiles_n = gx_cdiv(N, BN);
     const int ktiles = gx_cdiv(K, BK);
@@ -1001,7 +1024,7 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
                           const unsigned short* Bp, float* C, long ldc, float alpha, float beta, const float* row_scale,
                           const float* col_bias, const float* up_src, int up_rf, float* colmax_part, hipStream_t stream,
                           float* usum_part = nullptr, float sk_eps = 0.f, const GemmArgs* fin = nullptr,
-                          const int* m_live = nullptr, float a_range = 0.f) {
+                          const int* m_live = nullptr, float a_range = 0.f, const float* a_amax_dev = nullptr) {
     if (!A1 || !Bp || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !A2) || ldc < N) return GX_ERR_BAD_ARG;
     if (gemm_mode() != 1) return GX_ERR_BAD_ARG;
     const int K = K1 + K2;
@@ -1032,6 +1055,8 @@ static int launch_gemm_xw(int M, int N, int K1, const float* A1, long lda1, int 
     g.Bp = Bp; g.Bp_bytes = (unsigned)bpb;
     g.a_scale = h2 ? xh_scale_of(a_range) : 1.f;
     g.b_scale = 1.f; g.a_amax = nullptr; g.a_amax_mul = 1.f; g.fin_amax = nullptr;
+    g.b_amax_ws = nullptr; g.b_amax_mul = 1.f;
+    if (h2 && a_amax_dev) { g.a_amax = a_amax_dev; g.a_amax_mul = a_range; }   // the bound is *a_amax_dev x a_range, read on the device
     g.b_amax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + (size_t)g.tiles_n * (K >> 4) * 3 * 4096);
     {   // N tiles per group: their weight planes (K x 128 x 6 B each) should sit in an XCD's 4 MB L2 next to the A stream
         const long per_tile = (long)K * 128 * 6;
@@ -1110,15 +1135,16 @@ int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* 
 // kernel takes the launch (long k loops: the gradient GEMMs over pixels) it runs the f16x3 form — operands scaled by the
 // powers of two that bring the bounds to [2^13, 2^14), two fp16 planes, three products (csrc/gx_mfma_x6.h); elsewhere the
 // bounds are ignored (bf16x6).  An element above 4 x its bound comes out NaN; every element carries an absolute error of
-// bound x 2^-38, so a bound should sit within ~2^14 of its operand's RMS.
+// bound x 2^-38, so a bound should sit within ~2^14 of its operand's RMS.  a_amax_dev / b_amax_dev (optional device floats: the
+// operand's maximum magnitude as its producer left it): the bound is then *x_amax_dev x x_range, read on the device.
 int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                        int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
-                       const float* a_amax_dev, void* stream) {
+                       const float* a_amax_dev, const float* b_amax_dev, void* stream) {
     if ((k_live && !transA) || !(a_range > 0.f) || !(b_range > 0.f)) return GX_ERR_BAD_ARG;
     return gx::launch_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, row_scale, col_bias,
                            split_k, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, -1, nullptr, 0, nullptr, 0, -1,
-                           k_live, a_range, b_range, a_amax_dev);
+                           k_live, a_range, b_range, a_amax_dev, b_amax_dev);
 }
 // gx_gemm_f32_tn_cat with the bounds of gx_gemm_f32_ranged (A's on the device: *a_amax_dev x a_mul; |B1|, |B2| <= b_range)
 int gx_gemm_f32_tn_cat_ranged(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
@@ -1161,20 +1187,23 @@ size_t gx_gemm_weight_planes_bytes(int N, int K) { return (size_t)gx_cdiv(N, 128
 // a_range: 0 = b_planes are the three bf16 planes of gx_split_gemm_weights (bf16x6); > 0 = an upper bound of |A| (rounded up
 // to a power of two inside), b_planes the two fp16 planes of gx_split_gemm_weights_h2 (f16x3: half the matrix-core work).
 // An A element above a_range x 4 overflows fp16 and comes out NaN; every element carries an absolute error of a_range x 2^-38
-// (the fp16 subnormal step): the bound should sit within ~2^14 of A's RMS.
+// (the fp16 subnormal step): the bound should sit within ~2^14 of A's RMS.  a_amax_dev (optional, with a_range > 0): a device
+// float holding max |A| (or a bound of it) as A's producer left it — the bound is then *a_amax_dev x a_range, read by the kernel.
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, float* usum_part, float sk_eps, float a_range, void* stream) {
-    if (a_range < 0.f) return GX_ERR_BAD_ARG;
+                          float* colmax_part, float* usum_part, float sk_eps, float a_range, const float* a_amax_dev,
+                          void* stream) {
+    if (a_range < 0.f || (a_amax_dev && !(a_range > 0.f))) return GX_ERR_BAD_ARG;
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, K2, A2, lda2, b_planes, C, ldc, alpha, beta, row_scale, col_bias, coarse,
-                              fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps, nullptr, nullptr, a_range);
+                              fine_res, colmax_part, (hipStream_t)stream, usum_part, sk_eps, nullptr, nullptr, a_range, a_amax_dev);
 }
 // The gradient of the level below the finest one of the low-rank prototype path (K <= 16, pyramid.backward_lowrank) in ONE
 // kernel: G = A B^T (A = Tt (M, K1) from gx_fineq_bwd, B = Wf as planes) and, in the epilogue, the dense finish
 //   G[q] += coeffs[q][:K] Wc + coeffs[q][K] Z[q];   gWc = beta gWc + coeffs[:, :K]^T Z;   Gpool = 2x2 sums of G (may be NULL)
 // — what gx_gemm_f32_nt_planes + gx_proto_lowrank_finish(accumulate) do in two passes over G.  The M rows are the pixels of
 // res x res images (res a power of two >= 64), coeffs (M, ls = gx_lowrank_stride(K)), Z and G (M, N) dense, N % 128 == 0.
+// a_range / a_amax_dev: as in gx_gemm_f32_nt_planes (b_planes then from gx_split_gemm_weights_h2; gx_fineq_bwd leaves max |Tt|).
 int gx_gemm_finish_ok(int N, int K1, int res, int K) {
     return gx::gemm_mode() == 1 && N > 0 && (N & 127) == 0 && K1 > 0 && (K1 & 15) == 0 && res >= 64 && !(res & (res - 1)) &&
            K >= 1 && K <= 16;
@@ -1182,7 +1211,9 @@ int gx_gemm_finish_ok(int N, int K1, int res, int K) {
 size_t gx_gemm_finish_workspace_bytes(long M, int N, int K) { return ((size_t)(M / 128) + 8) * K * N * sizeof(float); }
 int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
                                  int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
-                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, void* stream) {
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, float a_range,
+                                 const float* a_amax_dev, void* stream) {
+    if (a_range < 0.f || (a_amax_dev && !(a_range > 0.f))) return GX_ERR_BAD_ARG;
     if (!gx_gemm_finish_ok(N, K1, res, K) || !coeffs || !Z || !Wc || !gWc || M <= 0 || M % ((long)res * res) ||
         M >= (1L << 31) || (((uintptr_t)coeffs | (uintptr_t)Z | (uintptr_t)Wc | (uintptr_t)Gpool) & 15))
         return GX_ERR_BAD_ARG;
@@ -1193,7 +1224,7 @@ int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long ld
     fin.fin_amax = reinterpret_cast<unsigned*>(g_amax);            // optional: max |G| (the caller zeroes it)
     while ((1 << fin.fin_rlog) < res) ++fin.fin_rlog;
     const int rc = gx::launch_gemm_xw((int)M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, G, N, 1.f, 0.f, nullptr, nullptr, nullptr,
-                                      0, nullptr, (hipStream_t)stream, nullptr, 0.f, &fin);
+                                      0, nullptr, (hipStream_t)stream, nullptr, 0.f, &fin, nullptr, a_range, a_amax_dev);
     if (rc) return rc;
     const int tiles_m = (int)(M / 128);
     gx::launch_partial_reduce(workspace, tiles_m, K * N, 1.f, beta, gWc, (hipStream_t)stream, workspace + (size_t)tiles_m * K * N);
@@ -1208,6 +1239,19 @@ int gx_gemm_f32_nt_planes_mlive(int M, int N, int K1, const float* A1, long lda1
     if (!m_live || a_range < 0.f) return GX_ERR_BAD_ARG;
     return gx::launch_gemm_xw(M, N, K1, A1, lda1, 0, nullptr, 0, b_planes, C, ldc, alpha, beta, nullptr, col_bias, nullptr, 0,
                               nullptr, (hipStream_t)stream, nullptr, 0.f, nullptr, m_live, a_range);
+}
+// *out = max |x| over an [rows][cols] matrix of row stride ld (sqrt_of: max sqrt(|x|) — e.g. a column of squared row norms
+// turns into a bound of the rows' elements); zero for an all-zero matrix.  The device-side bound gx_gemm_f32_nt_planes /
+// gx_gemm_f32_ranged take as a_amax_dev / b_amax_dev when no producer left one behind.
+int gx_absmax(const float* x, long rows, int cols, long ld, int sqrt_of, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return GX_ERR_BAD_ARG;
+    if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
+    const long n = rows * cols;
+    long want = (n + 1023) / 1024;
+    hipLaunchKernelGGL(gx::absmax_strided_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       cols, ld, sqrt_of, reinterpret_cast<unsigned*>(out));
+    GX_CHECK_LAUNCH();
+    return GX_OK;
 }
 // bytes of the colmax_part table of gx_gemm_f32_nt_planes: N floats per wave (32 rows of C) of every 128-row tile
 size_t gx_gemm_colmax_part_bytes(int M, int N) { return (size_t)4 * gx_cdiv(M, 128) * N * sizeof(float); }

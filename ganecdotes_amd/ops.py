@@ -117,11 +117,12 @@ def _chk2d(*ts):
 
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_scale=None, col_bias=None,
-         split_k=1, live=None, live_frac=1.0, a_range=None, b_range=None, a_amax=None):
+         split_k=1, live=None, live_frac=1.0, a_range=None, b_range=None, a_amax=None, b_amax=None):
     """out = alpha * row_scale[:,None] * op(a) @ op(b) + col_bias + beta*out on the fp32 MFMA.
     a_range / b_range (both, optional): upper bounds of |a|, |b| — the long-k launches then run the f16x3 form
     (gx_gemm_f32_ranged: half the matrix-core work; each bound within ~2^14 of its operand's RMS).  a_amax: a one-element HIP
-    tensor holding max |a| (left by a's producer); a_range is then the factor it is multiplied by (default 1).
+    tensor holding max |a| (left by a's producer); a_range is then the factor it is multiplied by (default 1).  b_amax / b_range
+    likewise.
     op(a) = a (M,K) or a.T for a stored (K,M); op(b) = b (K,N) or b.T for b stored (N,K).
     a, b, out may be row-strided views (leading dimension = stride(0)).
     live (trans_a only): int32 device scalar, the k rows that carry data (the rest is not read; the launch covers K with no
@@ -147,11 +148,13 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, alpha=1.0, beta=0.0, row_s
         raise RuntimeError("gemm: `live` is an int32 HIP scalar and needs trans_a")
     if a_amax is not None and a_range is None:
         a_range = 1.0
+    if b_amax is not None and b_range is None:
+        b_range = 1.0
     if GEMM_H2 and a_range is not None and b_range is not None and a_range > 0 and b_range > 0:
         with record("gemm_f32_kernel", 2.0 * m * n * k * (live_frac if live is not None else 1.0)):
             _lib.check(L.gx_gemm_f32_ranged(int(trans_a), int(trans_b), m, n, k, _p(a), a.stride(0), _p(b), b.stride(0),
                                             _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias), split_k, _p(ws),
-                                            wsb, _p(live), float(a_range), float(b_range), _p(a_amax), _stream()),
+                                            wsb, _p(live), float(a_range), float(b_range), _p(a_amax), _p(b_amax), _stream()),
                        "gx_gemm_f32_ranged")
         return out
     if live is not None:
@@ -255,13 +258,27 @@ def split_gemm_weights(b, h2=False):
     return WeightPlanes(planes, h2)
 
 
-def _a_range(b_planes, a_range, who):
-    """the a_range argument of the C call: 0 for bf16 planes; for f16x3 planes the caller's bound on |A| is mandatory"""
+def _a_range(b_planes, a_range, who, a_amax=None):
+    """the a_range argument of the C call: 0 for bf16 planes; for f16x3 planes the caller's bound on |A| is mandatory — a host
+    number, or a one-element HIP tensor a_amax (a_range is then the factor it is multiplied by, default 1)"""
     if not b_planes.h2:
         return 0.0
+    if a_amax is not None and a_range is None:
+        a_range = 1.0
     if a_range is None or not a_range > 0:
         raise RuntimeError(f"{who}: f16x3 weight planes need a_range, an upper bound of |A|")
     return float(a_range)
+
+
+def absmax(x, sqrt=False, out=None):
+    """one-element HIP tensor: max |x| of a 1-D / 2-D fp32 tensor (rows may be strided; a 1-D tensor any stride); sqrt: max sqrt |x|.
+    The device-side bound of the f16x3 GEMM forms (a_amax / b_amax) where no producer leaves one behind."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() not in (1, 2) or (x.dim() == 2 and x.stride(1) != 1):
+        raise RuntimeError("absmax: a 1-D, or a 2-D fp32 HIP tensor with unit inner stride")
+    rows, cols, ld = (x.shape[0], 1, max(1, x.stride(0))) if x.dim() == 1 else (x.shape[0], x.shape[1], x.stride(0))
+    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(lib().gx_absmax(_p(x), rows, cols, ld, int(bool(sqrt)), _p(out), _stream()), "gx_absmax")
+    return out
 
 
 def gemm_planes_ok(a1, a2, n, out):
@@ -295,13 +312,15 @@ def gemm_nt_planes_live(a, b_planes, out, live, live_frac, col_bias=None, alpha=
 
 
 def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, col_bias=None, coarse=None, fine_res=0,
-                   want_colmax=False, sk_eps=None, a_range=None):
+                   want_colmax=False, sk_eps=None, a_range=None, a_amax=None):
     """out = alpha * row_scale[:,None] * [a1 | a2] @ B.T + col_bias + beta*out (+ upsample2(coarse)) with B given as
     split_gemm_weights planes; a2 / row_scale / col_bias / coarse may be None.  Bitwise gemm / gemm_cat / gemm_upadd.
     want_colmax: also return out.amax(0), reduced from per-wave partials of the epilogue (no pass over out); an int g > 1:
     the maxima of g equal row groups, (g, N) (rows per group a multiple of 32).
     sk_eps (with want_colmax): also return the FIRST Sinkhorn pass, u = exp((out - colmax) / sk_eps).sum(0) (per group), from
-    per-slice sums of the same epilogue: (out, colmax, u)."""
+    per-slice sums of the same epilogue: (out, colmax, u).
+    a_range (f16x3 planes): the bound of |a1|, |a2|; with a_amax (one-element HIP tensor: max |a| as its producer left it) the
+    factor that multiplies it (default 1)."""
     _chk2d(a1, a2, out, coarse)
     _chk(row_scale, col_bias)
     m, k1 = a1.shape
@@ -326,7 +345,8 @@ def gemm_nt_planes(a1, a2, b_planes, out, alpha=1.0, beta=0.0, row_scale=None, c
         _lib.check(L.gx_gemm_f32_nt_planes(m, n, k1, _p(a1), a1.stride(0), k2, _p(a2), 0 if a2 is None else a2.stride(0),
                                            _p(b_planes.buf), _p(out), out.stride(0), alpha, beta, _p(row_scale), _p(col_bias),
                                            _p(coarse), fine_res, _p(part), _p(upart), 0.0 if sk_eps is None else float(sk_eps),
-                                           _a_range(b_planes, a_range, "gemm_nt_planes"), _stream()), "gx_gemm_f32_nt_planes")
+                                           _a_range(b_planes, a_range, "gemm_nt_planes", a_amax),
+                                           _p(a_amax) if b_planes.h2 else None, _stream()), "gx_gemm_f32_nt_planes")
     if want_colmax:
         g = 1 if want_colmax is True else int(want_colmax)
         if g > 1 and m % (32 * g):
@@ -551,6 +571,9 @@ def fineq_ok(k1, k2, k):
     return get_gemm_mode() == 1 and bool(lib().gx_fineq_ok(int(k1), int(k2), int(k)))
 
 
+FINEQ_NC_COL = 272          # the |Zc|^2 column of a fineq_ytable
+
+
 def fineq_ytable(rows_coarse, device):
     """the coarse table of fineq_fwd: (rows/4, ld) fp32 — columns [0, 256) Y2 = 2 Zc Wf, [256, 256 + K) Ac = Zc Wc^T,
     272 nc = |Zc|^2 — so that every share of a parent pixel reaches the kernel as a 128-B column block of one row"""
@@ -609,9 +632,9 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res, a_range=None):
     return rn, sc
 
 
-def fineq_bwd(coeffs, t1, t2, k, fine_res):
+def fineq_bwd(coeffs, t1, t2, k, fine_res, want_amax=False):
     """coefficient grid (rows, stride) + the finest taps, ONE pass over the taps -> S (256, 256) = sum_q e[q] t t^T,
-    P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride)"""
+    P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride) (+ max |Tt| as a one-element HIP tensor with want_amax)"""
     _chk(coeffs)
     _chk2d(t1, t2)
     rows, k1 = t1.shape
@@ -627,12 +650,13 @@ def fineq_bwd(coeffs, t1, t2, k, fine_res):
     cpool = torch.empty(rows // 4, coeffs.shape[1], dtype=torch.float32, device=dev)
     wsb = L.gx_fineq_bwd_workspace_bytes()
     ws = workspace("fineq_bwd", wsb, dev)
+    tt_amax = torch.empty(1, dtype=torch.float32, device=dev) if want_amax else None
     # the 10 of 16 64x64 blocks of S on / above the diagonal + the 32 coefficient rows (K of them live)
     with record("fineq_bwd_kernel", 2.0 * rows * 64 * 64 * 12, 4.0 * rows * (cf * 1.25 + coeffs.shape[1] * 1.25)):
         _lib.check(L.gx_fineq_bwd(_p(coeffs), rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2),
                                   0 if t2 is None else t2.stride(0), k, _p(s), _p(pm), _p(tt), _p(cpool), _p(ws), wsb,
-                                  _stream()), "gx_fineq_bwd")
-    return s, pm, tt, cpool
+                                  _p(tt_amax), _stream()), "gx_fineq_bwd")
+    return (s, pm, tt, cpool, tt_amax) if want_amax else (s, pm, tt, cpool)
 
 
 # ------------------------------------------------------------------------------------- generator pieces
@@ -742,10 +766,11 @@ def gemm_finish_ok(n, k1, res, k):
     return bool(lib().gx_gemm_finish_ok(n, k1, res, k))
 
 
-def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool, want_amax=False):
+def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool, want_amax=False, a_range=None, a_amax=None):
     """G = a b^T with the low-rank path's dense finish in the GEMM's epilogue (gx_gemm_f32_nt_planes_finish):
     G += coeffs[:, :K] wc + coeffs[:, K] .* z, gwc = beta gwc + coeffs[:, :K]^T z, and the 2x2 sums of G.
-    a (rows, K1) = pixels of res x res images, z (B, res, res, D); -> (G (B, res, res, D), Gpool (B, res/2, res/2, D) or None)"""
+    a (rows, K1) = pixels of res x res images, z (B, res, res, D); -> (G (B, res, res, D), Gpool (B, res/2, res/2, D) or None)
+    a_range / a_amax with f16x3 planes (split_gemm_weights(h2=True)): as in gemm_nt_planes"""
     _chk(coeffs, z, wc, gwc)
     _chk2d(a)
     bsz, r, _, d = z.shape
@@ -754,8 +779,8 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool,
     if r != res or z.shape[2] != r or a.shape[0] != rows or tuple(wc.shape) != (k, d) or tuple(gwc.shape) != (k, d) or \
             tuple(coeffs.shape) != (rows, L.gx_lowrank_stride(k)):
         raise RuntimeError("gemm_nt_planes_finish: shape mismatch")
-    if b_planes.h2 or b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(d, a.shape[1]):
-        raise RuntimeError("gemm_nt_planes_finish: planes do not match (N, K) (bf16 planes)")
+    if b_planes.numel() * 2 != L.gx_gemm_weight_planes_bytes(d, a.shape[1]):
+        raise RuntimeError("gemm_nt_planes_finish: planes do not match (N, K)")
     if not L.gx_gemm_finish_ok(d, a.shape[1], r, k):
         raise RuntimeError("gemm_nt_planes_finish: not this shape / engine (gemm_finish_ok)")
     g = torch.empty_like(z)
@@ -765,7 +790,9 @@ def gemm_nt_planes_finish(a, b_planes, coeffs, z, wc, gwc, beta, res, want_pool,
     ws = workspace("gemm_finish", wsb, z.device)
     with record("gemm_f32_kernel", 2.0 * rows * d * a.shape[1], 0.0):
         _lib.check(L.gx_gemm_f32_nt_planes_finish(rows, d, a.shape[1], _p(a), a.stride(0), _p(b_planes.buf), _p(g), r, _p(coeffs),
-                                                  _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _p(amax), _stream()),
+                                                  _p(z), _p(wc), k, _p(gp), _p(gwc), beta, _p(ws), wsb, _p(amax),
+                                                  _a_range(b_planes, a_range, "gemm_nt_planes_finish", a_amax),
+                                                  _p(a_amax) if b_planes.h2 else None, _stream()),
                    "gx_gemm_f32_nt_planes_finish")
     return (g, gp, amax) if want_amax else (g, gp)
 

@@ -128,10 +128,13 @@ class Pyramid:
         bq = ops.fineq_pack_weights(mg, wcf)
         zc2 = zc.reshape(-1, d)
         yt = ops.fineq_ytable(zc2.shape[0], wp.device)                  # per parent pixel: 2 Zc Wf | Zc Wc^T | |Zc|^2
-        ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous()), yt[:, :cf], alpha=2.0)
         ops.proto_raw_tables(zc2, wc, ytable=yt)
+        # a bound of |Zc| for the f16x3 forms of the two GEMMs that contract it (here and Zc^T Tt in the backward): the largest
+        # row norm, from the |Zc|^2 column the pass above just wrote — 1 MB read instead of a pass over the table
+        zc_amax = ops.absmax(yt[:, ops.FINEQ_NC_COL], sqrt=True) if ops.GEMM_H2 else None
+        ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous(), h2=True), yt[:, :cf], alpha=2.0, a_amax=zc_amax)
         rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq, h2=True), yt, bias, k, r, a_range=ops.FEATURE_RANGE)
-        self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf)
+        self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf, z_amax=zc_amax)
         return rn, sc, shift
 
     def table_pixels(self):
@@ -197,15 +200,18 @@ class Pyramid:
         wf = wp[:, off:off + cf]
         zc2 = zc.reshape(-1, d)
         # ONE pass over the level's taps: S = sum_q e[q] t t^T (e = C[:, K]), P = C[:, :K]^T t, Tt = 2x2-pooled e t, Cpool
-        s, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, k, r)
+        s, pm, tt, cpool, tt_amax = ops.fineq_bwd(coeffs, t1, t2, k, r, want_amax=True)
+        if not ops.GEMM_H2:
+            tt_amax = None
         g_amax = None
         # gradient of the level below: Gc = Tt Wf^T + Cpool[:, :K] Wc + epool .* Zc  (+ its 2x2 sum-pooling), gWc
         pool = top > 1
         rc = zc.shape[1]
         if fused_finish and ops.get_gemm_mode() == 1 and ops.gemm_finish_ok(d, cf, rc, k):
             # ... in ONE kernel: the finish rides on the GEMM's epilogue, G is written once (csrc/gx_gemm.hip)
-            gcz, gp, g_amax = ops.gemm_nt_planes_finish(tt, ops.split_gemm_weights(wf), cpool, zc, wc, gwc, 0.0, rc, pool,
-                                                        want_amax=True)
+            # (f16x3: Tt's bound is the maximum fineq_bwd left on the device)
+            gcz, gp, g_amax = ops.gemm_nt_planes_finish(tt, ops.split_gemm_weights(wf, h2=True), cpool, zc, wc, gwc, 0.0, rc, pool,
+                                                        want_amax=True, a_amax=tt_amax)
         else:
             gc = torch.empty_like(zc2)
             ops.gemm_nt_planes(tt, None, ops.split_gemm_weights(wf), gc)
@@ -218,7 +224,8 @@ class Pyramid:
         gcols = gwp[:, off:off + cf]
         rc_rows = zc2.shape[0]
         tiles = ((d + 127) // 128) * ((cf + 127) // 128)
-        ops.gemm(zc2, tt, True, False, out=gcols, beta=0.0, split_k=int(max(1, min(512 // tiles, rc_rows // 256))))
+        ops.gemm(zc2, tt, True, False, out=gcols, beta=0.0, split_k=int(max(1, min(512 // tiles, rc_rows // 256))),
+                 a_amax=lr.get("z_amax") if tt_amax is not None else None, b_amax=tt_amax)
         ops.gemm(wf, s, False, False, out=gcols, beta=1.0)
         ops.gemm(wc, pm, True, False, out=gcols, beta=1.0)
         if on_level is not None:

@@ -122,12 +122,18 @@ int gx_split_gemm_weights_h2(const float* B, int N, int K, long ldb, unsigned sh
 int gx_gemm_f32_nt_planes(int M, int N, int K1, const float* A1, long lda1, int K2, const float* A2, long lda2,
                           const unsigned short* b_planes, float* C, long ldc, float alpha, float beta,
                           const float* row_scale, const float* col_bias, const float* coarse, int fine_res,
-                          float* colmax_part, float* usum_part, float sk_eps, float a_range, void* stream);
+                          float* colmax_part, float* usum_part, float sk_eps, float a_range, const float* a_amax_dev,
+                          void* stream);
 /* a_range: 0 = b_planes from gx_split_gemm_weights (three bf16 planes, six products per fp32 product); > 0 = an upper bound of
  * |A1|, |A2| and b_planes from gx_split_gemm_weights_h2 (two fp16 planes, three products — csrc/gx_mfma_x6.h "f16x3": fp32-class
  * error, half the matrix-core work).  The A elements are scaled by the power of two that brings a_range to [2^13, 2^14): an
  * element above 4 x a_range overflows fp16 and comes out NaN; every element carries an absolute error of a_range x 2^-38
- * (the fp16 subnormal step), so the bound should sit within ~2^14 of A's RMS for fp32-class results. */
+ * (the fp16 subnormal step), so the bound should sit within ~2^14 of A's RMS for fp32-class results.  a_amax_dev (optional, with
+ * a_range > 0): a device float holding max |A| (or a bound of it) as A's producer left it — the bound is then *a_amax_dev x
+ * a_range, read by the kernel (gx_absmax, gx_fineq_bwd's tt_amax, gx_gemm_f32_nt_planes_finish's g_amax). */
+/* gx_absmax: *out = max |x| over an [rows][cols] matrix of row stride ld (sqrt_of != 0: max sqrt |x| — a column of squared row
+ * norms gives a bound of the rows' elements); 0 for an all-zero matrix */
+int gx_absmax(const float* x, long rows, int cols, long ld, int sqrt_of, float* out, void* stream);
 /* colmax_part (optional, beta == 0): gx_gemm_colmax_part_bytes(M, N) bytes = [4 ceil(M / 128)][N] partial column maxima of C, one row per 32 rows
  * of C (-inf where a slice is empty); their maximum over rows is gx_sinkhorn_colmax's result (set it with
  * gx_sinkhorn_cmax_set) without a pass of its own over the score matrix (swav_clustering.py:509-544) */
@@ -149,8 +155,8 @@ int gx_gemm_f32_klive(int transA, int transB, int M, int N, int K, const float* 
 int gx_gemm_f32_ranged(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* C, long ldc, float alpha, float beta, const float* row_scale, const float* col_bias,
                        int split_k, float* workspace, size_t workspace_bytes, const int* k_live, float a_range, float b_range,
-                       const float* a_amax_dev, void* stream);
-/* a_amax_dev (optional): A's bound lives on the device — max |A| as left behind by A's producer (g_amax of
+                       const float* a_amax_dev, const float* b_amax_dev, void* stream);
+/* a_amax_dev (optional; b_amax_dev / b_range likewise): A's bound lives on the device — max |A| as left behind by A's producer (g_amax of
  * gx_gemm_f32_nt_planes_finish) — and a_range is then the host factor it is multiplied by (4 per 2x2 sum-pooling since).
  * gx_gemm_f32_tn_cat_ranged: gx_gemm_f32_tn_cat the same way (|B1|, |B2| <= b_range). */
 int gx_gemm_f32_tn_cat_ranged(int M, int N1, int N2, int K, const float* A, long lda, const float* B1, long ldb1, const float* B2,
@@ -163,8 +169,10 @@ int gx_gemm_finish_ok(int N, int K1, int res, int K);
 size_t gx_gemm_finish_workspace_bytes(long M, int N, int K);
 int gx_gemm_f32_nt_planes_finish(long M, int N, int K1, const float* A1, long lda1, const unsigned short* b_planes, float* G,
                                  int res, const float* coeffs, const float* Z, const float* Wc, int K, float* Gpool,
-                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, void* stream);
-/* g_amax (optional; one float the caller has zeroed): max |G| over the launch, for gx_gemm_f32_ranged's a_amax_dev */
+                                 float* gWc, float beta, float* workspace, size_t workspace_bytes, float* g_amax, float a_range,
+                                 const float* a_amax_dev, void* stream);
+/* g_amax (optional; one float the caller has zeroed): max |G| over the launch, for gx_gemm_f32_ranged's a_amax_dev;
+ * a_range / a_amax_dev: as in gx_gemm_f32_nt_planes (a_range > 0: b_planes from gx_split_gemm_weights_h2, the f16x3 form) */
 /* usum_part (optional, with colmax_part; same size): per 32-row slice and column the sum of exp((C - that slice's maximum) /
  * sk_eps) — the FIRST Sinkhorn pass (swav_clustering.py:519-520: Q = exp(scores / eps), its row sums) left behind by the GEMM
  * that writes the scores.  gx_sinkhorn_first_from_parts merges the slices of `groups` equal row groups by log-sum-exp:
@@ -205,7 +213,9 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
  * gx_split_gemm_weights_h2 (the f16x3 form, as in gx_gemm_f32_nt_planes) */
 size_t gx_fineq_bwd_workspace_bytes(void);
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
-                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, void* stream);
+                 int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, float* tt_amax,
+                 void* stream);
+/* tt_amax (optional device float): max |Tt| over the launch — the a_amax_dev / b_amax_dev of the f16x3 GEMMs that contract Tt */
 /* dots[row * ld_dots + k] = (Z Wc^T)[row][k], sumsq[row * ld_sumsq] = |Z[row]|^2 of a finished table Z [rows][D] (no
  * normalisation, no bias); the strides let both land inside the coarse table of gx_fineq_fwd */
 int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, long ld_sumsq, float* dots,

@@ -121,7 +121,8 @@ def test_fineq_bwd_one_pass_vs_fp64(ops, k, two_taps, res):
     c = torch.zeros(rows, ls)
     c[:, :k + 1] = torch.randn(rows, k + 1) * 1e-2
     c = c.cuda()
-    s, pm, tt, cpool = ops.fineq_bwd(c, t1, t2, k, res)
+    s, pm, tt, cpool, tt_amax = ops.fineq_bwd(c, t1, t2, k, res, want_amax=True)
+    assert float(tt_amax) == float(tt.abs().max())      # the bound the f16x3 GEMMs on Tt read from the device
     t = (t1 if t2 is None else torch.cat([t1, t2], 1)).double()
     e = c[:, k].double()
     assert rel(s, (t * e[:, None]).t() @ t) < 3e-6
@@ -211,6 +212,22 @@ def test_fused_finish_gemm_vs_fp64_and_the_two_kernel_route(ops, k, res, pool):
     assert rel(g, g2f) < 2e-6 and rel(gwc, gwc2) < 2e-6
     if pool:
         assert rel(gp, gp2) < 2e-6
+    # the f16x3 form (two fp16 planes of Wf, Tt scaled from its maximum on the device): fp32-class too; also on gradient-sized Tt
+    if ops.GEMM_H2:
+        for scale in (1.0, 3e-7):
+            tts = tt * scale
+            ph = ops.split_gemm_weights(wf, h2=True)
+            assert ph.h2
+            with pytest.raises(RuntimeError):
+                ops.gemm_nt_planes_finish(tts, ph, coeffs, z, wc, gwc2.clone(), 0.0, res, pool)        # no bound given
+            gwh = torch.full((k, d), 3.0).cuda()
+            gh, gph, gmax = ops.gemm_nt_planes_finish(tts, ph, coeffs * scale, z, wc, gwh, 0.0, res, pool, want_amax=True,
+                                                      a_amax=ops.absmax(tts))
+            assert rel(gh.reshape(rows, d), want * scale) < 2e-6 and rel(gwh, c64[:, :k].t() @ z64 * scale) < 2e-6
+            assert float(gmax) == float(gh.abs().max())
+            if pool:
+                assert rel(gph, wp_ * scale) < 2e-6
+        assert not torch.equal(gh, g * scale)
     # accumulate into gWc (beta = 1), and idempotence (no atomics)
     g3, gp3 = ops.gemm_nt_planes_finish(tt, planes, coeffs, z, wc, gwc2, 1.0, res, pool)
     assert rel(gwc2, 2.0 * gwc) < 2e-6

@@ -949,6 +949,50 @@ def test_gemm_ranged_f16x3_form_of_the_long_k_gemms(ops):
         ops.set_gemm_mode(prev)
 
 
+def test_device_side_bounds_of_the_f16x3_forms(ops):
+    """gx_absmax (max |x| of a strided matrix / a strided column, optionally of sqrt |x|) and the a_amax / b_amax arguments of the
+    f16x3 GEMM forms: a bound read from the device gives the bits of the same bound passed as a host number."""
+    torch.manual_seed(33)
+    prev = ops.set_gemm_mode(1)
+    was = ops.GEMM_H2
+    ops.GEMM_H2 = True
+    try:
+        x = dev(torch.randn(1000, 300) * 7)
+        assert float(ops.absmax(x)) == float(x.abs().max())
+        assert float(ops.absmax(x[:, 5:77])) == float(x[:, 5:77].abs().max())
+        assert float(ops.absmax(x[:, 13])) == float(x[:, 13].abs().max())
+        assert float(ops.absmax(x[:, 13], sqrt=True)) == float(x[:, 13].abs().sqrt().max())
+        assert float(ops.absmax(torch.zeros(64, 8, device="cuda"))) == 0.0
+        big = dev(torch.randn(1 << 18, 280))
+        sq = (big * big).sum(1)
+        assert float(ops.absmax(sq, sqrt=True)) >= float(big.abs().max())           # a row norm bounds the row's elements
+        # the weight-plane GEMM: A's bound on the device
+        for (m, n, k, sa) in ((4096, 256, 512, 1.0), (1000, 132, 64, 2e-6)):
+            a, w = dev(torch.randn(m, k) * sa), dev(torch.randn(n, k) * 0.05)
+            ph = ops.split_gemm_weights(w, h2=True)
+            amax = ops.absmax(a)
+            o_dev = ops.gemm_nt_planes(a, None, ph, torch.empty(m, n, device="cuda"), alpha=2.0, a_amax=amax)
+            o_host = ops.gemm_nt_planes(a, None, ph, torch.empty(m, n, device="cuda"), alpha=2.0, a_range=float(amax))
+            assert torch.equal(o_dev, o_host)
+            assert rel_err(o_dev, 2.0 * a.double().cpu() @ w.double().cpu().t()) < 3e-6
+            o_mul = ops.gemm_nt_planes(a, None, ph, torch.empty(m, n, device="cuda"), alpha=2.0, a_amax=amax / 4, a_range=4.0)
+            assert torch.equal(o_mul, o_host)
+        with pytest.raises(RuntimeError):
+            ops.gemm_nt_planes(a, None, ph, torch.empty(m, n, device="cuda"))           # f16x3 planes, no bound
+        # the long-k TN GEMM: both bounds on the device
+        k, m, n = 24000, 512, 256
+        a, b = dev(torch.randn(k, m) * 0.3), dev(torch.randn(k, n) * 4e-6)
+        am, bm = ops.absmax(a), ops.absmax(b)
+        o_dev = ops.gemm(a, b, True, False, split_k=4, a_amax=am, b_amax=bm)
+        o_host = ops.gemm(a, b, True, False, split_k=4, a_range=float(am), b_range=float(bm))
+        assert torch.equal(o_dev, o_host)
+        assert rel_err(o_dev, a.double().cpu().t() @ b.double().cpu()) < 3e-6
+        assert not torch.equal(o_dev, ops.gemm(a, b, True, False, split_k=4))
+    finally:
+        ops.GEMM_H2 = was
+        ops.set_gemm_mode(prev)
+
+
 def test_gemm_tn_cat_one_pass_over_dz(ops, engine):
     """gx_gemm_f32_tn_cat: A^T [B1 | B2] in one launch == the two per-tap TN GEMMs (bitwise at equal split) == fp64"""
     torch.manual_seed(29)
