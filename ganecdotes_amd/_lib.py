@@ -108,6 +108,7 @@ SIGNATURES = {
     "gx_view_latents": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_style_pick": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "gx_demod_batch": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "gx_style_norm": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p]),
     "gx_rotflip_map_batch": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "gx_demod": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "gx_modconv_slab_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

@@ -898,6 +898,31 @@ __global__ void demod_batch_kernel(const float* __restrict__ s_packed, const flo
     if (lane == 0) demod[w] = sc * rsqrtf(sc * sc * a + 1e-8f);
 }
 
+// style_norm: one workgroup per (styled conv j, sample b) of demod_batch's table.  The conv is linear in the style, so
+//   demod[b][co] * conv(x * s[b]) = (demod[b][co] * c) * conv(x * (s[b] / c))   for any c;
+// with c = the power of two that brings max_ci |s[b][ci]| into [2, 4) both scalings are exact and what the convs see of a
+// style is a vector of magnitude < 4 whatever the checkpoint's affine layers produce (trained StyleGAN2 styles reach the
+// hundreds): the f16x3 planes' fixed range then bounds the ACTIVATIONS alone (|x| < 4094).  s and demod are scaled in place.
+__global__ __launch_bounds__(256) void style_norm_kernel(float* __restrict__ s_packed, float* __restrict__ demod, int B,
+                                                         const int* __restrict__ table) {
+    __shared__ float red[16];
+    const int j = blockIdx.x / B, b = blockIdx.x - j * B;
+    const int soff = table[5 * j], cin = table[5 * j + 1], cout = table[5 * j + 2], doff = table[5 * j + 4];
+    float* s = s_packed + (long)B * soff + (long)b * cin;
+    float m = 0.f;
+    for (int ci = threadIdx.x; ci < cin; ci += 256) m = fmaxf(m, fabsf(s[ci]));
+    m = gx_block_max(m, red);
+    const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);          // m in [2^(be - 127), 2^(be - 126))
+    if (be == 0 || be == 255) return;                                   // zero / subnormal / not finite: left alone
+    int e = be - 128;                                                   // m 2^-e in [2, 4)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    if (e == 0) return;
+    const float down = __uint_as_float((unsigned)(127 - e) << 23), up = __uint_as_float((unsigned)(127 + e) << 23);
+    for (int ci = threadIdx.x; ci < cin; ci += 256) s[ci] *= down;
+    float* d = demod + (long)B * doff + (long)b * cout;
+    for (int co = threadIdx.x; co < cout; co += 256) d[co] *= up;
+}
+
 // Blur of the (2H+1)^2 transposed-conv image with pad (1,1) + StyledConv epilogue:
 //   out[b,y,x,c] = act( demod[b,c] * sum_{fy,fx} kf[fy][fx] * T[b, y+fy-1, x+fx-1, c] + nw*noise + bias[c] )
 // kf is the FLIPPED 4x4 FIR (upfirdn2d correlates with the flipped kernel, model.py:88).
@@ -1763,6 +1788,15 @@ int gx_demod_batch(const float* s_packed, const float* wsq_all, int B, const int
     const long waves = (long)B * total_rows;
     hipLaunchKernelGGL(demod_batch_kernel, dim3(gx_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, s_packed, wsq_all,
                        B, table, scale, nconv, waves, demod);
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
+
+// Per (styled conv, sample) of gx_demod_batch's table: s /= c, demod *= c in place, c = the power of two that brings the
+// sample's largest |s| into [2, 4) (style_norm_kernel: exact, the convs' results are unchanged).  After gx_demod_batch.
+int gx_style_norm(float* s_packed, float* demod, int B, const int* table, int nconv, void* stream) {
+    if (!s_packed || !demod || !table || B <= 0 || nconv <= 0) return GX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(style_norm_kernel, dim3(B * nconv), dim3(256), 0, (hipStream_t)stream, s_packed, demod, B, table);
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -2825,7 +2825,10 @@ int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K
         // independent here, so ANY grouping by four will do — the kernel's 2 x 2 blocks of a (1 x 2) x (rows / 2) "image"
         const long ncoarse = rows / 4;
         long nbk = (ncoarse + 3) / 4;
-        if (nbk > 4096) nbk = 4096;
+#ifndef RAWTAB_BLOCKS
+#define RAWTAB_BLOCKS 4096     // lab: tools/lab/rawtab_lab.sh
+#endif
+        if (nbk > RAWTAB_BLOCKS) nbk = RAWTAB_BLOCKS;
         // B = 1 image of 2 rc x 2 rc pixels needs a square; use the degenerate geometry rc = rows / 4, rf = 2 rc with
         // per = rc * rc > ncoarse: every group g < ncoarse then has b = 0, cy = 0, cx = g: pixels 2 g, 2 g + 1, rf + 2 g, rf + 2 g + 1
         // -> rows {2g, 2g+1} of the first half and {2g, 2g+1} + rows/2 of the second: all rows exactly once

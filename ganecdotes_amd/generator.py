@@ -75,6 +75,9 @@ def _to_rgb_params(cin, style_dim, upsample, blur_kernel):
 # x-planes conv path (activations split once by their producer, both conv operands by LDS-DMA: csrc/gx_conv.hip
 # modconv_xp_kernel) for every layer big enough to fill the chip; GX_CONV_XP=0 keeps the in-kernel split everywhere
 CONV_XP = os.environ.get("GX_CONV_XP", "1") != "0"
+# per-sample power-of-two normalisation of every styled conv's style, folded into its demod coefficients (gx_style_norm: exact);
+# False only in the test that shows what it is for (huge styles against the f16x3 planes' range)
+STYLE_NORM = True
 
 
 class _OneStreamAtATime:
@@ -298,6 +301,10 @@ class Generator(nn.Module):
                          col_bias=d["mod.b"])
         sp = ops.style_pick(s_all, bsz, nl, d["mod.pick"], d["mod.nlayer"])
         dm = ops.demod_batch(sp, d["mod.wsq"], bsz, d["mod.dtab"], d["mod.dscale"], d["mod.nconv"], d["mod.drows"])
+        if STYLE_NORM:
+            # every styled conv's style to magnitude < 4 per sample, the power of two folded into its demod coefficients
+            # (exact): the conv engines' operand range then only has to hold the activations (the ToRGB styles stay as they are)
+            ops.style_norm_(sp, dm, bsz, d["mod.dtab"], d["mod.nconv"])
         return sp, dm
 
     @staticmethod

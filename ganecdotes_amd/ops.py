@@ -721,6 +721,13 @@ def demod_batch(s_packed, wsq_all, b, table, scale, nconv, total_rows):
     return out
 
 
+def style_norm_(s_packed, demod_packed, b, table, nconv):
+    """per (styled conv, sample), in place: s /= c, demod *= c with c the power of two that brings the sample's largest |s| into
+    [2, 4) — exact, demod * conv(x * s) is unchanged; what the convs see of a style is then bounded whatever the checkpoint"""
+    _chk(s_packed, demod_packed)
+    _lib.check(lib().gx_style_norm(_p(s_packed), _p(demod_packed), b, _p(table), nconv, _stream()), "gx_style_norm")
+
+
 def demod(s, wsq, scale):
     _chk(s, wsq)
     b, cin = s.shape

@@ -254,6 +254,11 @@ int gx_style_pick(const float* S_all, int B, int n_latent, int total, const int*
                   void* stream);
 int gx_demod_batch(const float* s_packed, const float* wsq_all, int B, const int* table, const float* scale, int nconv,
                    int total_rows, float* demod, void* stream);
+/* gx_style_norm (after gx_demod_batch, same table): per (styled conv, sample) s /= c and demod *= c in place, c the power of
+ * two that brings the sample's largest |s| into [2, 4).  Exact — demod * conv(x * s) is unchanged (ModulatedConv2d,
+ * model.py:239-262, is linear in the style) — and the f16x3 planes' fixed range (DESIGN.md par. 4.21) then bounds the
+ * activations alone, whatever magnitudes a trained checkpoint's style affines produce. */
+int gx_style_norm(float* s_packed, float* demod, int B, const int* table, int nconv, void* stream);
 int gx_demod(const float* s, const float* wsq, int B, int Cin, int Cout, float scale, float* demod, void* stream);
 size_t gx_modconv_slab_bytes(int B, int outH, int outW, int Cout);   /* optional split-K scratch (small layers) */
 int gx_modconv_fwd(const float* x, int B, int H, int W, int Cin, const float* wt, int ksize, int Cout, const float* s,

@@ -5,6 +5,8 @@ import copy
 
 import numpy as np
 import pytest
+import math
+
 import torch
 
 from conftest import golden_sd, load_golden
@@ -189,6 +191,66 @@ def test_generator_plane_formats_agree_and_the_f16x3_range_is_loud(gpu, tmp_path
         preds, labels = sw.predict_swav_codes(lat)
         assert bool(torch.isfinite(preds).all())
     finally:
+        ops.set_conv_planes(prev_fmt)
+        ops.set_gemm_mode(prev_mode)
+
+
+def test_style_norm_keeps_huge_styles_inside_the_f16x3_range(gpu):
+    """gx_style_norm: per (styled conv, sample) the style divided by the power of two that brings its largest magnitude into
+    [2, 4), the demod coefficients multiplied by it — exact (bitwise the same taps on the exact-fp32 engine), and what makes the
+    f16x3 planes' fixed range a bound of the ACTIVATIONS only: with every style affine scaled 30000 x (styles far beyond what
+    trained checkpoints reach) the un-normalised f16x3 convs overflow to NaN, the normalised ones stay within 1e-5 of
+    the exact engine."""
+    from ganecdotes_amd import generator as GM
+    from ganecdotes_amd import ops
+    # the kernel on a packed table: two "convs" (cin 70 / 300, cout 5 / 9), 3 samples
+    torch.manual_seed(5)
+    b = 3
+    table = torch.tensor([0, 70, 5, 0, 0, 70, 300, 9, 0, 5], dtype=torch.int32, device="cuda")
+    sp = torch.randn(b * 370, device="cuda") * torch.logspace(-3, 3, b * 370, device="cuda")[torch.randperm(b * 370, device="cuda")]
+    sp[b * 70 + 300:b * 70 + 600] = 0.0                                   # conv 1, sample 1: an all-zero style stays as it is
+    dm = torch.randn(b * 14, device="cuda")
+    s0, d0 = sp.clone(), dm.clone()
+    ops.style_norm_(sp, dm, b, table, 2)
+    for j, (soff, cin, cout, doff) in enumerate(((0, 70, 5, 0), (70, 300, 9, 5))):
+        for i in range(b):
+            a0, a1 = s0[b * soff + i * cin:b * soff + (i + 1) * cin], sp[b * soff + i * cin:b * soff + (i + 1) * cin]
+            e0, e1 = d0[b * doff + i * cout:b * doff + (i + 1) * cout], dm[b * doff + i * cout:b * doff + (i + 1) * cout]
+            m = float(a0.abs().max())
+            if m == 0.0:
+                assert torch.equal(a0, a1) and torch.equal(e0, e1)
+                continue
+            c = 2.0 ** (math.floor(math.log2(m)) - 1)
+            assert 2.0 <= float(a1.abs().max()) < 4.0
+            assert torch.equal(a1, a0 / c) and torch.equal(e1, e0 * c)
+    # the generator
+    torch.manual_seed(19)
+    g = GM.Generator(64, 512, 8)
+    for n, p in g.named_parameters():
+        if n.endswith("noise.weight"):
+            p.data.fill_(0.1)
+        if "modulation" in n and "to_rgb" not in n:
+            p.data.mul_(30000.0)
+    g = g.eval().to(gpu)
+    w = g.style(torch.randn(8, 512, device="cuda"))
+    kw = dict(truncation=0.7, truncation_latent=g.mean_latent(64), input_is_latent=True, randomize_noise=False)
+    prev_mode, prev_fmt, prev_norm = ops.set_gemm_mode(0), ops.get_conv_planes(), GM.STYLE_NORM
+    try:
+        GM.STYLE_NORM = False
+        ref = [t.clone() for t in g([w], **kw)[1]]
+        GM.STYLE_NORM = True
+        for a, r in zip(g([w], **kw)[1], ref):
+            assert torch.equal(a, r)                                      # exact-fp32 engine: powers of two commute with it
+        ops.set_gemm_mode(1)
+        for fmt in (1, 0):
+            ops.set_conv_planes(fmt)
+            for a, r in zip(g([w], **kw)[1], ref):
+                assert rel(a, r) < 1e-5
+        ops.set_conv_planes(1)
+        GM.STYLE_NORM = False
+        assert not all(bool(torch.isfinite(t).all()) for t in g([w], **kw)[1])          # what the normalisation is for
+    finally:
+        GM.STYLE_NORM = prev_norm
         ops.set_conv_planes(prev_fmt)
         ops.set_gemm_mode(prev_mode)
 
