@@ -78,9 +78,11 @@ SIGNATURES = {
     "gx_fineq_ok": (c_i, [c_i, c_i, c_i]),
     "gx_fineq_pack_weights": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gx_fineq_ytable_ld": (c_i, []),
-    "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p]),
+    "gx_fineq_fwd": (c_i, [c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_p]),
+    "gx_lowrank_coeff_amax": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "gx_fineq_bwd_workspace_bytes": (c_sz, []),
-    "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
+    "gx_fineq_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p, c_p,
+                           c_p]),
     "gx_proto_raw_tables": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p]),
     "gx_gemm_f32_upadd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p]),
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -37,6 +37,7 @@ struct FineqArgs {
     int M, K, shift;                       // rows, prototypes, log2(fine resolution)
     int ntile;                             // 128-row tiles
     float a_scale; const float* b_amax;    // f16x3 form (gx_mfma_x6.h): the taps' power-of-two scale, max |Bq| behind the planes
+    unsigned* t_amax;                      // optional: max |tap| over the launch (float bits, atomicMax; zeroed by the launcher)
 };
 
 #ifndef FQ_ABL
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
 
     f32x16 acc[6];
     float sp;                                                            // this lane's share of its row's t^T M t + t . Y2
+    float tmax = 0.f;                                                    // R waves: max |tap| of the fragments they read (every k-tile)
     for (int it = 0; it < my_tiles; ++it) {
         const int tn = (it + 1 < my_tiles) ? tm + tstride : tm;        // next tile (the last one prefetches itself: unused)
 #pragma unroll
@@ -220,6 +222,9 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + au0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + au1);
                 unsigned h[4], m[4], l[4];
+                if (!isL)       // (an R wave meets all 16 k-tiles of its 32 rows: the four of them see every tap value of the tile)
+                    tmax = fmaxf(fmaxf(fmaxf(tmax, fmaxf(fabsf(x0[0]), fabsf(x0[1]))), fmaxf(fabsf(x0[2]), fabsf(x0[3]))),
+                                 fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), fmaxf(fabsf(x1[2]), fabsf(x1[3]))));
                 if constexpr (H2) {
                     split2h(x0[0], x0[1], g.a_scale, h[0], l[0]);
                     split2h(x0[2], x0[3], g.a_scale, h[1], l[1]);
@@ -334,6 +339,10 @@ __global__ __launch_bounds__(512, 1) void fineq_fwd_kernel(FineqArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last tile's look-ahead DMAs still target this LDS
     __syncthreads();
+    if (g.t_amax && !isL) {                  // the taps' true maximum: the bound fineq_bwd_kernel<true> scales its images by
+        tmax = gx_wave_max(tmax);
+        if (lane == 0 && __float_as_uint(tmax) > *reinterpret_cast<volatile unsigned*>(g.t_amax)) atomicMax(g.t_amax, __float_as_uint(tmax));
+    }
 }
 
 // Bq [CF + 16][CF] (row stride CF) for fineq_fwd_kernel: rows j < CF = the lower-triangular form of the symmetric
@@ -391,6 +400,9 @@ struct FineqBwdArgs {
     float* Tt;                             // [rows / 4][256]
     float* Cpool;                          // [rows / 4][ls]
     unsigned* tt_amax;                     // optional: max |Tt| over the launch (float bits, atomicMax; zeroed by the launcher)
+    // fineq_bwd_kernel<true> (f16x3): device floats max |tap| (gx_fineq_fwd's t_amax) and {max |C[:, :K]|, max |C[:, K]|}
+    // (gx_lowrank_coeff_amax): the images are two fp16 planes of t sB, e t sA, c sC with the powers of two these bounds give
+    const float* t_amax; const float* c_amax;
 };
 
 // Consumer wave W of fineq_bwd_kernel.  Tasks (row block of the A image, column block of the B image), four MFMA tiles each:
@@ -429,8 +441,8 @@ __device__ __forceinline__ float fb_half_sum(float x) {
     asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
     return a + b;
 }
-template <int W8>
-__device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* lds, int nkt, int lane) {
+template <int W8, bool H2>
+__device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* lds, int nkt, int lane, float un_s, float un_p) {
     constexpr int W = W8 >> 1, N0 = 6 * (W8 & 1);                     // this wave: tiles N0 .. N0 + 5 of list W
     constexpr int AIMG = FB_IMG;
     const int toff = (8 * (lane >> 5) + ((lane & 15) >> 2)) * FB_RS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -441,16 +453,18 @@ __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* l
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int r32 = lane & 31, hh = lane >> 5;
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // l*h, h*l, m*m, m*h, h*m, h*h
+    constexpr int NPL = H2 ? 2 : 3;                                   // f16x3: planes 0 = h, 1 = l
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};               // l*h, h*l, h*h
     auto load_a = [&](const char* As, int row) {
         FbFrag f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.p[q] = fb_frag(As, q, row, toff);
+        for (int q = 0; q < NPL; ++q) f.p[q] = fb_frag(As, q, row, toff);
         return f;
     };
     auto load_b = [&](const char* Bs, int row) {
         FbFrag f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.p[q] = fb_frag(Bs, q, row, toff);
+        for (int q = 0; q < NPL; ++q) f.p[q] = fb_frag(Bs, q, row, toff);
         return f;
     };
     __syncthreads();                                                 // barrier 0
@@ -465,9 +479,16 @@ __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* l
             const bool a_changes = !last && FB_GA[W][n + 1 > 11 ? 11 : n + 1] != FB_GA[W][n];
             if (!last) nx = a_changes ? load_a(As, FB_GA[W][n + 1 > 11 ? 11 : n + 1]) : load_b(Bs, FB_GB[W][n + 1 > 11 ? 11 : n + 1]);
             const int ai = n - N0;
+            if constexpr (H2) {
 #pragma unroll
-            for (int u = 0; u < (FQ_ABL == 11 ? 1 : 6); ++u)
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[u]], b.p[TB[u]], acc[ai], 0, 0, 0);
+                for (int u = 0; u < (FQ_ABL == 11 ? 1 : 3); ++u)
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[HA[u]]),
+                                                                     __builtin_bit_cast(f16x8, b.p[HB[u]]), acc[ai], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < (FQ_ABL == 11 ? 1 : 6); ++u)
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[u]], b.p[TB[u]], acc[ai], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);                        // the order above is the schedule
             if (!last) { if (a_changes) a = nx; else b = nx; }
         }
@@ -481,11 +502,15 @@ __device__ __forceinline__ void fineq_bwd_consume(const FineqBwdArgs& g, char* l
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = FB_GA[W][n] + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (row < 272) out[row * 256 + col] = acc[ai][r];
+            // (f16x3: the scales leave — powers of two; the coefficient rows carry their own)
+            if (row < 272) out[row * 256 + col] = H2 ? acc[ai][r] * (FB_GA[W][n] >= 256 ? un_p : un_s) : acc[ai][r];
         }
     }
 }
 
+// H2: the f16x3 form — the producers scale t, e t and the coefficient columns by the powers of two of their device-side
+// bounds and write two fp16 planes per image, the consumers issue three products per tile and un-scale what they store.
+template <bool H2>
 __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
     __shared__ __attribute__((aligned(16))) char lds[2 * FB_SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -495,6 +520,11 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
     char* slot0 = lds;
     char* slot1 = lds + FB_SLOT;
     constexpr int AIMG = FB_IMG;
+    float sA = 1.f, sB = 1.f, sC = 1.f;
+    if constexpr (H2) {
+        const float tb = *g.t_amax;
+        sB = xh_scale_of(tb); sA = xh_scale_of(tb * g.c_amax[1]); sC = xh_scale_of(g.c_amax[0]);
+    }
     // columns 272 .. 287 of the A image are never written by the producers: zero them once (both slots, all planes, 16 k rows
     // x 32 B = 8 words each)
     for (int i = tid; i < 2 * 3 * 16 * 8; i += 768) {
@@ -540,13 +570,24 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
             char* A = slot;
             char* B = slot + AIMG;
             // k rows 2 kp (pixel q0) and 2 kp + 1 (pixel q0 + 1) of the images; four columns = 8 B per row and plane
-            auto put = [&](char* img, int col, const f32x4& v0, const f32x4& v1) {
+            auto put = [&](char* img, int col, const f32x4& v0, const f32x4& v1, float scale) {
                 unsigned h[4], m[4], l[4];
+                char* d = img + (2 * kp) * FB_RS + col * 2;
+                if constexpr (H2) {
+                    split2h(v0[0], v0[1], scale, h[0], l[0]);
+                    split2h(v0[2], v0[3], scale, h[1], l[1]);
+                    split2h(v1[0], v1[1], scale, h[2], l[2]);
+                    split2h(v1[2], v1[3], scale, h[3], l[3]);
+                    *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
+                    *reinterpret_cast<u32x2*>(d + FB_PL) = (u32x2){l[0], l[1]};
+                    *reinterpret_cast<u32x2*>(d + FB_RS) = (u32x2){h[2], h[3]};
+                    *reinterpret_cast<u32x2*>(d + FB_RS + FB_PL) = (u32x2){l[2], l[3]};
+                    return;
+                }
                 split3(v0[0], v0[1], h[0], m[0], l[0]);
                 split3(v0[2], v0[3], h[1], m[1], l[1]);
                 split3(v1[0], v1[1], h[2], m[2], l[2]);
                 split3(v1[2], v1[3], h[3], m[3], l[3]);
-                char* d = img + (2 * kp) * FB_RS + col * 2;
                 *reinterpret_cast<u32x2*>(d) = (u32x2){h[0], h[1]};
                 *reinterpret_cast<u32x2*>(d + FB_PL) = (u32x2){m[0], m[1]};
                 *reinterpret_cast<u32x2*>(d + 2 * FB_PL) = (u32x2){l[0], l[1]};
@@ -558,8 +599,8 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
             for (int j = 0; j < 2; ++j) {
                 const f32x4 t0 = T.v[2 * j], t1 = T.v[2 * j + 1];
                 const f32x4 s0 = e0 * t0, s1 = e1 * t1;
-                put(B, c4 + 128 * j, t0, t1);
-                put(A, c4 + 128 * j, s0, s1);
+                put(B, c4 + 128 * j, t0, t1, sB);
+                put(A, c4 + 128 * j, s0, s1, sA);
                 // Tt: this pair + the pair below / above it (the partner lane holds the same columns of the same parent)
                 f32x4 tt = s0 + s1;
 #pragma unroll
@@ -570,14 +611,22 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
             if (mm < 16) {                                                   // coefficient columns 256 .. 271 of the A image
                 const bool kok = mm < g.K;
                 unsigned h, m, l;                                            // low half: pixel q0's, high half: pixel q0 + 1's
-                split3(kok ? T.c0 : 0.f, kok ? T.c1 : 0.f, h, m, l);
                 char* d = A + (2 * kp) * FB_RS + (256 + mm) * 2;
+                if constexpr (H2) {
+                    split2h(kok ? T.c0 : 0.f, kok ? T.c1 : 0.f, sC, h, l);
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(d + FB_PL) = (unsigned short)(l & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(d + FB_RS) = (unsigned short)(h >> 16);
+                    *reinterpret_cast<unsigned short*>(d + FB_RS + FB_PL) = (unsigned short)(l >> 16);
+                } else {
+                split3(kok ? T.c0 : 0.f, kok ? T.c1 : 0.f, h, m, l);
                 *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h & 0xffffu);
                 *reinterpret_cast<unsigned short*>(d + FB_PL) = (unsigned short)(m & 0xffffu);
                 *reinterpret_cast<unsigned short*>(d + 2 * FB_PL) = (unsigned short)(l & 0xffffu);
                 *reinterpret_cast<unsigned short*>(d + FB_RS) = (unsigned short)(h >> 16);
                 *reinterpret_cast<unsigned short*>(d + FB_RS + FB_PL) = (unsigned short)(m >> 16);
                 *reinterpret_cast<unsigned short*>(d + FB_RS + 2 * FB_PL) = (unsigned short)(l >> 16);
+                }
             }
             const float cp = fb_half_sum(T.c0 + T.c1);
             if (half == 0 && mm < g.ls && T.live) g.Cpool[T.par * g.ls + mm] = cp;
@@ -618,15 +667,48 @@ __global__ __launch_bounds__(768, 1) void fineq_bwd_kernel(FineqBwdArgs g) {
     }
     // ---------------------------------------------------------------------- consumers
     __syncthreads();                                                 // (zero rows)
+    const float un_s = 1.f / (sA * sB), un_p = 1.f / (sC * sB);
     switch (wid) {
-        case 0: fineq_bwd_consume<0>(g, lds, nkt, lane); break;
-        case 1: fineq_bwd_consume<1>(g, lds, nkt, lane); break;
-        case 2: fineq_bwd_consume<2>(g, lds, nkt, lane); break;
-        case 3: fineq_bwd_consume<3>(g, lds, nkt, lane); break;
-        case 4: fineq_bwd_consume<4>(g, lds, nkt, lane); break;
-        case 5: fineq_bwd_consume<5>(g, lds, nkt, lane); break;
-        case 6: fineq_bwd_consume<6>(g, lds, nkt, lane); break;
-        default: fineq_bwd_consume<7>(g, lds, nkt, lane); break;
+        case 0: fineq_bwd_consume<0, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 1: fineq_bwd_consume<1, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 2: fineq_bwd_consume<2, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 3: fineq_bwd_consume<3, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 4: fineq_bwd_consume<4, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 5: fineq_bwd_consume<5, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        case 6: fineq_bwd_consume<6, H2>(g, lds, nkt, lane, un_s, un_p); break;
+        default: fineq_bwd_consume<7, H2>(g, lds, nkt, lane, un_s, un_p); break;
+    }
+}
+
+// out[0] = max |C[q][k]| over k < K, out[1] = max |C[q][K]| over the coefficient grid C [rows][ls] (float bits, atomicMax; the
+// launcher zeroes them): the bounds fineq_bwd_kernel<true> scales its coefficient columns and its e t image by
+__global__ void lowrank_coeff_amax_kernel(const float* __restrict__ C, long rows, int ls, int K, unsigned* __restrict__ out) {
+    __shared__ float red[16];
+    // flat 16-byte units: unit u holds columns 4 (u % (ls / 4)) .. + 3 of row u / (ls / 4); four units in flight per thread
+    const int upr = ls >> 2;
+    const long nu = rows * upr, stride = (long)gridDim.x * blockDim.x;
+    float mc = 0.f, me = 0.f;
+    auto take = [&](long u, const f32x4& v) {
+        const int c0 = (int)(u % upr) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = fabsf(v[e]);
+            if (c0 + e < K) mc = fmaxf(mc, a);
+            else if (c0 + e == K) me = fmaxf(me, a);
+        }
+    };
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; u + 3 * stride < nu; u += 4 * stride) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(C + u * 4), v1 = *reinterpret_cast<const f32x4*>(C + (u + stride) * 4);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(C + (u + 2 * stride) * 4), v3 = *reinterpret_cast<const f32x4*>(C + (u + 3 * stride) * 4);
+        take(u, v0); take(u + stride, v1); take(u + 2 * stride, v2); take(u + 3 * stride, v3);
+    }
+    for (; u < nu; u += stride) take(u, *reinterpret_cast<const f32x4*>(C + u * 4));
+    mc = gx_block_max(mc, red);
+    me = gx_block_max(me, red);
+    if (threadIdx.x == 0) {
+        if (mc > 0.f) atomicMax(out, __float_as_uint(mc));
+        if (me > 0.f) atomicMax(out + 1, __float_as_uint(me));
     }
 }
 
@@ -682,7 +764,7 @@ static int fineq_num_cus() {
 }
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
-                 float* sc_table, float a_range, void* stream) {
+                 float* sc_table, float a_range, float* t_amax, void* stream) {
     if (!t1 || !bq_planes || !ytable || !rn_table || !sc_table || rows <= 0 || (K2 > 0 && !t2) || a_range < 0.f) return GX_ERR_BAD_ARG;
     if (!gx_fineq_ok(K1, K2, K)) return GX_ERR_BAD_ARG;
     if (gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;                   // a bf16x6 kernel
@@ -706,6 +788,8 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
     // a_range > 0: bq_planes are gx_split_gemm_weights_h2's (two fp16 planes + the max-|Bq| trailer), the taps bounded by a_range
     g.a_scale = a_range > 0.f ? gx::xh_scale_of(a_range) : 1.f;
     g.b_amax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bq_planes) + gx_gemm_weight_planes_bytes(CF + 16, CF) - 16);
+    g.t_amax = reinterpret_cast<unsigned*>(t_amax);
+    if (t_amax && hipMemsetAsync(t_amax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
     if (a_range > 0.f) hipLaunchKernelGGL(gx::fineq_fwd_kernel<true>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(gx::fineq_fwd_kernel<false>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, g);
     GX_CHECK_LAUNCH();
@@ -715,11 +799,24 @@ int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int 
 // One pass over the finest taps for the whole backward of the level (fineq_bwd_kernel): S [256][256] = sum_q e[q] t t^T,
 // P [K][256], Tt [rows / 4][256], Cpool [rows / 4][stride].  bf16x6 engine; fine_res a power of two >= 16.
 // tt_amax (optional device float): max |Tt|, the a_amax_dev / b_amax_dev of the f16x3 GEMMs that contract Tt.
+// t_amax + c_amax (both or neither; device floats: max |tap| as gx_fineq_fwd left it, the two maxima of gx_lowrank_coeff_amax):
+// the f16x3 form of the pass — two fp16 planes per image, three products per tile, half the matrix-core work.
+int gx_lowrank_coeff_amax(const float* C, long rows, int K, float* out2, void* stream) {
+    if (!C || !out2 || rows <= 0 || K < 1 || K > 16 || ((uintptr_t)C & 15)) return GX_ERR_BAD_ARG;
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
+    const int ls = (K + 1 + 3) & ~3;
+    long want = (rows * (ls >> 2) + 1023) / 1024;
+    hipLaunchKernelGGL(gx::lowrank_coeff_amax_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, C,
+                       rows, ls, K, reinterpret_cast<unsigned*>(out2));
+    GX_CHECK_LAUNCH();
+    return GX_OK;
+}
 #define GX_FINEQ_BWD_WGS 256
 size_t gx_fineq_bwd_workspace_bytes(void) { return (size_t)GX_FINEQ_BWD_WGS * 272 * 256 * sizeof(float); }
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, float* tt_amax,
-                 void* stream) {
+                 const float* t_amax, const float* c_amax, void* stream) {
+    if ((t_amax == nullptr) != (c_amax == nullptr)) return GX_ERR_BAD_ARG;
     if (!C || !t1 || !S || !P || !Tt || !Cpool || rows <= 0 || (K2 > 0 && !t2)) return GX_ERR_BAD_ARG;
     if (!gx_fineq_ok(K1, K2, K) || gx_get_gemm_mode() != 1) return GX_ERR_BAD_ARG;
     if (fine_res < 16 || (fine_res & (fine_res - 1)) || (long)rows % ((long)fine_res * fine_res)) return GX_ERR_BAD_ARG;
@@ -739,7 +836,9 @@ int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1
     hipStream_t st = (hipStream_t)stream;
     g.tt_amax = reinterpret_cast<unsigned*>(tt_amax);
     if (tt_amax && hipMemsetAsync(tt_amax, 0, sizeof(float), st) != hipSuccess) return GX_ERR_LAUNCH;
-    hipLaunchKernelGGL(gx::fineq_bwd_kernel, dim3(nwg), dim3(768), 0, st, g);
+    g.t_amax = t_amax; g.c_amax = c_amax;
+    if (t_amax) hipLaunchKernelGGL(gx::fineq_bwd_kernel<true>, dim3(nwg), dim3(768), 0, st, g);
+    else hipLaunchKernelGGL(gx::fineq_bwd_kernel<false>, dim3(nwg), dim3(768), 0, st, g);
     GX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gx::fineq_bwd_reduce_kernel, dim3(gx_cdiv((256 + K) * 256, 256)), dim3(256), 0, st, workspace, nwg, K, S, P);
     GX_CHECK_LAUNCH();

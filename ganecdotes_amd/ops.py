@@ -609,7 +609,7 @@ def fineq_pack_weights(mg, wcf):
     return bq
 
 
-def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res, a_range=None):
+def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res, a_range=None, want_amax=False):
     """the finest level's score / rnorm tables from its taps t1 (rows, K1) [| t2 (rows, K2)] and the coarse table of the
     level below (fineq_ytable: y2 = 2 Zc Wf | ac = Zc Wc^T | nc = |Zc|^2): returns (rn_table (rows,), sc_table (rows, K))"""
     _chk2d(t1, t2)
@@ -623,18 +623,28 @@ def fineq_fwd(t1, t2, bq_planes, ytable, bias, k, fine_res, a_range=None):
         raise RuntimeError("fineq_fwd: planes do not match (CF + 16, CF)")
     rn = torch.empty(rows, dtype=torch.float32, device=t1.device)
     sc = torch.empty(rows, k, dtype=torch.float32, device=t1.device)
+    t_amax = torch.empty(1, dtype=torch.float32, device=t1.device) if want_amax else None      # max |tap| as the pass met them
     cf = k1 + k2
     flops = 2.0 * rows * 16 * 32 * (sum(cf // 32 - (t >> 1) for t in range(cf // 16)) + cf // 16)   # blocks on / below the diagonal + scores
     with record("fineq_fwd_kernel", flops):
         _lib.check(L.gx_fineq_fwd(rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2), 0 if t2 is None else t2.stride(0),
                                   _p(bq_planes.buf), _p(ytable), _p(bias), k, _p(rn), _p(sc), _a_range(bq_planes, a_range, "fineq_fwd"),
-                                  _stream()), "gx_fineq_fwd")
-    return rn, sc
+                                  _p(t_amax), _stream()), "gx_fineq_fwd")
+    return (rn, sc, t_amax) if want_amax else (rn, sc)
 
 
-def fineq_bwd(coeffs, t1, t2, k, fine_res, want_amax=False):
+def lowrank_coeff_amax(coeffs, k):
+    """(2,) HIP tensor: max |coeffs[:, :k]|, max |coeffs[:, k]| of a low-rank coefficient grid"""
+    _chk(coeffs)
+    out = torch.empty(2, dtype=torch.float32, device=coeffs.device)
+    _lib.check(lib().gx_lowrank_coeff_amax(_p(coeffs), coeffs.shape[0], k, _p(out), _stream()), "gx_lowrank_coeff_amax")
+    return out
+
+
+def fineq_bwd(coeffs, t1, t2, k, fine_res, want_amax=False, t_amax=None):
     """coefficient grid (rows, stride) + the finest taps, ONE pass over the taps -> S (256, 256) = sum_q e[q] t t^T,
-    P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride) (+ max |Tt| as a one-element HIP tensor with want_amax)"""
+    P (K, 256) = C[:, :K]^T t, Tt (rows/4, 256), Cpool (rows/4, stride) (+ max |Tt| as a one-element HIP tensor with want_amax).
+    t_amax (one-element HIP tensor: max |tap|, fineq_fwd's): the f16x3 form of the pass, the coefficient bounds found here."""
     _chk(coeffs)
     _chk2d(t1, t2)
     rows, k1 = t1.shape
@@ -651,11 +661,12 @@ def fineq_bwd(coeffs, t1, t2, k, fine_res, want_amax=False):
     wsb = L.gx_fineq_bwd_workspace_bytes()
     ws = workspace("fineq_bwd", wsb, dev)
     tt_amax = torch.empty(1, dtype=torch.float32, device=dev) if want_amax else None
+    c_amax = lowrank_coeff_amax(coeffs, k) if t_amax is not None else None
     # the 10 of 16 64x64 blocks of S on / above the diagonal + the 32 coefficient rows (K of them live)
     with record("fineq_bwd_kernel", 2.0 * rows * 64 * 64 * 12, 4.0 * rows * (cf * 1.25 + coeffs.shape[1] * 1.25)):
         _lib.check(L.gx_fineq_bwd(_p(coeffs), rows, fine_res, k1, _p(t1), t1.stride(0), k2, _p(t2),
                                   0 if t2 is None else t2.stride(0), k, _p(s), _p(pm), _p(tt), _p(cpool), _p(ws), wsb,
-                                  _p(tt_amax), _stream()), "gx_fineq_bwd")
+                                  _p(tt_amax), _p(t_amax), _p(c_amax), _stream()), "gx_fineq_bwd")
     return (s, pm, tt, cpool, tt_amax) if want_amax else (s, pm, tt, cpool)
 
 

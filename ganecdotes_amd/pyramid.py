@@ -133,8 +133,10 @@ class Pyramid:
         # row norm, from the |Zc|^2 column the pass above just wrote — 1 MB read instead of a pass over the table
         zc_amax = ops.absmax(yt[:, ops.FINEQ_NC_COL], sqrt=True) if ops.GEMM_H2 else None
         ops.gemm_nt_planes(zc2, None, ops.split_gemm_weights(wf.t().contiguous(), h2=True), yt[:, :cf], alpha=2.0, a_amax=zc_amax)
-        rn, sc = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq, h2=True), yt, bias, k, r, a_range=ops.FEATURE_RANGE)
-        self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf, z_amax=zc_amax)
+        rn, sc, t_amax = ops.fineq_fwd(t1, t2, ops.split_gemm_weights(bq, h2=True), yt, bias, k, r, a_range=ops.FEATURE_RANGE,
+                                       want_amax=True)
+        self._lr = dict(mode="quad", top=top, shift=shift, z=zc, t1=t1, t2=t2, off=off, cf=cf, z_amax=zc_amax,
+                        t_amax=t_amax if ops.GEMM_H2 else None)
         return rn, sc, shift
 
     def table_pixels(self):
@@ -200,7 +202,8 @@ class Pyramid:
         wf = wp[:, off:off + cf]
         zc2 = zc.reshape(-1, d)
         # ONE pass over the level's taps: S = sum_q e[q] t t^T (e = C[:, K]), P = C[:, :K]^T t, Tt = 2x2-pooled e t, Cpool
-        s, pm, tt, cpool, tt_amax = ops.fineq_bwd(coeffs, t1, t2, k, r, want_amax=True)
+        # (f16x3: the taps' true maximum as fineq_fwd met it + the coefficient grid's two maxima — a product of tight bounds)
+        s, pm, tt, cpool, tt_amax = ops.fineq_bwd(coeffs, t1, t2, k, r, want_amax=True, t_amax=lr.get("t_amax"))
         if not ops.GEMM_H2:
             tt_amax = None
         g_amax = None

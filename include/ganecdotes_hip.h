@@ -208,14 +208,19 @@ int gx_fineq_pack_weights(const float* Mg, const float* Wcf, int CF, int K, floa
 int gx_fineq_ytable_ld(void);   /* floats per parent pixel of the coarse table: [0, 256) Y2 | [256, 272) Ac | 272 nc | pad */
 int gx_fineq_fwd(int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  const unsigned short* bq_planes, const float* ytable, const float* bias, int K, float* rn_table,
-                 float* sc_table, float a_range, void* stream);
+                 float* sc_table, float a_range, float* t_amax, void* stream);
 /* a_range: 0 = bq_planes from gx_split_gemm_weights (bf16x6); > 0 = a bound of |t1|, |t2| and bq_planes from
- * gx_split_gemm_weights_h2 (the f16x3 form, as in gx_gemm_f32_nt_planes) */
+ * gx_split_gemm_weights_h2 (the f16x3 form, as in gx_gemm_f32_nt_planes); t_amax (optional device float): max |t1|, |t2| as the
+ * pass met them — the tight bound gx_fineq_bwd's f16x3 form takes */
+/* gx_lowrank_coeff_amax: out2[0] = max |C[q][k]| (k < K), out2[1] = max |C[q][K]| over the coefficient grid C [rows][gx_lowrank_stride(K)] */
+int gx_lowrank_coeff_amax(const float* C, long rows, int K, float* out2, void* stream);
 size_t gx_fineq_bwd_workspace_bytes(void);
 int gx_fineq_bwd(const float* C, int rows, int fine_res, int K1, const float* t1, long ld1, int K2, const float* t2, long ld2,
                  int K, float* S, float* P, float* Tt, float* Cpool, float* workspace, size_t workspace_bytes, float* tt_amax,
-                 void* stream);
-/* tt_amax (optional device float): max |Tt| over the launch — the a_amax_dev / b_amax_dev of the f16x3 GEMMs that contract Tt */
+                 const float* t_amax, const float* c_amax, void* stream);
+/* tt_amax (optional device float): max |Tt| over the launch — the a_amax_dev / b_amax_dev of the f16x3 GEMMs that contract Tt.
+ * t_amax + c_amax (both or neither; device floats from gx_fineq_fwd and gx_lowrank_coeff_amax): the pass runs its f16x3 form
+ * (images scaled by the powers of two of max |t|, max |C[:, K]| max |t| and max |C[:, :K]|; DESIGN.md par. 4.21) */
 /* dots[row * ld_dots + k] = (Z Wc^T)[row][k], sumsq[row * ld_sumsq] = |Z[row]|^2 of a finished table Z [rows][D] (no
  * normalisation, no bias); the strides let both land inside the coarse table of gx_fineq_fwd */
 int gx_proto_raw_tables(const float* Z, long rows, int D, const float* Wc, int K, float* sumsq, long ld_sumsq, float* dots,

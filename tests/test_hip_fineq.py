@@ -53,6 +53,11 @@ def test_fineq_tables_equal_the_projected_table_route(ops, k, two_taps, h2, monk
     pyr = Pyramid(ops.TapSet(taps), hlen)
     rn_q, sc_q, sh_q = pyr.project_tables(wp, wc, bias, quad=True)
     assert pyr._lr["mode"] == "quad" and sh_q == 0
+    fine = [t for t in taps if t.shape[1] == 64]
+    if h2:      # the taps' maximum as the forward pass met them: the bound of the backward pass's f16x3 form
+        assert float(pyr._lr["t_amax"]) == max(float(t.abs().max()) for t in fine)
+    else:
+        assert pyr._lr["t_amax"] is None and pyr._lr["z_amax"] is None
     rn_t, sc_t, sh_t = Pyramid(ops.TapSet(taps), hlen).project_tables(wp, wc, bias, quad=False)
     assert sh_t == 0
     # fp64 truth
@@ -130,6 +135,22 @@ def test_fineq_bwd_one_pass_vs_fp64(ops, k, two_taps, res):
     assert rel(pm, c[:, :k].double().t() @ t) < 3e-6
     pool = lambda x: x.reshape(b, res // 2, 2, res // 2, 2, -1).sum((2, 4)).reshape(rows // 4, -1)
     assert rel(tt, pool(t * e[:, None])) < 2e-6 and rel(cpool, pool(c.double())) < 2e-6
+    # the f16x3 form (images scaled from max |t| and the coefficient grid's two maxima, all on the device): fp32-class as well —
+    # also with gradient-sized coefficients whose prototype part and e part differ by three orders of magnitude
+    cm = ops.lowrank_coeff_amax(c, k)
+    assert float(cm[0]) == float(c[:, :k].abs().max()) and float(cm[1]) == float(c[:, k].abs().max())
+    t_amax = ops.absmax(torch.cat([t1.reshape(-1), t2.reshape(-1)]) if t2 is not None else t1.reshape(-1))
+    c2 = c * 1e-4
+    c2[:, k] *= 1e-3
+    for cc in (c, c2):
+        sh, pmh, tth, cph, tta = ops.fineq_bwd(cc, t1, t2, k, res, want_amax=True, t_amax=t_amax)
+        eh = cc[:, k].double()
+        err6 = [rel(x, y) for x, y in zip(ops.fineq_bwd(cc, t1, t2, k, res)[:2], ((t * eh[:, None]).t() @ t, cc[:, :k].double().t() @ t))]
+        assert rel(sh, (t * eh[:, None]).t() @ t) < max(3e-6, 1.5 * err6[0]) and rel(sh, sh.t()) < 1e-6
+        assert rel(pmh, cc[:, :k].double().t() @ t) < max(3e-6, 1.5 * err6[1])
+        assert rel(tth, pool(t * eh[:, None])) < 2e-6 and rel(cph, pool(cc.double())) < 2e-6
+        assert float(tta) == float(tth.abs().max())
+    assert not torch.equal(sh, ops.fineq_bwd(c2, t1, t2, k, res)[0])             # (the other form did run)
 
 
 def test_tables_shifted_below_levels_without_taps(ops):

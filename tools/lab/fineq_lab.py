@@ -76,6 +76,13 @@ if want("fwd"):
 if want("bwd"):
     show("fineq_bwd (S, P, Tt, Cpool in one pass)", timeit(lambda: ops.fineq_bwd(coeffs, t1, t2, K, R)), 2.0 * rows * 64 * 64 * 12, 4.0 * rows * CF * 1.25)
     s_, pm, tt, cpool = ops.fineq_bwd(coeffs, t1, t2, K, R)
+    tam = ops.absmax(torch.cat([t1.reshape(-1), t2.reshape(-1)]))
+    for _ in range(2):     # the f16x3 form (incl. its coefficient-maxima pass) beside the bf16x6 one, twice
+        show("fineq_bwd f16x3 (+ coefficient maxima)", timeit(lambda: ops.fineq_bwd(coeffs, t1, t2, K, R, t_amax=tam)), 2.0 * rows * 64 * 64 * 12, 4.0 * rows * CF * 1.25)
+        show("fineq_bwd bf16x6", timeit(lambda: ops.fineq_bwd(coeffs, t1, t2, K, R)), 2.0 * rows * 64 * 64 * 12, 4.0 * rows * CF * 1.25)
+    show("coefficient maxima alone", timeit(lambda: ops.lowrank_coeff_amax(coeffs, K)), 0, 4.0 * rows * ls)
+    sh = ops.fineq_bwd(coeffs, t1, t2, K, R, t_amax=tam)[0]
+    print(f"   S f16x3 vs bf16x6: {float((sh - s_).abs().max() / s_.abs().max()):.2e}", flush=True)
     gc = torch.empty(rc, D, device=dev)
     show("Gc = Tt Wf^T (0.5M x 256 -> 512)", timeit(lambda: ops.gemm_nt_planes(tt, None, wf_planes, gc)), 2.0 * rc * D * CF)
     gwc = torch.empty(K, D, device=dev)

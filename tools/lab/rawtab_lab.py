@@ -1,5 +1,10 @@
 """times ops.proto_raw_tables at the bench shape (the 128^2 level of 16 images: 262144 rows x 512, K = 8)"""
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
 from ganecdotes_amd import ops
 
