@@ -610,11 +610,13 @@ def main():
         "metric": "pretrain images/sec (ffhq-256 hfc_with_swav)", "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": (("fp32 in / fp32 out; the modulated convs" + (" and the weight-plane GEMMs" if ops.GEMM_H2 else "") +
+        "arithmetic": (("fp32 in / fp32 out; the modulated convs" +
+                        (", the weight-plane and long-k gradient GEMMs and the finest level's quadratic-form passes" if ops.GEMM_H2 else "") +
                         " as f16x3 on the fp16 matrix cores (operands scaled by powers of two and split into two fp16 planes, "
                         "three products, fp32 accumulate: the error against fp64 is that of an fp32 fma chain — "
                         "tools/lab/mfma_f16x3.hip, tests/test_hip_kernels.py::test_gemm_nt_planes_f16x3_form_is_fp32_class; operands "
-                        "out of the fp16 range come out NaN), the other contractions as bf16x6 (three bf16 planes, six products); "
+                        "out of the fp16 range come out NaN; every bound is stated, or found on the device by the operand's producer), the short "
+                        "contractions as bf16x6 (three bf16 planes, six products); "
                         "GX_CONV_PLANES=0 GX_GEMM_PLANES=0 select bf16x6 throughout, GX_GEMM_MODE=0 the exact-fp32 MFMA")
                        if x6 and ops.get_conv_planes() == 1 else
                        "fp32 in / fp32 out; contractions as bf16x6 on the bf16 matrix cores (every operand bit kept: fp32-level "

@@ -706,9 +706,9 @@ __global__ void lowrank_coeff_amax_kernel(const float* __restrict__ C, long rows
     for (; u < nu; u += stride) take(u, *reinterpret_cast<const f32x4*>(C + u * 4));
     mc = gx_block_max(mc, red);
     me = gx_block_max(me, red);
-    if (threadIdx.x == 0) {
-        if (mc > 0.f) atomicMax(out, __float_as_uint(mc));
-        if (me > 0.f) atomicMax(out + 1, __float_as_uint(me));
+    if (threadIdx.x == 0) {      // (read first: a thousand unconditional atomics on one word serialise in L2)
+        if (__float_as_uint(mc) > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(out, __float_as_uint(mc));
+        if (__float_as_uint(me) > *reinterpret_cast<volatile unsigned*>(out + 1)) atomicMax(out + 1, __float_as_uint(me));
     }
 }
 
@@ -806,7 +806,7 @@ int gx_lowrank_coeff_amax(const float* C, long rows, int K, float* out2, void* s
     if (hipMemsetAsync(out2, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return GX_ERR_LAUNCH;
     const int ls = (K + 1 + 3) & ~3;
     long want = (rows * (ls >> 2) + 1023) / 1024;
-    hipLaunchKernelGGL(gx::lowrank_coeff_amax_kernel, dim3((int)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, C,
+    hipLaunchKernelGGL(gx::lowrank_coeff_amax_kernel, dim3((int)(want < 1024 ? want : 1024)), dim3(256), 0, (hipStream_t)stream, C,
                        rows, ls, K, reinterpret_cast<unsigned*>(out2));
     GX_CHECK_LAUNCH();
     return GX_OK;

@@ -917,7 +917,7 @@ __global__ void absmax_strided_kernel(const float* __restrict__ x, long n, int c
         m = fmaxf(m, sqrt_of ? sqrtf(v) : v);
     }
     m = gx_block_max(m, red);
-    if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if (threadIdx.x == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(out, __float_as_uint(m));
 }
 
 // 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); 1: bf16x6 on the bf16 MFMA.
