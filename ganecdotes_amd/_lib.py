@@ -88,7 +88,7 @@ SIGNATURES = {
     "gx_upsample2_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "gx_sumpool2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "gx_gather_rows_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
-    "gx_normalize_bwd_scatter": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "gx_normalize_bwd_scatter": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_small_workspace_bytes": (c_sz, [c_i, c_i]),
     "gx_proto_fwd_small": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "gx_proto_bwd_small": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_sz,

@@ -1750,7 +1750,7 @@ __global__ void gather_rows_normalize_kernel(const float* __restrict__ Z, int HW
 __global__ void normalize_bwd_scatter_kernel(const float* __restrict__ dzh, const float* __restrict__ zh,
                                              const float* __restrict__ rnorm, int HW, int D,
                                              const int* __restrict__ picks, const int* __restrict__ maps,
-                                             int rows_per_img, long rows, float* __restrict__ G) {
+                                             int rows_per_img, long rows, float* __restrict__ G, unsigned* __restrict__ amax) {
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -1766,7 +1766,16 @@ __global__ void normalize_bwd_scatter_kernel(const float* __restrict__ dzh, cons
     const float rn = rnorm[row];
     const bool clamped = rn >= 1e12f;
     float* dst = G + ((long)b * HW + pix) * D;
-    for (int c = lane; c < D; c += 64) atomicAdd(dst + c, clamped ? gp[c] * rn : rn * (gp[c] - zp[c] * dot));
+    float m = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = clamped ? gp[c] * rn : rn * (gp[c] - zp[c] * dot);
+        atomicAdd(dst + c, v);
+        m = fmaxf(m, fabsf(v));
+    }
+    if (amax) {     // the largest single contribution (float bits): times the rows that can meet in one pixel, a bound of |G|
+        m = gx_wave_max(m);
+        if (lane == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(m));
+    }
 }
 
 }  // namespace gx
@@ -1810,12 +1819,12 @@ int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* pi
     return GX_OK;
 }
 int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float* rnorm, int B, int HW, int D,
-                             const int* picks, int rows_per_img, const int* maps, float* G, void* stream) {
+                             const int* picks, int rows_per_img, const int* maps, float* G, float* amax, void* stream) {
     if (!dzhat || !zhat || !rnorm || !picks || !G || B <= 0 || HW <= 0 || D <= 0 || rows_per_img <= 0)
         return GX_ERR_BAD_ARG;
     const long rows = (long)B * rows_per_img;
     hipLaunchKernelGGL(gx::normalize_bwd_scatter_kernel, dim3(gx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       dzhat, zhat, rnorm, HW, D, picks, maps, rows_per_img, rows, G);
+                       dzhat, zhat, rnorm, HW, D, picks, maps, rows_per_img, rows, G, reinterpret_cast<unsigned*>(amax));
     GX_CHECK_LAUNCH();
     return GX_OK;
 }

@@ -396,12 +396,13 @@ def gather_rows_normalize(z, picks, maps=None):
     return zhat, rn
 
 
-def normalize_bwd_scatter_(dzhat, zhat, rnorm, picks, maps, g):
-    """g (B, H, W, D) += scatter of normalize-backward(dzhat) rows (float atomics)."""
+def normalize_bwd_scatter_(dzhat, zhat, rnorm, picks, maps, g, amax=None):
+    """g (B, H, W, D) += scatter of normalize-backward(dzhat) rows (float atomics).  amax (one-element HIP tensor the caller
+    zeroed): raised to the largest single contribution (x the rows that can meet in one pixel: a bound of |g|)."""
     _chk(dzhat, zhat, rnorm, g)
     b, h, w, d = g.shape
     _lib.check(lib().gx_normalize_bwd_scatter(_p(dzhat), _p(zhat), _p(rnorm), b, h * w, d, _p(picks), picks.shape[1],
-                                              _p(maps), _p(g), _stream()), "gx_normalize_bwd_scatter")
+                                              _p(maps), _p(g), _p(amax), _stream()), "gx_normalize_bwd_scatter")
     return g
 
 

@@ -145,15 +145,15 @@ class Pyramid:
         return r * r
 
     # ------------------------------------------------------------------------------------- backward
-    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None, nlev=None, g_amax=None):
+    def backward(self, g, gwp, accumulate, g_pooled=None, on_level=None, nlev=None, g_amax=None, g_mul=1.0):
         """g (B, r, r, D) = d loss / d Z of level nlev - 1 (default: the finest) -> gwp (D, hlen) (+)= sum over the
         taps of the first nlev levels of G_level^T tap.  g_pooled: sumpool2(g) if the caller already has it.
         on_level([(off, width), ...]) is called once the GEMMs of a level are queued (its columns of gwp are final:
         a sharded caller starts their all-reduce there).  g_amax (one-element HIP tensor, optional): max |g| as its producer left
         it — the level GEMMs then run the f16x3 form (the taps' range is the convs' contract; a 2x2 sum-pooling multiplies the
-        bound by 4)."""
+        bound by 4); g_mul: the factor between *g_amax and the bound of |g| (a scatter leaves its largest single contribution)."""
         first = not accumulate
-        gmul = 1.0
+        gmul = float(g_mul)
         nlev = len(self.res) if nlev is None else nlev
         res, levels = self.res[:nlev], self.levels[:nlev]
         for r, taps in zip(reversed(res), reversed(levels)):

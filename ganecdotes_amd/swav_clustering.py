@@ -58,6 +58,11 @@ class _NullLogger:
         pass
 
 
+# output pixels of a view that the nearest rotate / flip map can send to ONE source pixel (two, rarely three: rotated lattice
+# points inside a unit cell), rounded up: the factor between the largest single row a scatter adds into G and a bound of |G|
+SCATTER_MEET = 4.0
+
+
 class Route(NamedTuple):
     """What one optimizer step runs — decided in ONE place (`SwAVClustering.plan_route`) from the configuration and the batch
     shape.  `train_step` dispatches on `name`; `bench.py` prints `describe()` into `config.workload`."""
@@ -330,6 +335,9 @@ class SwAVClustering(ViewMixin):
         K, D = Wc.shape
         npix = B * hw * hw
         picks_all = None if tb is not None else torch.arange(hw * hw, dtype=torch.int32, device=dev).repeat(B, 1)
+        # the largest single row the scatters add into the G tables: a table row is scattered once, and the nearest rotate / flip
+        # map sends at most two or three output pixels to one source pixel — x SCATTER_MEET it bounds |G| for the level GEMMs
+        g_amax = torch.zeros(1, dtype=torch.float32, device=dev) if ops.GEMM_H2 else None
         for v in range(2):
             dz = torch.empty(npix, D, dtype=torch.float32, device=dev)
             if tb is not None:
@@ -338,7 +346,7 @@ class SwAVClustering(ViewMixin):
                          split_k=self._split_k(K, D, npix), live=tb.live, live_frac=tb.live_frac, a_range=ds_range, b_range=1.0)
                 ops.gemm_nt_planes_live(dS_tab[v], wct_planes, dz, tb.live, tb.live_frac, a_range=ds_range)
                 with self._timed("scatter_rows"):
-                    ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D))
+                    ops.normalize_bwd_scatter_(dz, zt, rnt, tb.scat_picks, tb.maps_flat[v], Gt[v].reshape(1, B * hw, hw, D), amax=g_amax)
                 continue
             with self._timed("gather_rows"):
                 zt, rnt = ops.gather_rows_normalize(Zt[v], picks_all, views[v][1])       # z_hat of every (output) pixel
@@ -349,8 +357,9 @@ class SwAVClustering(ViewMixin):
             else:
                 ops.gemm(dS_tab[v][:, :K], Wc, False, False, out=dz)
             with self._timed("scatter_rows"):
-                ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v])
+                ops.normalize_bwd_scatter_(dz, zt, rnt, picks_all, views[v][1], Gt[v], amax=g_amax)
             del zt, rnt, dz
+        return g_amax
 
     # ------------------------------------------------------------------------------------- route of a step
     def plan_route(self, B, hw, N):
@@ -549,7 +558,9 @@ class SwAVClustering(ViewMixin):
                 else:
                     if on_heads is not None:
                         on_heads()
-                    c.pyr.backward(c.G_all, c.gWp, accumulate=False, on_level=on_level)
+                    # (tables route: the scatters left the largest single row of G on the device -> the level GEMMs' f16x3 form)
+                    ga = getattr(c, "g_amax", None)
+                    c.pyr.backward(c.G_all, c.gWp, accumulate=False, on_level=on_level, g_amax=ga, g_mul=SCATTER_MEET)
             c.Zt = c.Z_all = c.G_all = c.Gt = None
         elif self.sharded:
             pending.append(sharded.allreduce_flat_async(list(self._grads) + [c.loss], self.dist_group))
@@ -720,7 +731,7 @@ class SwAVClustering(ViewMixin):
                              q_s=skb[0].codes(), q_t=skb[ngroups].codes())
             del inv, Sc_all, skb
         c.first_acc = False
-        self._tables_backward(dS_tab, tb, c.views, c.Zt, c.Gt, c.Wc, wct_planes, c.gWc, B, hw, ds_range)
+        c.g_amax = self._tables_backward(dS_tab, tb, c.views, c.Zt, c.Gt, c.Wc, wct_planes, c.gWc, B, hw, ds_range)
 
     def _scores_gemm(self, c, z, sc, wc_planes, cmax_pre, key):
         """scores = z_hat Wc^T + b into sc (rows, K)"""

@@ -379,7 +379,9 @@ int gx_sumpool2(const float* fine, float* coarse, int B, int rc, int D, void* st
 int gx_gather_rows_normalize(const float* Z, int B, int HW, int D, const int* picks, int rows_per_img, const int* maps,
                              float* zhat, float* rnorm, void* stream);
 int gx_normalize_bwd_scatter(const float* dzhat, const float* zhat, const float* rnorm, int B, int HW, int D,
-                             const int* picks, int rows_per_img, const int* maps, float* G, void* stream);
+                             const int* picks, int rows_per_img, const int* maps, float* G, float* amax, void* stream);
+/* amax (optional; one float the caller has zeroed, shared by the calls that fill one G): the largest single contribution — times
+ * the number of rows that can meet in one pixel it bounds |G| (the a_amax_dev of the f16x3 level GEMMs of the pyramid backward) */
 
 /* ---- small-prototype fast path (K <= 16): the prototype layer as fused HBM-bound row kernels ----
  * gx_proto_fwd_small  = gx_gather_rows_normalize + scores = zhat Wc^T + b   (swav_clustering.py:171-175)
