@@ -1041,12 +1041,23 @@ def test_pyramid_pieces(ops):
     x1 = rows.reshape(-1, d).clone().requires_grad_(True)
     torch.nn.functional.normalize(x1, dim=1).backward(gin)
     gfull = torch.zeros(b, hw, hw, d, device="cuda")
-    ops.normalize_bwd_scatter_(dev(gin), zh, rn, picks, maps, gfull)
+    amax = torch.zeros(1, device="cuda")
+    ops.normalize_bwd_scatter_(dev(gin), zh, rn, picks, maps, gfull, amax=amax)
     want = torch.zeros(b, hw * hw, d)
     for i in range(b):
         ok = src[i] >= 0
         want[i].index_add_(0, src[i][ok], x1.grad.reshape(b, 100, d)[i][ok])
     assert rel_err(gfull.reshape(b, hw * hw, d), want) < 1e-5
+    # amax: the largest single row added (zero-filled picks add nothing) — x the rows that can meet in a pixel it bounds |G|
+    single = x1.grad.reshape(b, 100, d) * (src >= 0).float()[:, :, None]
+    assert abs(float(amax) - float(single.abs().max())) <= 1e-6 * float(single.abs().max())
+    from ganecdotes_amd.swav_clustering import SCATTER_MEET
+    assert float(gfull.abs().max()) <= SCATTER_MEET * float(amax)
+    # how many output pixels of a rotated view share a source pixel: never more than the factor the bound allows
+    for ang in (0.0, 9.0, 33.0, 45.0, 61.0, 90.0):
+        m = ops.rotflip_map(ang, ang > 30, 64, 64, "cuda")
+        cnt = torch.bincount(m[m >= 0].long(), minlength=64 * 64)
+        assert int(cnt.max()) <= int(SCATTER_MEET)
 
 
 @pytest.mark.parametrize("d", [256, 512, 768, 1024, 260])
