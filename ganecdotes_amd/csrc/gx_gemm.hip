@@ -560,7 +560,10 @@ template <bool USUM, bool FIN = false, bool H2 = false, bool TALL = false>   // 
                                          // low-rank path's dense finish in the epilogue, rows in 2 x 64-pixel tiles (xw_epilogue_fin)
 __global__ __launch_bounds__(GEMM_THREADS, TALL ? 2 : 3) void gemm_xw_kernel(GemmArgs g) {
     static_assert(!TALL || (H2 && !FIN), "the 256-row tile: f16x3, plain epilogues");
-    constexpr int NS = 2;       // A ring depth (3 and 4 measured 0 / -8 %: fewer workgroups per CU)
+#ifndef XW_TALL_NS
+#define XW_TALL_NS 2            // lab (tools/lab/xw_ring.sh): A ring depth of the f16x3 256-row form, with a raw barrier past 2
+#endif
+    constexpr int NS = TALL ? XW_TALL_NS : 2;       // A ring depth (128-row bf16x6 form: 3 and 4 measured 0 / -8 %: fewer workgroups per CU)
     constexpr int NPL = H2 ? 2 : 3, XW_B = NPL * 4096;               // one B tile (planes)
     constexpr int NRT = TALL ? 2 : 1, TBM = 128 * NRT, XW_A = 8192 * NRT, NU = 2 * NRT;   // 32-row tiles per wave; rows, bytes, DMAs per thread of an A tile
     // A ring of NS tiles, B ring of 2; FIN: + the four waves' coefficient rows [32][ls <= 20], DMA'd in before the k loop;
@@ -715,9 +718,12 @@ __global__ __launch_bounds__(GEMM_THREADS, TALL ? 2 : 3) void gemm_xw_kernel(Gem
     }
     int rd = 0, wr = NS - 1;
     for (int t = 0; t < nkt; ++t) {
-        if (NS > 2 && t + NS - 2 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // (the newest A tile's NU DMAs per thread may stay in flight; a __syncthreads() would drain them — hipcc puts a
+        // vmcnt(0) in front of it —, so a ring deeper than 2 takes the raw barrier)
+        if (NS > 2 && t + NS - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (NS > 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
         if (t + 1 < nkt) issue_b(t + 1, ldsB + ((t + 1) & 1) * XW_B);
         if (t + NS - 1 < nkt) issue_a(t + NS - 1, lds + wr * XW_A);
         compute(lds + rd * XW_A, ldsB + (t & 1) * XW_B);
