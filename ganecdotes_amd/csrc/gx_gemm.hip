@@ -846,6 +846,42 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm_x6ws_kernel(GemmArgs g) {
                 x6_store_tile<B_KC, WS_BN>(slot + XImg<WS_BM>::BYTES, rb, p);
             }
         };
+#ifndef WS_DEPTH
+#define WS_DEPTH 2      // lab (tools/lab/ws_depth.sh): register sets of k-tiles in flight per producer thread
+#endif
+        if constexpr (WS_DEPTH == 4) {
+            // LAB ONLY.  Four k-tiles in flight per producer thread (four register sets, 96 VGPRs): a tile's loads issued four
+            // barrier periods before it is staged, against one with two sets.  Measured same-box, alternating (round 5,
+            // profiles/r05_lab_ws_depth.txt): SLOWER — the step's TN / NT GEMMs 5.26 -> 5.46 ms at K = 8, 95.2 -> 97.4 ms at
+            // K = 5000: the producers are not waiting for their loads (45 % MFMA busy is the power budget shared with the
+            // operand streams, DESIGN par. 4.21), and 72 more live registers cost the consumers' schedule.
+            f32x4 ra2[4], rb2[2], ra3[4], rb3[2];
+            load_tiles(0, ra0, rb0);
+            load_tiles(1, ra1, rb1);
+            load_tiles(2, ra2, rb2);
+            load_tiles(3, ra3, rb3);
+            if (nkt > 0) stage(slot0, ra0, rb0);
+            load_tiles(4, ra0, rb0);
+            __syncthreads();                                         // barrier 0: tile 0 visible
+            for (int t = 0; t < nkt; t += 4) {
+                if (t + 1 < nkt) stage(slot1, ra1, rb1);
+                load_tiles(t + 5, ra1, rb1);
+                __syncthreads();                                     // barrier t+1
+                if (t + 1 >= nkt) break;
+                if (t + 2 < nkt) stage(slot0, ra2, rb2);
+                load_tiles(t + 6, ra2, rb2);
+                __syncthreads();                                     // barrier t+2
+                if (t + 2 >= nkt) break;
+                if (t + 3 < nkt) stage(slot1, ra3, rb3);
+                load_tiles(t + 7, ra3, rb3);
+                __syncthreads();                                     // barrier t+3
+                if (t + 3 >= nkt) break;
+                if (t + 4 < nkt) stage(slot0, ra0, rb0);
+                load_tiles(t + 8, ra0, rb0);
+                __syncthreads();                                     // barrier t+4
+            }
+            return;
+        }
         load_tiles(0, ra0, rb0);
         load_tiles(1, ra1, rb1);
         if (nkt > 0) stage(slot0, ra0, rb0);
