@@ -65,6 +65,9 @@ if want("fwd"):
     pl = ops.split_gemm_weights(ops.fineq_pack_weights(mg, wcf))
     nblk = sum(8 - (t >> 1) for t in range(16)) + 16
     show("fineq_fwd", timeit(lambda: ops.fineq_fwd(t1, t2, pl, yt, bias, K, R)), 2.0 * rows * 512 * nblk)
+    if ops.GEMM_H2:
+        pl3 = ops.split_gemm_weights(ops.fineq_pack_weights(mg, wcf), h2=True)
+        show("fineq_fwd f16x3", timeit(lambda: ops.fineq_fwd(t1, t2, pl3, yt, bias, K, R, a_range=ops.FEATURE_RANGE)), 2.0 * rows * 512 * nblk)
     fo = ops.fineq_fwd(t1, t2, pl, yt, bias, K, R)
     print("   fineq_fwd checksums (diff build to build):", " ".join(f"{float(x.double().sum()):.12e}" for x in fo), flush=True)
     # the projected-table route
