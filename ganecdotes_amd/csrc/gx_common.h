@@ -8,7 +8,7 @@
                          defined(XP_ABL_B2) || defined(XW_ABL_DIRECT) || defined(FIN_ABL) || defined(FQ_ABL) || \
                          defined(BK_LOAD_AUX) || defined(BK_STORE_AUX) || defined(BK_PASS_MINB) || defined(CE_PIX_NJ2) || \
                          defined(BLUR_MINB) || defined(FQ_LATE) || defined(BD_AHEAD) || defined(BD_ROWS) || defined(FQ_PRIO) || \
-                         defined(XH_STAGES) || defined(RAWTAB_BLOCKS) || defined(XW_TALL_NS) || defined(WS_DEPTH))
+                         defined(XH_STAGES) || defined(RAWTAB_BLOCKS) || defined(XW_TALL_NS) || defined(WS_DEPTH) || defined(XP_ABL_A3))
 #error "lab ablation macro set without -DGX_LAB: ablated kernels must not reach libganecdotes_hip.so (use tools/lab/labbuild.sh)"
 #endif
 #include <hip/hip_runtime.h>

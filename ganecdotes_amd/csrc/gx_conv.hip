@@ -576,7 +576,7 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
         const unsigned va = pixbyte + (unsigned)to;                  // signed add: the padded pixel is never negative
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
-#ifdef XP_ABL_A2
+#if defined(XP_ABL_A2) || defined(XP_ABL_A3)
             if (!with_a) break;
 #endif
             const char* base = xp + (long)(cc * NPL + p) * (long)g.xp_plane_bytes;
@@ -620,12 +620,26 @@ __device__ __forceinline__ void conv_mainloop_xp(const ConvArgs& g, const ConvSu
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap, ++k) {
                 const int ahead = min(NS - 2, total - 1 - k);           // newer tiles whose DMAs may still be in flight
+#ifdef XP_ABL_A3
+                // lab (tools/lab/conv_abl.sh -DXP_ABL_A3; WRONG values): the x planes fetched for ONE of every three taps — the
+                // upper bound of what a halo row shared by the dx = -1, 0, 1 taps would save; the counted waits follow
+                static_assert(NS == 3, "the ablation's wait counts are written for a ring of three");
+                constexpr int PB = NPL;                                 // a B-only tile's DMAs
+                const int c1 = (NT < 9 || ((tap + 1) % NT) % 3 == 0) ? PER : PB;
+                if (ahead >= 1) { if (c1 == PER) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                 if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const int nt_ = (tap + NS - 1) % NT, dc_ = (tap + NS - 1) / NT;      // (constants once the tap loop is unrolled)
+#ifdef XP_ABL_A3
+                if (k + NS - 1 < total) issue(cc + dc_, tapoff[nt_], wblk[nt_], lds + ws * STAGE, NT < 9 || nt_ % 3 == 0);
+#else
                 if (k + NS - 1 < total) issue(cc + dc_, tapoff[nt_], wblk[nt_], lds + ws * STAGE);
+#endif
                 const char* As = lds + rd * STAGE;
                 xh_mfma_tile<TALL ? 4 : 2, 2, TALL ? 256 : 128, 128>(As, As + BOFF, acc, wr * (TALL ? 128 : 64), wc * 64, lane);
                 rd = (rd + 1 == NS) ? 0 : rd + 1;
