@@ -82,6 +82,7 @@ class SimCLRClustering(ViewMixin):
         with torch.no_grad():
             self.mean_latent = self.model.mean_latent(self.model_config.num_latents_for_mean)
             self.truncation = self.model_config.truncation
+        self.feature_peak = self.probe_feature_range()          # a checkpoint outside the f16x3 window -> bf16x6, with a warning
         self.layer_hf_dim = layer_hf_dim
         self._bufs = None
         self._step_no = 0

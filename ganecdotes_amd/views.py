@@ -2,9 +2,14 @@
 hfc_with_swav/swav_clustering.py:574-656, lib/oneshot/image_augmentor.py:8-104): batch staging
 through pinned memory, latent perturbation, the batched NHWC generator forward and the
 rotate/flip index maps."""
+import logging
+import os
+
 import torch
 
 from . import ops
+
+_LOG = logging.getLogger("ganecdotes_amd")
 
 
 class PreparedBatch:
@@ -58,6 +63,42 @@ class ViewMixin(object):
         # keeps the predict paths from turning an out-of-range activation into silent garbage labels
         ops.check_finite(feats[-1][:, :, ::8, ::8], "generator taps")
         return feats
+
+    def probe_feature_range(self, n=4, margin=4.0):
+        """Called once by the preprocessors' constructors.  The f16x3 engine (DESIGN.md par. 4.21) holds fp32-class error inside
+        a window of magnitudes: |activation| < 8188 into a conv, taps under ops.FEATURE_RANGE into the projection — and the
+        generator is frozen, so whether a CHECKPOINT lives inside that window can be found before the first step: n untruncated
+        latents (the widest styles the mapping network gives; a private RNG stream, the draws of a run are untouched) go through it
+        once.  A tap that is not finite, or within `margin` of the window's edge, switches the process to the bf16x6 forms (fp32's
+        range, ops.set_conv_planes(0) + ops.GEMM_H2 = False) with a warning — instead of the first optimizer step returning NaN.
+        Nothing happens on the other engines, or when GX_CONV_PLANES / GX_GEMM_PLANES were set by hand.  -> the largest |tap|."""
+        if ops.get_gemm_mode() != 1 or (ops.get_conv_planes() != 1 and not ops.GEMM_H2):
+            return None
+        if "GX_CONV_PLANES" in os.environ or "GX_GEMM_PLANES" in os.environ:
+            return None
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(0x5EED)
+        z = torch.randn(n, self.model.style_dim, device=self.device, generator=gen)
+        prev = getattr(self.model, "want_image", True)
+        self.model.want_image = False
+        try:
+            with torch.no_grad():
+                _, feats = self.model([z], randomize_noise=False)
+        finally:
+            self.model.want_image = prev
+        peak = float(torch.stack([f.abs().max() for f in feats]).max())
+        limit = ops.FEATURE_RANGE / margin
+        if not (peak < limit):                                    # (NaN compares false)
+            ops.set_conv_planes(0)
+            ops.GEMM_H2 = False
+            msg = (f"generator activations reach {peak:.4g} (f16x3 window / {margin:g} = {limit:g}): the convs and the weight-plane "
+                   f"GEMMs of this process run their bf16x6 forms (fp32's range) from here on — GX_CONV_PLANES / GX_GEMM_PLANES "
+                   f"set by hand override this probe")
+            _LOG.warning(msg)
+            lg = getattr(self, "logger", None)
+            if lg is not None and hasattr(lg, "warning"):
+                lg.warning(msg)
+        return peak
 
     def _timed(self, tag, flops=0.0, nbytes=0.0):
         """HIP-event bracket of a phase of the step (active only when ops.PROFILE is a dict)."""

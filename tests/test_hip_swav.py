@@ -195,6 +195,38 @@ def test_generator_plane_formats_agree_and_the_f16x3_range_is_loud(gpu, tmp_path
         ops.set_gemm_mode(prev_mode)
 
 
+def test_feature_range_probe_falls_back_to_bf16x6(gpu, tmp_path):
+    """The preprocessors' constructors send a few untruncated latents through the frozen generator once: a checkpoint whose
+    activations sit outside the f16x3 window (here: the constant input x 3e5) switches the process to the bf16x6 forms with a
+    warning, and training / predicting then work; an ordinary generator leaves the engines alone."""
+    import os
+    from ganecdotes_amd import generator as GM
+    from ganecdotes_amd import ops
+    if ops.get_gemm_mode() != 1 or ops.get_conv_planes() != 1 or not ops.GEMM_H2 or \
+            "GX_CONV_PLANES" in os.environ or "GX_GEMM_PLANES" in os.environ:
+        pytest.skip("the probe only acts on the default engines")
+    torch.manual_seed(21)
+    g = GM.Generator(64, 512, 8).eval().to(gpu)
+    try:
+        sw = make_swav(g, gpu, tmp_path)
+        assert sw.feature_peak is not None and sw.feature_peak < ops.FEATURE_RANGE / 4
+        assert ops.get_conv_planes() == 1 and ops.GEMM_H2
+        state = torch.cuda.get_rng_state()
+        assert sw.probe_feature_range() == sw.feature_peak                     # a private RNG stream: repeatable ...
+        assert torch.equal(torch.cuda.get_rng_state(), state)                   # ... and the run's own draws are untouched
+        g.input.input.data.mul_(3e5)
+        g._invalidate()
+        sw2 = make_swav(g, gpu, tmp_path)
+        assert not (sw2.feature_peak < ops.FEATURE_RANGE / 4)
+        assert ops.get_conv_planes() == 0 and not ops.GEMM_H2
+        sw2.build_heads()
+        preds, labels = sw2.predict_swav_codes(g.style(torch.randn(2, 512, device="cuda")))
+        assert bool(torch.isfinite(preds).all())
+    finally:
+        ops.set_conv_planes(1)
+        ops.GEMM_H2 = True
+
+
 def test_style_norm_keeps_huge_styles_inside_the_f16x3_range(gpu):
     """gx_style_norm: per (styled conv, sample) the style divided by the power of two that brings its largest magnitude into
     [2, 4), the demod coefficients multiplied by it — exact (bitwise the same taps on the exact-fp32 engine), and what makes the
